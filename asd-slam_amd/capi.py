@@ -1,0 +1,289 @@
+"""ctypes binding of libasdhip's C ABI (include/asd_slam.h).
+
+Plumbing for tests and bench only -- the same entry points a C++ adapter in the reference's
+catkin workspace would call.  There is no fallback: if the shared library
+is missing or no HIP device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libasdhip.so")
+
+
+class AsdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libasdhip error {code}: {msg}")
+        self.code = code
+
+
+class asd_config(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("max_width", C.c_int32),
+                ("max_height", C.c_int32), ("max_patches", C.c_int32), ("device", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                     ("response", np.float32), ("octave", np.int32)])
+
+
+class asd_ba_problem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("poses", C.c_void_p), ("fixed", C.c_void_p), ("points", C.c_void_p),
+                ("e_point", C.c_void_p), ("e_pose", C.c_void_p), ("e_obs", C.c_void_p), ("e_info", C.c_void_p),
+                ("K", C.c_double * 4), ("its_first", C.c_int32), ("its_second", C.c_int32)]
+
+
+class asd_ba_result(C.Structure):
+    _fields_ = [("edge_chi2", C.c_void_p), ("edge_depth_pos", C.c_void_p), ("edge_outlier1", C.c_void_p),
+                ("chi2_first", C.c_double), ("chi2_second", C.c_double),
+                ("iters_first", C.c_int32), ("iters_second", C.c_int32)]
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def load_library():
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    return C.CDLL(path)
+
+
+class AsdHip:
+    """One asd_ctx (= one HIP device + stream)."""
+
+    def __init__(self, n_features=2000, scale_factor=1.2, n_levels=8, ini_th=20, min_th=7,
+                 max_width=1241, max_height=376, max_patches=None, device=0):
+        self.lib = load_library()
+        L = self.lib
+        L.asd_last_error.restype = C.c_char_p
+        L.asd_version.restype = C.c_char_p
+        L.asd_ctx_stream.restype = C.c_void_p
+        self.cfg = asd_config(n_features, scale_factor, n_levels, ini_th, min_th, max_width, max_height,
+                              max_patches if max_patches is not None else 2 * n_features, device)
+        self.ctx = C.c_void_p()
+        rc = L.asd_ctx_create(C.byref(self.cfg), C.byref(self.ctx))
+        if rc != 0:
+            raise AsdError(rc, "asd_ctx_create failed (no usable HIP device? there is no CPU fallback)")
+        self.n_levels = n_levels
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx:
+            self.lib.asd_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AsdError(rc, self.lib.asd_last_error(self.ctx).decode())
+
+    # ---- tables
+    def scale_tables(self):
+        n = self.n_levels
+        s, i, g, ig = (np.zeros(n, np.float32) for _ in range(4))
+        f = np.zeros(n, np.int32)
+        self._chk(self.lib.asd_get_scale_tables(self.ctx, _p(s), _p(i), _p(g), _p(ig), _p(f)))
+        return dict(scale=s, inv_scale=i, sigma2=g, inv_sigma2=ig, features_per_level=f)
+
+    # ---- ASDNet
+    def load_weights(self, layers, eps=1e-5):
+        ws = [_c(w, np.float32) for w, _, _ in layers]
+        ms = [_c(m, np.float32) for _, m, _ in layers]
+        vs = [_c(v, np.float32) for _, _, v in layers]
+        arr = lambda xs: (C.c_void_p * 7)(*[x.ctypes.data for x in xs])
+        self._keep = (ws, ms, vs)
+        self._chk(self.lib.asd_load_weights(self.ctx, arr(ws), arr(ms), arr(vs), C.c_float(eps)))
+
+    def describe(self, patches):
+        patches = _c(patches, np.uint8).reshape(-1, 32, 32)
+        n = patches.shape[0]
+        out = np.empty((n, 128), np.float32)
+        self._chk(self.lib.asd_describe(self.ctx, _p(patches), n, _p(out)))
+        return out
+
+    # ---- device utilities
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.asd_device_alloc(self.ctx, C.c_uint64(nbytes), C.byref(p)))
+        return p
+
+    def device_free(self, p):
+        self._chk(self.lib.asd_device_free(self.ctx, p))
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.lib.asd_memcpy_h2d(self.ctx, dptr, _p(arr), C.c_uint64(arr.nbytes)))
+
+    def d2h(self, arr, dptr):
+        self._chk(self.lib.asd_memcpy_d2h(self.ctx, _p(arr), dptr, C.c_uint64(arr.nbytes)))
+
+    def sync(self):
+        self._chk(self.lib.asd_sync(self.ctx))
+
+    def describe_timed(self, d_patches, n, d_desc, reps):
+        ms = C.c_float()
+        self._chk(self.lib.asd_describe_timed(self.ctx, d_patches, n, d_desc, reps, C.byref(ms)))
+        return ms.value
+
+    def describe_device(self, d_patches, n, d_desc):
+        self._chk(self.lib.asd_describe_device(self.ctx, d_patches, n, d_desc))
+
+    def last_stage_ms(self, stage):
+        ms = C.c_float()
+        self._chk(self.lib.asd_last_stage_ms(self.ctx, stage.encode(), C.byref(ms)))
+        return ms.value
+
+    # ---- extractor
+    def extract(self, image, n_features_override=0):
+        image = _c(image, np.uint8)
+        h, w = image.shape
+        cap = self.cfg.max_patches
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.empty((cap, 128), np.float32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_extract(self.ctx, _p(image), w, h, image.strides[0], n_features_override,
+                                       _p(kps), _p(desc), C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        self._chk(self.lib.asd_get_level_size(self.ctx, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def level_image(self, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        self._chk(self.lib.asd_get_level_image(self.ctx, level, int(blurred), _p(out)))
+        return out
+
+    def raw_corners(self, level, cap=200000):
+        x, y, r = (np.empty(cap, np.float32) for _ in range(3))
+        n = C.c_int32()
+        self._chk(self.lib.asd_get_raw_corners(self.ctx, level, cap, _p(x), _p(y), _p(r), C.byref(n)))
+        return x[:n.value].copy(), y[:n.value].copy(), r[:n.value].copy()
+
+    # ---- frames / matchers
+    def frame_set(self, slot, kps, desc, bounds):
+        kps = _c(kps, KP_DTYPE)
+        d = None if desc is None else _c(desc, np.float32)
+        self._chk(self.lib.asd_frame_set(self.ctx, slot, _p(kps), _p(d), len(kps), C.c_float(bounds[0]),
+                                         C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3])))
+
+    def features_in_area(self, slot, x, y, r, min_level=-1, max_level=-1, cap=8192):
+        out = np.empty(cap, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_frame_features_in_area(self.ctx, slot, C.c_float(x), C.c_float(y), C.c_float(r),
+                                                      min_level, max_level, cap, _p(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def dist_matrix(self, a, b):
+        a, b = _c(a, np.float32), _c(b, np.float32)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        self._chk(self.lib.asd_dist_matrix(self.ctx, _p(a), a.shape[0], _p(b), b.shape[0], _p(out)))
+        return out
+
+    def distinctive_descriptor(self, desc):
+        desc = _c(desc, np.float32)
+        best = C.c_int32()
+        self._chk(self.lib.asd_distinctive_descriptor(self.ctx, _p(desc), desc.shape[0], C.byref(best)))
+        return best.value
+
+    def match_project_frame(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_desc, Tcw, K, th, check_ori=True):
+        has_mp, Xw, mp_desc = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(mp_desc, np.float32)
+        Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
+        out = np.empty(n_cur, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_project_frame(self.ctx, slot_cur, slot_last, _p(has_mp), _p(Xw), _p(mp_desc),
+                                                   _p(Tcw), _p(K), C.c_float(th), int(check_ori), _p(out),
+                                                   C.byref(n)))
+        return out, n.value
+
+    def match_project_points(self, slot_cur, n_cur, in_view, proj, level, view_cos, desc, occupied, th, nn_ratio):
+        in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
+        view_cos, desc, occupied = _c(view_cos, np.float32), _c(desc, np.float32), _c(occupied, np.uint8)
+        out = np.empty(n_cur, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_project_points(self.ctx, slot_cur, len(in_view), _p(in_view), _p(proj),
+                                                    _p(level), _p(view_cos), _p(desc), _p(occupied), C.c_float(th),
+                                                    C.c_float(nn_ratio), _p(out), C.byref(n)))
+        return out, n.value
+
+    def frustum(self, slot_cur, Xw, normal, min_dist, max_dist, Tcw, K, cos_limit=0.5):
+        Xw, normal = _c(Xw, np.float32), _c(normal, np.float32)
+        min_dist, max_dist = _c(min_dist, np.float32), _c(max_dist, np.float32)
+        Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
+        n = Xw.shape[0]
+        in_view = np.zeros(n, np.uint8)
+        proj = np.zeros((n, 2), np.float32)
+        level = np.zeros(n, np.int32)
+        vc = np.zeros(n, np.float32)
+        self._chk(self.lib.asd_frustum(self.ctx, slot_cur, n, _p(Xw), _p(normal), _p(min_dist), _p(max_dist),
+                                       _p(Tcw), _p(K), C.c_float(cos_limit), _p(in_view), _p(proj), _p(level),
+                                       _p(vc)))
+        return in_view, proj, level, vc
+
+    def match_init(self, slot1, slot2, prev_matched, window=100, nn_ratio=0.9, check_ori=True):
+        pm = _c(prev_matched, np.float32).copy()
+        out = np.empty(pm.shape[0], np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_init(self.ctx, slot1, slot2, _p(pm), window, C.c_float(nn_ratio),
+                                          int(check_ori), _p(out), C.byref(n)))
+        return out, n.value, pm
+
+    # ---- optimizer
+    def pose_optimize(self, pose7, Xw, obs, inv_sigma2, K):
+        pose = _c(pose7, np.float64).copy()
+        Xw, obs, inv_sigma2, K = (_c(a, np.float64) for a in (Xw, obs, inv_sigma2, K))
+        n = Xw.shape[0]
+        outlier = np.zeros(n, np.uint8)
+        ninl = C.c_int32()
+        self._chk(self.lib.asd_pose_optimize(self.ctx, _p(pose), n, _p(Xw), _p(obs), _p(inv_sigma2), _p(K),
+                                             _p(outlier), C.byref(ninl)))
+        return pose, outlier, ninl.value
+
+    def local_ba(self, prob, its_first=5, its_second=10):
+        poses = _c(prob["poses"], np.float64).copy()
+        points = _c(prob["points"], np.float64).copy()
+        fixed = _c(prob["fixed"], np.uint8)
+        e_point, e_pose = _c(prob["e_point"], np.int32), _c(prob["e_pose"], np.int32)
+        e_obs, e_info = _c(prob["e_obs"], np.float64), _c(prob["e_info"], np.float64)
+        E = len(e_point)
+        chi2 = np.zeros(E, np.float64)
+        dpos = np.zeros(E, np.uint8)
+        out1 = np.zeros(E, np.uint8)
+        p = asd_ba_problem(len(poses), len(points), E, poses.ctypes.data, fixed.ctypes.data, points.ctypes.data,
+                           e_point.ctypes.data, e_pose.ctypes.data, e_obs.ctypes.data, e_info.ctypes.data,
+                           (C.c_double * 4)(*[float(k) for k in prob["K"]]), its_first, its_second)
+        r = asd_ba_result(chi2.ctypes.data, dpos.ctypes.data, out1.ctypes.data, 0.0, 0.0, 0, 0)
+        self._chk(self.lib.asd_local_ba(self.ctx, C.byref(p), C.byref(r)))
+        return dict(poses=poses, points=points, edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier1=out1,
+                    chi2_first=r.chi2_first, chi2_second=r.chi2_second, iters_first=r.iters_first,
+                    iters_second=r.iters_second)
+
+    def tcw_to_pose7(self, T):
+        T = _c(T, np.float32)
+        p = np.zeros(7, np.float64)
+        self.lib.asd_tcw_to_pose7(_p(T), _p(p))
+        return p
+
+    def pose7_to_tcw(self, p):
+        p = _c(p, np.float64)
+        T = np.zeros((4, 4), np.float32)
+        self.lib.asd_pose7_to_tcw(_p(p), _p(T))
+        return T

@@ -1,0 +1,381 @@
+// asdnet.hip -- ASDNet patch -> descriptor forward pass on gfx950.
+//
+// Replaces module->forward in computeSIFTDescriptors (reference
+// src/vslam/src/ORBextractor.cc:1125-1132), i.e. ASDNet.forward
+// (ASDNet/ASDNet/ASDNet.py:334-370) with L2Norm (Utils.py:15-22).  The reference launches
+// the TorchScript module once per pyramid level with an H2D and a D2H copy each
+// (ORBextractor.cc:1217-1231); here all levels' patches go through one batch.
+//
+// Arithmetic: f32 in / f32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32 is an
+// exact f32 fma chain), BatchNorm (eval, affine=False) folded into the conv weights and a
+// per-channel bias at upload.  Activations are NHWC f32 so the contraction index (cin) is
+// contiguous; every 3x3 conv is an implicit GEMM  [pixels x 9*cin] * [9*cin x cout]:
+//   A operand  = zero-padded input band staged once per workgroup in LDS,
+//   B operand  = per-(tap, cin-chunk) weight slices streamed through a 2-deep LDS ring,
+//   k order    = permuted so each lane fetches 4 consecutive cin with one ds_read_b128
+//                (lane half h, element jj <-> cin 8*c8 + 4*h + jj) -- the weight image is
+//                laid out to match, see build_wimg().
+#include "ctx.h"
+
+#include <cmath>
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct LayerSpec { int cout, cin, k, stride, pad; };
+const LayerSpec kLayers[7] = {{32, 1, 3, 1, 1},   {32, 32, 3, 1, 1},   {64, 32, 3, 2, 1},  {64, 64, 3, 1, 1},
+                              {128, 64, 3, 2, 1}, {128, 128, 3, 1, 1}, {128, 128, 8, 1, 0}};
+
+// ------------------------------------------------------------------------------------------
+// K0: input_norm (ASDNet.py:360-365) + conv1 + BN + ReLU, VALU (K = 9 is too short for MFMA).
+// One workgroup per patch; output NHWC [n][32][32][32].
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_norm_conv1(const uint8_t* __restrict__ patches,
+                                                    const float* __restrict__ w1, const float* __restrict__ b1,
+                                                    float* __restrict__ out) {
+  __shared__ float tile[34 * 34];
+  __shared__ float red[8];
+  __shared__ float wsh[32 * 9 + 32];
+  const int p = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int i = t; i < 34 * 34; i += 256) tile[i] = 0.f;
+  for (int i = t; i < 32 * 9; i += 256) wsh[i] = w1[i];
+  if (t < 32) wsh[288 + t] = b1[t];
+  const uchar4 v = reinterpret_cast<const uchar4*>(patches + (size_t)p * 1024)[t];
+  const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
+  float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
+  float s = (x[0] + x[1]) + (x[2] + x[3]);
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
+  float d[4], ss = 0.f;
+  for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) red[4 + wave] = ss;
+  __syncthreads();
+  const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
+  {
+    const int idx = t * 4, y = idx >> 5, x0 = idx & 31;
+    for (int k = 0; k < 4; ++k) tile[(y + 1) * 34 + x0 + k + 1] = d[k] / sd;
+  }
+  __syncthreads();
+  const int q = t & 7, pg = t >> 3;
+  float w[4][9], b[4];
+  for (int c = 0; c < 4; ++c) {
+    b[c] = wsh[288 + 4 * q + c];
+    for (int k = 0; k < 9; ++k) w[c][k] = wsh[(4 * q + c) * 9 + k];
+  }
+  float* op = out + (size_t)p * 32768;
+  for (int i = 0; i < 32; ++i) {
+    const int pix = i * 32 + pg, y = pix >> 5, xx = pix & 31;
+    float a[9];
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) a[ky * 3 + kx] = tile[(y + ky) * 34 + xx + kx];
+    f32x4 r;
+    for (int c = 0; c < 4; ++c) {
+      float acc = b[c];
+      for (int k = 0; k < 9; ++k) acc += a[k] * w[c][k];
+      r[c] = acc > 0.f ? acc : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(op + (size_t)pix * 32 + 4 * q) = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: 3x3 conv (pad 1, stride S) + folded BN + ReLU as an implicit GEMM on f32 MFMA.
+// One workgroup = ROWS output rows of one patch; 4 waves as WM (pixels) x WN (channels).
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
+struct ConvCfg {
+  static constexpr int HO = HIN / S;
+  static constexpr int INROWS = (ROWS - 1) * S + 3;
+  static constexpr int INCOLS = (HO - 1) * S + 3;
+  static constexpr int CPAD = CIN + 4;  // 16-B aligned pixel stride, odd multiple of 4 floats -> b128 reads spread over banks
+  static constexpr int M_WG = ROWS * HO;
+  static constexpr int MT = M_WG / 32 / WM;
+  static constexpr int NT = COUT / 32 / WN;
+  static constexpr int NCC = CIN / KC;
+  static constexpr int NSTAGE = 9 * NCC;
+  static constexpr int WCHUNK = KC * COUT;  // floats per weight stage
+  static constexpr int WREGS = WCHUNK / 4 / 256;
+  static constexpr int ACT_FLOATS = INROWS * INCOLS * CPAD;
+  static constexpr int LDS_BYTES = (ACT_FLOATS + 2 * WCHUNK) * 4;
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0, "tile split");
+  static_assert(WCHUNK % 1024 == 0, "weight stage must be a multiple of 256 float4");
+  static_assert(HO % ROWS == 0 && CIN % KC == 0 && KC % 8 == 0, "shape");
+};
+
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
+__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ wimg,
+                                                   const float* __restrict__ bias, float* __restrict__ out) {
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sact = smem;
+  float* sw = smem + C::ACT_FLOATS;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  constexpr int BANDS = C::HO / ROWS;
+  const int patch = blockIdx.x / BANDS, band = blockIdx.x % BANDS;
+  const int r0 = band * ROWS;
+  const float* inp = in + (size_t)patch * HIN * HIN * CIN;
+
+  // ---- stage the zero-padded input band (NHWC rows are contiguous: coalesced 16-B loads)
+  constexpr int C4 = CIN / 4;
+  for (int idx = t; idx < C::INROWS * C::INCOLS * C4; idx += 256) {
+    const int c4 = idx % C4, pix = idx / C4;
+    const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+    const int iy = r0 * S - 1 + j, ix = i - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < HIN && ix >= 0 && ix < HIN)
+      v = *reinterpret_cast<const f32x4*>(inp + ((size_t)iy * HIN + ix) * CIN + c4 * 4);
+    *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + c4 * 4) = v;
+  }
+  // ---- weight stage 0
+  for (int r = 0; r < C::WREGS; ++r)
+    *reinterpret_cast<f32x4*>(sw + (r * 256 + t) * 4) = *reinterpret_cast<const f32x4*>(wimg + (r * 256 + t) * 4);
+  __syncthreads();
+
+  f32x16 acc[C::MT][C::NT];
+  for (int mt = 0; mt < C::MT; ++mt)
+    for (int nt = 0; nt < C::NT; ++nt)
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int h = lane >> 5, li = lane & 31;
+  int abase[C::MT];
+  for (int mt = 0; mt < C::MT; ++mt) {
+    const int m = (wm * C::MT + mt) * 32 + li;
+    const int rr = m / C::HO, ox = m % C::HO;
+    abase[mt] = ((rr * S) * C::INCOLS + ox * S) * C::CPAD + 4 * h;
+  }
+  const int bbase = (h * COUT + wn * C::NT * 32 + li) * 4;
+
+  for (int s = 0; s < C::NSTAGE; ++s) {
+    f32x4 wreg[C::WREGS];
+    if (s + 1 < C::NSTAGE) {
+      const float* wsrc = wimg + (size_t)(s + 1) * C::WCHUNK;
+      for (int r = 0; r < C::WREGS; ++r) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * 256 + t) * 4);
+    }
+    const int tap = s / C::NCC, cc = s % C::NCC;
+    const int tapoff = ((tap / 3) * C::INCOLS + (tap % 3)) * C::CPAD + cc * KC;
+    const float* swb = sw + (s & 1) * C::WCHUNK;
+#pragma unroll
+    for (int c8 = 0; c8 < KC / 8; ++c8) {
+      f32x4 a[C::MT], b[C::NT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sact + abase[mt] + tapoff + c8 * 8);
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+        b[nt] = *reinterpret_cast<const f32x4*>(swb + bbase + c8 * 2 * COUT * 4 + nt * 128);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
+    }
+    if (s + 1 < C::NSTAGE) {
+      float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
+      for (int r = 0; r < C::WREGS; ++r) *reinterpret_cast<f32x4*>(swn + (r * 256 + t) * 4) = wreg[r];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias (folded BN) + ReLU, NHWC store.  Lane owns one cout column, 16 pixel rows.
+  float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
+  for (int nt = 0; nt < C::NT; ++nt) {
+    const int co = (wn * C::NT + nt) * 32 + li;
+    const float bv = bias[co];
+    for (int mt = 0; mt < C::MT; ++mt)
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[mt][nt][r] + bv;
+        op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: last layer, 8x8 valid conv == GEMM [n x 8192] * [8192 x 128], split-K over gridDim.y.
+// One workgroup = 32 patches x 128 couts x (8192 / SK) k; wave w owns couts [32w, 32w+32), so
+// every weight element is used by exactly one wave: B goes global -> VGPR, only A through LDS.
+// ------------------------------------------------------------------------------------------
+constexpr int FC_SK = 8;
+constexpr int FC_KCH = 128;
+__global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, const float* __restrict__ wimg,
+                                                 float* __restrict__ part, int n, int npad) {
+  __shared__ __attribute__((aligned(16))) float sa[32 * (FC_KCH + 4)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int h = lane >> 5, li = lane & 31;
+  const int p0 = blockIdx.x * 32, sk = blockIdx.y;
+  constexpr int KPER = 8192 / FC_SK;
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int st = 0; st < KPER / FC_KCH; ++st) {
+    const int k0 = sk * KPER + st * FC_KCH;
+    __syncthreads();
+    for (int idx = t; idx < 32 * (FC_KCH / 4); idx += 256) {
+      const int c4 = idx % (FC_KCH / 4), row = idx / (FC_KCH / 4);
+      int p = p0 + row;
+      if (p >= n) p = n - 1;
+      *reinterpret_cast<f32x4*>(sa + row * (FC_KCH + 4) + c4 * 4) =
+          *reinterpret_cast<const f32x4*>(act + (size_t)p * 8192 + k0 + c4 * 4);
+    }
+    __syncthreads();
+    const float* wb = wimg + ((size_t)(k0 / 8) * 2 + h) * 128 * 4 + (wave * 32 + li) * 4;
+#pragma unroll 4
+    for (int c8 = 0; c8 < FC_KCH / 8; ++c8) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sa + li * (FC_KCH + 4) + c8 * 8 + 4 * h);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(wb + (size_t)c8 * 2 * 128 * 4);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b[jj], acc, 0, 0, 0);
+    }
+  }
+  float* op = part + ((size_t)sk * npad + p0) * 128;
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+    op[(size_t)m * 128 + wave * 32 + li] = acc[r];
+  }
+}
+
+// K3: sum split-K partials in fixed order (deterministic), folded BN bias, L2Norm (Utils.py:15-22).
+__global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, const float* __restrict__ bias,
+                                                float* __restrict__ desc, int n, int npad) {
+  const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  float v0 = 0.f, v1 = 0.f;
+  for (int sk = 0; sk < FC_SK; ++sk) {
+    v0 += part[((size_t)sk * npad + p) * 128 + lane];
+    v1 += part[((size_t)sk * npad + p) * 128 + lane + 64];
+  }
+  v0 += bias[lane];
+  v1 += bias[lane + 64];
+  float ss = v0 * v0 + v1 * v1;
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+  const float norm = sqrtf(ss + 1e-10f);
+  desc[(size_t)p * 128 + lane] = v0 / norm;
+  desc[(size_t)p * 128 + lane + 64] = v1 / norm;
+}
+
+// layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC>
+#define L2_CFG 32, 32, 32, 1, 8, 4, 1, 32
+#define L3_CFG 32, 64, 32, 2, 4, 2, 2, 32
+#define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32
+#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 16
+#define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16
+
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
+hipError_t launch_conv(hipStream_t st, const float* in, const float* wimg, const float* bias, float* out, int n) {
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(n * (C::HO / ROWS)), dim3(256), C::LDS_BYTES, st, in, wimg, bias, out);
+  return hipGetLastError();
+}
+
+// B-operand image of a 3x3 layer: [tap][cin/8][h][cout][jj] with cin = 8*c8 + 4*h + jj, BN scale folded.
+void build_wimg(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<float>& img) {
+  img.assign((size_t)9 * L.cin * L.cout, 0.f);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int ci = 0; ci < L.cin; ++ci)
+      for (int co = 0; co < L.cout; ++co) {
+        const int c8 = ci / 8, hh = (ci % 8) / 4, jj = ci % 4;
+        const size_t dst = ((((size_t)tap * (L.cin / 8) + c8) * 2 + hh) * L.cout + co) * 4 + jj;
+        img[dst] = w[((size_t)co * L.cin + ci) * 9 + tap] * inv[co];
+      }
+}
+
+}  // namespace
+
+int asdnet_alloc(asd_ctx* ctx) {
+  const size_t np = (size_t)ctx->cfg.max_patches;
+  const size_t npad = (np + 31) / 32 * 32;
+  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_act[0], np * 32768 * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_act[1], np * 32768 * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_part, (size_t)FC_SK * npad * 128 * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_patches, np * 1024));
+  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_desc, np * 128 * sizeof(float)));
+  return ASD_OK;
+}
+
+void asdnet_free(asd_ctx* ctx) {
+  for (int i = 0; i < 2; ++i) if (ctx->d_act[i]) (void)hipFree(ctx->d_act[i]);
+  if (ctx->d_part) (void)hipFree(ctx->d_part);
+  if (ctx->d_patches) (void)hipFree(ctx->d_patches);
+  if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+  if (ctx->d_w1) (void)hipFree(ctx->d_w1);
+  for (int i = 0; i < 7; ++i) {
+    if (ctx->d_bias[i]) (void)hipFree(ctx->d_bias[i]);
+    if (ctx->d_wimg[i]) (void)hipFree(ctx->d_wimg[i]);
+  }
+}
+
+int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
+                        const float* const bn_var[7], float eps) {
+  for (int l = 0; l < 7; ++l) {
+    const LayerSpec& L = kLayers[l];
+    std::vector<float> inv(L.cout), bias(L.cout);
+    for (int c = 0; c < L.cout; ++c) {
+      inv[c] = 1.0f / std::sqrt(bn_var[l][c] + eps);
+      bias[c] = -bn_mean[l][c] * inv[c];
+    }
+    if (!ctx->d_bias[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_bias[l], L.cout * sizeof(float)));
+    ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_bias[l], bias.data(), L.cout * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<float> img;
+    if (l == 0) {
+      img.resize(32 * 9);
+      for (int co = 0; co < 32; ++co)
+        for (int k = 0; k < 9; ++k) img[co * 9 + k] = conv_w[0][co * 9 + k] * inv[co];
+      if (!ctx->d_w1) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_w1, img.size() * sizeof(float)));
+      ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_w1, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+      continue;
+    }
+    if (l < 6) {
+      build_wimg(L, conv_w[l], inv, img);
+    } else {
+      // k = px*128 + c (NHWC flatten of the 8x8x128 input), image [k/8][h][cout][jj]
+      img.assign((size_t)8192 * 128, 0.f);
+      for (int px = 0; px < 64; ++px)
+        for (int c = 0; c < 128; ++c)
+          for (int co = 0; co < 128; ++co) {
+            const int k = px * 128 + c, k8 = k / 8, hh = (k % 8) / 4, jj = k % 4;
+            img[(((size_t)k8 * 2 + hh) * 128 + co) * 4 + jj] = conv_w[6][((size_t)co * 128 + c) * 64 + px] * inv[co];
+          }
+    }
+    if (!ctx->d_wimg[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wimg[l], img.size() * sizeof(float)));
+    ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wimg[l], img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  ctx->weights_loaded = true;
+  return ASD_OK;
+}
+
+int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc) {
+  if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
+  if (n < 0 || n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
+  if (n == 0) return ASD_OK;
+  hipStream_t st = ctx->stream;
+  float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
+  const int npad = (n + 31) / 32 * 32;
+  hipLaunchKernelGGL(k_norm_conv1, dim3(n), dim3(256), 0, st, d_patches, ctx->d_w1, ctx->d_bias[0], a0);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG>(st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, n)));
+  ASD_HIP_CHECK(ctx, (launch_conv<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
+  ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
+  ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
+  ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
+  hipLaunchKernelGGL(k_fc_mfma, dim3(npad / 32, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_l2norm, dim3((n + 3) / 4), dim3(256), 0, st, ctx->d_part, ctx->d_bias[6], d_desc, n, npad);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  return ASD_OK;
+}

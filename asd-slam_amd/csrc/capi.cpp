@@ -1,0 +1,282 @@
+// capi.cpp -- C ABI entry points of libasdhip: context, ASDNet, utilities.
+// (extractor: frontend.hip, matchers: matcher.hip, optimizer: ba.hip)
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "ctx.h"
+
+int frontend_alloc(asd_ctx* ctx);
+void frontend_free(asd_ctx* ctx);
+void matcher_free(asd_ctx* ctx);
+void ba_free(asd_ctx* ctx);
+
+namespace {
+inline int cv_round(double v) { return (int)std::lrint(v); }  // cvRound: round-half-to-even
+inline int cv_floor(double v) { return (int)std::floor(v); }
+inline int cv_ceil(double v) { return (int)std::ceil(v); }
+
+// ORBextractor::ORBextractor (ORBextractor.cc:452-512): scale tables, per-level quotas, umax.
+void build_tables(asd_ctx* c) {
+  const int nl = c->cfg.n_levels;
+  const float scaleFactor = c->cfg.scale_factor;
+  c->scale[0] = 1.0f;
+  c->sigma2[0] = 1.0f;
+  for (int i = 1; i < nl; i++) {
+    c->scale[i] = (float)(c->scale[i - 1] * (double)scaleFactor);  // member scaleFactor is a double (ORBextractor.h:102)
+    c->sigma2[i] = c->scale[i] * c->scale[i];
+  }
+  for (int i = 0; i < nl; i++) {
+    c->inv_scale[i] = 1.0f / c->scale[i];
+    c->inv_sigma2[i] = 1.0f / c->sigma2[i];
+  }
+  const int nfeatures = c->cfg.n_features;
+  float factor = (float)(1.0f / (double)scaleFactor);
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int level = 0; level < nl - 1; level++) {
+    c->features_per_level[level] = cv_round(nDesired);
+    sum += c->features_per_level[level];
+    nDesired *= factor;
+  }
+  c->features_per_level[nl - 1] = std::max(nfeatures - sum, 0);
+  const int HP = 15;
+  int v, v0, vmax = cv_floor(HP * std::sqrt(2.f) / 2 + 1);
+  int vmin = cv_ceil(HP * std::sqrt(2.f) / 2);
+  const double hp2 = HP * HP;
+  for (v = 0; v <= vmax; ++v) c->umax[v] = cv_round(std::sqrt(hp2 - v * v));
+  for (v = HP, v0 = 0; v >= vmin; --v) {
+    while (c->umax[v0] == c->umax[v0 + 1]) ++v0;
+    c->umax[v] = v0;
+    ++v0;
+  }
+}
+}  // namespace
+
+void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out) {
+  float factor = (float)(1.0f / (double)scaleFactor);
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+  int sum = 0;
+  for (int level = 0; level < nl - 1; level++) {
+    out[level] = cv_round(nDesired);
+    sum += out[level];
+    nDesired *= factor;
+  }
+  out[nl - 1] = std::max(nfeatures - sum, 0);
+}
+
+extern "C" {
+
+const char* asd_version(void) { return "asdhip 0.1 (gfx950)"; }
+
+static thread_local std::string g_create_error;
+
+int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
+  if (!cfg || !out) return ASD_ERR_INVALID;
+  *out = nullptr;
+  if (cfg->n_levels < 1 || cfg->n_levels > ASD_MAX_LEVELS || cfg->n_features < 1 || cfg->scale_factor <= 1.0f ||
+      cfg->max_width < 64 || cfg->max_height < 64 || cfg->max_patches < cfg->n_features)
+    return ASD_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    fprintf(stderr, "libasdhip: no usable HIP device (count=%d, requested %d); there is no CPU fallback\n", ndev,
+            cfg->device);
+    return ASD_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(cfg->device) != hipSuccess) return ASD_ERR_NO_DEVICE;
+  asd_ctx* c = new (std::nothrow) asd_ctx();
+  if (!c) return ASD_ERR_INVALID;
+  c->cfg = *cfg;
+  build_tables(c);
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+      hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return ASD_ERR_NO_DEVICE;
+  }
+  int rc = asdnet_alloc(c);
+  if (rc == ASD_OK) rc = frontend_alloc(c);
+  if (rc != ASD_OK) {
+    fprintf(stderr, "libasdhip: %s\n", c->err.c_str());
+    asd_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return ASD_OK;
+}
+
+int asd_ctx_destroy(asd_ctx* ctx) {
+  if (!ctx) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  asdnet_free(ctx);
+  frontend_free(ctx);
+  matcher_free(ctx);
+  ba_free(ctx);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return ASD_OK;
+}
+
+const char* asd_last_error(const asd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int asd_get_scale_tables(const asd_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                         int32_t* fpl) {
+  if (!ctx) return ASD_ERR_INVALID;
+  const int nl = ctx->cfg.n_levels;
+  for (int i = 0; i < nl; ++i) {
+    if (scale) scale[i] = ctx->scale[i];
+    if (inv_scale) inv_scale[i] = ctx->inv_scale[i];
+    if (sigma2) sigma2[i] = ctx->sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = ctx->inv_sigma2[i];
+    if (fpl) fpl[i] = ctx->features_per_level[i];
+  }
+  return ASD_OK;
+}
+
+int asd_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
+                     const float* const bn_var[7], float bn_eps) {
+  if (!ctx || !conv_w || !bn_mean || !bn_var) return ASD_ERR_INVALID;
+  for (int i = 0; i < 7; ++i)
+    if (!conv_w[i] || !bn_mean[i] || !bn_var[i]) { ctx->set_error("null weight tensor %d", i); return ASD_ERR_INVALID; }
+  (void)hipSetDevice(ctx->cfg.device);
+  return asdnet_load_weights(ctx, conv_w, bn_mean, bn_var, bn_eps);
+}
+
+int asd_describe_device(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc) {
+  if (!ctx || (n > 0 && (!d_patches || !d_desc))) return ASD_ERR_INVALID;
+  return asdnet_forward_device(ctx, d_patches, n, d_desc);
+}
+
+int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc) {
+  if (!ctx || n < 0 || (n > 0 && (!patches || !desc))) return ASD_ERR_INVALID;
+  if (n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
+  if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
+  if (n == 0) return ASD_OK;
+  (void)hipSetDevice(ctx->cfg.device);
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_patches, patches, (size_t)n * 1024, hipMemcpyHostToDevice, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc);
+  if (rc != ASD_OK) return rc;
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_asdnet, ctx->ev0, ctx->ev1));
+  return ASD_OK;
+}
+
+int asd_describe_timed(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc, int32_t reps, float* avg_ms) {
+  if (!ctx || !avg_ms || reps < 1 || n < 1) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r) {
+    int rc = asdnet_forward_device(ctx, d_patches, n, d_desc);
+    if (rc != ASD_OK) return rc;
+  }
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0;
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_ms = ms / reps;
+  ctx->ms_asdnet = *avg_ms;
+  return ASD_OK;
+}
+
+int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms) {
+  if (!ctx || !stage || !ms) return ASD_ERR_INVALID;
+  if (!strcmp(stage, "asdnet")) *ms = ctx->ms_asdnet;
+  else if (!strcmp(stage, "extract")) *ms = ctx->ms_extract;
+  else if (!strcmp(stage, "match")) *ms = ctx->ms_match;
+  else if (!strcmp(stage, "ba")) *ms = ctx->ms_ba;
+  else return ASD_ERR_INVALID;
+  return ASD_OK;
+}
+
+void* asd_ctx_stream(asd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int asd_device_alloc(asd_ctx* ctx, uint64_t bytes, void** dptr) {
+  if (!ctx || !dptr) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  ASD_HIP_CHECK(ctx, hipMalloc(dptr, bytes));
+  return ASD_OK;
+}
+int asd_device_free(asd_ctx* ctx, void* dptr) {
+  if (!ctx) return ASD_ERR_INVALID;
+  ASD_HIP_CHECK(ctx, hipFree(dptr));
+  return ASD_OK;
+}
+int asd_memcpy_h2d(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx) return ASD_ERR_INVALID;
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ASD_OK;
+}
+int asd_memcpy_d2h(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
+  if (!ctx) return ASD_ERR_INVALID;
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ASD_OK;
+}
+int asd_sync(asd_ctx* ctx) {
+  if (!ctx) return ASD_ERR_INVALID;
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ASD_OK;
+}
+
+// Converter::toSE3Quat (Converter.cc:37-47) + SE3Quat(R,t) ctor (se3quat.h:58-60): Eigen
+// Quaterniond(Matrix3d) then normalizeRotation (w >= 0, unit norm).
+int asd_tcw_to_pose7(const float* T, double* p) {
+  if (!T || !p) return ASD_ERR_INVALID;
+  double R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[i][j] = (double)T[i * 4 + j];
+  double q[4];  // x y z w
+  const double tr = R[0][0] + R[1][1] + R[2][2];
+  if (tr > 0) {  // Eigen quaternion_base_assign_impl<Other,3,3>
+    double t = std::sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[2][1] - R[1][2]) * t;
+    q[1] = (R[0][2] - R[2][0]) * t;
+    q[2] = (R[1][0] - R[0][1]) * t;
+  } else {
+    int i = 0;
+    if (R[1][1] > R[0][0]) i = 1;
+    if (R[2][2] > R[i][i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double t = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[k][j] - R[j][k]) * t;
+    q[j] = (R[j][i] + R[i][j]) * t;
+    q[k] = (R[k][i] + R[i][k]) * t;
+  }
+  if (q[3] < 0) for (int i = 0; i < 4; ++i) q[i] = -q[i];
+  const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int i = 0; i < 4; ++i) p[i] = q[i] / nrm;
+  p[4] = T[3];
+  p[5] = T[7];
+  p[6] = T[11];
+  return ASD_OK;
+}
+
+// Converter::toCvMat(SE3Quat) (Converter.cc:57-71): to_homogeneous_matrix, cast to float.
+int asd_pose7_to_tcw(const double* p, float* T) {
+  if (!T || !p) return ASD_ERR_INVALID;
+  const double x = p[0], y = p[1], z = p[2], w = p[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx,
+                       txz - twy,       tyz + twx, 1 - (txx + tyy)};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j];
+    T[i * 4 + 3] = (float)p[4 + i];
+  }
+  T[12] = T[13] = T[14] = 0.f;
+  T[15] = 1.f;
+  return ASD_OK;
+}
+
+}  // extern "C"

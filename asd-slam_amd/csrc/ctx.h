@@ -1,0 +1,112 @@
+// ctx.h -- internal context of libasdhip (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/asd_slam.h"
+
+#define ASD_HIP_CHECK(ctx, expr)                                                          \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      (ctx)->set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return ASD_ERR_HIP;                                                                 \
+    }                                                                                     \
+  } while (0)
+
+struct AsdFrameSlot {
+  int n = 0;
+  float min_x = 0, max_x = 0, min_y = 0, max_y = 0;
+  float inv_w = 0, inv_h = 0;
+  // host mirrors (the order-dependent parts of the matchers run on the host)
+  std::vector<asd_keypoint> kps;
+  std::vector<int32_t> cell_start;  // [64*48+1] CSR, cell index = ix*48+iy (reference loop order)
+  std::vector<int32_t> cell_items;
+  // device
+  float* d_desc = nullptr;      // [cap][128]
+  float* d_kp_xy = nullptr;     // [cap][2]
+  int32_t* d_kp_oct = nullptr;  // [cap]
+  int32_t* d_cell_start = nullptr;
+  int32_t* d_cell_items = nullptr;
+};
+
+struct asd_ctx {
+  asd_config cfg{};
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // ---- extractor tables (ORBextractor.cc:459-512)
+  float scale[ASD_MAX_LEVELS], inv_scale[ASD_MAX_LEVELS], sigma2[ASD_MAX_LEVELS], inv_sigma2[ASD_MAX_LEVELS];
+  int features_per_level[ASD_MAX_LEVELS];
+  int umax[16];
+
+  // ---- ASDNet
+  bool weights_loaded = false;
+  float* d_w1 = nullptr;        // [32][9] folded
+  float* d_bias[7] = {};        // folded BN bias per layer
+  float* d_wimg[7] = {};        // MFMA B-operand images, layers 2..7 (index 1..6)
+  float* d_act[2] = {};         // ping-pong NHWC activations
+  float* d_part = nullptr;      // split-K partials of the last layer
+  uint8_t* d_patches = nullptr; // [max_patches][1024]
+  float* d_desc = nullptr;      // [max_patches][128] descriptors of the last extract / describe
+
+  // ---- front-end
+  int lvl_w[ASD_MAX_LEVELS] = {}, lvl_h[ASD_MAX_LEVELS] = {};
+  size_t lvl_off[ASD_MAX_LEVELS] = {};
+  size_t pyr_bytes = 0;
+  uint8_t* d_pyr = nullptr;     // all levels, tightly packed, no border
+  uint8_t* d_blur = nullptr;    // blurred copies
+  uint8_t* d_image_in = nullptr;
+  int16_t* d_score = nullptr;   // FAST score map (0 = not a corner at min threshold)
+  int* d_corner_count = nullptr;  // [levels]
+  int4* d_corners = nullptr;      // compacted NMS corners (x, y, score, cell)
+  int corners_cap = 0;
+  int4* h_corners = nullptr;      // pinned
+  int* h_corner_count = nullptr;  // pinned
+  float4* d_kp_sel = nullptr;     // selected keypoints per frame (level-local x,y, level, -)
+  float* d_angles = nullptr;
+  float4* h_kp_sel = nullptr;     // pinned
+  float* h_angles = nullptr;      // pinned
+  float* h_desc = nullptr;        // pinned
+  int last_w = 0, last_h = 0, last_n = 0;
+  std::vector<std::vector<float>> raw_x, raw_y, raw_r;  // last raw corners per level (reference order)
+
+  // ---- frames
+  AsdFrameSlot frames[ASD_MAX_FRAMES];
+
+  // ---- matcher scratch
+  int pairs_cap = 0;
+  int2* d_pairs = nullptr;   // (query, candidate)
+  float* d_pair_dist = nullptr;
+  int2* h_pairs = nullptr;   // pinned
+  float* h_pair_dist = nullptr;
+  float* d_qdesc = nullptr;  // query descriptors [cap][128]
+  int qdesc_cap = 0;
+
+  // ---- BA scratch (lazily grown)
+  void* ba = nullptr;
+
+  // ---- timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float ms_asdnet = 0, ms_extract = 0, ms_match = 0, ms_ba = 0;
+
+  void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+  }
+};
+
+// asdnet.hip
+int asdnet_alloc(asd_ctx* ctx);
+void asdnet_free(asd_ctx* ctx);
+int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
+                        const float* const bn_var[7], float eps);
+int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc);

@@ -1,0 +1,256 @@
+/*
+ * asd_slam.h -- C ABI of libasdhip: the MI355X (gfx950) implementation of ASD-SLAM's
+ * per-frame front-end and local-BA hot path.
+ *
+ * The reference has no plugin / FFI layer: the hot path is reached through C++ methods
+ * of libvslam with OpenCV types in every signature.  This header is the
+ * flat-array boundary drawn INSIDE those methods; each entry point cites the reference
+ * code it replaces (paths relative to the reference root, src/vslam/...).
+ * INTEGRATION.md shows the adapter a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C types, caller-owned buffers, row-major, no torch / OpenCV types;
+ *   - every call returns ASD_OK (0) or a negative asd_status; asd_last_error(ctx)
+ *     returns a human readable message for the last failure on that context;
+ *   - one asd_ctx = one HIP device + one HIP stream; a ctx is not thread-safe,
+ *     different ctxs may be used from different threads / processes;
+ *   - "host" pointers are ordinary CPU memory.  Results that the next stage consumes
+ *     (pyramid, descriptors, grid) also stay resident in HBM inside the ctx;
+ *   - there is NO CPU fallback: without a usable HIP device asd_ctx_create fails with
+ *     ASD_ERR_NO_DEVICE.
+ */
+#ifndef ASD_SLAM_H
+#define ASD_SLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASD_DESC_DIM 128      /* ORBmatcher.cc:1638 assumes exactly 128 columns          */
+#define ASD_PATCH 32          /* ORBextractor.cc:1115 Rect(x-16,y-16,32,32)               */
+#define ASD_MAX_LEVELS 16
+#define ASD_GRID_COLS 64      /* Frame.h:37  FRAME_GRID_COLS                              */
+#define ASD_GRID_ROWS 48      /* Frame.h:38  FRAME_GRID_ROWS                              */
+#define ASD_HISTO_LENGTH 30   /* ORBmatcher.cc:39                                         */
+
+typedef enum asd_status {
+  ASD_OK = 0,
+  ASD_ERR_INVALID = -1,     /* bad argument (null pointer, size out of range)             */
+  ASD_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure at create              */
+  ASD_ERR_HIP = -3,         /* a HIP call or kernel failed                                */
+  ASD_ERR_NO_WEIGHTS = -4,  /* asd_load_weights was not called                            */
+  ASD_ERR_CAPACITY = -5,    /* input exceeds the capacity given at asd_ctx_create         */
+  ASD_ERR_NUMERIC = -6      /* solver breakdown (non positive definite system)            */
+} asd_status;
+
+typedef struct asd_ctx asd_ctx;
+
+/* Replaces the ORBextractor constructor arguments (ORBextractor.cc:452-456; values given
+ * in Tracking.cc:77-85) plus device selection. */
+typedef struct asd_config {
+  int32_t n_features;     /* --feature_count, 2000                                        */
+  float   scale_factor;   /* --feature_scale_factor, 1.2                                  */
+  int32_t n_levels;       /* --feature_level, 8                                           */
+  int32_t ini_th_fast;    /* 20 (Tracking.cc:80)                                          */
+  int32_t min_th_fast;    /* 7  (Tracking.cc:81)                                          */
+  int32_t max_width;      /* largest image the ctx will see                               */
+  int32_t max_height;
+  int32_t max_patches;    /* capacity of asd_describe / extract (>= 2*n_features: init)   */
+  int32_t device;         /* HIP device ordinal                                           */
+} asd_config;
+
+/* cv::KeyPoint as produced by ExtractDesc (ORBextractor.cc:887-898,1236-1242). */
+typedef struct asd_keypoint {
+  float   x, y;       /* level-0 pixel coordinates (pt * mvScaleFactor[octave])           */
+  float   size;       /* (int)(31 * scale[octave]) stored as float                        */
+  float   angle;      /* IC_Angle, degrees in [0,360)                                     */
+  float   response;   /* FAST score                                                       */
+  int32_t octave;
+} asd_keypoint;
+
+/* ---- context ------------------------------------------------------------------------ */
+int asd_ctx_create(const asd_config* cfg, asd_ctx** out);
+int asd_ctx_destroy(asd_ctx* ctx);
+const char* asd_last_error(const asd_ctx* ctx);
+const char* asd_version(void);
+
+/* Scale tables of the extractor: ORBextractor.cc:459-492 (mvScaleFactor, mvLevelSigma2,
+ * their inverses, mnFeaturesPerLevel).  Each output holds n_levels entries; any may be
+ * NULL. */
+int asd_get_scale_tables(const asd_ctx* ctx, float* scale, float* inv_scale, float* sigma2,
+                         float* inv_sigma2, int32_t* features_per_level);
+
+/* ---- ASDNet descriptor (E6) --------------------------------------------------------- */
+/* Replaces torch::jit::load of bestmodel_c.pt (ORBextractor.cc:457-458).  Takes the 7
+ * conv weights in torch layout [cout][cin][kh][kw] and the 7 BatchNorm running
+ * mean/var vectors (affine=False, eps as given) of ASDNet.py:334-356; BN is folded into
+ * the conv on upload. */
+int asd_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
+                     const float* const bn_var[7], float bn_eps);
+
+/* Replaces computeSIFTDescriptors' forward pass (ORBextractor.cc:1125-1132 ->
+ * ASDNet.forward, ASDNet.py:360-370): n u8 patches [n][32][32] -> n unit-norm
+ * descriptors [n][128] f32.  Both pointers are host memory. */
+int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc);
+
+/* Same, device resident: d_patches / d_desc are HIP device pointers; no copies and no
+ * synchronisation -- the work is enqueued on the ctx stream (used by bench + extract). */
+int asd_describe_device(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc);
+
+/* ---- extractor (E1-E7) -------------------------------------------------------------- */
+/* Replaces ORBextractor::ExtractDesc(image, mask, keypoints, descriptors, use_orb=false)
+ * (ORBextractor.cc:1137-1249): pyramid, FAST + quadtree, orientation, blur, patch gather,
+ * ASDNet.  kps / desc have room for max_patches entries; *n_out receives the count.
+ * n_features_override > 0 replaces cfg.n_features for this call (the reference keeps a
+ * second extractor with 2*nFeatures for initialisation, Tracking.cc:85). */
+int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out);
+
+/* Intermediate products of the last asd_extract, for tests and for callers that read
+ * ORBextractor::mvImagePyramid (ORBextractor.h:87).  Level images are returned WITHOUT
+ * the 19 px border.  blurred != 0 selects the GaussianBlur'ed copy
+ * (ORBextractor.cc:1226-1227). */
+int asd_get_level_size(const asd_ctx* ctx, int32_t level, int32_t* width, int32_t* height);
+int asd_get_level_image(asd_ctx* ctx, int32_t level, int32_t blurred, uint8_t* out);
+/* Raw FAST corners of a level before the quadtree (ORBextractor.cc:858-876), in the
+ * reference's vToDistributeKeys order; coordinates are relative to minBorder (16). */
+int asd_get_raw_corners(asd_ctx* ctx, int32_t level, int32_t capacity, float* x, float* y,
+                        float* response, int32_t* n_out);
+
+/* ---- frames, grid (G1) and matchers (M0-M2, M4 init, M5) ----------------------------- */
+/* A frame slot keeps what the reference keeps in Frame: undistorted keypoints
+ * (mvKeysUn), descriptors (mDescriptors) and the 64x48 grid (Frame.cc:123-138), all
+ * resident in HBM.  Slots are small integers in [0, ASD_MAX_FRAMES). */
+#define ASD_MAX_FRAMES 8
+/* Replaces Frame::Frame(...) bookkeeping after ExtractORB: UndistortKeyPoints is the
+ * identity for zero distortion (Frame.cc:298-304), image bounds (Frame.cc:351-357),
+ * AssignFeaturesToGrid (Frame.cc:123-138).  desc may be NULL to adopt the descriptors of
+ * the last asd_extract without a round trip. */
+int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const float* desc,
+                  int32_t n, float min_x, float max_x, float min_y, float max_y);
+
+/* Replaces Frame::GetFeaturesInArea (Frame.cc:219-274): indices in reference order. */
+int asd_frame_features_in_area(asd_ctx* ctx, int32_t slot, float x, float y, float r,
+                               int32_t min_level, int32_t max_level, int32_t capacity,
+                               int32_t* idx_out, int32_t* n_out);
+
+/* M0: ORBmatcher::DescriptorDistance (ORBmatcher.cc:1629-1650) for every pair, in the
+ * reference's summation order (sequential f32, no FMA): out[na][nb].  Also the kernel of
+ * MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:271-338). */
+int asd_dist_matrix(asd_ctx* ctx, const float* a, int32_t na, const float* b, int32_t nb, float* out);
+
+/* M5: MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:271-338) for one map point:
+ * n observations' descriptors [n][128] -> index of the descriptor with the least median
+ * distance to the others. */
+int asd_distinctive_descriptor(asd_ctx* ctx, const float* desc, int32_t n, int32_t* best_idx);
+
+/* M1: ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono=true)
+ * (ORBmatcher.cc:1318-1452).  Inputs mirror what the method reads:
+ *   last frame: slot_last (keypoint octave/angle), per keypoint i: has_mp[i] (mvpMapPoints[i]
+ *   != NULL && !mvbOutlier[i]), world position Xw[i][3] (f32, MapPoint::GetWorldPos) and
+ *   the map point's descriptor mp_desc[i][128] (MapPoint::GetDescriptor);
+ *   cur frame: slot_cur, pose Tcw[16] f32 row-major 4x4, intrinsics K = fx,fy,cx,cy.
+ * Output: match_cur[n_cur] = index i of the last-frame keypoint whose map point was
+ * written into CurrentFrame.mvpMapPoints[j], or -1; *n_matches = the method's return
+ * value.  cur.mvpMapPoints is taken as all-NULL on entry (Tracking.cc:670).
+ * check_orientation mirrors mbCheckOrientation. */
+int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last,
+                            const uint8_t* has_mp, const float* Xw, const float* mp_desc,
+                            const float* Tcw, const float* K, float th, int32_t check_orientation,
+                            int32_t* match_cur, int32_t* n_matches);
+
+/* M2: ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th)
+ * (ORBmatcher.cc:44-122) after Frame::isInFrustum (Frame.cc:160-217) has filled the
+ * tracking fields.  Per map point m: in_view[m] (mbTrackInView && !isBad), proj[m] = (u,v),
+ * level[m] = mnTrackScaleLevel, view_cos[m], desc[m][128].  occupied[j] != 0 marks current
+ * keypoints that already hold a map point with Observations()>0 on entry.
+ * Output: match_cur[n_cur] = map point index m written to F.mvpMapPoints[j] or -1 (entries
+ * occupied on entry stay -1 unless overwritten); *n_matches = reference return value
+ * (counts each match twice, ORBmatcher.cc:116-117). */
+int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view,
+                             const float* proj, const int32_t* level, const float* view_cos,
+                             const float* desc, const uint8_t* occupied, float th, float nn_ratio,
+                             int32_t* match_cur, int32_t* n_matches);
+
+/* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
+ * n map points: Xw[n][3], normal[n][3], min_dist[n] / max_dist[n] (already scaled by
+ * 0.8 / 1.2 as GetMin/MaxDistanceInvariance return them).  Outputs as consumed by M2. */
+int asd_frustum(asd_ctx* ctx, int32_t slot_cur, int32_t n, const float* Xw, const float* normal,
+                const float* min_dist, const float* max_dist, const float* Tcw, const float* K,
+                float viewing_cos_limit, uint8_t* in_view, float* proj, int32_t* level, float* view_cos);
+
+/* M4 (bootstrap only): ORBmatcher::SearchForInitialization (ORBmatcher.cc:416-531).
+ * prev_matched[n1][2] in/out (vbPrevMatched), matches12[n1] out (index in frame 2 or -1). */
+int asd_match_init(asd_ctx* ctx, int32_t slot1, int32_t slot2, float* prev_matched, int32_t window,
+                   float nn_ratio, int32_t check_orientation, int32_t* matches12, int32_t* n_matches);
+
+/* ---- optimizer (P1, B1-B5, C1) ------------------------------------------------------- */
+/* Optimizer::PoseOptimization (Optimizer.cc:239-413) on g2o's EdgeSE3ProjectXYZOnlyPose
+ * (types_six_dof_expmap.h:194-222, .cpp:372-394) with Levenberg
+ * (optimization_algorithm_levenberg.cpp:61-189).
+ *   pose7: in/out (qx,qy,qz,qw,tx,ty,tz) f64, world->camera, as Converter::toSE3Quat
+ *   produces from the f32 Tcw (Converter.cc:37-47);
+ *   Xw[n][3], obs[n][2], inv_sigma2[n] as f64 (values are f32-representable);
+ *   outlier[n] out (mvbOutlier); *n_inliers = nInitialCorrespondences - nBad. */
+int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, const double* obs,
+                      const double* inv_sigma2, const double* K, uint8_t* outlier, int32_t* n_inliers);
+
+typedef struct asd_ba_problem {
+  int32_t n_poses;          /* local + fixed keyframes, ordered by ascending KF id        */
+  int32_t n_points;         /* local map points, ordered by ascending MP id               */
+  int32_t n_edges;          /* in the reference's insertion order (Optimizer.cc:534-593)  */
+  double*        poses;     /* [n_poses][7] in/out (qx,qy,qz,qw,tx,ty,tz)                 */
+  const uint8_t* fixed;     /* [n_poses] vSE3->setFixed (Optimizer.cc:490,505)            */
+  double*        points;    /* [n_points][3] in/out                                       */
+  const int32_t* e_point;   /* [n_edges] point index                                      */
+  const int32_t* e_pose;    /* [n_edges] pose index                                       */
+  const double*  e_obs;     /* [n_edges][2] kpUn.pt                                       */
+  const double*  e_info;    /* [n_edges] information scale (invSigma2, x10 global map)    */
+  double K[4];              /* fx, fy, cx, cy                                             */
+  int32_t its_first;        /* 5  (Optimizer.cc:602)                                      */
+  int32_t its_second;       /* 10 (Optimizer.cc:648)                                      */
+} asd_ba_problem;
+
+typedef struct asd_ba_result {
+  double*  edge_chi2;        /* [n_edges] final e->chi2()                                 */
+  uint8_t* edge_depth_pos;   /* [n_edges] final e->isDepthPositive()                      */
+  uint8_t* edge_outlier1;    /* [n_edges] moved to level 1 after the first round          */
+  double   chi2_first;       /* active robust chi2 after optimize(its_first)              */
+  double   chi2_second;      /* active chi2 after optimize(its_second)                    */
+  int32_t  iters_first;      /* LM iterations actually run                                */
+  int32_t  iters_second;
+} asd_ba_result;
+
+/* Numeric core of Optimizer::LocalBundleAdjustment (Optimizer.cc:484-650): BlockSolver_6_3
+ * (block_solver.hpp:354-604) + LinearSolverDense + Levenberg + Huber(sqrt 5.991), two
+ * rounds with the chi2 > 5.991 || depth <= 0 gating in between.  The caller applies the
+ * erase policy (Optimizer.cc:652-700) from edge_chi2 / edge_depth_pos. */
+int asd_local_ba(asd_ctx* ctx, asd_ba_problem* problem, asd_ba_result* result);
+
+/* Converter::toSE3Quat / toCvMat (Converter.cc:37-71): f32 4x4 <-> f64 quaternion + t. */
+int asd_tcw_to_pose7(const float* Tcw16, double* pose7);
+int asd_pose7_to_tcw(const double* pose7, float* Tcw16);
+
+/* ---- instrumentation ----------------------------------------------------------------- */
+/* Device-side duration of the kernels enqueued by the most recent call of the named stage,
+ * measured with hipEvents on the ctx stream.  stage: "asdnet", "extract", "match", "ba". */
+int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms);
+/* Raw handles for harnesses that keep inputs resident (bench.py): the ctx stream
+ * (hipStream_t) and device scratch. */
+void* asd_ctx_stream(asd_ctx* ctx);
+int asd_device_alloc(asd_ctx* ctx, uint64_t bytes, void** dptr);
+int asd_device_free(asd_ctx* ctx, void* dptr);
+int asd_memcpy_h2d(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int asd_memcpy_d2h(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes);
+int asd_sync(asd_ctx* ctx);
+/* Runs `reps` back-to-back repetitions of the ASDNet forward on resident buffers and
+ * returns the average per-repetition device time (hipEvents on the ctx stream). */
+int asd_describe_timed(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc,
+                       int32_t reps, float* avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASD_SLAM_H */

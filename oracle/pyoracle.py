@@ -1,0 +1,246 @@
+"""ctypes loader for oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY (see oracle/oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32), ("angle", np.float32),
+                     ("response", np.float32), ("octave", np.int32)])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class orc_ba_out(C.Structure):
+    _fields_ = [("chi2_first", C.c_double), ("chi2_second", C.c_double), ("iters_first", C.c_int32),
+                ("iters_second", C.c_int32)]
+
+
+class Oracle:
+    def __init__(self):
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        self.lib = L = C.CDLL(path)
+        for name, rt in (("orc_extractor_create", C.c_void_p), ("orc_frame_create", C.c_void_p),
+                         ("orc_descriptor_distance", C.c_float), ("orc_fast_atan2", C.c_float),
+                         ("orc_ic_angle", C.c_float)):
+            if hasattr(L, name):
+                getattr(L, name).restype = rt
+
+    # ---- ASDNet
+    def asdnet_forward(self, layers, patches, eps=1e-5, want_l6=False):
+        ws = [_c(w, np.float32) for w, _, _ in layers]
+        ms = [_c(m, np.float32) for _, m, _ in layers]
+        vs = [_c(v, np.float32) for _, _, v in layers]
+        arr = lambda xs: (C.c_void_p * 7)(*[x.ctypes.data for x in xs])
+        patches = _c(patches, np.uint8).reshape(-1, 32, 32)
+        n = patches.shape[0]
+        out = np.empty((n, 128), np.float32)
+        l6 = np.empty((n, 128, 8, 8), np.float32) if want_l6 else None
+        self.lib.orc_asdnet_forward(arr(ws), arr(ms), arr(vs), C.c_float(eps), _p(patches), n, _p(out), _p(l6))
+        return (out, l6) if want_l6 else out
+
+    # ---- extractor
+    def extractor(self, nfeatures=2000, scale=1.2, nlevels=8, ini_th=20, min_th=7):
+        return OracleExtractor(self, nfeatures, scale, nlevels, ini_th, min_th)
+
+    def resize_linear(self, src, dw, dh):
+        src = _c(src, np.uint8)
+        dst = np.empty((dh, dw), np.uint8)
+        self.lib.orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+        return dst
+
+    def gaussian_blur7(self, src):
+        src = _c(src, np.uint8)
+        dst = np.empty_like(src)
+        self.lib.orc_gaussian_blur7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), src.shape[1])
+        return dst
+
+    def fast_score(self, img, x, y, th):
+        img = _c(img, np.uint8)
+        return self.lib.orc_fast_score(_p(img), img.strides[0], x, y, th)
+
+    def fast_detect(self, img, th, cap=100000):
+        img = _c(img, np.uint8)
+        xs, ys, sc = (np.empty(cap, np.int32) for _ in range(3))
+        n = self.lib.orc_fast_detect(_p(img), img.shape[1], img.shape[0], img.strides[0], th, cap, _p(xs), _p(ys),
+                                     _p(sc))
+        return xs[:n].copy(), ys[:n].copy(), sc[:n].copy()
+
+    def fast_atan2(self, y, x):
+        return self.lib.orc_fast_atan2(C.c_float(y), C.c_float(x))
+
+    # ---- frames / matchers
+    def frame(self, kps, desc, bounds, nlevels=8, scale=1.2):
+        return OracleFrame(self, kps, desc, bounds, nlevels, scale)
+
+    def descriptor_distance(self, a, b):
+        a, b = _c(a, np.float32), _c(b, np.float32)
+        return self.lib.orc_descriptor_distance(_p(a), _p(b))
+
+    def dist_matrix(self, a, b):
+        a, b = _c(a, np.float32), _c(b, np.float32)
+        out = np.empty((a.shape[0], b.shape[0]), np.float32)
+        self.lib.orc_dist_matrix(_p(a), a.shape[0], _p(b), b.shape[0], _p(out))
+        return out
+
+    def distinctive_descriptor(self, desc):
+        desc = _c(desc, np.float32)
+        return self.lib.orc_distinctive_descriptor(_p(desc), desc.shape[0])
+
+    def match_project_frame(self, cur, last, has_mp, Xw, mp_desc, Tcw, K, th, check_ori=True):
+        has_mp, Xw, mp_desc = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(mp_desc, np.float32)
+        Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
+        out = np.empty(cur.n, np.int32)
+        n = self.lib.orc_match_project_frame(cur.h, last.h, _p(has_mp), _p(Xw), _p(mp_desc), _p(Tcw), _p(K),
+                                             C.c_float(th), int(check_ori), _p(out))
+        return out, n
+
+    def match_project_points(self, cur, in_view, proj, level, view_cos, desc, occupied, th, nn_ratio):
+        in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
+        view_cos, desc, occupied = _c(view_cos, np.float32), _c(desc, np.float32), _c(occupied, np.uint8)
+        out = np.empty(cur.n, np.int32)
+        n = self.lib.orc_match_project_points(cur.h, len(in_view), _p(in_view), _p(proj), _p(level), _p(view_cos),
+                                              _p(desc), _p(occupied), C.c_float(th), C.c_float(nn_ratio), _p(out))
+        return out, n
+
+    def frustum(self, cur, Xw, normal, min_dist, max_dist, Tcw, K, cos_limit=0.5):
+        Xw, normal = _c(Xw, np.float32), _c(normal, np.float32)
+        min_dist, max_dist = _c(min_dist, np.float32), _c(max_dist, np.float32)
+        Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
+        n = Xw.shape[0]
+        in_view = np.zeros(n, np.uint8)
+        proj = np.zeros((n, 2), np.float32)
+        level = np.zeros(n, np.int32)
+        vc = np.zeros(n, np.float32)
+        self.lib.orc_frustum(cur.h, n, _p(Xw), _p(normal), _p(min_dist), _p(max_dist), _p(Tcw), _p(K),
+                             C.c_float(cos_limit), _p(in_view), _p(proj), _p(level), _p(vc))
+        return in_view, proj, level, vc
+
+    def match_init(self, f1, f2, prev_matched, window=100, nn_ratio=0.9, check_ori=True):
+        pm = _c(prev_matched, np.float32).copy()
+        out = np.empty(f1.n, np.int32)
+        n = self.lib.orc_match_init(f1.h, f2.h, _p(pm), window, C.c_float(nn_ratio), int(check_ori), _p(out))
+        return out, n, pm
+
+    # ---- optimizer
+    def pose_optimize(self, pose7, Xw, obs, inv_sigma2, K):
+        pose = _c(pose7, np.float64).copy()
+        Xw, obs, inv_sigma2, K = (_c(a, np.float64) for a in (Xw, obs, inv_sigma2, K))
+        outlier = np.zeros(Xw.shape[0], np.uint8)
+        ninl = self.lib.orc_pose_optimize(_p(pose), Xw.shape[0], _p(Xw), _p(obs), _p(inv_sigma2), _p(K), _p(outlier))
+        return pose, outlier, ninl
+
+    def local_ba(self, prob, its_first=5, its_second=10):
+        poses = _c(prob["poses"], np.float64).copy()
+        points = _c(prob["points"], np.float64).copy()
+        fixed = _c(prob["fixed"], np.uint8)
+        e_point, e_pose = _c(prob["e_point"], np.int32), _c(prob["e_pose"], np.int32)
+        e_obs, e_info, K = _c(prob["e_obs"], np.float64), _c(prob["e_info"], np.float64), _c(prob["K"], np.float64)
+        E = len(e_point)
+        chi2 = np.zeros(E, np.float64)
+        dpos = np.zeros(E, np.uint8)
+        out1 = np.zeros(E, np.uint8)
+        o = orc_ba_out()
+        rc = self.lib.orc_local_ba(len(poses), len(points), E, _p(poses), _p(fixed), _p(points), _p(e_point),
+                                   _p(e_pose), _p(e_obs), _p(e_info), _p(K), its_first, its_second, _p(chi2),
+                                   _p(dpos), _p(out1), C.byref(o))
+        assert rc == 0
+        return dict(poses=poses, points=points, edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier1=out1,
+                    chi2_first=o.chi2_first, chi2_second=o.chi2_second, iters_first=o.iters_first,
+                    iters_second=o.iters_second)
+
+    def tcw_to_pose7(self, T):
+        T = _c(T, np.float32)
+        p = np.zeros(7, np.float64)
+        self.lib.orc_tcw_to_pose7(_p(T), _p(p))
+        return p
+
+    def pose7_to_tcw(self, p):
+        p = _c(p, np.float64)
+        T = np.zeros((4, 4), np.float32)
+        self.lib.orc_pose7_to_tcw(_p(p), _p(T))
+        return T
+
+
+class OracleExtractor:
+    def __init__(self, orc, nfeatures, scale, nlevels, ini_th, min_th):
+        self.orc, self.lib = orc, orc.lib
+        self.nlevels = nlevels
+        self.h = C.c_void_p(self.lib.orc_extractor_create(nfeatures, C.c_float(scale), nlevels, ini_th, min_th))
+
+    def __del__(self):
+        try:
+            self.lib.orc_extractor_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        s, i, g, ig = (np.zeros(n, np.float32) for _ in range(4))
+        f = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.lib.orc_extractor_tables(self.h, _p(s), _p(i), _p(g), _p(ig), _p(f), _p(um))
+        return dict(scale=s, inv_scale=i, sigma2=g, inv_sigma2=ig, features_per_level=f, umax=um)
+
+    def extract(self, image, cap=20000, want_patches=True):
+        image = _c(image, np.uint8)
+        kps = np.zeros(cap, KP_DTYPE)
+        patches = np.empty((cap, 32, 32), np.uint8) if want_patches else None
+        n = self.lib.orc_extract_keypoints(self.h, _p(image), image.shape[1], image.shape[0], image.strides[0],
+                                           _p(kps), _p(patches), cap)
+        return kps[:n].copy(), (patches[:n].copy() if want_patches else None)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        self.lib.orc_level_size(self.h, level, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def level_image(self, level, blurred=False):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        self.lib.orc_level_image(self.h, level, int(blurred), _p(out))
+        return out
+
+    def raw_corners(self, level, cap=200000):
+        x, y, r = (np.empty(cap, np.float32) for _ in range(3))
+        n = self.lib.orc_raw_corners(self.h, level, cap, _p(x), _p(y), _p(r))
+        return x[:n].copy(), y[:n].copy(), r[:n].copy()
+
+
+class OracleFrame:
+    def __init__(self, orc, kps, desc, bounds, nlevels, scale):
+        self.lib = orc.lib
+        kps = _c(kps, KP_DTYPE)
+        desc = _c(desc, np.float32)
+        self.n = len(kps)
+        self.h = C.c_void_p(self.lib.orc_frame_create(_p(kps), _p(desc), self.n, C.c_float(bounds[0]),
+                                                      C.c_float(bounds[1]), C.c_float(bounds[2]),
+                                                      C.c_float(bounds[3]), nlevels, C.c_float(scale)))
+
+    def __del__(self):
+        try:
+            self.lib.orc_frame_destroy(self.h)
+        except Exception:
+            pass
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1, cap=8192):
+        out = np.empty(cap, np.int32)
+        n = self.lib.orc_features_in_area(self.h, C.c_float(x), C.c_float(y), C.c_float(r), min_level, max_level,
+                                          cap, _p(out))
+        return out[:n].copy()
