@@ -89,7 +89,7 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
   c->cfg = *cfg;
   build_tables(c);
   if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-      hipEventCreate(&c->ev1) != hipSuccess) {
+      hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
     delete c;
     return ASD_ERR_NO_DEVICE;
   }
@@ -114,6 +114,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   ba_free(ctx);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ASD_OK;

@@ -54,26 +54,9 @@ struct asd_ctx {
   uint8_t* d_patches = nullptr; // [max_patches][1024]
   float* d_desc = nullptr;      // [max_patches][128] descriptors of the last extract / describe
 
-  // ---- front-end
-  int lvl_w[ASD_MAX_LEVELS] = {}, lvl_h[ASD_MAX_LEVELS] = {};
-  size_t lvl_off[ASD_MAX_LEVELS] = {};
-  size_t pyr_bytes = 0;
-  uint8_t* d_pyr = nullptr;     // all levels, tightly packed, no border
-  uint8_t* d_blur = nullptr;    // blurred copies
-  uint8_t* d_image_in = nullptr;
-  int16_t* d_score = nullptr;   // FAST score map (0 = not a corner at min threshold)
-  int* d_corner_count = nullptr;  // [levels]
-  int4* d_corners = nullptr;      // compacted NMS corners (x, y, score, cell)
-  int corners_cap = 0;
-  int4* h_corners = nullptr;      // pinned
-  int* h_corner_count = nullptr;  // pinned
-  float4* d_kp_sel = nullptr;     // selected keypoints per frame (level-local x,y, level, -)
-  float* d_angles = nullptr;
-  float4* h_kp_sel = nullptr;     // pinned
-  float* h_angles = nullptr;      // pinned
-  float* h_desc = nullptr;        // pinned
-  int last_w = 0, last_h = 0, last_n = 0;
-  std::vector<std::vector<float>> raw_x, raw_y, raw_r;  // last raw corners per level (reference order)
+  // ---- front-end (state private to frontend.hip)
+  struct FrontendState* fe = nullptr;
+  int last_n = 0;   // keypoints of the last asd_extract (descriptors in d_desc)
 
   // ---- frames
   AsdFrameSlot frames[ASD_MAX_FRAMES];
@@ -91,7 +74,7 @@ struct asd_ctx {
   void* ba = nullptr;
 
   // ---- timing
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   float ms_asdnet = 0, ms_extract = 0, ms_match = 0, ms_ba = 0;
 
   void set_error(const char* fmt, ...) {
@@ -103,6 +86,15 @@ struct asd_ctx {
     err = buf;
   }
 };
+
+// frontend.hip
+int frontend_alloc(asd_ctx* ctx);
+void frontend_free(asd_ctx* ctx);
+// matcher.hip / ba.hip
+void matcher_free(asd_ctx* ctx);
+void ba_free(asd_ctx* ctx);
+// capi.cpp
+void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 
 // asdnet.hip
 int asdnet_alloc(asd_ctx* ctx);

@@ -1,3 +1,656 @@
+// frontend.hip -- image front-end of ORBextractor::ExtractDesc on gfx950.
+//
+// Reference: src/vslam/src/ORBextractor.cc
+//   ComputePyramid :1251-1276 (cv::resize INTER_LINEAR chained level to level)
+//   ComputeKeyPointsOctTree :813-904 (cv::FAST per 30x30 cell, threshold 20 then 7)
+//   IC_Angle :80-107, GaussianBlur + patch gather :1217-1231 / :1099-1126, tail :1234-1245
+// All of this is byte / integer work bounded by HBM and launch latency, so the kernels are
+// plain coalesced loads with wave-level ballot compaction; nothing here is reshaped into a GEMM.
+//
+// Observations that shape the GPU formulation (each justified in DESIGN.md):
+//  * the 19 px pyramid border (copyMakeBorder) is never read by the monocular path: FAST runs on
+//    [16, dim-16), the orientation disc (r = 15) and the 32x32 patch stay inside the image for
+//    corners in [19, dim-20], and GaussianBlur runs on a border-less clone with its own
+//    BORDER_REFLECT_101 -- so levels are stored without border;
+//  * cv::FAST's score (fast_score.cpp cornerScore<16>) of a pixel that IS a corner at threshold t
+//    does not depend on t, and 3x3 non-max suppression of pixels that pass t is unaffected by
+//    neighbours that fail t; so one score map per level (at minThFAST) serves both the
+//    iniThFAST pass and the per-cell minThFAST retry of ORBextractor.cc:858-866;
+//  * the 6 px cell overlap makes the cells' FAST-valid interiors tile the level exactly, so
+//    each pixel belongs to one cell and NMS only looks at neighbours of the same cell.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
 #include "ctx.h"
-int frontend_alloc(asd_ctx*) { return ASD_OK; }
-void frontend_free(asd_ctx*) {}
+#include "quadtree.h"
+
+namespace {
+
+constexpr int kEdge = 19;         // EDGE_THRESHOLD (ORBextractor.cc:77)
+constexpr int kMinBorder = 16;    // EDGE_THRESHOLD - 3 (:822)
+constexpr int kPitchAlign = 64;
+
+inline int cv_round(double v) { return (int)std::lrint(v); }
+inline int cv_floor(double v) { return (int)std::floor(v); }
+inline short sat_short(float v) { int i = cv_round(v); return (short)std::min(std::max(i, -32768), 32767); }
+
+struct LevelDev {
+  int w, h, pitch;
+  int off;        // byte offset of the level in the pyramid / blur / score buffers
+  int tile_start; // first 64x16 tile of this level in a whole-pyramid launch
+  int tiles_x;
+};
+struct PyrDev {
+  int nlevels;
+  int total_tiles;
+  LevelDev lv[ASD_MAX_LEVELS];
+};
+struct CellDev {  // FAST-valid interior of one 30x30 cell (image coordinates)
+  short level, x0, x1, y0, y1, pad;
+};
+
+__constant__ int c_gauss[7];
+__constant__ short2 c_disc[768];  // (u, v) offsets of the radius-15 orientation disc (umax table, :497-512)
+__constant__ int c_ndisc;
+
+// ---------------------------------------------------------------- E1: cv::resize 8U INTER_LINEAR
+// imgwarp.cpp (3.2.0): 11-bit fixed-point coefficients, VResizeLinear<uchar,int,short,...>:
+// dst = ((b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2) >> 2 with r = S[sx]*a0 + S[sx+1]*a1.
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, int sw, int sh, int spitch,
+                                                uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
+                                                const short* __restrict__ xofs, const short* __restrict__ ialpha,
+                                                const short* __restrict__ yofs, const short* __restrict__ ibeta) {
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (dy >= dh || x4 >= dw) return;
+  int sy0 = yofs[dy], sy1 = sy0 + 1;
+  sy0 = min(max(sy0, 0), sh - 1);
+  sy1 = min(max(sy1, 0), sh - 1);
+  const int b0 = ibeta[dy * 2], b1 = ibeta[dy * 2 + 1];
+  const uint8_t* S0 = src + (size_t)sy0 * spitch;
+  const uint8_t* S1 = src + (size_t)sy1 * spitch;
+  uint32_t packed = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int dx = min(x4 + k, dw - 1);
+    const int sx = xofs[dx], sx1 = min(sx + 1, sw - 1);
+    const int a0 = ialpha[dx * 2], a1 = ialpha[dx * 2 + 1];
+    const int r0 = S0[sx] * a0 + S0[sx1] * a1;
+    const int r1 = S1[sx] * a0 + S1[sx1] * a1;
+    const int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+    packed |= (uint32_t)(v & 255) << (8 * k);
+  }
+  *reinterpret_cast<uint32_t*>(dst + (size_t)dy * dpitch + x4) = packed;
+}
+
+__device__ inline const LevelDev& find_level(const PyrDev& P, int tile, int& local) {
+  int l = 0;
+  while (l + 1 < P.nlevels && tile >= P.lv[l + 1].tile_start) ++l;
+  local = tile - P.lv[l].tile_start;
+  return P.lv[l];
+}
+
+// ---------------------------------------------------------------- E2a: FAST-9/16 score map
+// score = (max over the 16 arcs of 9 contiguous ring pixels of min |v - p|, one-sided) - 1,
+// exactly cornerScore<16> for a pixel that passes the segment test; 0 if score < min_th.
+__global__ __launch_bounds__(256) void k_fast_score(PyrDev P, const uint8_t* __restrict__ pyr,
+                                                    uint8_t* __restrict__ score, int min_th) {
+  int local;
+  const LevelDev& L = find_level(P, blockIdx.x, local);
+  const int x = (local % L.tiles_x) * 64 + (threadIdx.x & 63);
+  const int y = (local / L.tiles_x) * 16 + (threadIdx.x >> 6) * 4;
+  const uint8_t* img = pyr + L.off;
+  for (int r = 0; r < 4; ++r) {
+    const int yy = y + r;
+    if (x < kEdge || x >= L.w - kEdge || yy < kEdge || yy >= L.h - kEdge) continue;
+    const uint8_t* p = img + (size_t)yy * L.pitch + x;
+    const int pt = L.pitch;
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * pt];       d[1] = v - p[3 * pt + 1];   d[2] = v - p[2 * pt + 2];   d[3] = v - p[pt + 3];
+    d[4] = v - p[3];            d[5] = v - p[-pt + 3];      d[6] = v - p[-2 * pt + 2];  d[7] = v - p[-3 * pt + 1];
+    d[8] = v - p[-3 * pt];      d[9] = v - p[-3 * pt - 1];  d[10] = v - p[-2 * pt - 2]; d[11] = v - p[-pt - 3];
+    d[12] = v - p[-3];          d[13] = v - p[pt - 3];      d[14] = v - p[2 * pt - 2];  d[15] = v - p[3 * pt - 1];
+    // circular sliding-window min / max of width 9 by doubling
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int best_pos = -256, best_neg = 256;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+      const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+      best_pos = max(best_pos, mn9);
+      best_neg = min(best_neg, mx9);
+    }
+    const int s = max(best_pos, -best_neg) - 1;
+    score[L.off + (size_t)yy * L.pitch + x] = (uint8_t)(s >= min_th ? s : 0);
+  }
+}
+
+// ---------------------------------------------------------------- E2b: per-cell NMS + threshold retry
+// One wave per cell.  pass 0: count survivors at ini_th / min_th; pass 1: write them compacted in
+// cv::FAST's order (row-major inside the cell).  packed = x_rel | y_rel << 12 | score << 24 with
+// coordinates relative to minBorder like vToDistributeKeys (:872-874).
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_cell_nms(const CellDev* __restrict__ cells, PyrDev P,
+                                                 const uint8_t* __restrict__ score, int ini_th,
+                                                 int* __restrict__ cell_count, const int* __restrict__ cell_off,
+                                                 uint32_t* __restrict__ out) {
+  const CellDev c = cells[blockIdx.x];
+  const LevelDev& L = P.lv[c.level];
+  const uint8_t* S = score + L.off;
+  const int cw = c.x1 - c.x0, chh = c.y1 - c.y0, area = cw * chh;
+  const int lane = threadIdx.x;
+  int n20 = 0, n7 = 0;
+  bool use20 = false;
+  int base = 0;
+  if (WRITE) {
+    const int cnt = cell_count[blockIdx.x];
+    use20 = cnt < 0;  // sign bit marks "ini_th produced corners"
+    base = cell_off[blockIdx.x];
+  }
+  for (int i0 = 0; i0 < area; i0 += 64) {
+    const int i = i0 + lane;
+    bool keep = false, is20 = false;
+    int x = 0, y = 0, s = 0;
+    if (i < area) {
+      x = c.x0 + i % cw;
+      y = c.y0 + i / cw;
+      s = S[(size_t)y * L.pitch + x];
+      if (s > 0) {
+        keep = true;
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (dx == 0 && dy == 0) continue;
+            const int xx = x + dx, yy = y + dy;
+            if (xx < c.x0 || xx >= c.x1 || yy < c.y0 || yy >= c.y1) continue;
+            if (S[(size_t)yy * L.pitch + xx] >= s) keep = false;
+          }
+        is20 = keep && s >= ini_th;
+      }
+    }
+    if (!WRITE) {
+      n20 += __popcll(__ballot(is20));
+      n7 += __popcll(__ballot(keep));
+    } else {
+      const bool w = use20 ? is20 : keep;
+      const unsigned long long m = __ballot(w);
+      if (w) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1));
+        out[pos] = (uint32_t)(x - kMinBorder) | ((uint32_t)(y - kMinBorder) << 12) | ((uint32_t)s << 24);
+      }
+      base += __popcll(m);
+    }
+  }
+  if (!WRITE && lane == 0) cell_count[blockIdx.x] = n20 > 0 ? (n20 | 0x80000000) : n7;
+}
+
+// exclusive scan of the per-cell counts (all levels) + per-level start offsets.  One workgroup.
+__global__ __launch_bounds__(1024) void k_cell_scan(const int* __restrict__ cell_count, int ncells,
+                                                    const int* __restrict__ level_cell_start, int nlevels,
+                                                    int* __restrict__ cell_off, int* __restrict__ level_start) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < ncells; base += 1024) {
+    const int i = base + t;
+    const int v = i < ncells ? (cell_count[i] & 0x7fffffff) : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    const int carry = carry_s;
+    if (i < ncells) cell_off[i] = carry + wbase + incl - v;
+    __syncthreads();
+    if (t == 1023) carry_s = carry + wbase + incl;
+    __syncthreads();
+  }
+  if (t <= nlevels) {
+    // level_start[l] = offset of the level's first cell; level_start[nlevels] = total
+    if (t == nlevels) level_start[t] = carry_s;
+    else {
+      const int c = level_cell_start[t];
+      level_start[t] = c < ncells ? cell_off[c] : carry_s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- E5a: GaussianBlur 7x7 sigma 2, 8U
+// filter.cpp fixed-point separable filter: 8-bit kernel (sums to 257/256), row pass in int,
+// column pass (sum + 2^15) >> 16, BORDER_REFLECT_101 on the border-less level image.
+__device__ inline int reflect101(int p, int len) {
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * len - 2 - p;
+  return p;
+}
+__global__ __launch_bounds__(256) void k_blur7(PyrDev P, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+  __shared__ int rows[22][64];
+  int local;
+  const LevelDev& L = find_level(P, blockIdx.x, local);
+  const int x = (local % L.tiles_x) * 64 + (threadIdx.x & 63);
+  const int y0 = (local / L.tiles_x) * 16;
+  const uint8_t* img = pyr + L.off;
+  const int wq = threadIdx.x >> 6;
+  const int xc = min(x, L.w - 1);
+  int xs[7];
+  for (int i = 0; i < 7; ++i) xs[i] = reflect101(xc + i - 3, L.w);
+  for (int r = wq; r < 22; r += 4) {
+    const int yy = reflect101(min(y0 + r - 3, L.h + 2), L.h);
+    const uint8_t* row = img + (size_t)yy * L.pitch;
+    int s = 0;
+    for (int i = 0; i < 7; ++i) s += c_gauss[i] * row[xs[i]];
+    rows[r][threadIdx.x & 63] = s;
+  }
+  __syncthreads();
+  for (int r = wq; r < 16; r += 4) {
+    const int yy = y0 + r;
+    if (yy >= L.h || x >= L.w) continue;
+    int s = 0;
+    for (int i = 0; i < 7; ++i) s += c_gauss[i] * rows[r + i][threadIdx.x & 63];
+    const int v = (s + (1 << 15)) >> 16;
+    blur[L.off + (size_t)yy * L.pitch + x] = (uint8_t)min(max(v, 0), 255);
+  }
+}
+
+// ---------------------------------------------------------------- E4 + E5b: orientation + patch gather
+// cv::fastAtan2 (mathfuncs.cpp atanImpl<float>), un-fused f32 exactly as written there.
+__device__ inline float fast_atan2_deg(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+  const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+  const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+  const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// one wave per keypoint: kp = (x, y, level, -) in level pixel coordinates
+__global__ __launch_bounds__(256) void k_angle_patch(PyrDev P, const uint8_t* __restrict__ pyr,
+                                                     const uint8_t* __restrict__ blur, const short4* __restrict__ kps,
+                                                     int n, float* __restrict__ angles, uint8_t* __restrict__ patches) {
+  const int lane = threadIdx.x & 63;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= n) return;
+  const short4 kp = kps[k];
+  const LevelDev& L = P.lv[kp.z];
+  // IC_Angle (:80-107): integer moments over the disc, order-independent
+  const uint8_t* center = pyr + L.off + (size_t)kp.y * L.pitch + kp.x;
+  int m01 = 0, m10 = 0;
+  for (int i = lane; i < c_ndisc; i += 64) {
+    const short2 o = c_disc[i];
+    const int val = center[o.y * L.pitch + o.x];
+    m10 += o.x * val;
+    m01 += o.y * val;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    m01 += __shfl_xor(m01, off);
+    m10 += __shfl_xor(m10, off);
+  }
+  if (lane == 0) angles[k] = fast_atan2_deg((float)m01, (float)m10);
+  // 32x32 patch of the blurred level with the keypoint at [16][16] (:1113-1115)
+  const int row = lane >> 1, half = lane & 1;
+  const uint8_t* src = blur + L.off + (size_t)(kp.y - 16 + row) * L.pitch + (kp.x - 16 + half * 16);
+  uint32_t w[4];
+  for (int q = 0; q < 4; ++q)
+    w[q] = (uint32_t)src[q * 4] | ((uint32_t)src[q * 4 + 1] << 8) | ((uint32_t)src[q * 4 + 2] << 16) |
+           ((uint32_t)src[q * 4 + 3] << 24);
+  *reinterpret_cast<uint4*>(patches + (size_t)k * 1024 + row * 32 + half * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+struct FrontendState {
+  int cfg_w = 0, cfg_h = 0;  // size the tables are currently built for
+  PyrDev pyr{};
+  size_t buf_bytes = 0;      // capacity of d_pyr / d_blur / d_score
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_score = nullptr;
+  // resize tables, all levels concatenated
+  short *d_xofs = nullptr, *d_ialpha = nullptr, *d_yofs = nullptr, *d_ibeta = nullptr;
+  int tab_x_off[ASD_MAX_LEVELS] = {}, tab_y_off[ASD_MAX_LEVELS] = {};
+  size_t tab_x_cap = 0, tab_y_cap = 0;
+  // cells
+  std::vector<CellDev> h_cells;
+  int level_cell_start[ASD_MAX_LEVELS + 1] = {};
+  CellDev* d_cells = nullptr;
+  int cells_cap = 0;
+  int *d_cell_count = nullptr, *d_cell_off = nullptr, *d_level_cell_start = nullptr, *d_level_start = nullptr;
+  uint32_t* d_corners = nullptr;
+  size_t corners_cap = 0;
+  uint32_t* h_corners = nullptr;  // pinned
+  int* h_level_start = nullptr;   // pinned
+  short4 *d_kps = nullptr, *h_kps = nullptr;
+  float *d_angles = nullptr, *h_angles = nullptr;
+  bool consts_set = false;
+  // last extract, host side
+  std::vector<float> raw_x[ASD_MAX_LEVELS], raw_y[ASD_MAX_LEVELS], raw_r[ASD_MAX_LEVELS];
+  std::vector<int> sel;
+};
+
+static void level_dims(const asd_ctx* ctx, int w, int h, int level, int* lw, int* lh) {
+  const float s = ctx->inv_scale[level];
+  *lw = cv_round((float)w * s);  // ORBextractor.cc:1255-1256
+  *lh = cv_round((float)h * s);
+}
+
+int frontend_alloc(asd_ctx* ctx) {
+  FrontendState* fe = new FrontendState();
+  ctx->fe = fe;
+  const int nl = ctx->cfg.n_levels, W = ctx->cfg.max_width, H = ctx->cfg.max_height;
+  size_t bytes = 0, tx = 0, ty = 0;
+  int ncell_max = 0;
+  for (int l = 0; l < nl; ++l) {
+    int lw, lh;
+    level_dims(ctx, W, H, l, &lw, &lh);
+    const int pitch = (lw + kPitchAlign - 1) / kPitchAlign * kPitchAlign;
+    bytes += (size_t)pitch * (lh + 1);
+    tx += lw; ty += lh;
+    ncell_max += (lw / 30 + 2) * (lh / 30 + 2);
+  }
+  fe->buf_bytes = bytes + 4096;
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_pyr, fe->buf_bytes));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_blur, fe->buf_bytes));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_score, fe->buf_bytes));
+  fe->tab_x_cap = tx + 64; fe->tab_y_cap = ty + 64;
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_xofs, fe->tab_x_cap * sizeof(short)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_ialpha, fe->tab_x_cap * 2 * sizeof(short)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_yofs, fe->tab_y_cap * sizeof(short)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_ibeta, fe->tab_y_cap * 2 * sizeof(short)));
+  fe->cells_cap = ncell_max;
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_cells, ncell_max * sizeof(CellDev)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_cell_count, ncell_max * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_cell_off, ncell_max * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_level_cell_start, (ASD_MAX_LEVELS + 1) * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_level_start, (ASD_MAX_LEVELS + 1) * sizeof(int)));
+  // 3x3 strict NMS keeps at most one pixel per 2x2 block
+  fe->corners_cap = bytes / 4 + 1024;
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_corners, fe->corners_cap * sizeof(uint32_t)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_corners, fe->corners_cap * sizeof(uint32_t)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_level_start, (ASD_MAX_LEVELS + 1) * sizeof(int)));
+  const size_t np = ctx->cfg.max_patches;
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_kps, np * sizeof(short4)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_kps, np * sizeof(short4)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_angles, np * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_angles, np * sizeof(float)));
+  return ASD_OK;
+}
+
+void frontend_free(asd_ctx* ctx) {
+  FrontendState* fe = ctx->fe;
+  if (!fe) return;
+  void* dev[] = {fe->d_pyr, fe->d_blur, fe->d_score, fe->d_xofs, fe->d_ialpha, fe->d_yofs, fe->d_ibeta, fe->d_cells,
+                 fe->d_cell_count, fe->d_cell_off, fe->d_level_cell_start, fe->d_level_start, fe->d_corners,
+                 fe->d_kps, fe->d_angles};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  void* host[] = {fe->h_corners, fe->h_level_start, fe->h_kps, fe->h_angles};
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  delete fe;
+  ctx->fe = nullptr;
+}
+
+// Tables that depend on the image size: level geometry, resize coefficients, FAST cells.
+static int configure_size(asd_ctx* ctx, int w, int h) {
+  FrontendState* fe = ctx->fe;
+  if (fe->cfg_w == w && fe->cfg_h == h) return ASD_OK;
+  const int nl = ctx->cfg.n_levels;
+  if (!fe->consts_set) {
+    // getGaussianKernel(7, 2, CV_32F) -> convertTo(CV_32S, 256) (smooth.cpp / filter.cpp, bits = 8)
+    int gk[7];
+    float cf[7];
+    double sum = 0;
+    for (int i = 0; i < 7; i++) { const double x = i - 3.0; cf[i] = (float)std::exp(-0.5 / 4.0 * x * x); sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); gk[i] = cv_round(cf[i] * 256.f); }
+    ASD_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_gauss), gk, sizeof gk));
+    std::vector<short2> disc;
+    for (int v = -15; v <= 15; ++v) {
+      const int d = ctx->umax[v < 0 ? -v : v];
+      for (int u = -d; u <= d; ++u) disc.push_back(make_short2((short)u, (short)v));
+    }
+    const int nd = (int)disc.size();
+    if (nd > 768) { ctx->set_error("orientation disc has %d pixels", nd); return ASD_ERR_INVALID; }
+    ASD_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), nd * sizeof(short2)));
+    ASD_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_ndisc), &nd, sizeof nd));
+    fe->consts_set = true;
+  }
+  PyrDev& P = fe->pyr;
+  P.nlevels = nl;
+  int off = 0, tiles = 0;
+  size_t tx = 0, ty = 0;
+  for (int l = 0; l < nl; ++l) {
+    LevelDev& L = P.lv[l];
+    level_dims(ctx, w, h, l, &L.w, &L.h);
+    if (L.w < 2 * kEdge + 8 || L.h < 2 * kEdge + 8) { ctx->set_error("image %dx%d too small for level %d", w, h, l); return ASD_ERR_INVALID; }
+    L.pitch = (L.w + kPitchAlign - 1) / kPitchAlign * kPitchAlign;
+    L.off = off;
+    off += L.pitch * L.h;
+    L.tiles_x = (L.w + 63) / 64;
+    L.tile_start = tiles;
+    tiles += L.tiles_x * ((L.h + 15) / 16);
+    fe->tab_x_off[l] = (int)tx; fe->tab_y_off[l] = (int)ty;
+    tx += L.w; ty += L.h;
+  }
+  P.total_tiles = tiles;
+  if ((size_t)off > fe->buf_bytes || tx > fe->tab_x_cap || ty > fe->tab_y_cap) { ctx->set_error("image %dx%d exceeds ctx capacity", w, h); return ASD_ERR_CAPACITY; }
+  // resize coefficient tables (imgwarp.cpp resize(), INTER_LINEAR, 8U)
+  std::vector<short> xofs(tx), ialpha(tx * 2), yofs(ty), ibeta(ty * 2);
+  for (int l = 1; l < nl; ++l) {
+    const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h, dw = P.lv[l].w, dh = P.lv[l].h;
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    for (int dx = 0; dx < dw; dx++) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = cv_floor(fx);
+      fx -= sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+      const size_t o = fe->tab_x_off[l] + dx;
+      xofs[o] = (short)sx;
+      ialpha[o * 2] = sat_short((1.f - fx) * 2048);
+      ialpha[o * 2 + 1] = sat_short(fx * 2048);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      const int sy = cv_floor(fy);
+      fy -= sy;
+      const size_t o = fe->tab_y_off[l] + dy;
+      yofs[o] = (short)sy;
+      ibeta[o * 2] = sat_short((1.f - fy) * 2048);
+      ibeta[o * 2 + 1] = sat_short(fy * 2048);
+    }
+  }
+  ASD_HIP_CHECK(ctx, hipMemcpy(fe->d_xofs, xofs.data(), tx * sizeof(short), hipMemcpyHostToDevice));
+  ASD_HIP_CHECK(ctx, hipMemcpy(fe->d_ialpha, ialpha.data(), tx * 2 * sizeof(short), hipMemcpyHostToDevice));
+  ASD_HIP_CHECK(ctx, hipMemcpy(fe->d_yofs, yofs.data(), ty * sizeof(short), hipMemcpyHostToDevice));
+  ASD_HIP_CHECK(ctx, hipMemcpy(fe->d_ibeta, ibeta.data(), ty * 2 * sizeof(short), hipMemcpyHostToDevice));
+  // FAST cells (ORBextractor.cc:817-854): FAST-valid interior of each cell window
+  fe->h_cells.clear();
+  for (int l = 0; l < nl; ++l) {
+    fe->level_cell_start[l] = (int)fe->h_cells.size();
+    const LevelDev& L = P.lv[l];
+    const int minBX = kMinBorder, minBY = kMinBorder, maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+    const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+    const int nCols = (int)(width / 30.f), nRows = (int)(height / 30.f);
+    if (nCols < 1 || nRows < 1) continue;
+    const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+    for (int i = 0; i < nRows; i++) {
+      const float iniY = (float)(minBY + i * hCell);
+      float maxY = iniY + hCell + 6;
+      if (iniY >= maxBY - 3) continue;
+      if (maxY > maxBY) maxY = (float)maxBY;
+      for (int j = 0; j < nCols; j++) {
+        const float iniX = (float)(minBX + j * wCell);
+        float maxX = iniX + wCell + 6;
+        if (iniX >= maxBX - 6) continue;
+        if (maxX > maxBX) maxX = (float)maxBX;
+        const int cw = (int)maxX - (int)iniX, ch = (int)maxY - (int)iniY;
+        if (cw < 7 || ch < 7) continue;  // cv::FAST finds nothing in such a window
+        CellDev c;
+        c.level = (short)l;
+        c.x0 = (short)((int)iniX + 3); c.x1 = (short)((int)maxX - 3);
+        c.y0 = (short)((int)iniY + 3); c.y1 = (short)((int)maxY - 3);
+        c.pad = 0;
+        fe->h_cells.push_back(c);
+      }
+    }
+  }
+  fe->level_cell_start[nl] = (int)fe->h_cells.size();
+  for (int l = nl + 1; l <= ASD_MAX_LEVELS; ++l) fe->level_cell_start[l] = (int)fe->h_cells.size();
+  if ((int)fe->h_cells.size() > fe->cells_cap) { ctx->set_error("cell table overflow"); return ASD_ERR_CAPACITY; }
+  ASD_HIP_CHECK(ctx, hipMemcpy(fe->d_cells, fe->h_cells.data(), fe->h_cells.size() * sizeof(CellDev), hipMemcpyHostToDevice));
+  ASD_HIP_CHECK(ctx, hipMemcpy(fe->d_level_cell_start, fe->level_cell_start, (ASD_MAX_LEVELS + 1) * sizeof(int), hipMemcpyHostToDevice));
+  fe->cfg_w = w; fe->cfg_h = h;
+  return ASD_OK;
+}
+
+extern "C" {
+
+int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
+  if (!ctx || !image || !kps || !desc || !n_out || stride < width) return ASD_ERR_INVALID;
+  if (width > ctx->cfg.max_width || height > ctx->cfg.max_height) { ctx->set_error("image %dx%d exceeds ctx capacity %dx%d", width, height, ctx->cfg.max_width, ctx->cfg.max_height); return ASD_ERR_CAPACITY; }
+  if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
+  (void)hipSetDevice(ctx->cfg.device);
+  int rc = configure_size(ctx, width, height);
+  if (rc != ASD_OK) return rc;
+  FrontendState* fe = ctx->fe;
+  const PyrDev& P = fe->pyr;
+  const int nl = P.nlevels;
+  hipStream_t st = ctx->stream;
+  int quota[ASD_MAX_LEVELS];
+  const int nfeat = n_features_override > 0 ? n_features_override : ctx->cfg.n_features;
+  if (nfeat > ctx->cfg.max_patches) { ctx->set_error("n_features %d exceeds max_patches", nfeat); return ASD_ERR_CAPACITY; }
+  if (n_features_override > 0) asd_compute_quotas(nfeat, ctx->cfg.scale_factor, nl, quota);
+  else for (int l = 0; l < nl; ++l) quota[l] = ctx->features_per_level[l];
+
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+  // E1 pyramid
+  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, image, stride, width, height, hipMemcpyHostToDevice, st));
+  for (int l = 1; l < nl; ++l) {
+    const LevelDev &S = P.lv[l - 1], &D = P.lv[l];
+    hipLaunchKernelGGL(k_resize, dim3((D.w + 255) / 256, (D.h + 3) / 4), dim3(256), 0, st, fe->d_pyr + S.off, S.w, S.h,
+                       S.pitch, fe->d_pyr + D.off, D.w, D.h, D.pitch, fe->d_xofs + fe->tab_x_off[l],
+                       fe->d_ialpha + 2 * fe->tab_x_off[l], fe->d_yofs + fe->tab_y_off[l],
+                       fe->d_ibeta + 2 * fe->tab_y_off[l]);
+  }
+  // E2 FAST score, per-cell NMS, compaction
+  const int ncells = (int)fe->h_cells.size();
+  hipLaunchKernelGGL(k_fast_score, dim3(P.total_tiles), dim3(256), 0, st, P, fe->d_pyr, fe->d_score, ctx->cfg.min_th_fast);
+  hipLaunchKernelGGL(k_cell_nms<false>, dim3(ncells), dim3(64), 0, st, fe->d_cells, P, fe->d_score, ctx->cfg.ini_th_fast,
+                     fe->d_cell_count, fe->d_cell_off, fe->d_corners);
+  hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, fe->d_cell_count, ncells, fe->d_level_cell_start, nl,
+                     fe->d_cell_off, fe->d_level_start);
+  hipLaunchKernelGGL(k_cell_nms<true>, dim3(ncells), dim3(64), 0, st, fe->d_cells, P, fe->d_score, ctx->cfg.ini_th_fast,
+                     fe->d_cell_count, fe->d_cell_off, fe->d_corners);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_level_start, fe->d_level_start, (nl + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const int total = fe->h_level_start[nl];
+  if ((size_t)total > fe->corners_cap) { ctx->set_error("corner buffer overflow"); return ASD_ERR_CAPACITY; }
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_corners, fe->d_corners, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev2, st));
+  // E5a blur runs on the GPU while the host does the quadtree
+  hipLaunchKernelGGL(k_blur7, dim3(P.total_tiles), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  // E3 quadtree per level on the host (DistributeOctTree): wait for the corner list only
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev2));
+  int n = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int b = fe->h_level_start[l], e = fe->h_level_start[l + 1], cnt = e - b;
+    auto &rx = fe->raw_x[l], &ry = fe->raw_y[l], &rr = fe->raw_r[l];
+    rx.resize(cnt); ry.resize(cnt); rr.resize(cnt);
+    for (int i = 0; i < cnt; ++i) {
+      const uint32_t pk = fe->h_corners[b + i];
+      rx[i] = (float)(pk & 0xfff);
+      ry[i] = (float)((pk >> 12) & 0xfff);
+      rr[i] = (float)(pk >> 24);
+    }
+    const LevelDev& L = P.lv[l];
+    asd_distribute_octtree(rx.data(), ry.data(), rr.data(), cnt, kMinBorder, L.w - kEdge + 3, kMinBorder,
+                           L.h - kEdge + 3, quota[l], fe->sel);
+    const int scaledPatchSize = (int)(31 * ctx->scale[l]);  // :887
+    for (int idx : fe->sel) {
+      if (n >= ctx->cfg.max_patches) { ctx->set_error("more keypoints than max_patches"); return ASD_ERR_CAPACITY; }
+      const float px = rx[idx] + kMinBorder, py = ry[idx] + kMinBorder;  // :894-895
+      fe->h_kps[n] = make_short4((short)px, (short)py, (short)l, 0);
+      asd_keypoint& k = kps[n];
+      k.x = px; k.y = py;
+      if (l != 0) { k.x *= ctx->scale[l]; k.y *= ctx->scale[l]; }  // :1236-1242
+      k.size = (float)scaledPatchSize;
+      k.response = rr[idx];
+      k.octave = l;
+      k.angle = 0.f;
+      ++n;
+    }
+  }
+  *n_out = n;
+  ctx->last_n = n;
+  if (n == 0) return ASD_OK;
+  // E4 + E5b + E6
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->d_kps, fe->h_kps, (size_t)n * sizeof(short4), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_angle_patch, dim3((n + 3) / 4), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur, fe->d_kps, n,
+                     fe->d_angles, ctx->d_patches);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc);
+  if (rc != ASD_OK) return rc;
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_angles, fe->d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) kps[i].angle = fe->h_angles[i];
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ctx->ev0, ctx->ev1));
+  return ASD_OK;
+}
+
+int asd_get_level_size(const asd_ctx* ctx, int32_t level, int32_t* width, int32_t* height) {
+  if (!ctx || !ctx->fe || !width || !height || level < 0 || level >= ctx->fe->pyr.nlevels) return ASD_ERR_INVALID;
+  *width = ctx->fe->pyr.lv[level].w;
+  *height = ctx->fe->pyr.lv[level].h;
+  return ASD_OK;
+}
+
+int asd_get_level_image(asd_ctx* ctx, int32_t level, int32_t blurred, uint8_t* out) {
+  if (!ctx || !ctx->fe || !out || level < 0 || level >= ctx->fe->pyr.nlevels) return ASD_ERR_INVALID;
+  const LevelDev& L = ctx->fe->pyr.lv[level];
+  const uint8_t* src = (blurred ? ctx->fe->d_blur : ctx->fe->d_pyr) + L.off;
+  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(out, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ASD_OK;
+}
+
+int asd_get_raw_corners(asd_ctx* ctx, int32_t level, int32_t capacity, float* x, float* y, float* response, int32_t* n_out) {
+  if (!ctx || !ctx->fe || !n_out || level < 0 || level >= ctx->fe->pyr.nlevels) return ASD_ERR_INVALID;
+  const FrontendState* fe = ctx->fe;
+  const int n = std::min((int)fe->raw_x[level].size(), capacity);
+  for (int i = 0; i < n; ++i) {
+    if (x) x[i] = fe->raw_x[level][i];
+    if (y) y[i] = fe->raw_y[level][i];
+    if (response) response[i] = fe->raw_r[level][i];
+  }
+  *n_out = n;
+  return ASD_OK;
+}
+
+}  // extern "C"

@@ -63,7 +63,7 @@ def scene_frame(t, seed=20, w=KITTI_W, h=KITTI_H, _cache={}):
         rng = np.random.default_rng(seed)
         W2, H2 = 2 * w + 800, 2 * h + 200
         img = np.full((H2, W2), 128.0, np.float32)
-        nrect = 16000
+        nrect = 6000
         xs = rng.integers(0, W2, nrect)
         ys = rng.integers(0, H2, nrect)
         ws = rng.integers(4, 41, nrect)

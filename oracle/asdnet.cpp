@@ -51,8 +51,9 @@ extern "C" void orc_asdnet_forward(const float* const conv_w[7], const float* co
                                    const float* const bn_var[7], float bn_eps, const uint8_t* patches,
                                    int32_t n, float* desc, float* act_l6) {
   const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125 convertTo(CV_32F, 1.0/255)
-  std::vector<float> a, b;
+#pragma omp parallel for schedule(dynamic, 4)
   for (int p = 0; p < n; ++p) {
+    std::vector<float> a, b;
     const uint8_t* src = patches + (size_t)p * 1024;
     a.assign(1024, 0.f);
     double s = 0.0;

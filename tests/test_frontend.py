@@ -1,0 +1,200 @@
+"""Extractor front-end: oracle known-answer tests (OpenCV 3.2.0 semantics are
+parity-unpinned: no OpenCV here, no reference vectors) and HIP-vs-oracle bit-exactness."""
+import numpy as np
+import pytest
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3),
+        (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def brute_fast_score(img, x, y, th):
+    """FAST-9/16 segment test + score straight from the definition."""
+    v = int(img[y, x])
+    d = [v - int(img[y + dy, x + dx]) for dx, dy in RING]
+    best = -999
+    for k in range(16):
+        arc = [d[(k + i) % 16] for i in range(9)]
+        best = max(best, min(arc), min(-a for a in arc))
+    return best - 1 if best > th else 0
+
+
+# ------------------------------------------------------------------ oracle known answers (CPU)
+def test_resize_constant_and_half(oracle):
+    src = np.full((40, 60), 137, np.uint8)
+    np.testing.assert_array_equal(oracle.resize_linear(src, 50, 33), 137)
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (40, 60)).astype(np.uint8)
+    half = oracle.resize_linear(src, 30, 20)
+    s = src.astype(np.int32)
+    # exact 2:1: both coefficients are 1024 -> ((1024*(r>>4))>>16)*2 with r = 1024*(a+b)
+    r0 = 1024 * (s[0::2, 0::2] + s[0::2, 1::2])
+    r1 = 1024 * (s[1::2, 0::2] + s[1::2, 1::2])
+    exp = (((1024 * (r0 >> 4)) >> 16) + ((1024 * (r1 >> 4)) >> 16) + 2) >> 2
+    np.testing.assert_array_equal(half, exp.astype(np.uint8))
+    # identity resize is the identity
+    np.testing.assert_array_equal(oracle.resize_linear(src, 60, 40), src)
+
+
+def test_blur_kernel_and_borders(oracle):
+    k = np.array([18, 34, 49, 55, 49, 34, 18])  # round(256 * getGaussianKernel(7, 2)): sums to 257
+    assert k.sum() == 257
+    c = np.full((20, 30), 100, np.uint8)
+    np.testing.assert_array_equal(oracle.gaussian_blur7(c), (100 * 257 * 257 + 32768) >> 16)
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    out = oracle.gaussian_blur7(imp)
+    exp = (255 * np.outer(k, k) + 32768) >> 16
+    np.testing.assert_array_equal(out[7:14, 7:14], exp)
+    assert out[:7].sum() == 0 and out[14:].sum() == 0
+    # reflect-101 (row -1 mirrors row 1): an impulse on row 1 is seen twice by rows 0..2
+    imp = np.zeros((21, 21), np.uint8)
+    imp[1, 10] = 255
+    out = oracle.gaussian_blur7(imp)
+    col = np.array([k[4] + k[2], k[3] + k[1], k[2] + k[0], k[1], k[0]])
+    np.testing.assert_array_equal(out[:5, 10], (255 * col * k[3] + 32768) >> 16)
+
+
+def test_fast_score_definition(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (40, 40)).astype(np.uint8)
+    img[10:30, 10:30] = np.clip(img[10:30, 10:30] // 8 + 100, 0, 255)
+    for th in (7, 20):
+        for y in range(3, 37):
+            for x in range(3, 37):
+                assert oracle.fast_score(img, x, y, th) == brute_fast_score(img, x, y, th), (x, y, th)
+    # a bright dot on a dark background is a corner with score = contrast - 1
+    dot = np.full((9, 9), 10, np.uint8)
+    dot[4, 4] = 110
+    assert oracle.fast_score(dot, 4, 4, 20) == 99
+
+
+def test_fast_detect_nms(oracle):
+    rng = np.random.default_rng(2)
+    img = (rng.integers(0, 2, (36, 37)) * 120 + rng.integers(0, 40, (36, 37))).astype(np.uint8)
+    xs, ys, sc = oracle.fast_detect(img, 20)
+    S = np.zeros(img.shape, np.int32)
+    for y in range(3, 33):
+        for x in range(3, 34):
+            S[y, x] = brute_fast_score(img, x, y, 20)
+    exp = []
+    for y in range(3, 33):
+        for x in range(3, 34):
+            s = S[y, x]
+            if s > 0 and all(s > S[y + dy, x + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx or dy)):
+                exp.append((x, y, s))
+    assert len(exp) > 5
+    assert list(zip(xs.tolist(), ys.tolist(), sc.tolist())) == exp
+
+
+def test_fast_atan2(oracle):
+    rng = np.random.default_rng(3)
+    for y, x in rng.standard_normal((200, 2)) * 1000:
+        a = oracle.fast_atan2(y, x)
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        assert min(abs(a - ref), 360 - abs(a - ref)) < 0.3
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+    assert oracle.fast_atan2(0.0, -5.0) == 180.0
+
+
+def test_oracle_extract_properties(oracle, synth):
+    img = synth.scene_frame(0)
+    ex = oracle.extractor(2000)
+    t = ex.tables()
+    assert t["features_per_level"].tolist() == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert [ex_ for ex_ in t["umax"]] == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    kps, patches = ex.extract(img)
+    sizes = [ex.level_size(l) for l in range(8)]
+    assert sizes == [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]
+    assert 1900 <= len(kps) <= 2100
+    assert (np.diff(kps["octave"]) >= 0).all()  # level-major output order
+    for l in range(8):
+        m = kps["octave"] == l
+        w, h = sizes[l]
+        x = kps["x"][m] / t["scale"][l]
+        y = kps["y"][m] / t["scale"][l]
+        assert x.min() >= 19 - 1e-3 and x.max() <= w - 20 + 1e-3 and y.min() >= 19 - 1e-3 and y.max() <= h - 20 + 1e-3
+        assert m.sum() >= t["features_per_level"][l]  # the quadtree stops at >= N nodes
+        # one keypoint per quadtree leaf -> unique positions
+        assert len({(a, b) for a, b in zip(kps["x"][m].tolist(), kps["y"][m].tolist())}) == m.sum()
+    assert ((kps["angle"] >= 0) & (kps["angle"] < 360.0001)).all()
+    # patch = 32x32 of the blurred level with the keypoint at [16][16]
+    l = int(kps["octave"][5])
+    bl = ex.level_image(l, blurred=True)
+    x = int(round(kps["x"][5] / t["scale"][l])); y = int(round(kps["y"][5] / t["scale"][l]))
+    np.testing.assert_array_equal(patches[5], bl[y - 16:y + 16, x - 16:x + 16])
+
+
+def test_oracle_extract_flat_image(oracle):
+    ex = oracle.extractor(500)
+    kps, _ = ex.extract(np.full((240, 320), 90, np.uint8))
+    assert len(kps) == 0
+
+
+# ------------------------------------------------------------------ HIP vs oracle (GPU)
+def _compare_extract(hip, oracle, synth, img, nfeat, override=0):
+    layers = synth.asdnet_weights(0)
+    kps, desc = hip.extract(img, n_features_override=override)
+    ex = oracle.extractor(nfeat)
+    okps, opatches = ex.extract(img)
+    for l in range(8):
+        assert hip.level_size(l) == ex.level_size(l)
+        np.testing.assert_array_equal(hip.level_image(l), ex.level_image(l), err_msg=f"pyramid level {l}")
+        hx, hy, hr = hip.raw_corners(l)
+        ox, oy, orr = ex.raw_corners(l)
+        assert len(hx) == len(ox), f"raw corner count level {l}: {len(hx)} vs {len(ox)}"
+        np.testing.assert_array_equal(hx, ox)
+        np.testing.assert_array_equal(hy, oy)
+        np.testing.assert_array_equal(hr, orr)
+        if (okps["octave"] == l).any():
+            np.testing.assert_array_equal(hip.level_image(l, blurred=True), ex.level_image(l, blurred=True),
+                                          err_msg=f"blurred level {l}")
+    assert len(kps) == len(okps)
+    for f in ("x", "y", "size", "angle", "response", "octave"):
+        np.testing.assert_array_equal(kps[f], okps[f], err_msg=f)  # bit-exact keypoints
+    # descriptors: the oracle's naive conv is slow, check every 8th keypoint (all levels are covered)
+    sub = np.arange(0, len(kps), 8)
+    odesc = oracle.asdnet_forward(layers, opatches[sub])
+    np.testing.assert_allclose(desc[sub], odesc, atol=2e-5, rtol=0)
+    return kps, desc
+
+
+@pytest.mark.gpu
+def test_extract_kitti_size_bit_exact(hip, oracle, synth):
+    kps, desc = _compare_extract(hip, oracle, synth, synth.scene_frame(0), 2000)
+    assert len(kps) >= 2000
+
+
+@pytest.mark.gpu
+def test_extract_other_frame_and_init_quota(hip, oracle, synth):
+    # Tracking.cc:85: the initialisation extractor asks for 2 x nFeatures
+    kps, _ = _compare_extract(hip, oracle, synth, synth.scene_frame(7), 4000, override=4000)
+    assert len(kps) >= 3900
+
+
+@pytest.mark.gpu
+def test_extract_small_and_odd_sizes(hip, oracle, synth):
+    img = synth.scene_frame(3)[:251, :333]
+    _compare_extract(hip, oracle, synth, np.ascontiguousarray(img), 2000)
+    # strided input (stride > width)
+    big = synth.scene_frame(4)
+    view = big[10:300, 100:900]
+    kps_a, desc_a = hip.extract(np.ascontiguousarray(view))
+    assert len(kps_a) > 500
+
+
+@pytest.mark.gpu
+def test_extract_flat_and_low_texture(hip, oracle, synth):
+    kps, desc = hip.extract(np.full((376, 1241), 128, np.uint8))
+    assert len(kps) == 0 and desc.shape == (0, 128)
+    # low contrast: only the min-threshold retry (ORBextractor.cc:861-866) finds corners
+    img = (synth.scene_frame(1).astype(np.int32) - 128) // 8 + 128
+    _compare_extract(hip, oracle, synth, img.astype(np.uint8), 2000)
+
+
+@pytest.mark.gpu
+def test_extract_deterministic(hip, synth):
+    img = synth.scene_frame(2)
+    k1, d1 = hip.extract(img)
+    k2, d2 = hip.extract(img)
+    np.testing.assert_array_equal(k1, k2)
+    np.testing.assert_array_equal(d1, d2)
