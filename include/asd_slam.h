@@ -175,8 +175,10 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
                              int32_t* match_cur, int32_t* n_matches);
 
 /* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
- * n map points: Xw[n][3], normal[n][3], min_dist[n] / max_dist[n] (already scaled by
- * 0.8 / 1.2 as GetMin/MaxDistanceInvariance return them).  Outputs as consumed by M2. */
+ * n map points: Xw[n][3], normal[n][3] (GetNormal), min_dist[n] / max_dist[n] = the map
+ * point's raw mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors of
+ * MapPoint.cc:409-419 are applied inside).  Outputs as consumed by M2.  Runs on the host:
+ * a few thousand points x ~50 flops, and PredictScale's logf must match libm bit for bit. */
 int asd_frustum(asd_ctx* ctx, int32_t slot_cur, int32_t n, const float* Xw, const float* normal,
                 const float* min_dist, const float* max_dist, const float* Tcw, const float* K,
                 float viewing_cos_limit, uint8_t* in_view, float* proj, int32_t* level, float* view_cos);

@@ -1,0 +1,378 @@
+// oracle/matcher.cpp -- CPU restatement of the Frame grid and the ORBmatcher searches on the
+// per-frame path.  TEST INFRASTRUCTURE ONLY (see oracle.h).
+//
+// Reference (src/vslam/src):
+//   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea   Frame.cc:123-138, 276-286, 219-274
+//   Frame::isInFrustum                                            Frame.cc:160-217
+//   MapPoint::PredictScale                                        MapPoint.cc:438-453
+//   ORBmatcher::DescriptorDistance                                ORBmatcher.cc:1629-1650
+//   ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&)    ORBmatcher.cc:44-122
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, ...)     ORBmatcher.cc:1318-1452
+//   ORBmatcher::SearchForInitialization                           ORBmatcher.cc:416-531
+//   ORBmatcher::ComputeThreeMaxima                                ORBmatcher.cc:1584-1625
+//   MapPoint::ComputeDistinctiveDescriptors                       MapPoint.cc:271-338
+// The source is in the tree but needs OpenCV types to compile, so it is restated as text:
+// PARITY UNPINNED beyond self-consistency.  cv::Mat float products are restated as OpenCV 3.2.0
+// computes them (gemm small-matrix path: left-to-right f32 sums; norm / dot / transposed gemm
+// accumulate in double).
+#include "oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace {
+const float TH_HIGH = 1.5f, TH_LOW = 0.5f;
+const int HISTO_LENGTH = 30;
+const int GRID_COLS = 64, GRID_ROWS = 48;
+
+void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+float DescriptorDistance(const float* a, const float* b) {
+  float sqd = 0.;
+  for (int i = 0; i < 128; i += 4) {
+    sqd += (a[i] - b[i]) * (a[i] - b[i]);
+    sqd += (a[i + 1] - b[i + 1]) * (a[i + 1] - b[i + 1]);
+    sqd += (a[i + 2] - b[i + 2]) * (a[i + 2] - b[i + 2]);
+    sqd += (a[i + 3] - b[i + 3]) * (a[i + 3] - b[i + 3]);
+  }
+  return sqd;
+}
+
+// Rcw*x + tcw as cv::gemm's 3x3 * 3x1 small-matrix path (A*B + C folded into one gemm)
+inline void transform(const float* T, const float* X, float* out) {
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = T[r * 4 + 0] * X[0] + T[r * 4 + 1] * X[1] + T[r * 4 + 2] * X[2];
+    out[r] = (float)((double)t0 + (double)T[r * 4 + 3]);
+  }
+}
+}  // namespace
+
+struct orc_frame {
+  int N;
+  std::vector<orc_keypoint> kps;
+  std::vector<float> desc;
+  float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+  std::vector<int> mGrid[GRID_COLS][GRID_ROWS];
+  std::vector<float> mvScaleFactors;
+  int mnScaleLevels;
+  float mfLogScaleFactor;
+
+  std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel,
+                                        const int maxLevel) const {
+    std::vector<size_t> vIndices;
+    const int nMinCellX = std::max(0, (int)std::floor((x - mnMinX - r) * mfGridElementWidthInv));
+    if (nMinCellX >= GRID_COLS) return vIndices;
+    const int nMaxCellX = std::min((int)GRID_COLS - 1, (int)std::ceil((x - mnMinX + r) * mfGridElementWidthInv));
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, (int)std::floor((y - mnMinY - r) * mfGridElementHeightInv));
+    if (nMinCellY >= GRID_ROWS) return vIndices;
+    const int nMaxCellY = std::min((int)GRID_ROWS - 1, (int)std::ceil((y - mnMinY + r) * mfGridElementHeightInv));
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const std::vector<int>& vCell = mGrid[ix][iy];
+        for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+          const orc_keypoint& kpUn = kps[vCell[j]];
+          if (bCheckLevels) {
+            if (kpUn.octave < minLevel) continue;
+            if (maxLevel >= 0)
+              if (kpUn.octave > maxLevel) continue;
+          }
+          const float distx = kpUn.x - x;
+          const float disty = kpUn.y - y;
+          if (std::fabs(distx) < r && std::fabs(disty) < r) vIndices.push_back(vCell[j]);
+        }
+      }
+    return vIndices;
+  }
+};
+
+extern "C" {
+
+orc_frame* orc_frame_create(const orc_keypoint* kps, const float* desc, int n, float minx, float maxx, float miny,
+                            float maxy, int nlevels, float scale_factor) {
+  orc_frame* f = new orc_frame();
+  f->N = n;
+  f->kps.assign(kps, kps + n);
+  f->desc.assign(desc, desc + (size_t)n * 128);
+  f->mnMinX = minx; f->mnMaxX = maxx; f->mnMinY = miny; f->mnMaxY = maxy;
+  f->mfGridElementWidthInv = static_cast<float>(GRID_COLS) / static_cast<float>(maxx - minx);   // Frame.cc:106
+  f->mfGridElementHeightInv = static_cast<float>(GRID_ROWS) / static_cast<float>(maxy - miny);  // Frame.cc:107
+  for (int i = 0; i < n; i++) {  // AssignFeaturesToGrid + PosInGrid
+    const int posX = (int)std::round((kps[i].x - minx) * f->mfGridElementWidthInv);
+    const int posY = (int)std::round((kps[i].y - miny) * f->mfGridElementHeightInv);
+    if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+    f->mGrid[posX][posY].push_back(i);
+  }
+  // ORBextractor scale tables as Frame copies them (Frame.cc:72-79)
+  f->mnScaleLevels = nlevels;
+  f->mvScaleFactors.resize(nlevels);
+  f->mvScaleFactors[0] = 1.0f;
+  const double sf = scale_factor;
+  for (int i = 1; i < nlevels; i++) f->mvScaleFactors[i] = (float)(f->mvScaleFactors[i - 1] * sf);
+  f->mfLogScaleFactor = std::log((float)scale_factor);  // Frame.cc:74 log(mfScaleFactor), float
+  return f;
+}
+void orc_frame_destroy(orc_frame* f) { delete f; }
+
+int orc_features_in_area(const orc_frame* f, float x, float y, float r, int minlevel, int maxlevel, int cap,
+                         int32_t* out) {
+  const std::vector<size_t> v = f->GetFeaturesInArea(x, y, r, minlevel, maxlevel);
+  const int n = std::min((int)v.size(), cap);
+  for (int i = 0; i < n; ++i) out[i] = (int32_t)v[i];
+  return n;
+}
+
+float orc_descriptor_distance(const float* a, const float* b) { return DescriptorDistance(a, b); }
+
+void orc_dist_matrix(const float* a, int na, const float* b, int nb, float* out) {
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < nb; ++j) out[(size_t)i * nb + j] = DescriptorDistance(a + (size_t)i * 128, b + (size_t)j * 128);
+}
+
+int orc_distinctive_descriptor(const float* desc, int n) {
+  const size_t N = n;
+  std::vector<float> Distances(N * N);
+  for (size_t i = 0; i < N; i++) {
+    Distances[i * N + i] = 0;
+    for (size_t j = i + 1; j < N; j++) {
+      const float distij = DescriptorDistance(desc + i * 128, desc + j * 128);
+      Distances[i * N + j] = distij;
+      Distances[j * N + i] = distij;
+    }
+  }
+  float BestMedian = 100;
+  int BestIdx = 0;
+  for (size_t i = 0; i < N; i++) {
+    std::vector<float> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+    std::sort(vDists.begin(), vDists.end());
+    const float median = vDists[(size_t)(0.5 * (N - 1))];
+    if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+  }
+  return BestIdx;
+}
+
+int orc_match_project_frame(const orc_frame* cur, const orc_frame* last, const uint8_t* has_mp, const float* Xw,
+                            const float* mp_desc, const float* Tcw, const float* K, float th, int check_ori,
+                            int32_t* match_cur) {
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  for (int j = 0; j < cur->N; ++j) match_cur[j] = -1;  // CurrentFrame.mvpMapPoints all NULL (Tracking.cc:670)
+  for (int i = 0; i < last->N; i++) {
+    if (!has_mp[i]) continue;  // pMP && !mvbOutlier[i]
+    float x3Dc[3];
+    transform(Tcw, Xw + 3 * i, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = 1.0 / x3Dc[2];
+    if (invzc < 0) continue;
+    float u = fx * xc * invzc + cx;
+    float v = fy * yc * invzc + cy;
+    if (u < cur->mnMinX || u > cur->mnMaxX) continue;
+    if (v < cur->mnMinY || v > cur->mnMaxY) continue;
+    const int nLastOctave = last->kps[i].octave;
+    const float radius = th * cur->mvScaleFactors[nLastOctave];
+    const std::vector<size_t> vIndices2 = cur->GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    const float* dMP = mp_desc + (size_t)i * 128;
+    float bestDist = 100;
+    int bestIdx2 = -1;
+    for (size_t k = 0; k < vIndices2.size(); ++k) {
+      const size_t i2 = vIndices2[k];
+      if (match_cur[i2] >= 0) continue;  // already holds a map point (Observations() > 0)
+      const float dist = DescriptorDistance(dMP, cur->desc.data() + i2 * 128);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      match_cur[bestIdx2] = i;
+      nmatches++;
+      if (check_ori) {
+        float rot = last->kps[i].angle - cur->kps[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          match_cur[rotHist[i][j]] = -1;
+          nmatches--;
+        }
+  }
+  return nmatches;
+}
+
+int orc_match_project_points(const orc_frame* F, int n_mp, const uint8_t* in_view, const float* proj,
+                             const int32_t* level, const float* view_cos, const float* desc, const uint8_t* occupied,
+                             float th, float nn_ratio, int32_t* match_cur) {
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int j = 0; j < F->N; ++j) match_cur[j] = -1;
+  for (int iMP = 0; iMP < n_mp; iMP++) {
+    if (!in_view[iMP]) continue;  // mbTrackInView && !isBad()
+    const int nPredictedLevel = level[iMP];
+    float r = view_cos[iMP] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
+    if (bFactor) r *= th;
+    const std::vector<size_t> vIndices = F->GetFeaturesInArea(proj[2 * iMP], proj[2 * iMP + 1],
+                                                              r * F->mvScaleFactors[nPredictedLevel],
+                                                              nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    const float* MPdescriptor = desc + (size_t)iMP * 128;
+    float bestDist = 256;
+    int bestLevel = -1;
+    float bestDist2 = 256;
+    int bestLevel2 = -1;
+    int bestIdx = -1;
+    for (size_t k = 0; k < vIndices.size(); ++k) {
+      const size_t idx = vIndices[k];
+      if (occupied[idx] || match_cur[idx] >= 0) continue;  // F.mvpMapPoints[idx] with Observations() > 0
+      const float dist = DescriptorDistance(MPdescriptor, F->desc.data() + idx * 128);
+      if (dist < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = dist;
+        bestLevel2 = bestLevel;
+        bestLevel = F->kps[idx].octave;
+        bestIdx = (int)idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = F->kps[idx].octave;
+        bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nn_ratio * bestDist2) continue;
+      match_cur[bestIdx] = iMP;
+      nmatches++;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+void orc_frustum(const orc_frame* F, int n, const float* Xw, const float* normal, const float* min_dist,
+                 const float* max_dist, const float* Tcw, const float* K, float viewingCosLimit, uint8_t* in_view,
+                 float* proj, int32_t* level, float* view_cos) {
+  const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  // mOw = -mRcw.t()*mtcw (Frame.cc:157): general gemm path, double accumulation, one rounding
+  float Ow[3];
+  for (int i = 0; i < 3; ++i) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (double)Tcw[k * 4 + i] * (double)Tcw[k * 4 + 3];
+    Ow[i] = (float)(-1.0 * s);
+  }
+  for (int m = 0; m < n; ++m) {
+    in_view[m] = 0; proj[2 * m] = proj[2 * m + 1] = 0; level[m] = 0; view_cos[m] = 0;
+    const float* P = Xw + 3 * m;
+    float Pc[3];
+    transform(Tcw, P, Pc);
+    const float PcX = Pc[0], PcY = Pc[1], PcZ = Pc[2];
+    if (PcZ < 0.0f) continue;
+    const float invz = 1.0f / PcZ;
+    const float u = fx * PcX * invz + cx;
+    const float v = fy * PcY * invz + cy;
+    if (u < F->mnMinX || u > F->mnMaxX) continue;
+    if (v < F->mnMinY || v > F->mnMaxY) continue;
+    const float maxDistance = 1.2f * max_dist[m];  // GetMaxDistanceInvariance (MapPoint.cc:415-419)
+    const float minDistance = 0.8f * min_dist[m];  // GetMinDistanceInvariance
+    const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    double nn = 0;
+    for (int k = 0; k < 3; ++k) nn += (double)PO[k] * (double)PO[k];
+    const float dist = (float)std::sqrt(nn);  // cv::norm
+    if (dist < minDistance || dist > maxDistance) continue;
+    const float* Pn = normal + 3 * m;
+    double dot = 0;
+    for (int k = 0; k < 3; ++k) dot += (double)PO[k] * (double)Pn[k];
+    const float viewCos = (float)(dot / dist);
+    if (viewCos < viewingCosLimit) continue;
+    // MapPoint::PredictScale (MapPoint.cc:438-453)
+    const float ratio = max_dist[m] / dist;
+    int nScale = (int)std::ceil(std::log(ratio) / F->mfLogScaleFactor);
+    if (nScale < 0) nScale = 0;
+    else if (nScale >= F->mnScaleLevels) nScale = F->mnScaleLevels - 1;
+    in_view[m] = 1;
+    proj[2 * m] = u; proj[2 * m + 1] = v;
+    level[m] = nScale;
+    view_cos[m] = viewCos;
+  }
+}
+
+int orc_match_init(const orc_frame* F1, const orc_frame* F2, float* vbPrevMatched, int windowSize, float nn_ratio,
+                   int check_ori, int32_t* vnMatches12) {
+  int nmatches = 0;
+  for (int i = 0; i < F1->N; ++i) vnMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<float> vMatchedDistance(F2->N, 100);
+  std::vector<int> vnMatches21(F2->N, -1);
+  for (int i1 = 0; i1 < F1->N; i1++) {
+    const orc_keypoint kp1 = F1->kps[i1];
+    const int level1 = kp1.octave;
+    if (level1 > 0) continue;
+    const std::vector<size_t> vIndices2 =
+        F2->GetFeaturesInArea(vbPrevMatched[2 * i1], vbPrevMatched[2 * i1 + 1], (float)windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const float* d1 = F1->desc.data() + (size_t)i1 * 128;
+    float bestDist = 100.0, bestDist2 = 100.0;
+    int bestIdx2 = -1;
+    for (size_t k = 0; k < vIndices2.size(); ++k) {
+      const size_t i2 = vIndices2[k];
+      const float dist = DescriptorDistance(d1, F2->desc.data() + i2 * 128);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+      else if (dist < bestDist2) bestDist2 = dist;
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nn_ratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_ori) {
+          float rot = F1->kps[i1].angle - F2->kps[bestIdx2].angle;
+          if (rot < 0.0) rot += 360.0f;
+          int bin = (int)std::round(rot * factor);
+          if (bin == HISTO_LENGTH) bin = 0;
+          rotHist[bin].push_back(i1);
+        }
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        const int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (int i1 = 0; i1 < F1->N; i1++)
+    if (vnMatches12[i1] >= 0) {
+      vbPrevMatched[2 * i1] = F2->kps[vnMatches12[i1]].x;
+      vbPrevMatched[2 * i1 + 1] = F2->kps[vnMatches12[i1]].y;
+    }
+  return nmatches;
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+"""Frame grid + matchers: oracle self-checks on CPU, HIP vs oracle
+bit-exact (indices, match ids, distances) on the GPU."""
+import numpy as np
+import pytest
+
+BOUNDS = (0.0, 1241.0, 0.0, 376.0)
+SCALES = np.float32(1.2) ** np.arange(8)
+
+
+def make_frame(n, seed):
+    """Random keypoints with the extractor's per-level structure + unit descriptors."""
+    rng = np.random.default_rng(seed)
+    from tests.conftest import load_package
+    KP = load_package().capi.KP_DTYPE
+    kps = np.zeros(n, KP)
+    octv = np.sort(rng.choice(8, n, p=np.array([434, 362, 302, 251, 209, 175, 145, 122]) / 2000.0))
+    kps["octave"] = octv
+    kps["x"] = rng.uniform(19, 1221, n).astype(np.float32)
+    kps["y"] = rng.uniform(19, 356, n).astype(np.float32)
+    kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kps["response"] = rng.integers(7, 200, n)
+    kps["size"] = 31
+    d = rng.standard_normal((n, 128)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return kps, d.astype(np.float32)
+
+
+def perturbed_descriptors(desc, sigma, seed):
+    rng = np.random.default_rng(seed)
+    d = desc + rng.standard_normal(desc.shape).astype(np.float32) * np.float32(sigma)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return d.astype(np.float32)
+
+
+def pose_T(rv=(0.01, -0.02, 0.005), t=(0.1, -0.05, 0.3)):
+    from tests.conftest import load_package
+    s = load_package().synth
+    T = np.eye(4, dtype=np.float32)
+    T[:3, :3] = s._rot(np.array(rv)).astype(np.float32)
+    T[:3, 3] = np.array(t, np.float32)
+    return T
+
+
+def backproject(T, K, uv, depth):
+    fx, fy, cx, cy = K
+    Xc = np.stack([(uv[:, 0] - cx) / fx * depth, (uv[:, 1] - cy) / fy * depth, depth], 1).astype(np.float64)
+    R, t = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    return ((Xc - t) @ R).astype(np.float32)  # R^T (Xc - t)
+
+
+# ------------------------------------------------------------------ oracle self-checks (CPU)
+def test_descriptor_distance_order(oracle, synth):
+    d = synth.unit_descriptors(6, seed=1)
+    for i in range(6):
+        for j in range(6):
+            acc = np.float32(0)
+            for k in range(128):
+                diff = np.float32(d[i, k] - d[j, k])
+                acc = np.float32(acc + np.float32(diff * diff))
+            assert oracle.descriptor_distance(d[i], d[j]) == acc
+    M = oracle.dist_matrix(d, d)
+    assert (np.diag(M) == 0).all() and (M == M.T).all()
+
+
+def test_grid_query_vs_bruteforce(oracle):
+    kps, desc = make_frame(1500, 5)
+    F = oracle.frame(kps, desc, BOUNDS)
+    rng = np.random.default_rng(6)
+    inv_w, inv_h = np.float32(64) / np.float32(1241), np.float32(48) / np.float32(376)
+    cx = np.round((kps["x"] - np.float32(0)) * inv_w).astype(int)
+    cy = np.round((kps["y"] - np.float32(0)) * inv_h).astype(int)
+    for _ in range(200):
+        x, y = np.float32(rng.uniform(-30, 1270)), np.float32(rng.uniform(-30, 400))
+        r = np.float32(rng.uniform(1, 60))
+        lo, hi = int(rng.integers(-1, 8)), int(rng.integers(-1, 8))
+        got = F.features_in_area(x, y, r, lo, hi)
+        x0 = max(0, int(np.floor((x - r) * inv_w))); x1 = min(63, int(np.ceil((x + r) * inv_w)))
+        y0 = max(0, int(np.floor((y - r) * inv_h))); y1 = min(47, int(np.ceil((y + r) * inv_h)))
+        exp = []
+        if x0 < 64 and x1 >= 0 and y0 < 48 and y1 >= 0:
+            for ix in range(x0, x1 + 1):
+                for iy in range(y0, y1 + 1):
+                    for i in np.nonzero((cx == ix) & (cy == iy))[0]:
+                        o = kps["octave"][i]
+                        if lo > 0 or hi >= 0:
+                            if o < lo or (hi >= 0 and o > hi):
+                                continue
+                        if abs(kps["x"][i] - x) < r and abs(kps["y"][i] - y) < r:
+                            exp.append(int(i))
+        assert got.tolist() == exp
+
+
+def test_distinctive_descriptor_oracle(oracle, synth):
+    base = synth.unit_descriptors(1, seed=9)[0]
+    obs = np.stack([perturbed_descriptors(base[None], s, 10 + i)[0] for i, s in enumerate([0.02, 0.3, 0.25, 0.01, 0.4])])
+    best = oracle.distinctive_descriptor(obs)
+    M = oracle.dist_matrix(obs, obs)
+    med = np.sort(M, axis=1)[:, 2]
+    assert best == int(np.argmin(med))
+
+
+def test_oracle_m1_recovers_true_matches(oracle, synth):
+    kl, dl = make_frame(1200, 21)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    # current frame = same keypoints shifted by a few px, descriptors slightly perturbed, shuffled
+    rng = np.random.default_rng(22)
+    perm = rng.permutation(len(kl))
+    kc = kl[perm].copy()
+    kc["x"] += rng.uniform(-3, 3, len(kc)).astype(np.float32)
+    kc["y"] += rng.uniform(-3, 3, len(kc)).astype(np.float32)
+    dc = perturbed_descriptors(dl[perm], 0.02, 23)
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    uv = np.stack([kc["x"][inv], kc["y"][inv]], 1)
+    Xw = backproject(T, K, uv, rng.uniform(5, 40, len(kl)))
+    has = (rng.uniform(size=len(kl)) < 0.8).astype(np.uint8)
+    cur, last = oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS)
+    m, n = oracle.match_project_frame(cur, last, has, Xw, dl, T, K, 15.0, check_ori=False)
+    good = sum(1 for j in range(len(kc)) if m[j] >= 0 and m[j] == perm[j])
+    assert n == (m >= 0).sum() and good > 0.9 * has.sum() * 0.9
+
+
+# ------------------------------------------------------------------ HIP vs oracle (GPU)
+@pytest.mark.gpu
+def test_dist_matrix_bit_exact(hip, oracle, synth):
+    a, b = synth.unit_descriptors(70, seed=31), synth.unit_descriptors(300, seed=32)
+    np.testing.assert_array_equal(hip.dist_matrix(a, b), oracle.dist_matrix(a, b))
+    assert hip.dist_matrix(a[:0], b).shape == (0, 300)
+    one = hip.dist_matrix(a[:1], b[:1])
+    assert one[0, 0] == oracle.descriptor_distance(a[0], b[0])
+
+
+@pytest.mark.gpu
+def test_dist_matrix_full_size(hip, oracle, synth):
+    d = synth.unit_descriptors(2000, seed=33)
+    M = hip.dist_matrix(d, d)
+    assert (np.diag(M) == 0).all() and (M == M.T).all()
+    np.testing.assert_array_equal(M, oracle.dist_matrix(d, d))
+    ref = ((d[:50, None, :].astype(np.float64) - d[None, :50, :]) ** 2).sum(-1)
+    np.testing.assert_allclose(M[:50, :50], ref, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_grid_queries(hip, oracle):
+    kps, desc = make_frame(2000, 41)
+    hip.frame_set(0, kps, desc, BOUNDS)
+    F = oracle.frame(kps, desc, BOUNDS)
+    rng = np.random.default_rng(42)
+    for _ in range(300):
+        x, y, r = rng.uniform(-30, 1270), rng.uniform(-30, 400), rng.uniform(0.5, 80)
+        lo, hi = int(rng.integers(-1, 8)), int(rng.integers(-1, 8))
+        np.testing.assert_array_equal(hip.features_in_area(0, x, y, r, lo, hi), F.features_in_area(x, y, r, lo, hi))
+
+
+def _m1_case(synth, n, seed, shift=3.0, sigma=0.05, frac=0.8):
+    kl, dl = make_frame(n, seed)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(seed + 1)
+    perm = rng.permutation(n)
+    kc = kl[perm].copy()
+    kc["x"] += rng.uniform(-shift, shift, n).astype(np.float32)
+    kc["y"] += rng.uniform(-shift, shift, n).astype(np.float32)
+    kc["angle"] = (kc["angle"] + rng.normal(0, 4, n)).astype(np.float32) % np.float32(360)
+    dc = perturbed_descriptors(dl[perm], sigma, seed + 2)
+    inv = np.empty_like(perm); inv[perm] = np.arange(n)
+    uv = np.stack([kc["x"][inv], kc["y"][inv]], 1)
+    Xw = backproject(T, K, uv, rng.uniform(5, 40, n))
+    has = (rng.uniform(size=n) < frac).astype(np.uint8)
+    mp_desc = perturbed_descriptors(dl, 0.02, seed + 3)
+    return kl, dl, kc, dc, Xw, has, mp_desc, T, K
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,th,ori", [(2000, 15.0, True), (2000, 30.0, True), (500, 15.0, False), (37, 15.0, True)])
+def test_match_project_frame(hip, oracle, synth, n, th, ori):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 50 + n)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    got, ng = hip.match_project_frame(0, 1, n, has, Xw, mp_desc, T, K, th, ori)
+    exp, ne = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw, mp_desc,
+                                         T, K, th, ori)
+    np.testing.assert_array_equal(got, exp)
+    assert ng == ne
+    if n >= 500:
+        assert ng > 0.5 * has.sum()
+
+
+@pytest.mark.gpu
+def test_match_project_frame_degenerate(hip, oracle, synth):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, 300, 77)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    got, ng = hip.match_project_frame(0, 1, 300, np.zeros(300, np.uint8), Xw, mp_desc, T, K, 15.0, True)
+    assert ng == 0 and (got == -1).all()
+    # points behind the camera / outside the image are skipped
+    Xw2 = Xw.copy(); Xw2[:100, 2] -= 500
+    got, ng = hip.match_project_frame(0, 1, 300, has, Xw2, mp_desc, T, K, 15.0, True)
+    exp, ne = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw2, mp_desc,
+                                         T, K, 15.0, True)
+    np.testing.assert_array_equal(got, exp)
+    assert ng == ne
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mp,th", [(6000, 1.0), (3000, 5.0), (10, 1.0)])
+def test_frustum_and_match_project_points(hip, oracle, synth, n_mp, th):
+    kc, dc = make_frame(2000, 90)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(91 + n_mp)
+    src = rng.integers(0, 2000, n_mp)
+    uv = np.stack([kc["x"][src], kc["y"][src]], 1) + rng.uniform(-2, 2, (n_mp, 2)).astype(np.float32)
+    uv[: n_mp // 10] += 3000  # some outside the image
+    depth = rng.uniform(3, 60, n_mp)
+    Xw = backproject(T, K, uv, depth)
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    normal = Xw.astype(np.float64) - Ow
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    normal = (normal + rng.normal(0, 0.3, normal.shape)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    dist = np.linalg.norm(Xw.astype(np.float64) - Ow, axis=1)
+    lvl = kc["octave"][src]
+    maxd = (dist * SCALES[lvl] * rng.uniform(0.9, 1.1, n_mp)).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    F = oracle.frame(kc, dc, BOUNDS)
+    g = hip.frustum(0, Xw, normal, mind, maxd, T, K)
+    e = oracle.frustum(F, Xw, normal, mind, maxd, T, K)
+    for a, b in zip(g, e):
+        np.testing.assert_array_equal(a, b)
+    in_view, proj, level, vc = g
+    assert 0.3 * n_mp < in_view.sum() <= n_mp
+    desc = perturbed_descriptors(dc[src], 0.05, 92)
+    occupied = (rng.uniform(size=2000) < 0.1).astype(np.uint8)
+    got, ng = hip.match_project_points(0, 2000, in_view, proj, level, vc, desc, occupied, th, 0.8)
+    exp, ne = oracle.match_project_points(F, in_view, proj, level, vc, desc, occupied, th, 0.8)
+    np.testing.assert_array_equal(got, exp)
+    assert ng == ne
+    assert not ((got >= 0) & (occupied > 0)).any()
+
+
+@pytest.mark.gpu
+def test_match_init(hip, oracle, synth):
+    k1, d1 = make_frame(4000, 101)
+    rng = np.random.default_rng(102)
+    perm = rng.permutation(4000)
+    k2 = k1[perm].copy()
+    k2["x"] += rng.uniform(-20, 20, 4000).astype(np.float32)
+    k2["y"] += rng.uniform(-8, 8, 4000).astype(np.float32)
+    d2 = perturbed_descriptors(d1[perm], 0.03, 103)
+    hip.frame_set(2, k1, d1, BOUNDS)
+    hip.frame_set(3, k2, d2, BOUNDS)
+    prev = np.stack([k1["x"], k1["y"]], 1)
+    got, ng, pm_g = hip.match_init(2, 3, prev, 100, 0.9, True)
+    exp, ne, pm_e = oracle.match_init(oracle.frame(k1, d1, BOUNDS), oracle.frame(k2, d2, BOUNDS), prev, 100, 0.9, True)
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(pm_g, pm_e)
+    assert ng == ne and ng > 200
+    assert (got[k1["octave"] > 0] == -1).all()  # level-0 keypoints only (ORBmatcher.cc:434-436)
+
+
+@pytest.mark.gpu
+def test_distinctive_descriptor(hip, oracle, synth):
+    base = synth.unit_descriptors(1, seed=111)[0]
+    for n in (1, 2, 7, 30):
+        obs = np.stack([perturbed_descriptors(base[None], 0.05 * (1 + (i * 7) % 5), 112 + i)[0] for i in range(n)])
+        assert hip.distinctive_descriptor(obs) == oracle.distinctive_descriptor(obs)
+
+
+@pytest.mark.gpu
+def test_matchers_on_real_extraction(hip, oracle, synth):
+    """End to end on the synthetic stream: extract two frames, adopt device-resident descriptors
+    (desc=None), track frame 1 against frame 0 with a planar scene model."""
+    K = np.array(synth.KITTI_K, np.float32)
+    k0, d0 = hip.extract(synth.scene_frame(0))
+    hip.frame_set(1, k0, None, BOUNDS)
+    k1, d1 = hip.extract(synth.scene_frame(1))
+    hip.frame_set(0, k1, None, BOUNDS)
+    T = np.eye(4, dtype=np.float32)
+    # frame t+1 = frame t shifted by (-3, -0.2) px and zoomed by ~0.3 % about the image centre
+    z = 1.003 / 1.0
+    uv = np.stack([(k0["x"] - 620.5) * z + 620.5 - 3 * z, (k0["y"] - 188) * z + 188 - 0.2 * z], 1).astype(np.float32)
+    Xw = backproject(T, K, uv, np.full(len(k0), 20.0))
+    has = np.ones(len(k0), np.uint8)
+    got, ng = hip.match_project_frame(0, 1, len(k1), has, Xw, d0, T, K, 15.0, True)
+    exp, ne = oracle.match_project_frame(oracle.frame(k1, d1, BOUNDS), oracle.frame(k0, d0, BOUNDS), has, Xw, d0, T, K,
+                                         15.0, True)
+    np.testing.assert_array_equal(got, exp)
+    assert ng == ne and ng > 300
