@@ -178,6 +178,47 @@ class Oracle:
         return T
 
 
+class RefG2O:
+    """The reference's own vendored g2o compiled in place (oracle/ref_g2o -> oracle/_ref/libg2o_ref.so).
+    Same calling convention as Oracle.pose_optimize / Oracle.local_ba."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "_ref", "libg2o_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libg2o_ref.so"))
+
+    def pose_optimize(self, pose7, Xw, obs, inv_sigma2, K):
+        pose = _c(pose7, np.float64).copy()
+        Xw, obs, inv_sigma2, K = (_c(a, np.float64) for a in (Xw, obs, inv_sigma2, K))
+        outlier = np.zeros(Xw.shape[0], np.uint8)
+        ninl = self.lib.ref_pose_optimize(_p(pose), Xw.shape[0], _p(Xw), _p(obs), _p(inv_sigma2), _p(K), _p(outlier))
+        return pose, outlier, ninl
+
+    def local_ba(self, prob, its_first=5, its_second=10):
+        poses = _c(prob["poses"], np.float64).copy()
+        points = _c(prob["points"], np.float64).copy()
+        fixed = _c(prob["fixed"], np.uint8)
+        e_point, e_pose = _c(prob["e_point"], np.int32), _c(prob["e_pose"], np.int32)
+        e_obs, e_info, K = _c(prob["e_obs"], np.float64), _c(prob["e_info"], np.float64), _c(prob["K"], np.float64)
+        E = len(e_point)
+        chi2 = np.zeros(E, np.float64)
+        dpos = np.zeros(E, np.uint8)
+        out1 = np.zeros(E, np.uint8)
+        o = orc_ba_out()
+        rc = self.lib.ref_local_ba(len(poses), len(points), E, _p(poses), _p(fixed), _p(points), _p(e_point),
+                                   _p(e_pose), _p(e_obs), _p(e_info), _p(K), its_first, its_second, _p(chi2),
+                                   _p(dpos), _p(out1), C.byref(o))
+        assert rc == 0
+        return dict(poses=poses, points=points, edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier1=out1,
+                    chi2_first=o.chi2_first, chi2_second=o.chi2_second, iters_first=o.iters_first,
+                    iters_second=o.iters_second)
+
+
 class OracleExtractor:
     def __init__(self, orc, nfeatures, scale, nlevels, ini_th, min_th):
         self.orc, self.lib = orc, orc.lib
