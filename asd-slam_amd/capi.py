@@ -161,6 +161,24 @@ class AsdHip:
                                        _p(kps), _p(desc), C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def extract_device(self, d_image, w, h, stride, n_features_override=0):
+        cap = self.cfg.max_patches
+        if not hasattr(self, "_kps_buf"):
+            self._kps_buf = np.zeros(cap, KP_DTYPE)
+            self._desc_buf = np.empty((cap, 128), np.float32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_extract_device(self.ctx, d_image, w, h, stride, n_features_override,
+                                              _p(self._kps_buf), _p(self._desc_buf), C.byref(n)))
+        return self._kps_buf[:n.value], self._desc_buf[:n.value]
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.asd_profile_enable(self.ctx, int(on)))
+
+    def profile_get(self, layer):
+        ms, calls, patches = C.c_double(), C.c_int32(), C.c_int64()
+        self._chk(self.lib.asd_profile_get(self.ctx, layer, C.byref(ms), C.byref(calls), C.byref(patches)))
+        return ms.value, calls.value, patches.value
+
     def level_size(self, level):
         w, h = C.c_int32(), C.c_int32()
         self._chk(self.lib.asd_get_level_size(self.ctx, level, C.byref(w), C.byref(h)))

@@ -366,16 +366,44 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   hipStream_t st = ctx->stream;
   float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
   const int npad = (n + 31) / 32 * 32;
+  const bool prof = ctx->prof_on;
+  if (prof && ctx->prof_pending) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
+#define PROF_MARK(i) do { if (prof) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[i], st)); } while (0)
+  PROF_MARK(0);
   hipLaunchKernelGGL(k_norm_conv1, dim3(n), dim3(256), 0, st, d_patches, ctx->d_w1, ctx->d_bias[0], a0);
   ASD_HIP_CHECK(ctx, hipGetLastError());
+  PROF_MARK(1);
   ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG>(st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, n)));
+  PROF_MARK(2);
   ASD_HIP_CHECK(ctx, (launch_conv<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
+  PROF_MARK(3);
   ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
+  PROF_MARK(4);
   ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
+  PROF_MARK(5);
   ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
+  PROF_MARK(6);
   hipLaunchKernelGGL(k_fc_mfma, dim3(npad / 32, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
   ASD_HIP_CHECK(ctx, hipGetLastError());
+  PROF_MARK(7);
   hipLaunchKernelGGL(k_l2norm, dim3((n + 3) / 4), dim3(256), 0, st, ctx->d_part, ctx->d_bias[6], d_desc, n, npad);
   ASD_HIP_CHECK(ctx, hipGetLastError());
+  PROF_MARK(8);
+#undef PROF_MARK
+  if (prof) { ctx->prof_pending = true; ctx->prof_pending_n = n; }
+  return ASD_OK;
+}
+
+int asdnet_profile_collect(asd_ctx* ctx) {
+  if (!ctx->prof_pending) return ASD_OK;
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->prof_ev[8]));
+  for (int l = 0; l < 8; ++l) {
+    float ms = 0;
+    ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[l], ctx->prof_ev[l + 1]));
+    ctx->prof_ms[l] += ms;
+    ctx->prof_calls[l] += 1;
+    ctx->prof_patches[l] += ctx->prof_pending_n;
+  }
+  ctx->prof_pending = false;
   return ASD_OK;
 }

@@ -73,6 +73,15 @@ struct asd_ctx {
   // ---- BA scratch (lazily grown)
   void* ba = nullptr;
 
+  // ---- per-layer profiling (asd_profile_enable)
+  bool prof_on = false;
+  hipEvent_t prof_ev[9] = {};
+  bool prof_pending = false;
+  int prof_pending_n = 0;
+  double prof_ms[8] = {};
+  int prof_calls[8] = {};
+  long long prof_patches[8] = {};
+
   // ---- timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   float ms_asdnet = 0, ms_extract = 0, ms_match = 0, ms_ba = 0;
@@ -102,3 +111,4 @@ void asdnet_free(asd_ctx* ctx);
 int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
                         const float* const bn_var[7], float eps);
 int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc);
+int asdnet_profile_collect(asd_ctx* ctx);  // folds pending layer events into the totals (needs a synced stream)

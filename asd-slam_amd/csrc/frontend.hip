@@ -527,8 +527,8 @@ static int configure_size(asd_ctx* ctx, int w, int h) {
 
 extern "C" {
 
-int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
-                int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
+static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device, int32_t width, int32_t height,
+                        int32_t stride, int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
   if (!ctx || !image || !kps || !desc || !n_out || stride < width) return ASD_ERR_INVALID;
   if (width > ctx->cfg.max_width || height > ctx->cfg.max_height) { ctx->set_error("image %dx%d exceeds ctx capacity %dx%d", width, height, ctx->cfg.max_width, ctx->cfg.max_height); return ASD_ERR_CAPACITY; }
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
@@ -547,7 +547,8 @@ int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t heigh
 
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
   // E1 pyramid
-  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, image, stride, width, height, hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, image, stride, width, height,
+                                      image_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   for (int l = 1; l < nl; ++l) {
     const LevelDev &S = P.lv[l - 1], &D = P.lv[l];
     hipLaunchKernelGGL(k_resize, dim3((D.w + 255) / 256, (D.h + 3) / 4), dim3(256), 0, st, fe->d_pyr + S.off, S.w, S.h,
@@ -622,6 +623,16 @@ int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t heigh
   for (int i = 0; i < n; ++i) kps[i].angle = fe->h_angles[i];
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ctx->ev0, ctx->ev1));
   return ASD_OK;
+}
+
+int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
+                int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
+  return extract_impl(ctx, image, false, width, height, stride, n_features_override, kps, desc, n_out);
+}
+
+int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int32_t height, int32_t stride,
+                       int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
+  return extract_impl(ctx, d_image, true, width, height, stride, n_features_override, kps, desc, n_out);
 }
 
 int asd_get_level_size(const asd_ctx* ctx, int32_t level, int32_t* width, int32_t* height) {

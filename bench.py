@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the per-frame hot path + LocalBA on MI355X (BASELINE.json metric).
+
+One "step" = one frame of the synthetic KITTI-00-shaped stream (1241x376 u8, 2000 keypoints) through the
+full HIP path (BASELINE.json configs[2]): extract (pyramid, FAST, quadtree, orientation, blur, patch
+gather, ASDNet) -> frame grid -> SearchByProjection vs the previous frame -> PoseOptimization ->
+isInFrustum + SearchByProjection vs a local map -> PoseOptimization; every 15th step (the reference's
+--max_step_KF=15, run_vslam_kitti.sh:7) also runs LocalBundleAdjustment on the SURVEY 8(d) nominal problem
+(24 free + 12 fixed keyframes, 6000 map points, ~29k edges).  Frames are resident in HBM before the timed
+region.  SLAM is sequential per trajectory, so N GPUs = N independent sequences (replicas, no collective on
+the data path; a gloo barrier brackets the timed region).
+
+Prints ONE JSON line (rank 0).  `cpu_baseline` times the same step with the CPU restatement (oracle/:
+front-end, matchers, pose optimisation; PyTorch-CPU ASDNet run per level like the reference) and, when
+oracle/_ref is present, the reference's own g2o for LocalBA -- as a reported baseline, never the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+KF_INTERVAL = 15
+N_FRAMES = 30          # distinct synthetic frames kept resident in HBM, cycled
+BOUNDS = (0.0, 1241.0, 0.0, 376.0)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense f32 matrix)
+L2_MACS = 9_437_184            # conv2 (32->32 @32x32) MACs per patch, SURVEY 8(a) E6
+
+
+# ------------------------------------------------------------------ distributed plumbing (control plane only)
+def dist_env():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+class Dist:
+    """gloo process group used ONLY for the barrier and the max-over-ranks of the timed region."""
+
+    def __init__(self, world):
+        self.world = world
+        self.rank, self.local_rank, _ = dist_env()
+        self.pg = None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="gloo", rank=self.rank, world_size=world)
+            self.pg = dist
+
+    def barrier(self):
+        if self.pg:
+            self.pg.barrier()
+
+    def max(self, v):
+        if not self.pg:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.MAX)
+        return float(t[0])
+
+    def sum(self, v):
+        if not self.pg:
+            return v
+        import torch
+        t = torch.tensor([v], dtype=torch.float64)
+        self.pg.all_reduce(t, op=self.pg.ReduceOp.SUM)
+        return float(t[0])
+
+    def close(self):
+        if self.pg:
+            self.pg.destroy_process_group()
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def device_sync():
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+# ------------------------------------------------------------------ synthetic tracking inputs
+def backproject_identity(K, uv, depth):
+    fx, fy, cx, cy = K
+    return np.stack([(uv[:, 0] - cx) / fx * depth, (uv[:, 1] - cy) / fy * depth,
+                     np.full(len(uv), depth)], 1).astype(np.float32)
+
+
+def predicted_uv(kps):
+    """where frame t's keypoints land in frame t+1 of synth.scene_frame (3 px drift, 0.3 % zoom)"""
+    z = 1.003
+    return np.stack([(kps["x"] - 620.5) * z + 620.5 - 3 * z, (kps["y"] - 188.0) * z + 188.0 - 0.2 * z], 1).astype(np.float32)
+
+
+class Workload:
+    def __init__(self, synth, seed_offset=0):
+        self.K32 = np.array(synth.KITTI_K, np.float32)
+        self.K64 = np.array(synth.KITTI_K, np.float64)
+        self.T = np.eye(4, dtype=np.float32)
+        self.pose0 = np.array([0.002, -0.001, 0.0015, 1.0, 0.01, -0.02, 0.03])
+        self.pose0[:4] /= np.linalg.norm(self.pose0[:4])
+        self.ba = synth.ba_problem(seed=1 + seed_offset)
+        self.inv_sigma2 = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float64)
+        self.frames = [synth.scene_frame(t + 3 * seed_offset) for t in range(N_FRAMES)]
+
+
+def track_step(be, wl, image_handle, last, do_ba):
+    """One frame through extract -> M1 -> P1 -> frustum/M2 -> P1 (-> LocalBA).  `be` is a backend
+    (HIP or CPU restatement) exposing the same five operations."""
+    kps, desc = be.extract(image_handle)
+    cur = be.make_frame(kps, desc)
+    stats = {"n_kp": len(kps)}
+    if last is not None:
+        lk, ld, lframe = last
+        uv = predicted_uv(lk)
+        Xw = backproject_identity(wl.K32, uv, 20.0)
+        has = np.ones(len(lk), np.uint8)
+        m1, n1 = be.match_frame(cur, lframe, len(kps), has, Xw, ld, wl.T, wl.K32, 15.0)
+        j = np.nonzero(m1 >= 0)[0]
+        stats["m1"] = int(n1)
+        if len(j) >= 3:
+            obs = np.stack([kps["x"][j], kps["y"][j]], 1).astype(np.float64)
+            be.pose_opt(wl.pose0, Xw[m1[j]].astype(np.float64), obs, wl.inv_sigma2[kps["octave"][j]], wl.K64)
+        # local map: the last frame's points plus a second, jittered copy (~2x keypoints, like a local map)
+        Xw2 = np.concatenate([Xw, Xw + np.float32(0.02)])
+        d2 = np.concatenate([ld, ld])
+        n = Xw2 / np.linalg.norm(Xw2, axis=1, keepdims=True)
+        dist = np.linalg.norm(Xw2, axis=1).astype(np.float32)
+        lv = np.concatenate([lk["octave"], lk["octave"]])
+        maxd = (dist * (np.float32(1.2) ** lv)).astype(np.float32)
+        mind = (maxd / np.float32(1.2 ** 7)).astype(np.float32)
+        fr = be.frustum(cur, Xw2, n.astype(np.float32), mind, maxd, wl.T, wl.K32)
+        occ = (m1 >= 0).astype(np.uint8)
+        m2, n2 = be.match_points(cur, len(kps), fr, d2, occ, 1.0, 0.8)
+        stats["m2"] = int(n2)
+        jj = np.nonzero((m1 >= 0) | (m2 >= 0))[0]
+        if len(jj) >= 3:
+            X = np.where((m1[jj] >= 0)[:, None], Xw[np.maximum(m1[jj], 0)], Xw2[np.maximum(m2[jj], 0)])
+            obs = np.stack([kps["x"][jj], kps["y"][jj]], 1).astype(np.float64)
+            _, _, ninl = be.pose_opt(wl.pose0, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
+            stats["inliers"] = int(ninl)
+    if do_ba:
+        r = be.local_ba(wl.ba)
+        stats["ba_chi2"] = float(r["chi2_second"])
+    return (kps.copy(), desc.copy(), cur), stats
+
+
+class HipBackend:
+    def __init__(self, pkg, wl, device):
+        self.hip = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096, device=device)
+        self.hip.load_weights(pkg.synth.asdnet_weights(0))
+        self.d_frames = []
+        for f in wl.frames:   # frames resident in HBM before the timed region
+            p = self.hip.device_alloc(f.nbytes)
+            self.hip.h2d(p, f)
+            self.d_frames.append(p)
+        self.slot = 0
+
+    def image(self, t):
+        return self.d_frames[t % len(self.d_frames)]
+
+    def extract(self, h):
+        return self.hip.extract_device(h, 1241, 376, 1241)
+
+    def make_frame(self, kps, desc):
+        self.slot ^= 1
+        self.hip.frame_set(self.slot, kps, None, BOUNDS)   # adopts the device-resident descriptors
+        return self.slot
+
+    def match_frame(self, cur, last, n_cur, has, Xw, mp_desc, T, K, th):
+        return self.hip.match_project_frame(cur, last, n_cur, has, Xw, mp_desc, T, K, th, True)
+
+    def pose_opt(self, pose, Xw, obs, info, K):
+        return self.hip.pose_optimize(pose, Xw, obs, info, K)
+
+    def frustum(self, cur, Xw, normal, mind, maxd, T, K):
+        return self.hip.frustum(cur, Xw, normal, mind, maxd, T, K)
+
+    def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
+        return self.hip.match_project_points(cur, n_cur, fr[0], fr[1], fr[2], fr[3], desc, occ, th, ratio)
+
+    def local_ba(self, prob):
+        return self.hip.local_ba(prob)
+
+    def close(self):
+        self.hip.close()
+
+
+class CpuBackend:
+    """CPU restatement (oracle/) -- baseline only."""
+
+    def __init__(self, pkg, wl):
+        po = graft.load_oracle()
+        po.build()
+        self.orc = po.Oracle()
+        self.ex = self.orc.extractor(2000)
+        self.ref = po.RefG2O() if po.RefG2O.available() else None
+        from oracle import asdnet_torch
+        import torch
+        self.torch = torch
+        self.cores = host_cores()
+        torch.set_num_threads(self.cores)
+        self.at = asdnet_torch
+        self.net = asdnet_torch.build(pkg.synth.asdnet_weights(0))
+        self.frames = wl.frames
+
+    def image(self, t):
+        return self.frames[t % len(self.frames)]
+
+    def extract(self, img):
+        kps, patches = self.ex.extract(img)
+        return kps, self.at.describe_per_level(self.net, patches, kps["octave"])
+
+    def make_frame(self, kps, desc):
+        return self.orc.frame(kps, desc, BOUNDS)
+
+    def match_frame(self, cur, last, n_cur, has, Xw, mp_desc, T, K, th):
+        return self.orc.match_project_frame(cur, last, has, Xw, mp_desc, T, K, th, True)
+
+    def pose_opt(self, pose, Xw, obs, info, K):
+        return self.orc.pose_optimize(pose, Xw, obs, info, K)
+
+    def frustum(self, cur, Xw, normal, mind, maxd, T, K):
+        return self.orc.frustum(cur, Xw, normal, mind, maxd, T, K)
+
+    def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
+        return self.orc.match_project_points(cur, fr[0], fr[1], fr[2], fr[3], desc, occ, th, ratio)
+
+    def local_ba(self, prob):
+        return (self.ref or self.orc).local_ba(prob)
+
+
+def run_steps(be, wl, t0, n, last):
+    stats = {}
+    for i in range(n):
+        t = t0 + i
+        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1))
+    return last, stats
+
+
+def selftest_dist(args):
+    """CPU-only rehearsal of the N>1 control plane (gloo): rendezvous, barrier, max-over-ranks, aggregation."""
+    d = Dist(args.gpus)
+    d.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (1 + d.rank))
+    dt = time.perf_counter() - t0
+    d.barrier()
+    tmax = d.max(dt)
+    total = d.sum(float(args.steps))
+    if d.rank == 0:
+        print(json.dumps({"selftest": "dist", "n_gpus": args.gpus, "t_max": tmax, "frames_total": total,
+                          "value": total / tmax}))
+    d.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--cpu-frames", type=int, default=15, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--selftest-dist", action="store_true")
+    args = ap.parse_args()
+    if args.selftest_dist:
+        return selftest_dist(args)
+
+    rank, local_rank, world = dist_env()
+    world = max(world, 1)
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    graft.build() if not os.path.exists(os.path.join(ROOT, "asd-slam_amd", "libasdhip.so")) else None
+    pkg = graft.load_package()
+    dist = Dist(world)
+    wl = Workload(pkg.synth, seed_offset=rank)
+    be = HipBackend(pkg, wl, device=local_rank if world > 1 else 0)
+
+    last, _ = run_steps(be, wl, 0, args.warmup, None)            # untimed warm-up
+    be.hip.profile_enable(True)
+    be.hip.sync(); device_sync(); dist.barrier()
+    t0 = time.perf_counter()
+    last, stats = run_steps(be, wl, args.warmup, args.steps, last)  # EXACTLY K timed steps
+    be.hip.sync(); device_sync(); dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = dist.max(dt)
+    frames_total = dist.sum(float(args.steps))
+
+    # per-kernel device time of the dominant kernel (ASDNet conv2, f32 MFMA), hipEvents on the ctx stream
+    layer_names = ["norm+conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7(fc)", "l2norm"]
+    layers = {}
+    for l, name in enumerate(layer_names):
+        ms, calls, patches = be.hip.profile_get(l)
+        layers[name] = {"avg_us": 1e3 * ms / max(calls, 1), "calls": calls, "patches_per_call": patches / max(calls, 1)}
+    ms2, calls2, patches2 = be.hip.profile_get(1)
+    achieved = (2.0 * L2_MACS * patches2) / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
+    asdnet_ms = sum(be.hip.profile_get(l)[0] for l in range(8)) / max(calls2, 1)
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic_conv2.json")
+    if os.path.exists(tp):
+        traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+    be.close()
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "frames/sec end-to-end tracking+LocalBA, KITTI 00 mono @2000 keypoints",
+            "value": frames_total / tmax, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: KITTI-00-shaped synthetic stream 1241x376, 2000 kpts/frame, "
+                                   "full HIP path: extract(E1-E7)+grid+SearchByProjection(frame)+PoseOptimization+"
+                                   "isInFrustum+SearchByProjection(map)+PoseOptimization per frame, LocalBA "
+                                   "(24+12 KF, 6000 MP, ~29k edges) every 15 frames",
+                       "keypoints": int(stats.get("n_kp", 0)), "kf_interval": KF_INTERVAL,
+                       "parallelism": f"replicas x{world} (independent sequences, no collective)"},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "avg_launch_us": layers["conv2"]["avg_us"], "asdnet_forward_ms": asdnet_ms,
+                         "asdnet_tflops": (2.0 * 39_092_224 * layers["conv2"]["patches_per_call"]) / (asdnet_ms * 1e-3) / 1e12 if asdnet_ms > 0 else 0.0},
+            "asdnet_layers": layers,
+            "last_step": stats,
+        }
+        if args.cpu_frames > 0:
+            cb = CpuBackend(pkg, wl)
+            nf = args.cpu_frames
+            cl, _ = run_steps(cb, wl, 0, 1, None)        # one untimed frame (torch warm-up, page-in)
+            t0 = time.perf_counter()
+            run_steps(cb, wl, KF_INTERVAL - nf, nf, cl)  # nf frames ending on a keyframe -> exactly one LocalBA
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {
+                "value": nf / cdt, "unit": "frames/s", "cores": cb.cores, "kind": "port",
+                "sample": f"{nf} frames of the same workload incl. 1 LocalBA: oracle/ C++ restatement single-thread "
+                          f"(front-end, matchers, pose optimisation), PyTorch-CPU ASDNet per level on {cb.torch.get_num_threads()} threads, "
+                          + ("LocalBA by the reference's own g2o (oracle/_ref, single thread)" if cb.ref else "LocalBA by the oracle port"),
+            }
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    dist.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,11 @@ int asd_describe_device(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float
 int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
                 int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out);
 
+/* Same with the image already resident in HBM (d_image = HIP device pointer, row stride in
+ * bytes): what a camera driver with a device-side ring buffer, or bench.py, calls. */
+int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int32_t height, int32_t stride,
+                       int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out);
+
 /* Intermediate products of the last asd_extract, for tests and for callers that read
  * ORBextractor::mvImagePyramid (ORBextractor.h:87).  Level images are returned WITHOUT
  * the 19 px border.  blurred != 0 selects the GaussianBlur'ed copy
@@ -239,6 +244,11 @@ int asd_pose7_to_tcw(const double* pose7, float* Tcw16);
 /* Device-side duration of the kernels enqueued by the most recent call of the named stage,
  * measured with hipEvents on the ctx stream.  stage: "asdnet", "extract", "match", "ba". */
 int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms);
+/* Per-kernel device time of the ASDNet forward, accumulated with hipEvents recorded on the ctx
+ * stream between the layer launches of every forward while enabled.  layer 0 = input_norm+conv1,
+ * 1..5 = conv2..conv6 (MFMA implicit GEMM), 6 = 8x8 conv (split-K GEMM), 7 = reduce+L2Norm. */
+int asd_profile_enable(asd_ctx* ctx, int32_t on);
+int asd_profile_get(asd_ctx* ctx, int32_t layer, double* total_ms, int32_t* calls, int64_t* patches);
 /* Raw handles for harnesses that keep inputs resident (bench.py): the ctx stream
  * (hipStream_t) and device scratch. */
 void* asd_ctx_stream(asd_ctx* ctx);
