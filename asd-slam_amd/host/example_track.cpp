@@ -1,0 +1,67 @@
+// example_track.cpp -- two-frame tracking with the host-side mirror classes (asd_adapters.hpp):
+// what Tracking::GrabImageMonocular + TrackWithMotionModel do with the hot path (Tracking.cc:102-110,
+// 664-723), minus the map.  Usage: example_track weights.bin frame0.raw frame1.raw W H
+// weights.bin = 7 x (conv_w, bn_mean, bn_var) f32 blobs in ASDNet.py:334-356 order.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+
+#include "asd_adapters.hpp"
+
+static std::vector<uint8_t> slurp(const char* path) {
+  std::ifstream f(path, std::ios::binary);
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: %s weights.bin frame0.raw frame1.raw W H\n", argv[0]); return 2; }
+  const int W = atoi(argv[4]), H = atoi(argv[5]);
+  const int cout_[7] = {32, 32, 64, 64, 128, 128, 128}, cin_[7] = {1, 32, 32, 64, 64, 128, 128}, k_[7] = {3, 3, 3, 3, 3, 3, 8};
+  std::vector<uint8_t> wb = slurp(argv[1]);
+  const float* p = reinterpret_cast<const float*>(wb.data());
+  const float *cw[7], *bm[7], *bv[7];
+  for (int l = 0; l < 7; ++l) {
+    cw[l] = p; p += (size_t)cout_[l] * cin_[l] * k_[l] * k_[l];
+    bm[l] = p; p += cout_[l];
+    bv[l] = p; p += cout_[l];
+  }
+  if ((const uint8_t*)p != wb.data() + wb.size()) { fprintf(stderr, "weights.bin has the wrong size\n"); return 2; }
+  try {
+    asd::Context ctx(2000, 1.2f, 8, 20, 7, W, H);
+    asd::ORBextractor extractor(ctx, cw, bm, bv);
+    const asd::Camera K{718.856f, 718.856f, 607.1928f, 185.2157f};
+    asd::FrameView F[2];
+    for (int t = 0; t < 2; ++t) {
+      std::vector<uint8_t> img = slurp(argv[2 + t]);
+      if ((int)img.size() != W * H) { fprintf(stderr, "frame %d has the wrong size\n", t); return 2; }
+      F[t].slot = t;
+      F[t].mnMinX = 0; F[t].mnMaxX = (float)W; F[t].mnMinY = 0; F[t].mnMaxY = (float)H;
+      if (extractor.ExtractDesc(img.data(), W, H, W, F[t].mvKeysUn, F[t].mDescriptors) < 0) { fprintf(stderr, "%s\n", ctx.error()); return 1; }
+      if (asd::FrameAssignFeaturesToGrid(ctx, F[t]) != ASD_OK) { fprintf(stderr, "%s\n", ctx.error()); return 1; }
+    }
+    // every keypoint of frame 0 carries a map point 20 m in front of the camera (planar stand-in for the map)
+    std::vector<asd::MapPointView> mps(F[0].N());
+    std::vector<const asd::MapPointView*> pmp(F[0].N());
+    F[0].mvpMapPoints.resize(F[0].N());
+    for (int i = 0; i < F[0].N(); ++i) {
+      const float z = 20.f, u = (F[0].mvKeysUn[i].x - 620.5f) * 1.003f + 620.5f - 3.009f, v = (F[0].mvKeysUn[i].y - 188.f) * 1.003f + 188.f - 0.2006f;
+      mps[i].Xw[0] = (u - K.cx) / K.fx * z; mps[i].Xw[1] = (v - K.cy) / K.fy * z; mps[i].Xw[2] = z;
+      mps[i].normal[0] = 0; mps[i].normal[1] = 0; mps[i].normal[2] = 1;
+      mps[i].mfMinDistance = 1; mps[i].mfMaxDistance = 200;
+      mps[i].descriptor = &F[0].mDescriptors[(size_t)i * ASD_DESC_DIM];
+      pmp[i] = &mps[i];
+      F[0].mvpMapPoints[i] = i;
+    }
+    asd::ORBmatcher matcher(ctx, 0.8f, true);                                   // Tracking.cc:666
+    const int nmatches = matcher.SearchByProjection(F[1], F[0], pmp, K, 15.f);  // Tracking.cc:679
+    std::vector<const asd::MapPointView*> cur_pts(F[1].N(), nullptr);
+    for (int j = 0; j < F[1].N(); ++j) if (F[1].mvpMapPoints[j] >= 0) cur_pts[j] = &mps[F[1].mvpMapPoints[j]];
+    const int ninl = asd::Optimizer::PoseOptimization(ctx, &F[1], cur_pts, K, extractor.GetInverseScaleSigmaSquares());  // :693
+    printf("kp0=%d kp1=%d matches=%d inliers=%d t=(%.4f %.4f %.4f)\n", F[0].N(), F[1].N(), nmatches, ninl, F[1].mTcw[3], F[1].mTcw[7], F[1].mTcw[11]);
+    return (nmatches > 100 && ninl > 50) ? 0 : 1;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "error: %s\n", e.what());
+    return 3;
+  }
+}

@@ -288,3 +288,21 @@ def test_matchers_on_real_extraction(hip, oracle, synth):
                                          15.0, True)
     np.testing.assert_array_equal(got, exp)
     assert ng == ne and ng > 300
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_example(synth, tmp_path):
+    """asd-slam_amd/host: the C++ mirror of ORBextractor / ORBmatcher / Optimizer drives the C ABI end to end."""
+    import os, subprocess
+    from tests.conftest import ROOT
+    exe = os.path.join(ROOT, "asd-slam_amd", "host", "example_track")
+    assert os.path.exists(exe), "host example not built (run __graft_entry__.build())"
+    with open(tmp_path / "w.bin", "wb") as f:
+        for w, m, v in synth.asdnet_weights(0):
+            f.write(w.tobytes()); f.write(m.tobytes()); f.write(v.tobytes())
+    for t in (0, 1):
+        synth.scene_frame(t).tofile(tmp_path / f"f{t}.raw")
+    p = subprocess.run([exe, str(tmp_path / "w.bin"), str(tmp_path / "f0.raw"), str(tmp_path / "f1.raw"), "1241", "376"],
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "matches=" in p.stdout
