@@ -86,105 +86,113 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 }
 
 // ---------------------------------------------------------------- P1: PoseOptimization, one workgroup
+// Edge data ([n][6] = Xw, obs, info), the stored errors and the level / outlier flags live in LDS for
+// the whole optimisation (64 B + 2 B per edge: n <= 2300 fits the 160 KiB of a CU; larger n streams
+// from HBM).  Every pass over the edges evaluates residuals, robust cost AND the normal equations
+// at the trial pose, so an accepted Levenberg trial already holds the next iteration's system
+// (g2o recomputes both at the same estimate: identical values, one pass instead of three).
 struct PoseOptArgs {
   int n;
-  const double *Xw, *obs, *info;
+  const double* edges;  // [n][6]
   double fx, fy, cx, cy;
-  double* err;       // [n][2] scratch: edge->_error as last computed
-  uint8_t* level;    // [n] scratch
-  uint8_t* outlier;  // [n] out
-  double* pose;      // [7] in/out
-  int* n_bad;        // out
+  double* err_g;        // [n][2] global scratch (used when the problem does not fit LDS)
+  uint8_t* flags_g;     // [2n] global scratch: level, outlier
+  double* io;           // in: pose[7]; out: pose[7], n_bad (as double), then outlier bytes at io + 8
+  int use_lds;
 };
 
 struct PoseShared {
   Pose7 T, T0, Tbak;
   double H[36], b[6], x[6];
-  double sums[28];
-  double red[4 * 28];
+  double sums[29];
+  double red[4 * 29];
   double lambda, ni, currentChi, iniChi, rho;
-  int qmax, nBad, cont, stop, ok;
-  int icount;
+  int qmax, cont, ok, sys_valid, stop, pad[1];
 };
+static_assert(sizeof(PoseShared) % 16 == 0, "keeps the dynamic LDS region 16-B aligned");
 
-__device__ inline void pose_edge_error(const PoseOptArgs& a, const Pose7& T, int i) {
-  double Xc[3];
-  pose_map(T, a.Xw + 3 * i, Xc);
-  a.err[2 * i] = a.obs[2 * i] - (Xc[0] / Xc[2] * a.fx + a.cx);
-  a.err[2 * i + 1] = a.obs[2 * i + 1] - (Xc[1] / Xc[2] * a.fy + a.cy);
+// one pass over the active edges at pose T: sums[0..20] = upper H, [21..26] = b, [27] = robust chi2, [28] = #active
+__device__ inline void pose_pass(const PoseOptArgs& a, const double* ed, double* er, const uint8_t* lvl, PoseShared& S,
+                                 bool robust) {
+  const Pose7 T = S.T;
+  double acc[29];
+#pragma unroll
+  for (int k = 0; k < 29; ++k) acc[k] = 0.0;
+  for (int i = threadIdx.x; i < a.n; i += 256) {
+    if (lvl[i]) continue;
+    const double* e = ed + 6 * i;
+    double Xc[3], J[12];
+    pose_map(T, e, Xc);
+    const double e0 = e[3] - (Xc[0] / Xc[2] * a.fx + a.cx);
+    const double e1 = e[4] - (Xc[1] / Xc[2] * a.fy + a.cy);
+    er[2 * i] = e0; er[2 * i + 1] = e1;
+    const double c = (e0 * e0 + e1 * e1) * e[5];
+    double r0 = c, w = 1.0;
+    if (robust) huber(c, huber_delta(), r0, w);
+    jac_pose(Xc[0], Xc[1], Xc[2], a.fx, a.fy, J);
+    const double om = e[5] * w;
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = r; cc < 6; ++cc) acc[k++] += om * (J[r] * J[cc] + J[6 + r] * J[6 + cc]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] -= om * (J[r] * e0 + J[6 + r] * e1);
+    acc[27] += r0;
+    acc[28] += 1.0;
+  }
+  block_reduce<29>(acc, S.red, S.sums);
 }
 
-__device__ inline double pose_active_chi2(const PoseOptArgs& a, PoseShared& S, bool robust, bool recompute) {
-  const Pose7 T = S.T;
-  double part[1] = {0.0};
-  for (int i = threadIdx.x; i < a.n; i += 256) {
-    if (a.level[i]) continue;
-    if (recompute) pose_edge_error(a, T, i);
-    const double e0 = a.err[2 * i], e1 = a.err[2 * i + 1];
-    const double c = (e0 * e0 + e1 * e1) * a.info[i];
-    double r0 = c, r1;
-    if (robust) huber(c, huber_delta(), r0, r1);
-    part[0] += r0;
-  }
-  block_reduce<1>(part, S.red, S.sums);
-  return S.sums[0];
+__device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H, b
+  int k = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) { S.H[r * 6 + c] = S.sums[k]; S.H[c * 6 + r] = S.sums[k]; ++k; }
+  for (int r = 0; r < 6; ++r) S.b[r] = S.sums[21 + r];
 }
 
 __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
   __shared__ PoseShared S;
+  extern __shared__ __attribute__((aligned(16))) double dyn[];
   const int t = threadIdx.x;
+  const double* ed = a.edges;
+  double* er = a.err_g;
+  uint8_t* lvl = a.flags_g;
+  uint8_t* outl = a.flags_g + a.n;
+  if (a.use_lds) {
+    double* led = dyn;
+    er = dyn + (size_t)6 * a.n;
+    lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)8 * a.n);
+    outl = lvl + a.n;
+    for (int i = t; i < 6 * a.n; i += 256) led[i] = a.edges[i];
+    ed = led;
+  }
+  for (int i = t; i < a.n; i += 256) { lvl[i] = 0; outl[i] = 0; }
   if (t == 0) {
-    Pose7 T0{a.pose[0], a.pose[1], a.pose[2], a.pose[3], a.pose[4], a.pose[5], a.pose[6]};
+    Pose7 T0{a.io[0], a.io[1], a.io[2], a.io[3], a.io[4], a.io[5], a.io[6]};
     quat_normalize(T0.qx, T0.qy, T0.qz, T0.qw);
     S.T0 = T0;
     S.T = T0;
-    S.nBad = 0;
   }
-  for (int i = t; i < a.n; i += 256) { a.level[i] = 0; a.outlier[i] = 0; }
   __syncthreads();
   bool robust = true;
+  int nBad = 0;
   for (int round = 0; round < 4; ++round) {
     if (t == 0) S.T = S.T0;  // every round restarts from the input pose (Optimizer.cc:337)
-    double cnt[1] = {0.0};
-    for (int i = t; i < a.n; i += 256) cnt[0] += a.level[i] ? 0.0 : 1.0;
-    block_reduce<1>(cnt, S.red, S.sums);
-    const bool any_active = S.sums[0] > 0.5;
     __syncthreads();
+    pose_pass(a, ed, er, lvl, S, robust);
+    const bool any_active = S.sums[28] > 0.5;
     if (any_active) {
       // ---- g2o optimize(10): Levenberg (optimization_algorithm_levenberg.cpp:61-189)
       int nBadIt = 0;
+      if (t == 0) S.sys_valid = 1;
+      __syncthreads();
       for (int it = 0; it < 10; ++it) {
-        const double chi = pose_active_chi2(a, S, robust, true);
-        if (t == 0) { S.currentChi = chi; S.iniChi = chi; }
-        // buildSystem: H (21 upper entries) and b
-        double acc[27];
-        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-        {
-          const Pose7 T = S.T;
-          for (int i = t; i < a.n; i += 256) {
-            if (a.level[i]) continue;
-            double Xc[3], J[12];
-            pose_map(T, a.Xw + 3 * i, Xc);
-            jac_pose(Xc[0], Xc[1], Xc[2], a.fx, a.fy, J);
-            const double e0 = a.err[2 * i], e1 = a.err[2 * i + 1];
-            double w = 1.0, r0;
-            if (robust) huber((e0 * e0 + e1 * e1) * a.info[i], huber_delta(), r0, w);
-            const double om = a.info[i] * w;
-            int k = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-              for (int c = r; c < 6; ++c) acc[k++] += om * (J[r] * J[c] + J[6 + r] * J[6 + c]);
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[21 + r] -= om * (J[r] * e0 + J[6 + r] * e1);
-          }
-        }
-        block_reduce<27>(acc, S.red, S.sums);
+        if (!S.sys_valid) pose_pass(a, ed, er, lvl, S, robust);  // only after a non-finite trial
         if (t == 0) {
-          int k = 0;
-          for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) { S.H[r * 6 + c] = S.sums[k]; S.H[c * 6 + r] = S.sums[k]; ++k; }
-          for (int r = 0; r < 6; ++r) S.b[r] = S.sums[21 + r];
+          S.currentChi = S.sums[27];
+          S.iniChi = S.sums[27];
+          pose_take_system(S);
           if (it == 0) {
             double md = 0;
             for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[j * 7]), md);
@@ -203,8 +211,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
             if (S.ok) S.T = pose_oplus(S.T, S.x);
           }
           __syncthreads();
-          double tempChi = pose_active_chi2(a, S, robust, true);
+          pose_pass(a, ed, er, lvl, S, robust);
           if (t == 0) {
+            double tempChi = S.sums[27];
             if (!S.ok) tempChi = 1.7976931348623157e308;
             double rho = S.currentChi - tempChi;
             double scale = 0;
@@ -217,10 +226,12 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
               S.lambda *= fmax(1. / 3., alpha);
               S.ni = 2;
               S.currentChi = tempChi;
+              S.sys_valid = 1;  // sums hold the system at the accepted estimate
             } else {
               S.lambda *= S.ni;
               S.ni *= 2;
               S.T = S.Tbak;
+              S.sys_valid = 0;
             }
             S.rho = rho;
             S.qmax++;
@@ -228,14 +239,17 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
           }
           __syncthreads();
         } while (S.cont);
-        bool stop = false;
-        if (S.qmax == 10 || S.rho == 0) stop = true;
-        else {
-          if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) nBadIt++; else nBadIt = 0;
-          if (nBadIt >= 3) stop = true;
+        if (t == 0) {
+          int stop = 0;
+          if (S.qmax == 10 || S.rho == 0) stop = 1;
+          else {
+            if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) nBadIt++; else nBadIt = 0;
+            if (nBadIt >= 3) stop = 1;
+          }
+          S.stop = stop;
         }
         __syncthreads();
-        if (stop) break;
+        if (S.stop) break;
       }
     }
     // ---- re-classification (Optimizer.cc:341-368)
@@ -243,24 +257,33 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
     {
       const Pose7 T = S.T;
       for (int i = t; i < a.n; i += 256) {
-        if (a.outlier[i]) pose_edge_error(a, T, i);
-        const double e0 = a.err[2 * i], e1 = a.err[2 * i + 1];
-        const float chi2 = (float)((e0 * e0 + e1 * e1) * a.info[i]);
-        if (chi2 > kChi2Mono) { a.outlier[i] = 1; a.level[i] = 1; nb[0] += 1.0; }
-        else { a.outlier[i] = 0; a.level[i] = 0; }
+        const double* e = ed + 6 * i;
+        if (outl[i]) {  // e->computeError()
+          double Xc[3];
+          pose_map(T, e, Xc);
+          er[2 * i] = e[3] - (Xc[0] / Xc[2] * a.fx + a.cx);
+          er[2 * i + 1] = e[4] - (Xc[1] / Xc[2] * a.fy + a.cy);
+        }
+        const double e0 = er[2 * i], e1 = er[2 * i + 1];
+        const float chi2 = (float)((e0 * e0 + e1 * e1) * e[5]);
+        if (chi2 > kChi2Mono) { outl[i] = 1; lvl[i] = 1; nb[0] += 1.0; }
+        else { outl[i] = 0; lvl[i] = 0; }
       }
     }
+    __syncthreads();
     block_reduce<1>(nb, S.red, S.sums);
-    if (t == 0) S.nBad = (int)(S.sums[0] + 0.5);
+    nBad = (int)(S.sums[0] + 0.5);
     __syncthreads();
     if (round == 2) robust = false;  // e->setRobustKernel(0)
     if (a.n < 10) break;             // optimizer.edges().size() < 10
   }
   if (t == 0) {
-    a.pose[0] = S.T.qx; a.pose[1] = S.T.qy; a.pose[2] = S.T.qz; a.pose[3] = S.T.qw;
-    a.pose[4] = S.T.tx; a.pose[5] = S.T.ty; a.pose[6] = S.T.tz;
-    *a.n_bad = S.nBad;
+    a.io[0] = S.T.qx; a.io[1] = S.T.qy; a.io[2] = S.T.qz; a.io[3] = S.T.qw;
+    a.io[4] = S.T.tx; a.io[5] = S.T.ty; a.io[6] = S.T.tz;
+    a.io[7] = (double)nBad;
   }
+  uint8_t* og = reinterpret_cast<uint8_t*>(a.io + 8);
+  for (int i = t; i < a.n; i += 256) og[i] = outl[i];
 }
 
 // ---------------------------------------------------------------- LocalBA kernels
@@ -369,22 +392,26 @@ __device__ inline void atomic_max_pos_double(unsigned long long* addr, double v)
   atomicMax(addr, (unsigned long long)__double_as_longlong(v));
 }
 
-// Hpp_i, bp_i = fixed-shape segmented sum over the pose's edges: 8 groups x 32 lanes
+// Hpp_i, bp_i = segmented sum over the pose's edges with a fixed shape: thread-strided partial sums,
+// then the fixed-order block reduction (bit-reproducible).
 __global__ __launch_bounds__(256) void k_ba_reduce_pose(BaDev d) {
-  __shared__ double part[8][27];
-  const int h = blockIdx.x, g = threadIdx.x >> 5, l = threadIdx.x & 31;
+  __shared__ double red[4 * 27], out[27];
+  const int h = blockIdx.x;
   const int b = d.ps_start[h], e = d.ps_start[h + 1];
-  double acc = 0.0;
-  if (l < 27)
-    for (int i = b + g; i < e; i += 8) acc += d.Hc[(size_t)d.ps_edges[i] * 27 + l];
-  if (l < 27) part[g][l] = acc;
-  __syncthreads();
+  double acc[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+  for (int i = b + threadIdx.x; i < e; i += 256) {
+    const double* hc = d.Hc + (size_t)d.ps_edges[i] * 27;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) acc[q] += hc[q];
+  }
+  block_reduce<27>(acc, red, out);
   if (threadIdx.x < 27) {
-    double s = 0.0;
-    for (int gg = 0; gg < 8; ++gg) s += part[gg][threadIdx.x];
-    d.Hpp[(size_t)h * 27 + threadIdx.x] = s;
-    // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
     const int t = threadIdx.x;
+    const double s = out[t];
+    d.Hpp[(size_t)h * 27 + t] = s;
+    // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
     if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(d.maxdiag_bits, fabs(s));
   }
 }
@@ -437,29 +464,34 @@ struct SchurBlocks {
   const int2* pairs;
 };
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb, double lambda) {
-  __shared__ double part[4][42];
+  __shared__ double red[4 * 42], out[42];
   const int blk = blockIdx.x, bi = sb.blk_i[blk], bj = sb.blk_j[blk];
-  const int g = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int n = 6 * d.nPf;
-  double acc = 0.0;
-  if (l < 36) {
-    const int r = l / 6, c = l % 6;
-    for (int p = sb.pair_start[blk] + g; p < sb.pair_start[blk + 1]; p += 4) {
-      const int2 pr = sb.pairs[p];
-      const double* Y = d.Yk + (size_t)pr.x * 18 + r * 3;
-      const double* B = d.Bk + (size_t)pr.y * 18 + c * 3;
-      acc += Y[0] * B[0] + Y[1] * B[1] + Y[2] * B[2];
-    }
-  } else if (l < 42 && bi == bj) {
-    const int r = l - 36;
-    for (int i = d.ps_start[bi] + g; i < d.ps_start[bi + 1]; i += 4) acc += d.ck[(size_t)d.ps_edges[i] * 6 + r];
+  double acc[42];
+#pragma unroll
+  for (int q = 0; q < 42; ++q) acc[q] = 0.0;
+  for (int p = sb.pair_start[blk] + threadIdx.x; p < sb.pair_start[blk + 1]; p += 256) {
+    const int2 pr = sb.pairs[p];
+    const double* Y = d.Yk + (size_t)pr.x * 18;
+    const double* B = d.Bk + (size_t)pr.y * 18;
+    double y[18], bb[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) { y[q] = Y[q]; bb[q] = B[q]; }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc[r * 6 + c] += y[r * 3] * bb[c * 3] + y[r * 3 + 1] * bb[c * 3 + 1] + y[r * 3 + 2] * bb[c * 3 + 2];
   }
-  if (l < 42) part[g][l] = acc;
-  __syncthreads();
+  if (bi == bj)
+    for (int i = d.ps_start[bi] + threadIdx.x; i < d.ps_start[bi + 1]; i += 256) {
+      const double* cc = d.ck + (size_t)d.ps_edges[i] * 6;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[36 + r] += cc[r];
+    }
+  block_reduce<42>(acc, red, out);
   if (threadIdx.x < 36) {
     const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-    const double s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    double v = -s;
+    double v = -out[threadIdx.x];
     if (bi == bj) {
       const int rr = min(r, c), cc = max(r, c);
       const int q = rr * 6 - rr * (rr - 1) / 2 + (cc - rr);  // index in the upper-packed 6x6
@@ -469,9 +501,126 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb, doubl
     if (bi != bj) d.A[(size_t)(6 * bj + c) * n + 6 * bi + r] = v;
   } else if (threadIdx.x < 42 && bi == bj) {
     const int r = threadIdx.x - 36;
-    const double s = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-    d.bs[6 * bi + r] = d.Hpp[(size_t)bi * 27 + 21 + r] - s;
+    d.bs[6 * bi + r] = d.Hpp[(size_t)bi * 27 + 21 + r] - out[threadIdx.x];
   }
+}
+
+// Dense SPD solve with the matrix resident in LDS: lower triangle packed by 6x6 blocks
+// (block (I,J), J <= I at ((I(I+1)/2 + J) * 36), up to 32 pose blocks = 152 KB).  Right-looking
+// block Cholesky, then block forward / backward substitution.  One workgroup, 1024 threads.
+__global__ __launch_bounds__(1024) void k_ba_chol_lds(const double* __restrict__ A, const double* __restrict__ bs,
+                                                      double* __restrict__ x, int n, int* status) {
+  // all LDS in the dynamic region (a static in front of it would shift its base off 16-B alignment)
+  extern __shared__ __attribute__((aligned(16))) double L[];
+  const int t = threadIdx.x, nt = blockDim.x, nb = n / 6;
+  const int nblk = nb * (nb + 1) / 2;
+  double* xs = L + (size_t)nblk * 36;
+  int& ok = *reinterpret_cast<int*>(xs + 192);
+#define LB(I, J) (L + ((size_t)((I) * ((I) + 1) / 2 + (J))) * 36)
+  for (int idx = t; idx < nblk * 36; idx += nt) {
+    const int blk = idx / 36, e = idx % 36;
+    int I = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= blk) ++I;
+    while (I * (I + 1) / 2 > blk) --I;
+    const int J = blk - I * (I + 1) / 2;
+    L[idx] = A[(size_t)(6 * I + e / 6) * n + 6 * J + e % 6];
+  }
+  for (int i = t; i < n; i += nt) xs[i] = bs[i];
+  if (t == 0) ok = 1;
+  __syncthreads();
+  for (int jb = 0; jb < nb; ++jb) {
+    if (t == 0) {  // factor the diagonal block in place
+      double* a = LB(jb, jb);
+      for (int j = 0; j < 6; ++j) {
+        double dgl = a[j * 6 + j];
+        for (int k = 0; k < j; ++k) dgl -= a[j * 6 + k] * a[j * 6 + k];
+        if (!(dgl > 0)) { ok = 0; dgl = 1.0; }
+        dgl = sqrt(dgl);
+        a[j * 6 + j] = dgl;
+        for (int i = j + 1; i < 6; ++i) {
+          double s = a[i * 6 + j];
+          for (int k = 0; k < j; ++k) s -= a[i * 6 + k] * a[j * 6 + k];
+          a[i * 6 + j] = s / dgl;
+        }
+        for (int c = j + 1; c < 6; ++c) a[j * 6 + c] = 0.0;
+      }
+    }
+    __syncthreads();
+    const double* Ljj = LB(jb, jb);
+    // panel: every row below solves against Ljj^T
+    for (int row = t; row < (nb - jb - 1) * 6; row += nt) {
+      const int I = jb + 1 + row / 6, r = row % 6;
+      double* a = LB(I, jb) + r * 6;
+      double v[6];
+      for (int c = 0; c < 6; ++c) v[c] = a[c];
+      for (int c = 0; c < 6; ++c) {
+        double s = v[c];
+        for (int k = 0; k < c; ++k) s -= v[k] * Ljj[c * 6 + k];
+        v[c] = s / Ljj[c * 6 + c];
+      }
+      for (int c = 0; c < 6; ++c) a[c] = v[c];
+    }
+    __syncthreads();
+    // trailing update: block (I,K), I >= K > jb
+    const int m = nb - jb - 1, mblk = m * (m + 1) / 2;
+    for (int idx = t; idx < mblk * 36; idx += nt) {
+      const int bq = idx / 36, e = idx % 36;
+      int Ii = (int)((sqrt(8.0 * bq + 1.0) - 1.0) * 0.5);
+      while ((Ii + 1) * (Ii + 2) / 2 <= bq) ++Ii;
+      while (Ii * (Ii + 1) / 2 > bq) --Ii;
+      const int Ki = bq - Ii * (Ii + 1) / 2;
+      const int I = jb + 1 + Ii, K = jb + 1 + Ki, r = e / 6, c = e % 6;
+      const double* li = LB(I, jb) + r * 6;
+      const double* lk = LB(K, jb) + c * 6;
+      double s = 0.0;
+      for (int k = 0; k < 6; ++k) s += li[k] * lk[k];
+      LB(I, K)[e] -= s;
+    }
+    __syncthreads();
+  }
+  // forward substitution
+  for (int jb = 0; jb < nb; ++jb) {
+    if (t == 0) {
+      const double* a = LB(jb, jb);
+      for (int r = 0; r < 6; ++r) {
+        double s = xs[6 * jb + r];
+        for (int k = 0; k < r; ++k) s -= a[r * 6 + k] * xs[6 * jb + k];
+        xs[6 * jb + r] = s / a[r * 6 + r];
+      }
+    }
+    __syncthreads();
+    for (int row = t; row < (nb - jb - 1) * 6; row += nt) {
+      const int I = jb + 1 + row / 6, r = row % 6;
+      const double* a = LB(I, jb) + r * 6;
+      double s = 0.0;
+      for (int c = 0; c < 6; ++c) s += a[c] * xs[6 * jb + c];
+      xs[6 * I + r] -= s;
+    }
+    __syncthreads();
+  }
+  // backward substitution (L^T)
+  for (int jb = nb - 1; jb >= 0; --jb) {
+    if (t == 0) {
+      const double* a = LB(jb, jb);
+      for (int r = 5; r >= 0; --r) {
+        double s = xs[6 * jb + r];
+        for (int k = r + 1; k < 6; ++k) s -= a[k * 6 + r] * xs[6 * jb + k];
+        xs[6 * jb + r] = s / a[r * 6 + r];
+      }
+    }
+    __syncthreads();
+    for (int row = t; row < jb * 6; row += nt) {
+      const int I = row / 6, r = row % 6;  // x_I -= L(jb,I)^T x_jb
+      const double* a = LB(jb, I);
+      double s = 0.0;
+      for (int c = 0; c < 6; ++c) s += a[c * 6 + r] * xs[6 * jb + c];
+      xs[6 * I + r] -= s;
+    }
+    __syncthreads();
+  }
+#undef LB
+  for (int i = t; i < n; i += nt) x[i] = xs[i];
+  if (t == 0) *status = ok;
 }
 
 // dense SPD solve A x = bs (n = 6 nPf) in one workgroup: right-looking Cholesky on 6-wide panels,
@@ -675,6 +824,8 @@ struct BaState {
   double* h_partial = nullptr;  // pinned
   size_t h_partial_cap = 0;
   int* h_misc = nullptr;        // pinned: status, maxdiag (2 ints), n_bad
+  char* h_po = nullptr;         // pinned staging of asd_pose_optimize
+  size_t h_po_cap = 0;
 };
 
 BaState* ba_state(asd_ctx* ctx) {
@@ -695,6 +846,7 @@ void ba_free(asd_ctx* ctx) {
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (s->h_partial) (void)hipHostFree(s->h_partial);
   if (s->h_misc) (void)hipHostFree(s->h_misc);
+  if (s->h_po) (void)hipHostFree(s->h_po);
   delete s;
   ctx->ba = nullptr;
 }
@@ -709,36 +861,51 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   (void)hipSetDevice(ctx->cfg.device);
   BaState* s = ba_state(ctx);
   int rc;
-  if ((rc = s->po_Xw.ensure(ctx, (size_t)n * 24)) || (rc = s->po_obs.ensure(ctx, (size_t)n * 16)) ||
-      (rc = s->po_info.ensure(ctx, (size_t)n * 8)) || (rc = s->po_err.ensure(ctx, (size_t)n * 16)) ||
-      (rc = s->po_level.ensure(ctx, n)) || (rc = s->po_outlier.ensure(ctx, n)) || (rc = s->po_pose.ensure(ctx, 64)))
+  const size_t in_bytes = (size_t)n * 48 + 64, io_bytes = 64 + (size_t)n + 64;
+  if ((rc = s->po_Xw.ensure(ctx, in_bytes)) || (rc = s->po_err.ensure(ctx, (size_t)n * 16)) ||
+      (rc = s->po_level.ensure(ctx, (size_t)2 * n)) || (rc = s->po_pose.ensure(ctx, io_bytes)))
     return rc;
-  if (!s->h_misc) ASD_HIP_CHECK(ctx, hipHostMalloc(&s->h_misc, 64));
+  if (s->h_po_cap < in_bytes + io_bytes) {
+    if (s->h_po) (void)hipHostFree(s->h_po);
+    s->h_po_cap = 0;
+    ASD_HIP_CHECK(ctx, hipHostMalloc(&s->h_po, 2 * (in_bytes + io_bytes)));
+    s->h_po_cap = 2 * (in_bytes + io_bytes);
+  }
+  // one pinned staging buffer: [n][6] edges, then the io block
+  double* hin = reinterpret_cast<double*>(s->h_po);
+  for (int i = 0; i < n; ++i) {
+    hin[6 * i] = Xw[3 * i]; hin[6 * i + 1] = Xw[3 * i + 1]; hin[6 * i + 2] = Xw[3 * i + 2];
+    hin[6 * i + 3] = obs[2 * i]; hin[6 * i + 4] = obs[2 * i + 1]; hin[6 * i + 5] = inv_sigma2[i];
+  }
+  double* hio = reinterpret_cast<double*>(s->h_po + in_bytes);
+  memcpy(hio, pose7, 56);
   hipStream_t st = ctx->stream;
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_Xw.p, Xw, (size_t)n * 24, hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_obs.p, obs, (size_t)n * 16, hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_info.p, inv_sigma2, (size_t)n * 8, hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_pose.p, pose7, 56, hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_Xw.p, hin, (size_t)n * 48, hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_pose.p, hio, 56, hipMemcpyHostToDevice, st));
   PoseOptArgs a;
   a.n = n;
-  a.Xw = s->po_Xw.as<double>(); a.obs = s->po_obs.as<double>(); a.info = s->po_info.as<double>();
+  a.edges = s->po_Xw.as<double>();
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
-  a.err = s->po_err.as<double>(); a.level = s->po_level.as<uint8_t>(); a.outlier = s->po_outlier.as<uint8_t>();
-  a.pose = s->po_pose.as<double>();
-  a.n_bad = reinterpret_cast<int*>(s->po_pose.as<double>() + 7);
+  a.err_g = s->po_err.as<double>();
+  a.flags_g = s->po_level.as<uint8_t>();
+  a.io = s->po_pose.as<double>();
+  const size_t lds = (size_t)n * 64 + (size_t)2 * n + 16;
+  a.use_lds = lds <= 150 * 1024 ? 1 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), a.use_lds ? lds : 0, st, a);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
-  double out[8];
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(out, s->po_pose.p, 64, hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(outlier, s->po_outlier.p, n, hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(hio, s->po_pose.p, 64 + (size_t)n, hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_ba, ctx->ev0, ctx->ev1));
-  memcpy(pose7, out, 56);
-  int nbad;
-  memcpy(&nbad, &out[7], sizeof(int));
-  *n_inliers = n - nbad;
+  memcpy(pose7, hio, 56);
+  memcpy(outlier, hio + 8, n);
+  *n_inliers = n - (int)(hio[7] + 0.5);
   return ASD_OK;
 }
 
@@ -939,7 +1106,17 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
         hipLaunchKernelGGL(k_ba_point_dinv, dim3(gL), dim3(256), 0, st, d, lambda);
         if (nPf > 0) {
           hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, st, d, sb, lambda);
-          hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, d.A, d.bs, d.x, n, d.status);
+          if (nPf <= 32) {
+            const size_t lds = (size_t)(nPf * (nPf + 1) / 2) * 36 * sizeof(double) + 192 * sizeof(double) + 16;
+            static bool chol_attr = false;
+            if (!chol_attr) {
+              ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+              chol_attr = true;
+            }
+            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), lds, st, d.A, d.bs, d.x, n, d.status);
+          } else {
+            hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, d.A, d.bs, d.x, n, d.status);
+          }
         }
         hipLaunchKernelGGL(k_ba_backsub, dim3(gL), dim3(256), 0, st, d, lambda);
         hipLaunchKernelGGL(k_ba_update_pose, dim3(gP), dim3(256), 0, st, d, lambda, d.scale_off + gL);
