@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libasdhip.so")
+    # ASDHIP_LIB: tuning aid to A/B differently built libraries; the default is the in-tree build
+    return os.environ.get("ASDHIP_LIB") or os.path.join(_HERE, "libasdhip.so")
 
 
 class AsdError(RuntimeError):

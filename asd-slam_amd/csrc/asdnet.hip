@@ -30,61 +30,6 @@ const LayerSpec kLayers[7] = {{32, 1, 3, 1, 1},   {32, 32, 3, 1, 1},   {64, 32, 
                               {128, 64, 3, 2, 1}, {128, 128, 3, 1, 1}, {128, 128, 8, 1, 0}};
 
 // ------------------------------------------------------------------------------------------
-// K0: input_norm (ASDNet.py:360-365) + conv1 + BN + ReLU, VALU (K = 9 is too short for MFMA).
-// One workgroup per patch; output NHWC [n][32][32][32].
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_norm_conv1(const uint8_t* __restrict__ patches,
-                                                    const float* __restrict__ w1, const float* __restrict__ b1,
-                                                    float* __restrict__ out) {
-  __shared__ float tile[34 * 34];
-  __shared__ float red[8];
-  __shared__ float wsh[32 * 9 + 32];
-  const int p = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int i = t; i < 34 * 34; i += 256) tile[i] = 0.f;
-  for (int i = t; i < 32 * 9; i += 256) wsh[i] = w1[i];
-  if (t < 32) wsh[288 + t] = b1[t];
-  const uchar4 v = reinterpret_cast<const uchar4*>(patches + (size_t)p * 1024)[t];
-  const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
-  float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
-  float s = (x[0] + x[1]) + (x[2] + x[3]);
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
-  float d[4], ss = 0.f;
-  for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
-  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-  if (lane == 0) red[4 + wave] = ss;
-  __syncthreads();
-  const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
-  {
-    const int idx = t * 4, y = idx >> 5, x0 = idx & 31;
-    for (int k = 0; k < 4; ++k) tile[(y + 1) * 34 + x0 + k + 1] = d[k] / sd;
-  }
-  __syncthreads();
-  const int q = t & 7, pg = t >> 3;
-  float w[4][9], b[4];
-  for (int c = 0; c < 4; ++c) {
-    b[c] = wsh[288 + 4 * q + c];
-    for (int k = 0; k < 9; ++k) w[c][k] = wsh[(4 * q + c) * 9 + k];
-  }
-  float* op = out + (size_t)p * 32768;
-  for (int i = 0; i < 32; ++i) {
-    const int pix = i * 32 + pg, y = pix >> 5, xx = pix & 31;
-    float a[9];
-    for (int ky = 0; ky < 3; ++ky)
-      for (int kx = 0; kx < 3; ++kx) a[ky * 3 + kx] = tile[(y + ky) * 34 + xx + kx];
-    f32x4 r;
-    for (int c = 0; c < 4; ++c) {
-      float acc = b[c];
-      for (int k = 0; k < 9; ++k) acc += a[k] * w[c][k];
-      r[c] = acc > 0.f ? acc : 0.f;
-    }
-    *reinterpret_cast<f32x4*>(op + (size_t)pix * 32 + 4 * q) = r;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // K1: 3x3 conv (pad 1, stride S) + folded BN + ReLU as an implicit GEMM on f32 MFMA.
 // One workgroup = ROWS output rows of one patch; 4 waves as WM (pixels) x WN (channels).
 // ------------------------------------------------------------------------------------------
@@ -109,9 +54,13 @@ struct ConvCfg {
   static_assert(HO % ROWS == 0 && CIN % KC == 0 && KC % 8 == 0, "shape");
 };
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
-__global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in, const float* __restrict__ wimg,
-                                                   const float* __restrict__ bias, float* __restrict__ out) {
+// FUSE1: the kernel is conv2 and computes its own input (input_norm + conv1 + BN + ReLU, ASDNet.py:334-336,
+// 360-365) from the raw u8 patch while filling the LDS band, so conv1's 128 KB/patch activation never
+// exists in HBM.  `in` is then the u8 patch array and w1 / b1 the folded conv1 weights.
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int ABL = 0, bool FUSE1 = false>
+__global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_, const float* __restrict__ wimg,
+                                                   const float* __restrict__ bias, float* __restrict__ out,
+                                                   const float* __restrict__ w1, const float* __restrict__ b1) {
   using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sact = smem;
@@ -121,18 +70,72 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
   constexpr int BANDS = C::HO / ROWS;
   const int patch = blockIdx.x / BANDS, band = blockIdx.x % BANDS;
   const int r0 = band * ROWS;
-  const float* inp = in + (size_t)patch * HIN * HIN * CIN;
 
-  // ---- stage the zero-padded input band (NHWC rows are contiguous: coalesced 16-B loads)
-  constexpr int C4 = CIN / 4;
-  for (int idx = t; idx < C::INROWS * C::INCOLS * C4; idx += 256) {
-    const int c4 = idx % C4, pix = idx / C4;
-    const int i = pix % C::INCOLS, j = pix / C::INCOLS;
-    const int iy = r0 * S - 1 + j, ix = i - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (iy >= 0 && iy < HIN && ix >= 0 && ix < HIN)
-      v = *reinterpret_cast<const f32x4*>(inp + ((size_t)iy * HIN + ix) * CIN + c4 * 4);
-    *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + c4 * 4) = v;
+  if constexpr (FUSE1) {
+    static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1), "conv1 fusion is for conv2 only");
+    // extra LDS behind the weight ring: normalised input rows r0-2 .. r0+ROWS+1 (34 wide, zero padded),
+    // conv1 weights + bias, reduction scratch
+    float* pin = sw + 2 * C::WCHUNK;              // [(ROWS+4)][36]
+    float* wsh = pin + (ROWS + 4) * 36;           // [32*9 + 32]
+    float* red = wsh + 320;                       // [8]
+    const uint8_t* patches = static_cast<const uint8_t*>(in_);
+    for (int i = t; i < (ROWS + 4) * 36; i += 256) pin[i] = 0.f;
+    for (int i = t; i < 288; i += 256) wsh[i] = w1[i];
+    if (t < 32) wsh[288 + t] = b1[t];
+    const uchar4 v = reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t];
+    const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
+    float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
+    float s = (x[0] + x[1]) + (x[2] + x[3]);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
+    float d[4], ss = 0.f;
+    for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[4 + wave] = ss;
+    __syncthreads();
+    const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
+    {
+      const int idx = t * 4, y = idx >> 5, x0 = idx & 31;  // this thread's 4 pixels sit in row y
+      const int j = y - (r0 - 2);
+      if (j >= 0 && j < ROWS + 4)
+        for (int k = 0; k < 4; ++k) pin[j * 36 + x0 + k + 1] = d[k] / sd;
+    }
+    __syncthreads();
+    // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding)
+    constexpr int NPIX = C::INROWS * C::INCOLS;
+    for (int item = t; item < NPIX * 8; item += 256) {
+      const int q = item & 7, pix = item >> 3;
+      const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+      const int oy = r0 - 1 + j, ox = i - 1;
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+      if (oy >= 0 && oy < 32 && ox >= 0 && ox < 32) {
+        float a[9];
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) a[ky * 3 + kx] = pin[(j + ky) * 36 + ox + kx];  // pin row j <-> image row oy-1
+        for (int c = 0; c < 4; ++c) {
+          float acc1 = wsh[288 + 4 * q + c];
+          for (int k = 0; k < 9; ++k) acc1 += a[k] * wsh[(4 * q + c) * 9 + k];
+          r[c] = acc1 > 0.f ? acc1 : 0.f;
+        }
+      }
+      *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + 4 * q) = r;
+    }
+  } else {
+    const float* inp = static_cast<const float*>(in_) + (size_t)patch * HIN * HIN * CIN;
+    // ---- stage the zero-padded input band (NHWC rows are contiguous: coalesced 16-B loads)
+    constexpr int C4 = CIN / 4;
+    if (ABL != 1)
+    for (int idx = t; idx < C::INROWS * C::INCOLS * C4; idx += 256) {
+      const int c4 = idx % C4, pix = idx / C4;
+      const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+      const int iy = r0 * S - 1 + j, ix = i - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < HIN && ix >= 0 && ix < HIN)
+        v = *reinterpret_cast<const f32x4*>(inp + ((size_t)iy * HIN + ix) * CIN + c4 * 4);
+      *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + c4 * 4) = v;
+    }
   }
   // ---- weight stage 0
   for (int r = 0; r < C::WREGS; ++r)
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < C::NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
+            if (ABL != 2) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
+            else { asm volatile("" :: "v"(a[mt][jj]), "v"(b[nt][jj])); }
     }
     if (s + 1 < C::NSTAGE) {
       float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
@@ -194,7 +198,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const float* __restrict__ in,
       for (int r = 0; r < 16; ++r) {
         const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = acc[mt][nt][r] + bv;
-        op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
+        if (ABL != 3) op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
+        else { asm volatile("" :: "v"(v)); }
       }
   }
 }
@@ -262,24 +267,35 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
 }
 
 // layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC>
-#define L2_CFG 32, 32, 32, 1, 8, 4, 1, 32
-#define L3_CFG 32, 64, 32, 2, 4, 2, 2, 32
+#ifndef L2_CFG
+#define L2_CFG 32, 32, 32, 1, 4, 4, 1, 32
+#endif
+#ifndef L3_CFG
+#define L3_CFG 32, 64, 32, 2, 4, 2, 2, 16
+#endif
+#ifndef L4_CFG
 #define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32
-#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 16
+#endif
+#ifndef L5_CFG
+#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 8
+#endif
+#ifndef L6_CFG
 #define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16
+#endif
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
-hipError_t launch_conv(hipStream_t st, const float* in, const float* wimg, const float* bias, float* out, int n) {
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, bool FUSE1 = false>
+hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const float* bias, float* out, int n,
+                       const float* w1 = nullptr, const float* b1 = nullptr) {
   using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
-  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC, 0, FUSE1>;
+  constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       C::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n * (C::HO / ROWS)), dim3(256), C::LDS_BYTES, st, in, wimg, bias, out);
+  hipLaunchKernelGGL(kern, dim3(n * (C::HO / ROWS)), dim3(256), lds, st, in, wimg, bias, out, w1, b1);
   return hipGetLastError();
 }
 
@@ -370,10 +386,8 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   if (prof && ctx->prof_pending) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
 #define PROF_MARK(i) do { if (prof) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[i], st)); } while (0)
   PROF_MARK(0);
-  hipLaunchKernelGGL(k_norm_conv1, dim3(n), dim3(256), 0, st, d_patches, ctx->d_w1, ctx->d_bias[0], a0);
-  ASD_HIP_CHECK(ctx, hipGetLastError());
-  PROF_MARK(1);
-  ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG>(st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, n)));
+  PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
+  ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);
   ASD_HIP_CHECK(ctx, (launch_conv<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
   PROF_MARK(3);
@@ -405,5 +419,24 @@ int asdnet_profile_collect(asd_ctx* ctx) {
     ctx->prof_patches[l] += ctx->prof_pending_n;
   }
   ctx->prof_pending = false;
+  return ASD_OK;
+}
+
+// debug / tuning aid (not part of the C ABI header): time conv2 with parts of the kernel removed
+// mode 0 = full, 1 = no activation staging, 2 = no MFMA, 3 = no epilogue stores
+extern "C" int asd_debug_conv2_ablate(asd_ctx* ctx, int n, int mode, int reps, float* ms) {
+  hipStream_t st = ctx->stream;
+  float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
+  using C = ConvCfg<L2_CFG>;
+  auto k0 = k_conv_mfma<L2_CFG, 0>; auto k1 = k_conv_mfma<L2_CFG, 1>; auto k2 = k_conv_mfma<L2_CFG, 2>; auto k3 = k_conv_mfma<L2_CFG, 3>;
+  decltype(k0) ks[4] = {k0, k1, k2, k3};
+  for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(ks[mode], dim3(n * (32 / 4)), dim3(256), C::LDS_BYTES, st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, (const float*)nullptr, (const float*)nullptr);
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[mode], dim3(n * (32 / 4)), dim3(256), C::LDS_BYTES, st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, (const float*)nullptr, (const float*)nullptr);
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  *ms /= reps;
   return ASD_OK;
 }

@@ -14,4 +14,6 @@ hip.h2d(dp, patches)
 hip.describe_timed(dp, n, dd, 3)
 ms = hip.describe_timed(dp, n, dd, reps)
 tf = n * pkg.synth.ASDNET_FLOP_PER_PATCH / (ms * 1e-3) / 1e12
+hip.profile_enable(True); hip.describe_timed(dp, n, dd, 10)
+print("  per-layer us:", " ".join(f"{1e3*hip.profile_get(l)[0]/max(hip.profile_get(l)[1],1):.0f}" for l in range(8)))
 print(f"asdnet N={n}: {ms:.3f} ms/forward, {tf:.1f} TFLOP/s f32 ({tf/157.3*100:.1f}% of 157.3 TF peak)")
