@@ -17,6 +17,7 @@
 //                laid out to match, see build_wimg().
 #include "ctx.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -205,6 +206,141 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
 }
 
 // ------------------------------------------------------------------------------------------
+// K1p: the same implicit GEMM as a PERSISTENT workgroup with a double-buffered input band: while the
+// MFMAs of tile i run, the band of tile i+gridDim.x is fetched from HBM into registers (issued in
+// stage 0 behind that stage's weight prefetch, so the counted vmcnt of the weight write does not
+// drain it) and written to the other LDS buffer at the end of stage 1; the epilogue stores of tile i
+// drain under tile i+1's MFMAs.  The weight ring simply keeps cycling across tiles.
+// ------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
+__global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ in, const float* __restrict__ wimg,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int ntiles) {
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  static_assert(C::NSTAGE >= 2, "need two stages to hide the band prefetch");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sact0 = smem;
+  float* sw = smem + 2 * C::ACT_FLOATS;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  constexpr int BANDS = C::HO / ROWS;
+  constexpr int C4 = CIN / 4;
+  constexpr int NELEM = C::INROWS * C::INCOLS * C4;
+  constexpr int NPREF = (NELEM + 255) / 256;
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+
+  f32x4 pre[NPREF];
+#define LOAD_TILE(TILE)                                                                           \
+  {                                                                                               \
+    const int patch_ = (TILE) / BANDS, r0_ = ((TILE) % BANDS) * ROWS;                             \
+    const float* inp_ = in + (size_t)patch_ * HIN * HIN * CIN;                                    \
+    _Pragma("unroll") for (int p = 0; p < NPREF; ++p) {                                           \
+      const int idx = t + p * 256;                                                                \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                             \
+      if (idx < NELEM) {                                                                          \
+        const int c4 = idx % C4, pix = idx / C4;                                                  \
+        const int i = pix % C::INCOLS, j = pix / C::INCOLS;                                       \
+        const int iy = r0_ * S - 1 + j, ix = i - 1;                                               \
+        if (iy >= 0 && iy < HIN && ix >= 0 && ix < HIN)                                           \
+          v = *reinterpret_cast<const f32x4*>(inp_ + ((size_t)iy * HIN + ix) * CIN + c4 * 4);     \
+      }                                                                                           \
+      pre[p] = v;                                                                                 \
+    }                                                                                             \
+  }
+#define STORE_TILE(DST)                                                                           \
+  {                                                                                               \
+    _Pragma("unroll") for (int p = 0; p < NPREF; ++p) {                                           \
+      const int idx = t + p * 256;                                                                \
+      if (idx < NELEM) {                                                                          \
+        const int c4 = idx % C4, pix = idx / C4;                                                  \
+        *reinterpret_cast<f32x4*>((DST) + pix * C::CPAD + c4 * 4) = pre[p];                       \
+      }                                                                                           \
+    }                                                                                             \
+  }
+  LOAD_TILE(tile);
+  STORE_TILE(sact0);
+  for (int r = 0; r < C::WREGS; ++r)
+    *reinterpret_cast<f32x4*>(sw + (r * 256 + t) * 4) = *reinterpret_cast<const f32x4*>(wimg + (r * 256 + t) * 4);
+  __syncthreads();
+
+  const int h = lane >> 5, li = lane & 31;
+  int abase[C::MT];
+  for (int mt = 0; mt < C::MT; ++mt) {
+    const int m = (wm * C::MT + mt) * 32 + li;
+    const int rr = m / C::HO, ox = m % C::HO;
+    abase[mt] = ((rr * S) * C::INCOLS + ox * S) * C::CPAD + 4 * h;
+  }
+  const int bbase = (h * COUT + wn * C::NT * 32 + li) * 4;
+  float bv[C::NT];
+  for (int nt = 0; nt < C::NT; ++nt) bv[nt] = bias[(wn * C::NT + nt) * 32 + li];
+
+  int cur = 0, g = 0;
+  while (true) {
+    const int next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+    const float* sact = sact0 + cur * C::ACT_FLOATS;
+    f32x16 acc[C::MT][C::NT];
+    for (int mt = 0; mt < C::MT; ++mt)
+      for (int nt = 0; nt < C::NT; ++nt)
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    for (int s = 0; s < C::NSTAGE; ++s) {
+      f32x4 wreg[C::WREGS];
+      {
+        const int sn = (s + 1 == C::NSTAGE) ? 0 : s + 1;  // the ring keeps cycling across tiles
+        const float* wsrc = wimg + (size_t)sn * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * 256 + t) * 4);
+      }
+      if (s == 0 && has_next) LOAD_TILE(next);
+      const int tap = s / C::NCC, cc = s % C::NCC;
+      const int tapoff = ((tap / 3) * C::INCOLS + (tap % 3)) * C::CPAD + cc * KC;
+      const float* swb = sw + (g & 1) * C::WCHUNK;
+#pragma unroll
+      for (int c8 = 0; c8 < KC / 8; ++c8) {
+        f32x4 a[C::MT], b[C::NT];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sact + abase[mt] + tapoff + c8 * 8);
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+          b[nt] = *reinterpret_cast<const f32x4*>(swb + bbase + c8 * 2 * COUT * 4 + nt * 128);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
+      }
+      {
+        float* swn = sw + ((g + 1) & 1) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r) *reinterpret_cast<f32x4*>(swn + (r * 256 + t) * 4) = wreg[r];
+      }
+      if (s == 1 && has_next) STORE_TILE(sact0 + (cur ^ 1) * C::ACT_FLOATS);
+      __syncthreads();
+      ++g;
+    }
+    // epilogue: bias (folded BN) + ReLU, NHWC store; drains under the next tile's MFMAs
+    {
+      const int patch = tile / BANDS, r0 = (tile % BANDS) * ROWS;
+      float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const int co = (wn * C::NT + nt) * 32 + li;
+        for (int mt = 0; mt < C::MT; ++mt)
+          for (int r = 0; r < 16; ++r) {
+            const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = acc[mt][nt][r] + bv[nt];
+            op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
+          }
+      }
+    }
+    if (!has_next) break;
+    tile = next;
+    cur ^= 1;
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: last layer, 8x8 valid conv == GEMM [n x 8192] * [8192 x 128], split-K over gridDim.y.
 // One workgroup = 32 patches x 128 couts x (8192 / SK) k; wave w owns couts [32w, 32w+32), so
 // every weight element is used by exactly one wave: B goes global -> VGPR, only A through LDS.
@@ -299,6 +435,25 @@ hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const 
   return hipGetLastError();
 }
 
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
+hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, const float* bias, float* out, int n, int num_cu) {
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  auto kern = k_conv_mfma_p<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+  constexpr int lds = (2 * C::ACT_FLOATS + 2 * C::WCHUNK) * 4;
+  static_assert(lds <= 160 * 1024, "double-buffered band does not fit LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int ntiles = n * (C::HO / ROWS);
+  const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
+  const int grid = std::min(ntiles, num_cu * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, in, wimg, bias, out, ntiles);
+  return hipGetLastError();
+}
+
 // B-operand image of a 3x3 layer: [tap][cin/8][h][cout][jj] with cin = 8*c8 + 4*h + jj, BN scale folded.
 void build_wimg(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<float>& img) {
   img.assign((size_t)9 * L.cin * L.cout, 0.f);
@@ -389,7 +544,7 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
   ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);
-  ASD_HIP_CHECK(ctx, (launch_conv<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
+  ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
   PROF_MARK(3);
   ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);

@@ -87,6 +87,10 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
   asd_ctx* c = new (std::nothrow) asd_ctx();
   if (!c) return ASD_ERR_INVALID;
   c->cfg = *cfg;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+  }
   build_tables(c);
   if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
       hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {

@@ -37,6 +37,7 @@ struct AsdFrameSlot {
 struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
+  int num_cu = 256;
   std::string err;
 
   // ---- extractor tables (ORBextractor.cc:459-512)
