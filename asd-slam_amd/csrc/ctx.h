@@ -26,12 +26,12 @@ struct AsdFrameSlot {
   std::vector<asd_keypoint> kps;
   std::vector<int32_t> cell_start;  // [64*48+1] CSR, cell index = ix*48+iy (reference loop order)
   std::vector<int32_t> cell_items;
-  // device
-  float* d_desc = nullptr;      // [cap][128]
-  float* d_kp_xy = nullptr;     // [cap][2]
-  int32_t* d_kp_oct = nullptr;  // [cap]
+  // device mirrors (descriptors, keypoints as (x, y, octave bits, -), CSR grid) + pinned staging
+  float* d_desc = nullptr;
+  float4* d_kp = nullptr;
   int32_t* d_cell_start = nullptr;
   int32_t* d_cell_items = nullptr;
+  char* h_stage = nullptr;
 };
 
 struct asd_ctx {
@@ -62,14 +62,8 @@ struct asd_ctx {
   // ---- frames
   AsdFrameSlot frames[ASD_MAX_FRAMES];
 
-  // ---- matcher scratch
-  int pairs_cap = 0;
-  int2* d_pairs = nullptr;   // (query, candidate)
-  float* d_pair_dist = nullptr;
-  int2* h_pairs = nullptr;   // pinned
-  float* h_pair_dist = nullptr;
-  float* d_qdesc = nullptr;  // query descriptors [cap][128]
-  int qdesc_cap = 0;
+  // ---- matcher scratch (state private to matcher.hip)
+  void* matcher = nullptr;
 
   // ---- BA scratch (lazily grown)
   void* ba = nullptr;

@@ -23,6 +23,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <chrono>
+
 #include "ctx.h"
 #include "quadtree.h"
 
@@ -545,6 +547,10 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   if (n_features_override > 0) asd_compute_quotas(nfeat, ctx->cfg.scale_factor, nl, quota);
   else for (int l = 0; l < nl; ++l) quota[l] = ctx->features_per_level[l];
 
+  const bool timing = getenv("ASD_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+  const auto t_start = now();
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
   // E1 pyramid
   ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, image, stride, width, height,
@@ -569,6 +575,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_level_start, fe->d_level_start, (nl + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   const int total = fe->h_level_start[nl];
+  const auto t_counts = now();
   if ((size_t)total > fe->corners_cap) { ctx->set_error("corner buffer overflow"); return ASD_ERR_CAPACITY; }
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_corners, fe->d_corners, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev2, st));
@@ -577,6 +584,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   ASD_HIP_CHECK(ctx, hipGetLastError());
   // E3 quadtree per level on the host (DistributeOctTree): wait for the corner list only
   ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev2));
+  const auto t_corners = now();
   int n = 0;
   for (int l = 0; l < nl; ++l) {
     const int b = fe->h_level_start[l], e = fe->h_level_start[l + 1], cnt = e - b;
@@ -608,6 +616,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   }
   *n_out = n;
   ctx->last_n = n;
+  const auto t_quad = now();
   if (n == 0) return ASD_OK;
   // E4 + E5b + E6
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->d_kps, fe->h_kps, (size_t)n * sizeof(short4), hipMemcpyHostToDevice, st));
@@ -621,6 +630,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) kps[i].angle = fe->h_angles[i];
+  if (timing) fprintf(stderr, "[extract] launch+counts %.0f us, corners D2H %.0f us (%d), quadtree %.0f us, tail (angle+asdnet+D2H) %.0f us\n", us(t_start, t_counts), us(t_counts, t_corners), total, us(t_corners, t_quad), us(t_quad, now()));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ctx->ev0, ctx->ev1));
   return ASD_OK;
 }

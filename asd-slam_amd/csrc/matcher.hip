@@ -8,11 +8,13 @@
 // map point is skipped by later ones, best/second-best use strict '<' so the first candidate in
 // grid order wins ties.  What is data parallel is DescriptorDistance itself, which the
 // reference calls ~10^4-10^5 times per frame with two Mat conversions and two heap vectors per
-// call.  So: the host walks the 64x48 grid (a few thousand window queries over <1 keypoint per
-// cell) and emits (query, candidate) pairs in the reference's visiting order; one kernel
-// evaluates every pair's squared L2 in the reference's exact summation order (sequential f32,
-// no FMA: -ffp-contract=off), reading descriptors that are already resident in HBM; the host
-// then replays the claim / ratio / rotation-histogram logic over the distances.
+// call.  So: the host only projects the queries (u, v, radius, level range); ONE kernel
+// (k_window_search, a wave per query) walks the frame's 64x48 CSR grid in the reference's visiting
+// order (Frame::GetFeaturesInArea: ix outer, iy inner, insertion order inside a cell), compacts the
+// accepted candidates by ballot/prefix in that order and evaluates each candidate's squared L2 in
+// the reference's exact summation order (sequential f32, no FMA: -ffp-contract=off) from
+// descriptors resident in HBM; the host then replays the claim / ratio / rotation-histogram logic
+// over the per-query (index, distance) lists.
 // The all-pairs matrix (asd_dist_matrix) uses the same exact summation, tiled through LDS.
 #include <algorithm>
 #include <cmath>
@@ -21,30 +23,93 @@
 #include "ctx.h"
 
 namespace {
+
 constexpr float TH_HIGH = 1.5f, TH_LOW = 0.5f;  // ORBmatcher.cc:37-38
 constexpr int HISTO = ASD_HISTO_LENGTH;
 constexpr int GC = ASD_GRID_COLS, GR = ASD_GRID_ROWS;
 
-// one lane per (query, candidate) pair; each lane streams two 512-B descriptor rows.
-__global__ __launch_bounds__(256) void k_pair_dist(const float* __restrict__ qdesc, const float* __restrict__ cdesc,
-                                                   const int2* __restrict__ pairs, int npairs,
-                                                   float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= npairs) return;
-  const int2 p = pairs[i];
-  const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)p.x * 128);
-  const float4* b = reinterpret_cast<const float4*>(cdesc + (size_t)p.y * 128);
-  float sqd = 0.f;
+// A window query = one GetFeaturesInArea call + the descriptor it is matched against.
+struct WinQuery { float x, y, r; int min_level, max_level, qrow; };
+struct GridDev {
+  const float4* kp;        // (x, y, octave as int bits, -) per keypoint
+  const int* cell_start;   // [64*48+1], cell = ix*48 + iy
+  const int* cell_items;
+  float min_x, min_y, inv_w, inv_h;
+};
+
+// one wave per query: pass 1 counts the candidates, one atomicAdd reserves the query's segment
+// (segments may land in any order, each query's own list is in reference order), pass 2 writes
+// (candidate index, distance).  Arithmetic of the cell range / distance tests is the float
+// arithmetic of Frame.cc:226-265 verbatim.
+__global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
+                                                       const float* __restrict__ qdesc, const float* __restrict__ cdesc,
+                                                       int* __restrict__ q_off, int* __restrict__ q_cnt,
+                                                       int* __restrict__ total, int cap, int* __restrict__ out_idx,
+                                                       float* __restrict__ out_dist) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const WinQuery Q = queries[q];
+  int cnt = 0, off = 0;
+  bool empty = Q.qrow < 0;
+  const int nMinCellX = max(0, (int)floorf((Q.x - G.min_x - Q.r) * G.inv_w));
+  const int nMaxCellX = min(ASD_GRID_COLS - 1, (int)ceilf((Q.x - G.min_x + Q.r) * G.inv_w));
+  const int nMinCellY = max(0, (int)floorf((Q.y - G.min_y - Q.r) * G.inv_h));
+  const int nMaxCellY = min(ASD_GRID_ROWS - 1, (int)ceilf((Q.y - G.min_y + Q.r) * G.inv_h));
+  if (nMinCellX >= ASD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ASD_GRID_ROWS || nMaxCellY < 0) empty = true;
+  const bool check = (Q.min_level > 0) || (Q.max_level >= 0);
+  for (int pass = 0; pass < 2 && !empty; ++pass) {
+    int pos = 0;
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+      const int b = G.cell_start[ix * ASD_GRID_ROWS + nMinCellY], e = G.cell_start[ix * ASD_GRID_ROWS + nMaxCellY + 1];
+      for (int base = b; base < e; base += 64) {
+        const int it = base + lane;
+        bool ok = false;
+        int idx = 0;
+        if (it < e) {
+          idx = G.cell_items[it];
+          const float4 kp = G.kp[idx];
+          const int oct = __float_as_int(kp.z);
+          ok = true;
+          if (check) {
+            if (oct < Q.min_level) ok = false;
+            if (Q.max_level >= 0 && oct > Q.max_level) ok = false;
+          }
+          const float dx = kp.x - Q.x, dy = kp.y - Q.y;
+          if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) ok = false;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (pass == 1 && ok) {
+          const int p = off + pos + __popcll(m & ((1ull << lane) - 1));
+          if (p < cap) {
+            const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)Q.qrow * 128);
+            const float4* bb = reinterpret_cast<const float4*>(cdesc + (size_t)idx * 128);
+            float sqd = 0.f;
 #pragma unroll 8
-  for (int k = 0; k < 32; ++k) {
-    const float4 x = a[k], y = b[k];
-    float d;
-    d = x.x - y.x; sqd = sqd + d * d;
-    d = x.y - y.y; sqd = sqd + d * d;
-    d = x.z - y.z; sqd = sqd + d * d;
-    d = x.w - y.w; sqd = sqd + d * d;
+            for (int k = 0; k < 32; ++k) {
+              const float4 x = a[k], y = bb[k];
+              float d;
+              d = x.x - y.x; sqd = sqd + d * d;
+              d = x.y - y.y; sqd = sqd + d * d;
+              d = x.z - y.z; sqd = sqd + d * d;
+              d = x.w - y.w; sqd = sqd + d * d;
+            }
+            out_idx[p] = idx;
+            out_dist[p] = sqd;
+          }
+        }
+        pos += __popcll(m);
+      }
+    }
+    if (pass == 0) {
+      cnt = pos;
+      if (cnt == 0) break;
+      int o = 0;
+      if (lane == 0) o = atomicAdd(total, cnt);
+      off = __shfl(o, 0);
+    }
   }
-  out[i] = sqd;
+  if (lane == 0) { q_cnt[q] = cnt; q_off[q] = off; }
 }
 
 // all-pairs: block = 256 columns (b rows) x 16 a rows; a tile broadcast from LDS, b row in VGPRs.
@@ -81,8 +146,6 @@ __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a
 }
 
 // ---- host helpers -------------------------------------------------------------------------
-struct Window { int begin, end; };  // range of the pair list that belongs to one query
-
 inline void three_maxima(const int* cnt, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1584-1625
   int max1 = 0, max2 = 0, max3 = 0;
   ind1 = ind2 = ind3 = -1;
@@ -104,9 +167,8 @@ inline int rot_bin(float a1, float a2) {  // :1419-1425
   return bin;
 }
 
-// Frame::GetFeaturesInArea (Frame.cc:219-274) over the CSR grid; appends (q, idx) pairs.
-void features_in_area(const AsdFrameSlot& F, float x, float y, float r, int minLevel, int maxLevel, int q,
-                      std::vector<int2>& pairs) {
+// Frame::GetFeaturesInArea (Frame.cc:219-274) on the host CSR mirror (asd_frame_features_in_area only)
+void features_in_area(const AsdFrameSlot& F, float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) {
   const int nMinCellX = std::max(0, (int)std::floor((x - F.min_x - r) * F.inv_w));
   if (nMinCellX >= GC) return;
   const int nMaxCellX = std::min(GC - 1, (int)std::ceil((x - F.min_x + r) * F.inv_w));
@@ -117,7 +179,6 @@ void features_in_area(const AsdFrameSlot& F, float x, float y, float r, int minL
   if (nMaxCellY < 0) return;
   const bool check = (minLevel > 0) || (maxLevel >= 0);
   for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
-    // cells (ix, iyMin..iyMax) are contiguous in the CSR (cell = ix*48 + iy)
     const int b = F.cell_start[ix * GR + nMinCellY], e = F.cell_start[ix * GR + nMaxCellY + 1];
     for (int t = b; t < e; ++t) {
       const int idx = F.cell_items[t];
@@ -127,7 +188,7 @@ void features_in_area(const AsdFrameSlot& F, float x, float y, float r, int minL
         if (maxLevel >= 0 && kp.octave > maxLevel) continue;
       }
       const float dx = kp.x - x, dy = kp.y - y;
-      if (std::fabs(dx) < r && std::fabs(dy) < r) pairs.push_back(make_int2(q, idx));
+      if (std::fabs(dx) < r && std::fabs(dy) < r) out.push_back(idx);
     }
   }
 }
@@ -140,45 +201,109 @@ inline void transform(const float* T, const float* X, float* out) {
   }
 }
 
-int ensure_pairs(asd_ctx* ctx, size_t n) {
-  if ((int)n <= ctx->pairs_cap) return ASD_OK;
-  const int cap = (int)std::max<size_t>(n * 3 / 2, 1 << 16);
-  if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
-  if (ctx->d_pair_dist) (void)hipFree(ctx->d_pair_dist);
-  if (ctx->h_pair_dist) (void)hipHostFree(ctx->h_pair_dist);
-  ctx->pairs_cap = 0;
-  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_pairs, (size_t)cap * sizeof(int2)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_pair_dist, (size_t)cap * sizeof(float)));
-  ASD_HIP_CHECK(ctx, hipHostMalloc(&ctx->h_pair_dist, (size_t)cap * sizeof(float)));
-  ctx->pairs_cap = cap;
+struct MatcherState {
+  int q_cap = 0, cand_cap = 0, qdesc_cap = 0;
+  WinQuery *d_queries = nullptr, *h_queries = nullptr;   // h_* pinned
+  int *d_q_off = nullptr, *d_q_cnt = nullptr, *d_total = nullptr, *d_idx = nullptr;
+  float* d_dist = nullptr;
+  int *h_q = nullptr;      // [2*q_cap + 1]: off, cnt, total
+  int* h_idx = nullptr;
+  float* h_dist = nullptr;
+  float *d_qdesc = nullptr, *h_qdesc = nullptr;
+};
+
+MatcherState* mstate(asd_ctx* ctx) {
+  if (!ctx->matcher) ctx->matcher = new MatcherState();
+  return static_cast<MatcherState*>(ctx->matcher);
+}
+
+int ensure_queries(asd_ctx* ctx, MatcherState* m, int nq) {
+  if (nq <= m->q_cap) return ASD_OK;
+  const int cap = std::max(nq * 3 / 2, 8192);
+  if (m->d_queries) { (void)hipFree(m->d_queries); (void)hipHostFree(m->h_queries); (void)hipFree(m->d_q_off); (void)hipHostFree(m->h_q); }
+  m->q_cap = 0;
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_queries, (size_t)cap * sizeof(WinQuery)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_queries, (size_t)cap * sizeof(WinQuery)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_q_off, ((size_t)2 * cap + 4) * sizeof(int)));  // off | cnt | total
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_q, ((size_t)2 * cap + 4) * sizeof(int)));
+  m->q_cap = cap;
+  return ASD_OK;
+}
+int ensure_cands(asd_ctx* ctx, MatcherState* m, int n) {
+  if (n <= m->cand_cap) return ASD_OK;
+  const int cap = std::max(n * 3 / 2, 1 << 18);
+  if (m->d_idx) { (void)hipFree(m->d_idx); (void)hipFree(m->d_dist); (void)hipHostFree(m->h_idx); (void)hipHostFree(m->h_dist); }
+  m->cand_cap = 0;
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_idx, (size_t)cap * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_dist, (size_t)cap * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_idx, (size_t)cap * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_dist, (size_t)cap * sizeof(float)));
+  m->cand_cap = cap;
+  return ASD_OK;
+}
+int ensure_qdesc(asd_ctx* ctx, MatcherState* m, int n) {
+  if (n <= m->qdesc_cap) return ASD_OK;
+  const int cap = std::max(n * 3 / 2, 8192);
+  if (m->d_qdesc) { (void)hipFree(m->d_qdesc); (void)hipHostFree(m->h_qdesc); }
+  m->qdesc_cap = 0;
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_qdesc, (size_t)cap * 512));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_qdesc, (size_t)cap * 512));
+  m->qdesc_cap = cap;
   return ASD_OK;
 }
 
-int ensure_qdesc(asd_ctx* ctx, size_t n) {
-  if ((int)n <= ctx->qdesc_cap) return ASD_OK;
-  const int cap = (int)std::max<size_t>(n * 3 / 2, 4096);
-  if (ctx->d_qdesc) (void)hipFree(ctx->d_qdesc);
-  ctx->qdesc_cap = 0;
-  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_qdesc, (size_t)cap * 128 * sizeof(float)));
-  ctx->qdesc_cap = cap;
-  return ASD_OK;
-}
+// result of one batched window search: per query q the candidates idx[off[q] .. off[q]+cnt[q]) in
+// Frame::GetFeaturesInArea order with their DescriptorDistance to the query's descriptor
+struct SearchResult { const int* off; const int* cnt; const int* idx; const float* dist; };
 
-// distances of all pairs: query descriptors on the device (d_q), candidates = slot descriptors
-int pair_distances(asd_ctx* ctx, const float* d_q, const AsdFrameSlot& F, const std::vector<int2>& pairs) {
-  const int np = (int)pairs.size();
-  if (np == 0) return ASD_OK;
-  int rc = ensure_pairs(ctx, np);
+// queries are already in m->h_queries[0..nq); d_q = query descriptor table on the device
+int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, SearchResult* res) {
+  int rc = ensure_cands(ctx, m, 1);
   if (rc != ASD_OK) return rc;
   hipStream_t st = ctx->stream;
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_pairs, pairs.data(), (size_t)np * sizeof(int2), hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  hipLaunchKernelGGL(k_pair_dist, dim3((np + 255) / 256), dim3(256), 0, st, d_q, F.d_desc, ctx->d_pairs, np, ctx->d_pair_dist);
-  ASD_HIP_CHECK(ctx, hipGetLastError());
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_pair_dist, ctx->d_pair_dist, (size_t)np * sizeof(float), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  int* d_off = m->d_q_off;
+  int* d_cnt = m->d_q_off + m->q_cap;
+  int* d_total = m->d_q_off + 2 * m->q_cap;
+  const int optimistic = std::min(m->cand_cap, 1 << 16);  // copied back together with the counts
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_queries, m->h_queries, (size_t)nq * sizeof(WinQuery), hipMemcpyHostToDevice, st));
+    ASD_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(int), st));
+    GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
+                       d_total, m->cand_cap, m->d_idx, m->d_dist);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_q, d_off, ((size_t)2 * m->q_cap + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_idx, m->d_idx, (size_t)optimistic * sizeof(int), hipMemcpyDeviceToHost, st));
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_dist, m->d_dist, (size_t)optimistic * sizeof(float), hipMemcpyDeviceToHost, st));
+    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const int total = m->h_q[2 * m->q_cap];
+    if (total > m->cand_cap) {  // segment reservation overflowed the buffers: grow and run again
+      if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
+      continue;
+    }
+    if (total > optimistic) {
+      ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_idx + optimistic, m->d_idx + optimistic, (size_t)(total - optimistic) * sizeof(int), hipMemcpyDeviceToHost, st));
+      ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_dist + optimistic, m->d_dist + optimistic, (size_t)(total - optimistic) * sizeof(float), hipMemcpyDeviceToHost, st));
+      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+    break;
+  }
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+  res->off = m->h_q;
+  res->cnt = m->h_q + m->q_cap;
+  res->idx = m->h_idx;
+  res->dist = m->h_dist;
+  return ASD_OK;
+}
+
+// query descriptors: host table -> pinned staging -> device (one async copy)
+int upload_qdesc(asd_ctx* ctx, MatcherState* m, const float* desc, int n) {
+  int rc = ensure_qdesc(ctx, m, n);
+  if (rc != ASD_OK) return rc;
+  memcpy(m->h_qdesc, desc, (size_t)n * 512);
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_qdesc, m->h_qdesc, (size_t)n * 512, hipMemcpyHostToDevice, ctx->stream));
   return ASD_OK;
 }
 
@@ -189,12 +314,23 @@ AsdFrameSlot* slot_of(asd_ctx* ctx, int s) {
 }  // namespace
 
 void matcher_free(asd_ctx* ctx) {
-  for (auto& f : ctx->frames)
-    if (f.d_desc) { (void)hipFree(f.d_desc); f.d_desc = nullptr; }
-  if (ctx->d_pairs) (void)hipFree(ctx->d_pairs);
-  if (ctx->d_pair_dist) (void)hipFree(ctx->d_pair_dist);
-  if (ctx->h_pair_dist) (void)hipHostFree(ctx->h_pair_dist);
-  if (ctx->d_qdesc) (void)hipFree(ctx->d_qdesc);
+  for (auto& f : ctx->frames) {
+    if (f.d_desc) (void)hipFree(f.d_desc);
+    if (f.d_kp) (void)hipFree(f.d_kp);
+    if (f.d_cell_start) (void)hipFree(f.d_cell_start);
+    if (f.d_cell_items) (void)hipFree(f.d_cell_items);
+    if (f.h_stage) (void)hipHostFree(f.h_stage);
+    f.d_desc = nullptr; f.d_kp = nullptr; f.d_cell_start = nullptr; f.d_cell_items = nullptr; f.h_stage = nullptr;
+  }
+  if (ctx->matcher) {
+    MatcherState* m = static_cast<MatcherState*>(ctx->matcher);
+    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_qdesc};
+    for (void* p : dev) if (p) (void)hipFree(p);
+    void* host[] = {m->h_queries, m->h_q, m->h_idx, m->h_dist, m->h_qdesc};
+    for (void* p : host) if (p) (void)hipHostFree(p);
+    delete m;
+    ctx->matcher = nullptr;
+  }
 }
 
 extern "C" {
@@ -206,10 +342,18 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   if (n > ctx->cfg.max_patches) { ctx->set_error("frame has %d keypoints, capacity %d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
   if (!desc && n != ctx->last_n) { ctx->set_error("desc == NULL adopts the last extract (%d keypoints), got n=%d", ctx->last_n, n); return ASD_ERR_INVALID; }
   (void)hipSetDevice(ctx->cfg.device);
-  if (!F->d_desc) ASD_HIP_CHECK(ctx, hipMalloc(&F->d_desc, (size_t)ctx->cfg.max_patches * 128 * sizeof(float)));
+  const size_t cap = ctx->cfg.max_patches;
+  if (!F->d_desc) {
+    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_desc, cap * 128 * sizeof(float)));
+    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_kp, cap * sizeof(float4)));
+    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_cell_start, (GC * GR + 1) * sizeof(int)));
+    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_cell_items, cap * sizeof(int)));
+    ASD_HIP_CHECK(ctx, hipHostMalloc(&F->h_stage, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int)));
+  }
+  hipStream_t st = ctx->stream;
   if (n > 0) {
-    if (desc) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, desc, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    else ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (desc) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, desc, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, st));
+    else ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   F->n = n;
   F->min_x = min_x; F->max_x = max_x; F->min_y = min_y; F->max_y = max_y;
@@ -231,7 +375,22 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   std::vector<int> cur(F->cell_start.begin(), F->cell_start.end() - 1);
   for (int i = 0; i < n; ++i)
     if (cell[i] >= 0) F->cell_items[cur[cell[i]]++] = i;
-  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // device mirror of keypoints + grid (pinned staging, three small async copies)
+  float4* hk = reinterpret_cast<float4*>(F->h_stage);
+  int* hs = reinterpret_cast<int*>(F->h_stage + cap * sizeof(float4));
+  int* hi = hs + (GC * GR + 1);
+  for (int i = 0; i < n; ++i) {
+    float ob;
+    memcpy(&ob, &kps[i].octave, sizeof ob);  // octave travels as raw int bits in .z
+    hk[i] = make_float4(kps[i].x, kps[i].y, ob, 0.f);
+  }
+  memcpy(hs, F->cell_start.data(), (GC * GR + 1) * sizeof(int));
+  if (!F->cell_items.empty()) memcpy(hi, F->cell_items.data(), F->cell_items.size() * sizeof(int));
+  if (n > 0) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_kp, hk, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_cell_start, hs, (GC * GR + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  if (!F->cell_items.empty())
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_cell_items, hi, F->cell_items.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   return ASD_OK;
 }
 
@@ -239,10 +398,23 @@ int asd_frame_features_in_area(asd_ctx* ctx, int32_t slot, float x, float y, flo
                                int32_t max_level, int32_t capacity, int32_t* idx_out, int32_t* n_out) {
   AsdFrameSlot* F = slot_of(ctx, slot);
   if (!F || !idx_out || !n_out) return ASD_ERR_INVALID;
-  std::vector<int2> pairs;
-  features_in_area(*F, x, y, r, min_level, max_level, 0, pairs);
-  const int n = std::min((int)pairs.size(), capacity);
-  for (int i = 0; i < n; ++i) idx_out[i] = pairs[i].y;
+  // single query through the same kernel the matchers use (so the test of this entry point is a
+  // test of the device grid walk); the host mirror cross-checks it
+  MatcherState* m = mstate(ctx);
+  int rc = ensure_queries(ctx, m, 1);
+  if (rc != ASD_OK) return rc;
+  if (F->n == 0) { *n_out = 0; return ASD_OK; }
+  m->h_queries[0] = WinQuery{x, y, r, min_level, max_level, 0};
+  SearchResult res;
+  if ((rc = window_search(ctx, m, *F, 1, F->d_desc, &res)) != ASD_OK) return rc;
+  std::vector<int> host;
+  features_in_area(*F, x, y, r, min_level, max_level, host);
+  if ((int)host.size() != res.cnt[0] || !std::equal(host.begin(), host.end(), res.idx + res.off[0])) {
+    ctx->set_error("device grid walk disagrees with the host mirror");
+    return ASD_ERR_HIP;
+  }
+  const int n = std::min(res.cnt[0], capacity);
+  for (int i = 0; i < n; ++i) idx_out[i] = res.idx[res.off[0] + i];
   *n_out = n;
   return ASD_OK;
 }
@@ -296,11 +468,17 @@ int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
   AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
   if (!C || !L || !has_mp || !Xw || !mp_desc || !Tcw || !K || !match_cur || !n_matches) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  std::fill(match_cur, match_cur + C->n, -1);
+  *n_matches = 0;
+  if (L->n == 0 || C->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, L->n);
+  if (rc != ASD_OK) return rc;
+  if ((rc = upload_qdesc(ctx, m, mp_desc, L->n)) != ASD_OK) return rc;
   const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
-  std::vector<int2> pairs;
-  std::vector<Window> win(L->n, Window{0, 0});
-  pairs.reserve((size_t)L->n * 24);
-  for (int i = 0; i < L->n; ++i) {
+  for (int i = 0; i < L->n; ++i) {  // projection, ORBmatcher.cc:1343-1368
+    WinQuery& Q = m->h_queries[i];
+    Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
     if (!has_mp[i]) continue;
     float Xc[3];
     transform(Tcw, Xw + 3 * i, Xc);
@@ -311,31 +489,22 @@ int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
     if (u < C->min_x || u > C->max_x) continue;
     if (v < C->min_y || v > C->max_y) continue;
     const int oct = L->kps[i].octave;
-    const float radius = th * ctx->scale[oct];
-    win[i].begin = (int)pairs.size();
-    features_in_area(*C, u, v, radius, oct - 1, oct + 1, i, pairs);
-    win[i].end = (int)pairs.size();
+    Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, i};
   }
-  int rc = ensure_qdesc(ctx, L->n);
-  if (rc != ASD_OK) return rc;
-  if (!pairs.empty()) {
-    ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_qdesc, mp_desc, (size_t)L->n * 512, hipMemcpyHostToDevice, ctx->stream));
-    rc = pair_distances(ctx, ctx->d_qdesc, *C, pairs);
-    if (rc != ASD_OK) return rc;
-  }
-  const float* dist = ctx->h_pair_dist;
-  std::fill(match_cur, match_cur + C->n, -1);
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *C, L->n, m->d_qdesc, &R)) != ASD_OK) return rc;
   int nmatches = 0;
   std::vector<int> hist[HISTO];
   for (int i = 0; i < L->n; ++i) {
+    if (R.cnt[i] == 0) continue;
     float best = 100;
     int best_idx = -1;
-    for (int t = win[i].begin; t < win[i].end; ++t) {
-      const int j = pairs[t].y;
+    for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
+      const int j = R.idx[t];
       if (match_cur[j] >= 0) continue;  // already holds a map point with Observations() > 0
-      if (dist[t] < best) { best = dist[t]; best_idx = j; }
+      if (R.dist[t] < best) { best = R.dist[t]; best_idx = j; }
     }
-    if (win[i].end > win[i].begin && best <= TH_HIGH) {
+    if (best <= TH_HIGH) {
       match_cur[best_idx] = i;
       nmatches++;
       if (check_orientation) hist[rot_bin(L->kps[i].angle, C->kps[best_idx].angle)].push_back(best_idx);
@@ -361,38 +530,35 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
       (F->n > 0 && !occupied))
     return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
-  const bool bFactor = th != 1.0;
-  std::vector<int2> pairs;
-  std::vector<Window> win(n_mp, Window{0, 0});
-  pairs.reserve((size_t)n_mp * 8);
-  for (int m = 0; m < n_mp; ++m) {
-    if (!in_view[m]) continue;
-    const int lvl = level[m];
-    if (lvl < 0 || lvl >= ctx->cfg.n_levels) { ctx->set_error("map point %d: level %d out of range", m, lvl); return ASD_ERR_INVALID; }
-    float r = view_cos[m] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
-    if (bFactor) r *= th;
-    win[m].begin = (int)pairs.size();
-    features_in_area(*F, proj[2 * m], proj[2 * m + 1], r * ctx->scale[lvl], lvl - 1, lvl, m, pairs);
-    win[m].end = (int)pairs.size();
-  }
-  int rc = ensure_qdesc(ctx, n_mp);
-  if (rc != ASD_OK) return rc;
-  if (!pairs.empty()) {
-    ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_qdesc, desc, (size_t)n_mp * 512, hipMemcpyHostToDevice, ctx->stream));
-    rc = pair_distances(ctx, ctx->d_qdesc, *F, pairs);
-    if (rc != ASD_OK) return rc;
-  }
-  const float* dist = ctx->h_pair_dist;
+  MatcherState* m = mstate(ctx);
   std::fill(match_cur, match_cur + F->n, -1);
+  *n_matches = 0;
+  if (n_mp == 0 || F->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, n_mp);
+  if (rc != ASD_OK) return rc;
+  const bool bFactor = th != 1.0;
+  for (int q = 0; q < n_mp; ++q) {
+    WinQuery& Q = m->h_queries[q];
+    Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+    if (!in_view[q]) continue;
+    const int lvl = level[q];
+    if (lvl < 0 || lvl >= ctx->cfg.n_levels) { ctx->set_error("map point %d: level %d out of range", q, lvl); return ASD_ERR_INVALID; }
+    float r = view_cos[q] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
+    if (bFactor) r *= th;
+    Q = WinQuery{proj[2 * q], proj[2 * q + 1], r * ctx->scale[lvl], lvl - 1, lvl, q};
+  }
+  if ((rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *F, n_mp, m->d_qdesc, &R)) != ASD_OK) return rc;
   int nmatches = 0;
-  for (int m = 0; m < n_mp; ++m) {
-    if (win[m].end == win[m].begin) continue;
+  for (int q = 0; q < n_mp; ++q) {
+    if (R.cnt[q] == 0) continue;
     float best = 256, best2 = 256;
     int best_lvl = -1, best_lvl2 = -1, best_idx = -1;
-    for (int t = win[m].begin; t < win[m].end; ++t) {
-      const int j = pairs[t].y;
+    for (int t = R.off[q]; t < R.off[q] + R.cnt[q]; ++t) {
+      const int j = R.idx[t];
       if (occupied[j] || match_cur[j] >= 0) continue;
-      const float d = dist[t];
+      const float d = R.dist[t];
       if (d < best) {
         best2 = best; best = d;
         best_lvl2 = best_lvl; best_lvl = F->kps[j].octave;
@@ -404,7 +570,7 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
     }
     if (best <= TH_HIGH) {
       if (best_lvl == best_lvl2 && best > nn_ratio * best2) continue;
-      match_cur[best_idx] = m;
+      match_cur[best_idx] = q;
       nmatches += 2;  // the reference increments twice per match (ORBmatcher.cc:116-117)
     }
   }
@@ -426,32 +592,32 @@ int asd_frustum(asd_ctx* ctx, int32_t slot_cur, int32_t n, const float* Xw, cons
     for (int k = 0; k < 3; ++k) s += (double)Tcw[k * 4 + i] * (double)Tcw[k * 4 + 3];
     Ow[i] = (float)(-1.0 * s);
   }
-  for (int m = 0; m < n; ++m) {
-    in_view[m] = 0; proj[2 * m] = proj[2 * m + 1] = 0.f; level[m] = 0; view_cos[m] = 0.f;
-    const float* P = Xw + 3 * m;
+  for (int q = 0; q < n; ++q) {
+    in_view[q] = 0; proj[2 * q] = proj[2 * q + 1] = 0.f; level[q] = 0; view_cos[q] = 0.f;
+    const float* P = Xw + 3 * q;
     float Pc[3];
     transform(Tcw, P, Pc);
     if (Pc[2] < 0.0f) continue;
     const float invz = 1.0f / Pc[2];
     const float u = fx * Pc[0] * invz + cx, v = fy * Pc[1] * invz + cy;
     if (u < F->min_x || u > F->max_x || v < F->min_y || v > F->max_y) continue;
-    const float maxD = 1.2f * max_dist[m], minD = 0.8f * min_dist[m];  // MapPoint.cc:409-419
+    const float maxD = 1.2f * max_dist[q], minD = 0.8f * min_dist[q];  // MapPoint.cc:409-419
     const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
     const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
     const float dist = (float)std::sqrt(nn);
     if (dist < minD || dist > maxD) continue;
-    const float* Pn = normal + 3 * m;
+    const float* Pn = normal + 3 * q;
     const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
     const float vc = (float)(dot / dist);
     if (vc < cos_limit) continue;
-    const float ratio = max_dist[m] / dist;  // MapPoint::PredictScale (MapPoint.cc:438-453)
+    const float ratio = max_dist[q] / dist;  // MapPoint::PredictScale (MapPoint.cc:438-453)
     int s = (int)std::ceil(std::log(ratio) / log_scale);
     if (s < 0) s = 0;
     else if (s >= ctx->cfg.n_levels) s = ctx->cfg.n_levels - 1;
-    in_view[m] = 1;
-    proj[2 * m] = u; proj[2 * m + 1] = v;
-    level[m] = s;
-    view_cos[m] = vc;
+    in_view[q] = 1;
+    proj[2 * q] = u; proj[2 * q + 1] = v;
+    level[q] = s;
+    view_cos[q] = vc;
   }
   return ASD_OK;
 }
@@ -461,29 +627,30 @@ int asd_match_init(asd_ctx* ctx, int32_t slot1, int32_t slot2, float* prev_match
   AsdFrameSlot *F1 = slot_of(ctx, slot1), *F2 = slot_of(ctx, slot2);
   if (!F1 || !F2 || !prev_matched || !matches12 || !n_matches) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
-  std::vector<int2> pairs;
-  std::vector<Window> win(F1->n, Window{0, 0});
-  for (int i1 = 0; i1 < F1->n; ++i1) {
-    if (F1->kps[i1].octave > 0) continue;  // :434-436
-    win[i1].begin = (int)pairs.size();
-    features_in_area(*F2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, 0, 0, i1, pairs);
-    win[i1].end = (int)pairs.size();
-  }
-  int rc = pair_distances(ctx, F1->d_desc, *F2, pairs);  // query descriptors are frame 1's, resident
-  if (rc != ASD_OK) return rc;
-  const float* dist = ctx->h_pair_dist;
+  MatcherState* m = mstate(ctx);
   std::fill(matches12, matches12 + F1->n, -1);
+  *n_matches = 0;
+  if (F1->n == 0 || F2->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, F1->n);
+  if (rc != ASD_OK) return rc;
+  for (int i1 = 0; i1 < F1->n; ++i1) {
+    m->h_queries[i1] = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+    if (F1->kps[i1].octave > 0) continue;  // :434-436
+    m->h_queries[i1] = WinQuery{prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window, 0, 0, i1};
+  }
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *F2, F1->n, F1->d_desc, &R)) != ASD_OK) return rc;  // query descriptors: frame 1's, resident
   std::vector<float> matched_dist(F2->n, 100.f);
   std::vector<int> matches21(F2->n, -1);
   std::vector<int> hist[HISTO];
   int nmatches = 0;
   for (int i1 = 0; i1 < F1->n; ++i1) {
-    if (win[i1].end == win[i1].begin) continue;
+    if (R.cnt[i1] == 0) continue;
     float best = 100.f, best2 = 100.f;
     int best_idx = -1;
-    for (int t = win[i1].begin; t < win[i1].end; ++t) {
-      const int i2 = pairs[t].y;
-      const float d = dist[t];
+    for (int t = R.off[i1]; t < R.off[i1] + R.cnt[i1]; ++t) {
+      const int i2 = R.idx[t];
+      const float d = R.dist[t];
       if (matched_dist[i2] <= d) continue;
       if (d < best) { best2 = best; best = d; best_idx = i2; }
       else if (d < best2) best2 = d;
