@@ -23,7 +23,12 @@
 #include <cmath>
 #include <cstring>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 
 #include "ctx.h"
 #include "quadtree.h"
@@ -321,6 +326,63 @@ __global__ __launch_bounds__(256) void k_angle_patch(PyrDev P, const uint8_t* __
   *reinterpret_cast<uint4*>(patches + (size_t)k * 1024 + row * 32 + half * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+
+// Small persistent worker pool: the per-level quadtrees are independent, level 0 holds ~40 % of the
+// corners, so 3 helpers + the calling thread bring the host part down to about the largest level.
+class LevelPool {
+ public:
+  explicit LevelPool(int nworkers) {
+    for (int i = 0; i < nworkers; ++i) th_.emplace_back([this] { worker(); });
+  }
+  ~LevelPool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : th_) t.join();
+  }
+  // runs job(0..ntasks-1), tasks handed out dynamically; returns when all are done
+  void run(int ntasks, const std::function<void(int)>& job) {
+    {
+      std::lock_guard<std::mutex> l(m_);
+      job_ = &job; ntasks_ = ntasks; next_.store(0); active_ = (int)th_.size(); ++gen_;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> l(m_);
+    done_cv_.wait(l, [this] { return active_ == 0; });
+    job_ = nullptr;
+  }
+ private:
+  void drain() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= ntasks_) break;
+      (*job_)(i);
+    }
+  }
+  void worker() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      drain();
+      { std::lock_guard<std::mutex> l(m_); --active_; }
+      done_cv_.notify_one();
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex m_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(int)>* job_ = nullptr;
+  std::atomic<int> next_{0};
+  int ntasks_ = 0, active_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -344,11 +406,12 @@ struct FrontendState {
   uint32_t* h_corners = nullptr;  // pinned
   int* h_level_start = nullptr;   // pinned
   short4 *d_kps = nullptr, *h_kps = nullptr;
-  float *d_angles = nullptr, *h_angles = nullptr;
+  float *d_angles = nullptr, *h_angles = nullptr, *h_desc = nullptr;
   bool consts_set = false;
   // last extract, host side
   std::vector<float> raw_x[ASD_MAX_LEVELS], raw_y[ASD_MAX_LEVELS], raw_r[ASD_MAX_LEVELS];
-  std::vector<int> sel;
+  std::vector<int> sel[ASD_MAX_LEVELS];
+  LevelPool* pool = nullptr;
 };
 
 static void level_dims(const asd_ctx* ctx, int w, int h, int level, int* lw, int* lh) {
@@ -360,6 +423,7 @@ static void level_dims(const asd_ctx* ctx, int w, int h, int level, int* lw, int
 int frontend_alloc(asd_ctx* ctx) {
   FrontendState* fe = new FrontendState();
   ctx->fe = fe;
+  fe->pool = new LevelPool(3);
   const int nl = ctx->cfg.n_levels, W = ctx->cfg.max_width, H = ctx->cfg.max_height;
   size_t bytes = 0, tx = 0, ty = 0;
   int ncell_max = 0;
@@ -396,6 +460,7 @@ int frontend_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_kps, np * sizeof(short4)));
   ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_angles, np * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_angles, np * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_desc, np * 128 * sizeof(float)));
   return ASD_OK;
 }
 
@@ -406,8 +471,9 @@ void frontend_free(asd_ctx* ctx) {
                  fe->d_cell_count, fe->d_cell_off, fe->d_level_cell_start, fe->d_level_start, fe->d_corners,
                  fe->d_kps, fe->d_angles};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {fe->h_corners, fe->h_level_start, fe->h_kps, fe->h_angles};
+  void* host[] = {fe->h_corners, fe->h_level_start, fe->h_kps, fe->h_angles, fe->h_desc};
   for (void* p : host) if (p) (void)hipHostFree(p);
+  delete fe->pool;
   delete fe;
   ctx->fe = nullptr;
 }
@@ -585,8 +651,8 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   // E3 quadtree per level on the host (DistributeOctTree): wait for the corner list only
   ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev2));
   const auto t_corners = now();
-  int n = 0;
-  for (int l = 0; l < nl; ++l) {
+  // unpack + quadtree per level in parallel (levels are independent), then assemble in level order
+  const std::function<void(int)> level_job = [&](int l) {
     const int b = fe->h_level_start[l], e = fe->h_level_start[l + 1], cnt = e - b;
     auto &rx = fe->raw_x[l], &ry = fe->raw_y[l], &rr = fe->raw_r[l];
     rx.resize(cnt); ry.resize(cnt); rr.resize(cnt);
@@ -598,9 +664,14 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
     }
     const LevelDev& L = P.lv[l];
     asd_distribute_octtree(rx.data(), ry.data(), rr.data(), cnt, kMinBorder, L.w - kEdge + 3, kMinBorder,
-                           L.h - kEdge + 3, quota[l], fe->sel);
+                           L.h - kEdge + 3, quota[l], fe->sel[l]);
+  };
+  fe->pool->run(nl, level_job);
+  int n = 0;
+  for (int l = 0; l < nl; ++l) {
+    auto &rx = fe->raw_x[l], &ry = fe->raw_y[l], &rr = fe->raw_r[l];
     const int scaledPatchSize = (int)(31 * ctx->scale[l]);  // :887
-    for (int idx : fe->sel) {
+    for (int idx : fe->sel[l]) {
       if (n >= ctx->cfg.max_patches) { ctx->set_error("more keypoints than max_patches"); return ASD_ERR_CAPACITY; }
       const float px = rx[idx] + kMinBorder, py = ry[idx] + kMinBorder;  // :894-895
       fe->h_kps[n] = make_short4((short)px, (short)py, (short)l, 0);
@@ -626,9 +697,10 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc);
   if (rc != ASD_OK) return rc;
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_angles, fe->d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  memcpy(desc, fe->h_desc, (size_t)n * 128 * sizeof(float));  // pinned staging: the caller's buffer is pageable
   for (int i = 0; i < n; ++i) kps[i].angle = fe->h_angles[i];
   if (timing) fprintf(stderr, "[extract] launch+counts %.0f us, corners D2H %.0f us (%d), quadtree %.0f us, tail (angle+asdnet+D2H) %.0f us\n", us(t_start, t_counts), us(t_counts, t_corners), total, us(t_corners, t_quad), us(t_quad, now()));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ctx->ev0, ctx->ev1));
