@@ -39,25 +39,89 @@ constexpr float kChi2Mono = 5.991f;
 __host__ __device__ inline double huber_delta() { return (double)(float)2.4476519360399936; }  // (float)sqrt(5.991)
 
 // ---------------------------------------------------------------- deterministic block reductions
-template <int N>
-__device__ inline void block_reduce(double (&v)[N], double* red /*[4][N]*/, double* out /*[N] in LDS*/) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// Wave-level sum of up to 32 values per lane as a reduce-scatter: each butterfly step exchanges only
+// the half of the values the lane does not keep, so 32 values cost 16+8+4+2+1+1 = 32 cross-lane moves
+// instead of 32*6.  Afterwards lane l holds the wave total of value (l >> 1).  Fixed order: bit-reproducible.
+template <int M>
+__device__ inline void rs_step(double (&v)[2 * M], double (&o)[M], int off, bool up) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    double x = v[k];
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-    if (lane == 0) red[wave * N + k] = x;
+  for (int k = 0; k < M; ++k) {
+    const double send = up ? v[k] : v[k + M];
+    const double keep = up ? v[k + M] : v[k];
+    o[k] = keep + __shfl_xor(send, off);
+  }
+}
+__device__ inline double wave_reduce_scatter32(double (&v)[32]) {
+  const int lane = threadIdx.x & 63;
+  double a[16], b[8], c[4], d[2], e[1];
+  rs_step<16>(v, a, 32, (lane & 32) != 0);
+  rs_step<8>(a, b, 16, (lane & 16) != 0);
+  rs_step<4>(b, c, 8, (lane & 8) != 0);
+  rs_step<2>(c, d, 4, (lane & 4) != 0);
+  rs_step<1>(d, e, 2, (lane & 2) != 0);
+  return e[0] + __shfl_xor(e[0], 1);
+}
+
+__device__ inline double wave_reduce_scatter64(double (&v)[64]) {  // lane l ends with the total of value l
+  const int lane = threadIdx.x & 63;
+  double z[32], a[16], b[8], c[4], d[2], e[1];
+  rs_step<32>(v, z, 32, (lane & 32) != 0);
+  rs_step<16>(z, a, 16, (lane & 16) != 0);
+  rs_step<8>(a, b, 8, (lane & 8) != 0);
+  rs_step<4>(b, c, 4, (lane & 4) != 0);
+  rs_step<2>(c, d, 2, (lane & 2) != 0);
+  rs_step<1>(d, e, 1, (lane & 1) != 0);
+  return e[0];
+}
+
+// red: [NW][32] for N <= 32, [NW][64] for 32 < N <= 64
+template <int N, int NW = 4>
+__device__ inline void block_reduce(double (&v)[N], double* red, double* out /*[N] in LDS*/) {
+  static_assert(N <= 64, "block_reduce handles up to 64 values");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if constexpr (N > 32) {
+    double w[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) w[k] = k < N ? v[k] : 0.0;
+    const double tot = wave_reduce_scatter64(w);
+    red[wave * 64 + lane] = tot;
+    __syncthreads();
+    if (threadIdx.x < N) {
+      double s = red[threadIdx.x];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; ++w2) s += red[w2 * 64 + threadIdx.x];
+      out[threadIdx.x] = s;
+    }
+    __syncthreads();
+    return;
+  }
+  if constexpr (N <= 2) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double x = v[k];
+      for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+      if (lane == 0) red[wave * 32 + k] = x;
+    }
+  } else {
+    double w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = k < N ? v[k] : 0.0;
+    const double tot = wave_reduce_scatter32(w);
+    if ((lane & 1) == 0) red[wave * 32 + (lane >> 1)] = tot;
   }
   __syncthreads();
   if (threadIdx.x < N) {
     const int k = threadIdx.x;
-    out[k] = ((red[k] + red[N + k]) + red[2 * N + k]) + red[3 * N + k];
+    double s = red[k];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) s += red[w2 * 32 + k];  // fixed order
+    out[k] = s;
   }
   __syncthreads();
 }
 
 __device__ inline bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
-  double A[36];
+  double A[36], inv[6];
   for (int i = 0; i < 36; ++i) A[i] = H[i];
   for (int j = 0; j < 6; ++j) A[j * 7] += lambda;
   for (int j = 0; j < 6; ++j) {
@@ -66,21 +130,22 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
     if (!(d > 0)) return false;
     d = sqrt(d);
     A[j * 6 + j] = d;
+    inv[j] = 1.0 / d;
     for (int i = j + 1; i < 6; ++i) {
       double s = A[i * 6 + j];
       for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
-      A[i * 6 + j] = s / d;
+      A[i * 6 + j] = s * inv[j];
     }
   }
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
     for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * x[k];
-    x[i] = s / A[i * 6 + i];
+    x[i] = s * inv[i];
   }
   for (int i = 5; i >= 0; --i) {
     double s = x[i];
     for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * x[k];
-    x[i] = s / A[i * 6 + i];
+    x[i] = s * inv[i];
   }
   return true;
 }
@@ -101,11 +166,12 @@ struct PoseOptArgs {
   int use_lds;
 };
 
+constexpr int kPoseThreads = 256, kPoseWaves = kPoseThreads / 64;
 struct PoseShared {
   Pose7 T, T0, Tbak;
   double H[36], b[6], x[6];
   double sums[29];
-  double red[4 * 29];
+  double red[kPoseWaves * 32];
   double lambda, ni, currentChi, iniChi, rho;
   int qmax, cont, ok, sys_valid, stop, pad[1];
 };
@@ -114,34 +180,54 @@ static_assert(sizeof(PoseShared) % 16 == 0, "keeps the dynamic LDS region 16-B a
 // one pass over the active edges at pose T: sums[0..20] = upper H, [21..26] = b, [27] = robust chi2, [28] = #active
 __device__ inline void pose_pass(const PoseOptArgs& a, const double* ed, double* er, const uint8_t* lvl, PoseShared& S,
                                  bool robust) {
+  // fp64 issue on ONE CU bounds this loop (a wave64 fp64 op takes 4 cycles, a division ~35 ops), so the
+  // arithmetic is kept lean: rotation matrix instead of the quaternion sandwich, one reciprocal per
+  // edge, weighted Jacobian rows shared by all 27 accumulators.
   const Pose7 T = S.T;
+  double R[9];
+  quat_to_rot(T, R);
+  const double hd = huber_delta(), hd2 = hd * hd;
   double acc[29];
 #pragma unroll
   for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-  for (int i = threadIdx.x; i < a.n; i += 256) {
+  for (int i = threadIdx.x; i < a.n; i += kPoseThreads) {
     if (lvl[i]) continue;
     const double* e = ed + 6 * i;
-    double Xc[3], J[12];
-    pose_map(T, e, Xc);
-    const double e0 = e[3] - (Xc[0] / Xc[2] * a.fx + a.cx);
-    const double e1 = e[4] - (Xc[1] / Xc[2] * a.fy + a.cy);
+    const double X = e[0], Y = e[1], Z = e[2];
+    const double x = R[0] * X + R[1] * Y + R[2] * Z + T.tx;
+    const double y = R[3] * X + R[4] * Y + R[5] * Z + T.ty;
+    const double z = R[6] * X + R[7] * Y + R[8] * Z + T.tz;
+    const double iz = 1.0 / z;
+    const double xz = x * iz, yz = y * iz;
+    const double e0 = e[3] - (xz * a.fx + a.cx);
+    const double e1 = e[4] - (yz * a.fy + a.cy);
     er[2 * i] = e0; er[2 * i + 1] = e1;
     const double c = (e0 * e0 + e1 * e1) * e[5];
     double r0 = c, w = 1.0;
-    if (robust) huber(c, huber_delta(), r0, w);
-    jac_pose(Xc[0], Xc[1], Xc[2], a.fx, a.fy, J);
+    if (robust && c > hd2) {  // Huber (robust_kernel_impl.cpp:78-91)
+      const double s = sqrt(c);
+      r0 = 2 * s * hd - hd2;
+      w = hd / s;
+    }
+    const double fiz = a.fx * iz, giz = a.fy * iz;
+    // Jacobian rows (types_six_dof_expmap.cpp:382-394), [omega | upsilon]
+    const double J0[6] = {xz * yz * a.fx, -(1 + xz * xz) * a.fx, yz * a.fx, -fiz, 0.0, xz * fiz};
+    const double J1[6] = {(1 + yz * yz) * a.fy, -xz * yz * a.fy, -xz * a.fy, 0.0, -giz, yz * giz};
     const double om = e[5] * w;
+    double W0[6], W1[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) { W0[r] = om * J0[r]; W1[r] = om * J1[r]; }
     int k = 0;
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int cc = r; cc < 6; ++cc) acc[k++] += om * (J[r] * J[cc] + J[6 + r] * J[6 + cc]);
+      for (int cc = r; cc < 6; ++cc) acc[k++] += W0[r] * J0[cc] + W1[r] * J1[cc];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) acc[21 + r] -= om * (J[r] * e0 + J[6 + r] * e1);
+    for (int r = 0; r < 6; ++r) acc[21 + r] -= W0[r] * e0 + W1[r] * e1;
     acc[27] += r0;
     acc[28] += 1.0;
   }
-  block_reduce<29>(acc, S.red, S.sums);
+  block_reduce<29, kPoseWaves>(acc, S.red, S.sums);
 }
 
 __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H, b
@@ -151,7 +237,7 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
   for (int r = 0; r < 6; ++r) S.b[r] = S.sums[21 + r];
 }
 
-__global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
+__global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
   __shared__ PoseShared S;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   const int t = threadIdx.x;
@@ -164,10 +250,10 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
     er = dyn + (size_t)6 * a.n;
     lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)8 * a.n);
     outl = lvl + a.n;
-    for (int i = t; i < 6 * a.n; i += 256) led[i] = a.edges[i];
+    for (int i = t; i < 6 * a.n; i += kPoseThreads) led[i] = a.edges[i];
     ed = led;
   }
-  for (int i = t; i < a.n; i += 256) { lvl[i] = 0; outl[i] = 0; }
+  for (int i = t; i < a.n; i += kPoseThreads) { lvl[i] = 0; outl[i] = 0; }
   if (t == 0) {
     Pose7 T0{a.io[0], a.io[1], a.io[2], a.io[3], a.io[4], a.io[5], a.io[6]};
     quat_normalize(T0.qx, T0.qy, T0.qz, T0.qw);
@@ -221,7 +307,8 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && isfinite(tempChi)) {
-              double alpha = 1. - pow((2 * rho - 1), 3);
+              const double q = 2 * rho - 1;
+              double alpha = 1. - q * q * q;
               alpha = fmin(alpha, 2. / 3.);
               S.lambda *= fmax(1. / 3., alpha);
               S.ni = 2;
@@ -256,7 +343,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
     double nb[1] = {0.0};
     {
       const Pose7 T = S.T;
-      for (int i = t; i < a.n; i += 256) {
+      for (int i = t; i < a.n; i += kPoseThreads) {
         const double* e = ed + 6 * i;
         if (outl[i]) {  // e->computeError()
           double Xc[3];
@@ -271,7 +358,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
       }
     }
     __syncthreads();
-    block_reduce<1>(nb, S.red, S.sums);
+    block_reduce<1, kPoseWaves>(nb, S.red, S.sums);
     nBad = (int)(S.sums[0] + 0.5);
     __syncthreads();
     if (round == 2) robust = false;  // e->setRobustKernel(0)
@@ -283,7 +370,7 @@ __global__ __launch_bounds__(256) void k_pose_opt(PoseOptArgs a) {
     a.io[7] = (double)nBad;
   }
   uint8_t* og = reinterpret_cast<uint8_t*>(a.io + 8);
-  for (int i = t; i < a.n; i += 256) og[i] = outl[i];
+  for (int i = t; i < a.n; i += kPoseThreads) og[i] = outl[i];
 }
 
 // ---------------------------------------------------------------- LocalBA kernels
@@ -336,7 +423,7 @@ __device__ inline void ba_project_error(const BaDev& d, int e) {
 
 // computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114): partial[blockIdx] = block sum
 __global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust) {
-  __shared__ double red[4], out[1];
+  __shared__ double red[4 * 32], out[1];
   const int k = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (k < d.Ea) {
@@ -395,7 +482,7 @@ __device__ inline void atomic_max_pos_double(unsigned long long* addr, double v)
 // Hpp_i, bp_i = segmented sum over the pose's edges with a fixed shape: thread-strided partial sums,
 // then the fixed-order block reduction (bit-reproducible).
 __global__ __launch_bounds__(256) void k_ba_reduce_pose(BaDev d) {
-  __shared__ double red[4 * 27], out[27];
+  __shared__ double red[4 * 32], out[27];
   const int h = blockIdx.x;
   const int b = d.ps_start[h], e = d.ps_start[h + 1];
   double acc[27];
@@ -464,7 +551,7 @@ struct SchurBlocks {
   const int2* pairs;
 };
 __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb, double lambda) {
-  __shared__ double red[4 * 42], out[42];
+  __shared__ double red[4 * 64], out[42];
   const int blk = blockIdx.x, bi = sb.blk_i[blk], bj = sb.blk_j[blk];
   const int n = 6 * d.nPf;
   double acc[42];
@@ -720,7 +807,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 
 // xl = Dinv (bl - B^T xp); backup + update of the point; gain-ratio partial sum_j x_j (lambda x_j + b_j)
 __global__ __launch_bounds__(256) void k_ba_backsub(BaDev d, double lambda) {
-  __shared__ double red[4], out[1];
+  __shared__ double red[4 * 32], out[1];
   const int h = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (h < d.nLa) {
@@ -751,7 +838,7 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev d, double lambda) {
 
 // pose update (oplus) with backup; pose part of the gain-ratio denominator into partial[offset + block]
 __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, double lambda, int partial_off) {
-  __shared__ double red[4], out[1];
+  __shared__ double red[4 * 32], out[1];
   const int h = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (h < d.nPf) {
@@ -776,7 +863,7 @@ __global__ __launch_bounds__(256) void k_ba_restore(BaDev d) {
 
 // activeRobustChi2() over the stored errors (no recomputation)
 __global__ __launch_bounds__(256) void k_ba_chi2_stored(BaDev d, int robust) {
-  __shared__ double red[4], out[1];
+  __shared__ double red[4 * 32], out[1];
   const int k = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (k < d.Ea) {
@@ -897,7 +984,7 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
     attr_set = true;
   }
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), a.use_lds ? lds : 0, st, a);
+  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(kPoseThreads), a.use_lds ? lds : 0, st, a);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(hio, s->po_pose.p, 64 + (size_t)n, hipMemcpyDeviceToHost, st));

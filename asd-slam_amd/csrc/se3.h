@@ -52,8 +52,11 @@ ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
   if (theta < 0.00001) {  // se3quat.h:237-243 (kept as is: R = I + W + W^2, V = R)
     for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
   } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
-    const double c = (theta - sin(theta)) / (theta * theta * theta);
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    const double it = 1.0 / theta, it2 = it * it;
+    const double a = sn * it, b = (1 - cs) * it2;
+    const double c = (theta - sn) * it2 * it;
     for (int i = 0; i < 9; ++i) {
       const double I = (i % 4 == 0 ? 1.0 : 0.0);
       R[i] = I + a * O[i] + b * O2[i];
