@@ -172,6 +172,18 @@ class AsdHip:
                                               _p(self._kps_buf), _p(self._desc_buf), C.byref(n)))
         return self._kps_buf[:n.value], self._desc_buf[:n.value]
 
+    def extract_submit(self, image, w, h, stride, device_resident=True, n_features_override=0):
+        self._chk(self.lib.asd_extract_submit(self.ctx, image, int(device_resident), w, h, stride, n_features_override))
+
+    def extract_wait(self):
+        cap = self.cfg.max_patches
+        if not hasattr(self, "_kps_buf"):
+            self._kps_buf = np.zeros(cap, KP_DTYPE)
+            self._desc_buf = np.empty((cap, 128), np.float32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_extract_wait(self.ctx, _p(self._kps_buf), _p(self._desc_buf), C.byref(n)))
+        return self._kps_buf[:n.value], self._desc_buf[:n.value]
+
     def profile_enable(self, on=True):
         self._chk(self.lib.asd_profile_enable(self.ctx, int(on)))
 

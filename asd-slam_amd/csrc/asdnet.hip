@@ -534,7 +534,7 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
   if (n < 0 || n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
   if (n == 0) return ASD_OK;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ctx->cur_stream ? ctx->cur_stream : ctx->stream;
   float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
   const int npad = (n + 31) / 32 * 32;
   const bool prof = ctx->prof_on;

@@ -92,7 +92,10 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
   }
   build_tables(c);
-  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+  // tracking kernels (small, latency critical) outrank the pipelined extractor's stream
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
       hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess) {
     delete c;
     return ASD_ERR_NO_DEVICE;
@@ -112,6 +115,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   if (!ctx) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  frontend_async_shutdown(ctx);
   asdnet_free(ctx);
   frontend_free(ctx);
   matcher_free(ctx);

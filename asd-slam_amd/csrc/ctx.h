@@ -37,6 +37,10 @@ struct AsdFrameSlot {
 struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
+  hipStream_t cur_stream = nullptr;  // stream the extractor / ASDNet enqueue on (stream, or stream_x for the pipelined extractor)
+  hipStream_t stream_x = nullptr;
+  hipEvent_t evx[3] = {};
+  struct AsyncExtract* ax = nullptr;
   int num_cu = 256;
   std::string err;
 
@@ -94,6 +98,7 @@ struct asd_ctx {
 // frontend.hip
 int frontend_alloc(asd_ctx* ctx);
 void frontend_free(asd_ctx* ctx);
+void frontend_async_shutdown(asd_ctx* ctx);
 // matcher.hip / ba.hip
 void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);

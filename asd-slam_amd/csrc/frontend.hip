@@ -596,7 +596,8 @@ static int configure_size(asd_ctx* ctx, int w, int h) {
 extern "C" {
 
 static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device, int32_t width, int32_t height,
-                        int32_t stride, int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
+                        int32_t stride, int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out,
+                        bool async_ctx = false) {
   if (!ctx || !image || !kps || !desc || !n_out || stride < width) return ASD_ERR_INVALID;
   if (width > ctx->cfg.max_width || height > ctx->cfg.max_height) { ctx->set_error("image %dx%d exceeds ctx capacity %dx%d", width, height, ctx->cfg.max_width, ctx->cfg.max_height); return ASD_ERR_CAPACITY; }
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
@@ -606,7 +607,10 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   FrontendState* fe = ctx->fe;
   const PyrDev& P = fe->pyr;
   const int nl = P.nlevels;
-  hipStream_t st = ctx->stream;
+  // the pipelined extractor runs on its own stream + events so tracking kernels on ctx->stream are not queued behind ASDNet
+  hipStream_t st = async_ctx ? ctx->stream_x : ctx->stream;
+  hipEvent_t ev_begin = async_ctx ? ctx->evx[0] : ctx->ev0, ev_end = async_ctx ? ctx->evx[1] : ctx->ev1,
+             ev_corners = async_ctx ? ctx->evx[2] : ctx->ev2;
   int quota[ASD_MAX_LEVELS];
   const int nfeat = n_features_override > 0 ? n_features_override : ctx->cfg.n_features;
   if (nfeat > ctx->cfg.max_patches) { ctx->set_error("n_features %d exceeds max_patches", nfeat); return ASD_ERR_CAPACITY; }
@@ -617,7 +621,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   const auto t_start = now();
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ev_begin, st));
   // E1 pyramid
   ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, image, stride, width, height,
                                       image_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
@@ -644,12 +648,12 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   const auto t_counts = now();
   if ((size_t)total > fe->corners_cap) { ctx->set_error("corner buffer overflow"); return ASD_ERR_CAPACITY; }
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_corners, fe->d_corners, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev2, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ev_corners, st));
   // E5a blur runs on the GPU while the host does the quadtree
   hipLaunchKernelGGL(k_blur7, dim3(P.total_tiles), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   // E3 quadtree per level on the host (DistributeOctTree): wait for the corner list only
-  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev2));
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(ev_corners));
   const auto t_corners = now();
   // unpack + quadtree per level in parallel (levels are independent), then assemble in level order
   const std::function<void(int)> level_job = [&](int l) {
@@ -694,16 +698,18 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   hipLaunchKernelGGL(k_angle_patch, dim3((n + 3) / 4), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur, fe->d_kps, n,
                      fe->d_angles, ctx->d_patches);
   ASD_HIP_CHECK(ctx, hipGetLastError());
+  ctx->cur_stream = st;
   rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc);
+  ctx->cur_stream = nullptr;
   if (rc != ASD_OK) return rc;
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_angles, fe->d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ev_end, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   memcpy(desc, fe->h_desc, (size_t)n * 128 * sizeof(float));  // pinned staging: the caller's buffer is pageable
   for (int i = 0; i < n; ++i) kps[i].angle = fe->h_angles[i];
   if (timing) fprintf(stderr, "[extract] launch+counts %.0f us, corners D2H %.0f us (%d), quadtree %.0f us, tail (angle+asdnet+D2H) %.0f us\n", us(t_start, t_counts), us(t_counts, t_corners), total, us(t_corners, t_quad), us(t_quad, now()));
-  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ctx->ev0, ctx->ev1));
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ev_begin, ev_end));
   return ASD_OK;
 }
 
@@ -715,6 +721,99 @@ int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t heigh
 int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int32_t height, int32_t stride,
                        int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
   return extract_impl(ctx, d_image, true, width, height, stride, n_features_override, kps, desc, n_out);
+}
+
+// ---- pipelined extraction -------------------------------------------------------------------
+}  // extern "C"
+
+struct AsyncExtract {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  bool have_job = false, done = false, stop = false, in_flight = false;
+  const uint8_t* image = nullptr;
+  bool on_device = false;
+  int w = 0, h = 0, stride = 0, nfeat = 0;
+  std::vector<asd_keypoint> kps;
+  std::vector<float> desc;
+  int n = 0, rc = ASD_OK;
+};
+
+static void async_worker(asd_ctx* ctx) {
+  AsyncExtract* ax = ctx->ax;
+  (void)hipSetDevice(ctx->cfg.device);
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> l(ax->m);
+      ax->cv.wait(l, [&] { return ax->have_job || ax->stop; });
+      if (ax->stop) return;
+      ax->have_job = false;
+    }
+    int32_t n = 0;
+    const int rc = extract_impl(ctx, ax->image, ax->on_device, ax->w, ax->h, ax->stride, ax->nfeat, ax->kps.data(),
+                                ax->desc.data(), &n, true);
+    {
+      std::lock_guard<std::mutex> l(ax->m);
+      ax->n = n; ax->rc = rc; ax->done = true;
+    }
+    ax->cv.notify_all();
+  }
+}
+
+void frontend_async_shutdown(asd_ctx* ctx) {
+  if (!ctx->ax) return;
+  { std::lock_guard<std::mutex> l(ctx->ax->m); ctx->ax->stop = true; }
+  ctx->ax->cv.notify_all();
+  if (ctx->ax->th.joinable()) ctx->ax->th.join();
+  delete ctx->ax;
+  ctx->ax = nullptr;
+  if (ctx->stream_x) { (void)hipStreamDestroy(ctx->stream_x); ctx->stream_x = nullptr; }
+  for (auto& e : ctx->evx) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+}
+
+extern "C" {
+
+int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width, int32_t height,
+                       int32_t stride, int32_t n_features_override) {
+  if (!ctx || !image) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  if (!ctx->ax) {
+    // lowest stream priority: the latency-critical tracking kernels on ctx->stream go first.
+    // (Masking a few CUs off this stream with hipExtStreamCreateWithCUMask was tried and measured
+    //  slower: extraction 2.0 -> 3.1 ms, no gain for the tracking kernels.)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_x, hipStreamDefault, prio_least));
+    for (auto& e : ctx->evx) ASD_HIP_CHECK(ctx, hipEventCreate(&e));
+    ctx->ax = new AsyncExtract();
+    ctx->ax->kps.resize(ctx->cfg.max_patches);
+    ctx->ax->desc.resize((size_t)ctx->cfg.max_patches * 128);
+    ctx->ax->th = std::thread(async_worker, ctx);
+  }
+  AsyncExtract* ax = ctx->ax;
+  {
+    std::lock_guard<std::mutex> l(ax->m);
+    if (ax->in_flight) { ctx->set_error("asd_extract_submit: a submission is already in flight"); return ASD_ERR_INVALID; }
+    ax->image = image; ax->on_device = device_resident != 0; ax->w = width; ax->h = height; ax->stride = stride;
+    ax->nfeat = n_features_override;
+    ax->have_job = true; ax->done = false; ax->in_flight = true;
+  }
+  ax->cv.notify_all();
+  return ASD_OK;
+}
+
+int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out) {
+  if (!ctx || !ctx->ax || !kps || !desc || !n_out) return ASD_ERR_INVALID;
+  AsyncExtract* ax = ctx->ax;
+  std::unique_lock<std::mutex> l(ax->m);
+  if (!ax->in_flight) { ctx->set_error("asd_extract_wait: nothing was submitted"); return ASD_ERR_INVALID; }
+  ax->cv.wait(l, [&] { return ax->done; });
+  ax->in_flight = false;
+  if (ax->rc != ASD_OK) return ax->rc;
+  memcpy(kps, ax->kps.data(), (size_t)ax->n * sizeof(asd_keypoint));
+  memcpy(desc, ax->desc.data(), (size_t)ax->n * 128 * sizeof(float));
+  *n_out = ax->n;
+  return ASD_OK;
 }
 
 int asd_get_level_size(const asd_ctx* ctx, int32_t level, int32_t* width, int32_t* height) {

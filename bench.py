@@ -123,11 +123,16 @@ class Workload:
         self.frames = [synth.scene_frame(t + 3 * seed_offset) for t in range(N_FRAMES)]
 
 
-def track_step(be, wl, image_handle, last, do_ba):
+def track_step(be, wl, image_handle, last, do_ba, next_handle=None):
     """One frame through extract -> M1 -> P1 -> frustum/M2 -> P1 (-> LocalBA).  `be` is a backend
-    (HIP or CPU restatement) exposing the same five operations."""
+    (HIP or CPU restatement) exposing the same operations.  ExtractDesc of the NEXT frame does not depend
+    on this frame's tracking, so the HIP backend starts it (asd_extract_submit, second stream) as soon as
+    this frame's descriptors are adopted; every frame still goes through every stage."""
     kps, desc = be.extract(image_handle)
     cur = be.make_frame(kps, desc)
+    kps, desc = kps.copy(), desc.copy()
+    if next_handle is not None:
+        be.prefetch(next_handle)
     stats = {"n_kp": len(kps)}
     if last is not None:
         lk, ld, lframe = last
@@ -161,11 +166,11 @@ def track_step(be, wl, image_handle, last, do_ba):
     if do_ba:
         r = be.local_ba(wl.ba)
         stats["ba_chi2"] = float(r["chi2_second"])
-    return (kps.copy(), desc.copy(), cur), stats
+    return (kps, desc, cur), stats
 
 
 class HipBackend:
-    def __init__(self, pkg, wl, device):
+    def __init__(self, pkg, wl, device, pipeline=True):
         self.hip = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096, device=device)
         self.hip.load_weights(pkg.synth.asdnet_weights(0))
         self.d_frames = []
@@ -174,12 +179,25 @@ class HipBackend:
             self.hip.h2d(p, f)
             self.d_frames.append(p)
         self.slot = 0
+        self.pending = None
+        self.pipeline = pipeline
 
     def image(self, t):
         return self.d_frames[t % len(self.d_frames)]
 
     def extract(self, h):
+        if self.pending is not None and self.pending.value == h.value:
+            self.pending = None
+            return self.hip.extract_wait()
+        if self.pending is not None:      # a different frame was prefetched: drain it first
+            self.hip.extract_wait()
+            self.pending = None
         return self.hip.extract_device(h, 1241, 376, 1241)
+
+    def prefetch(self, h):
+        if self.pipeline:
+            self.hip.extract_submit(h, 1241, 376, 1241, device_resident=True)
+            self.pending = h
 
     def make_frame(self, kps, desc):
         self.slot ^= 1
@@ -202,6 +220,9 @@ class HipBackend:
         return self.hip.local_ba(prob)
 
     def close(self):
+        if self.pending is not None:
+            self.hip.extract_wait()
+            self.pending = None
         self.hip.close()
 
 
@@ -226,6 +247,9 @@ class CpuBackend:
     def image(self, t):
         return self.frames[t % len(self.frames)]
 
+    def prefetch(self, h):
+        pass
+
     def extract(self, img):
         kps, patches = self.ex.extract(img)
         return kps, self.at.describe_per_level(self.net, patches, kps["octave"])
@@ -249,11 +273,14 @@ class CpuBackend:
         return (self.ref or self.orc).local_ba(prob)
 
 
-def run_steps(be, wl, t0, n, last):
+def run_steps(be, wl, t0, n, last, prefetch_beyond=False):
+    """n frames t0 .. t0+n-1.  The extraction of frame t+1 is started during frame t; the frame after the
+    last one is only prefetched when the caller will consume it (prefetch_beyond)."""
     stats = {}
     for i in range(n):
         t = t0 + i
-        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1))
+        nxt = be.image(t + 1) if (i + 1 < n or prefetch_beyond) else None
+        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1), next_handle=nxt)
     return last, stats
 
 
@@ -280,6 +307,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--cpu-frames", type=int, default=15, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--selftest-dist", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
     args = ap.parse_args()
     if args.selftest_dist:
         return selftest_dist(args)
@@ -292,9 +320,9 @@ def main():
     pkg = graft.load_package()
     dist = Dist(world)
     wl = Workload(pkg.synth, seed_offset=rank)
-    be = HipBackend(pkg, wl, device=local_rank if world > 1 else 0)
+    be = HipBackend(pkg, wl, device=local_rank if world > 1 else 0, pipeline=not args.no_pipeline)
 
-    last, _ = run_steps(be, wl, 0, args.warmup, None)            # untimed warm-up
+    last, _ = run_steps(be, wl, 0, args.warmup, None, prefetch_beyond=True)            # untimed warm-up
     be.hip.profile_enable(True)
     be.hip.sync(); device_sync(); dist.barrier()
     t0 = time.perf_counter()
@@ -331,7 +359,8 @@ def main():
                                    "isInFrustum+SearchByProjection(map)+PoseOptimization per frame, LocalBA "
                                    "(24+12 KF, 6000 MP, ~29k edges) every 15 frames",
                        "keypoints": int(stats.get("n_kp", 0)), "kf_interval": KF_INTERVAL,
-                       "parallelism": f"replicas x{world} (independent sequences, no collective)"},
+                       "parallelism": f"replicas x{world} (independent sequences, no collective)",
+                       "pipeline": "ExtractDesc(t+1) overlapped with tracking(t) on a second HIP stream" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

@@ -113,6 +113,16 @@ int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t heigh
 int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int32_t height, int32_t stride,
                        int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out);
 
+/* Pipelined extraction.  ExtractDesc of frame t+1 does not depend on the tracking of frame t, and a
+ * replay reads its images from disk (Examples/Monocular/kitti.cc:116-155), so the two can overlap:
+ * asd_extract_submit starts the extraction on a second HIP stream driven by a worker thread and
+ * returns at once; asd_extract_wait blocks until it has finished and hands back the same results
+ * asd_extract would.  One submission in flight per ctx; `image` must stay valid until the wait;
+ * do not call asd_extract / asd_describe between submit and wait (they share the ASDNet buffers). */
+int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width,
+                       int32_t height, int32_t stride, int32_t n_features_override);
+int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out);
+
 /* Intermediate products of the last asd_extract, for tests and for callers that read
  * ORBextractor::mvImagePyramid (ORBextractor.h:87).  Level images are returned WITHOUT
  * the 19 px border.  blurred != 0 selects the GaussianBlur'ed copy

@@ -198,3 +198,34 @@ def test_extract_deterministic(hip, synth):
     k2, d2 = hip.extract(img)
     np.testing.assert_array_equal(k1, k2)
     np.testing.assert_array_equal(d1, d2)
+
+
+@pytest.mark.gpu
+def test_pipelined_extract_equals_sync(hip, synth):
+    """asd_extract_submit / asd_extract_wait (second stream + worker thread) return exactly what asd_extract does,
+    also while the main stream is busy with other work."""
+    imgs = [synth.scene_frame(t) for t in (5, 6)]
+    ref = [hip.extract(im) for im in imgs]
+    d = []
+    for im in imgs:
+        p = hip.device_alloc(im.nbytes)
+        hip.h2d(p, im)
+        d.append(p)
+    for k in range(2):
+        hip.extract_submit(d[k], 1241, 376, 1241, device_resident=True)
+        # unrelated work on the main stream while the extraction runs
+        a = synth.unit_descriptors(300, seed=k)
+        M = hip.dist_matrix(a, a)
+        assert (np.diag(M) == 0).all()
+        kps, desc = hip.extract_wait()
+        np.testing.assert_array_equal(kps, ref[k][0])
+        np.testing.assert_array_equal(desc, ref[k][1])
+    # protocol errors are reported, not crashed on
+    with pytest.raises(Exception):
+        hip.extract_wait()
+    hip.extract_submit(d[0], 1241, 376, 1241, device_resident=True)
+    with pytest.raises(Exception):
+        hip.extract_submit(d[1], 1241, 376, 1241, device_resident=True)
+    hip.extract_wait()
+    for p in d:
+        hip.device_free(p)

@@ -1,11 +1,13 @@
 """Wall-clock per API call of the bench step (host view), 30 frames."""
 import sys, os, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.argv = ['bench.py']
+_pipe = '--pipeline' in sys.argv
+sys.argv = ['bench.py'] + (['--pipeline'] if _pipe else [])
 import bench, numpy as np
 pkg = bench.graft.load_package()
 wl = bench.Workload(pkg.synth)
-be = bench.HipBackend(pkg, wl, 0)
+import sys as _s
+be = bench.HipBackend(pkg, wl, 0, pipeline=('--pipeline' in _s.argv))
 acc = collections.defaultdict(float); cnt = collections.Counter()
 def wrap(name):
     f = getattr(be, name)
@@ -14,7 +16,7 @@ def wrap(name):
     setattr(be, name, g)
 for n in ('extract', 'make_frame', 'match_frame', 'pose_opt', 'frustum', 'match_points', 'local_ba'):
     wrap(n)
-last, _ = bench.run_steps(be, wl, 0, 15, None)
+last, _ = bench.run_steps(be, wl, 0, 15, None, prefetch_beyond=True)
 acc.clear(); cnt.clear()
 t0 = time.perf_counter()
 last, st = bench.run_steps(be, wl, 15, 30, last)
