@@ -33,6 +33,25 @@ KP_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("size", np.float32),
                      ("response", np.float32), ("octave", np.int32)])
 
 
+class asd_feature_vector(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("start", C.c_void_p), ("idx", C.c_void_p)]
+
+
+def make_fv(node_of_kp):
+    """node id per keypoint (-1 = none) -> (struct, keep-alive arrays) in DBoW2::FeatureVector order"""
+    node_of_kp = np.asarray(node_of_kp)
+    ids = np.unique(node_of_kp[node_of_kp >= 0]).astype(np.int32)
+    start = np.zeros(len(ids) + 1, np.int32)
+    idx = []
+    for k, nid in enumerate(ids):
+        members = np.nonzero(node_of_kp == nid)[0]
+        idx.append(members)
+        start[k + 1] = start[k] + len(members)
+    idx = (np.concatenate(idx) if idx else np.zeros(0)).astype(np.int32)
+    fv = asd_feature_vector(len(ids), ids.ctypes.data, start.ctypes.data, idx.ctypes.data)
+    return fv, (ids, start, idx)
+
+
 class asd_ba_problem(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("poses", C.c_void_p), ("fixed", C.c_void_p), ("points", C.c_void_p),
@@ -276,6 +295,26 @@ class AsdHip:
         self._chk(self.lib.asd_match_init(self.ctx, slot1, slot2, _p(pm), window, C.c_float(nn_ratio),
                                           int(check_ori), _p(out), C.byref(n)))
         return out, n.value, pm
+
+    def match_bow(self, slot_kf, slot_f, n_f, nodes_kf, nodes_f, has_mp_kf, nn_ratio=0.7, check_ori=True):
+        fa, ka = make_fv(nodes_kf)
+        fb, kb = make_fv(nodes_f)
+        has = _c(has_mp_kf, np.uint8)
+        out = np.empty(n_f, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_bow(self.ctx, slot_kf, slot_f, C.byref(fa), C.byref(fb), _p(has), C.c_float(nn_ratio),
+                                         int(check_ori), _p(out), C.byref(n)))
+        return out, n.value
+
+    def match_triangulate(self, slot1, slot2, n1, nodes1, nodes2, has_mp1, has_mp2, F12, ex, ey, check_ori=False):
+        fa, ka = make_fv(nodes1)
+        fb, kb = make_fv(nodes2)
+        h1, h2, F = _c(has_mp1, np.uint8), _c(has_mp2, np.uint8), _c(F12, np.float32)
+        out = np.empty(n1, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_triangulate(self.ctx, slot1, slot2, C.byref(fa), C.byref(fb), _p(h1), _p(h2), _p(F),
+                                                 C.c_float(ex), C.c_float(ey), int(check_ori), _p(out), C.byref(n)))
+        return out, n.value
 
     # ---- optimizer
     def pose_optimize(self, pose7, Xw, obs, inv_sigma2, K):

@@ -112,6 +112,34 @@ __global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery
   if (lane == 0) { q_cnt[q] = cnt; q_off[q] = off; }
 }
 
+// Node-restricted search (BoW-guided matchers): query q is matched against the explicit candidate list
+// cand[cbeg[q] .. cend[q]) (the frame-2 members of the query's vocabulary node); distances land at
+// out[ooff[q] + t] in list order.  One wave per query, lanes over candidates.
+struct ListQuery { int qrow, cbeg, cend, ooff; };
+__global__ __launch_bounds__(256) void k_list_dist(const ListQuery* __restrict__ queries, int nq,
+                                                   const int* __restrict__ cand, const float* __restrict__ qdesc,
+                                                   const float* __restrict__ cdesc, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq) return;
+  const ListQuery Q = queries[q];
+  const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)Q.qrow * 128);
+  for (int t = Q.cbeg + lane; t < Q.cend; t += 64) {
+    const float4* b = reinterpret_cast<const float4*>(cdesc + (size_t)cand[t] * 128);
+    float sqd = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float4 x = a[k], y = b[k];
+      float d;
+      d = x.x - y.x; sqd = sqd + d * d;
+      d = x.y - y.y; sqd = sqd + d * d;
+      d = x.z - y.z; sqd = sqd + d * d;
+      d = x.w - y.w; sqd = sqd + d * d;
+    }
+    out[Q.ooff + (t - Q.cbeg)] = sqd;
+  }
+}
+
 // all-pairs: block = 256 columns (b rows) x 16 a rows; a tile broadcast from LDS, b row in VGPRs.
 __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a, int na, const float* __restrict__ b,
                                                      int nb, float* __restrict__ out) {
@@ -572,6 +600,174 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
       if (best_lvl == best_lvl2 && best > nn_ratio * best2) continue;
       match_cur[best_idx] = q;
       nmatches += 2;  // the reference increments twice per match (ORBmatcher.cc:116-117)
+    }
+  }
+  *n_matches = nmatches;
+  return ASD_OK;
+}
+
+}  // extern "C"
+
+// merge-join of two DBoW2 feature vectors (std::map iteration + lower_bound, ORBmatcher.cc:183-278):
+// calls fn(a, b) for every node present in both
+template <typename Fn>
+static void node_join(const asd_feature_vector* A, const asd_feature_vector* B, Fn fn) {
+  int a = 0, b = 0;
+  while (a < A->n_nodes && b < B->n_nodes) {
+    if (A->node_id[a] == B->node_id[b]) { fn(a, b); ++a; ++b; }
+    else if (A->node_id[a] < B->node_id[b]) a = (int)(std::lower_bound(A->node_id, A->node_id + A->n_nodes, B->node_id[b]) - A->node_id);
+    else b = (int)(std::lower_bound(B->node_id, B->node_id + B->n_nodes, A->node_id[a]) - B->node_id);
+  }
+}
+
+static bool fv_valid(const asd_feature_vector* fv, int n) {
+  if (!fv || fv->n_nodes < 0 || (fv->n_nodes > 0 && (!fv->node_id || !fv->start || !fv->idx))) return false;
+  for (int i = 0; i < fv->n_nodes; ++i) {
+    if (i > 0 && fv->node_id[i] <= fv->node_id[i - 1]) return false;
+    if (fv->start[i + 1] < fv->start[i]) return false;
+  }
+  for (int t = fv->n_nodes ? fv->start[0] : 0; t < (fv->n_nodes ? fv->start[fv->n_nodes] : 0); ++t)
+    if (fv->idx[t] < 0 || fv->idx[t] >= n) return false;
+  return true;
+}
+
+// distances of every (query keypoint of A, same-node keypoint of B) pair; queries in reference visiting order.
+// On return lq[k] describes query k (qrow = keypoint in A, candidates fvB->idx[cbeg..cend), distances at dist[ooff..]).
+static int list_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& A, const AsdFrameSlot& B,
+                       const asd_feature_vector* fvA, const asd_feature_vector* fvB, const uint8_t* skipA, bool skip_if_set,
+                       std::vector<ListQuery>& lq, const float** dist_out) {
+  lq.clear();
+  int total = 0;
+  node_join(fvA, fvB, [&](int a, int b) {
+    const int cb = fvB->start[b], ce = fvB->start[b + 1];
+    for (int t = fvA->start[a]; t < fvA->start[a + 1]; ++t) {
+      const int i = fvA->idx[t];
+      if ((skipA[i] != 0) == skip_if_set) continue;
+      lq.push_back(ListQuery{i, cb, ce, total});
+      total += ce - cb;
+    }
+  });
+  *dist_out = nullptr;
+  if (lq.empty() || total == 0) return ASD_OK;
+  int rc;
+  if ((rc = ensure_cands(ctx, m, std::max(total, fvB->start[fvB->n_nodes]))) != ASD_OK) return rc;
+  if ((rc = ensure_queries(ctx, m, (int)lq.size())) != ASD_OK) return rc;
+  static_assert(sizeof(ListQuery) <= sizeof(WinQuery), "query staging is shared");
+  hipStream_t st = ctx->stream;
+  memcpy(m->h_queries, lq.data(), lq.size() * sizeof(ListQuery));
+  const int ncand = fvB->start[fvB->n_nodes];
+  memcpy(m->h_idx, fvB->idx, (size_t)ncand * sizeof(int));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_queries, m->h_queries, lq.size() * sizeof(ListQuery), hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_idx, m->h_idx, (size_t)ncand * sizeof(int), hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+  hipLaunchKernelGGL(k_list_dist, dim3(((int)lq.size() + 3) / 4), dim3(256), 0, st, reinterpret_cast<const ListQuery*>(m->d_queries),
+                     (int)lq.size(), m->d_idx, A.d_desc, B.d_desc, m->d_dist);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_dist, m->d_dist, (size_t)total * sizeof(float), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+  *dist_out = m->h_dist;
+  return ASD_OK;
+}
+
+extern "C" {
+
+int asd_match_bow(asd_ctx* ctx, int32_t slot_kf, int32_t slot_f, const asd_feature_vector* fv_kf,
+                  const asd_feature_vector* fv_f, const uint8_t* has_mp_kf, float nn_ratio, int32_t check_orientation,
+                  int32_t* match_f, int32_t* n_matches) {
+  AsdFrameSlot *KF = slot_of(ctx, slot_kf), *F = slot_of(ctx, slot_f);
+  if (!KF || !F || !has_mp_kf || !match_f || !n_matches || !fv_valid(fv_kf, KF->n) || !fv_valid(fv_f, F->n)) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  std::fill(match_f, match_f + F->n, -1);
+  *n_matches = 0;
+  std::vector<ListQuery> lq;
+  const float* dist = nullptr;
+  int rc = list_search(ctx, m, *KF, *F, fv_kf, fv_f, has_mp_kf, /*skip_if_set=*/false, lq, &dist);
+  if (rc != ASD_OK) return rc;
+  int nmatches = 0;
+  std::vector<int> hist[HISTO];
+  for (const ListQuery& Q : lq) {  // reference order: node by node, KF keypoints of the node in order (:194-262)
+    float best1 = 256, best2 = 256;
+    int best_idx = -1;
+    for (int t = Q.cbeg; t < Q.cend; ++t) {
+      const int j = fv_f->idx[t];
+      if (match_f[j] >= 0) continue;
+      const float d = dist[Q.ooff + (t - Q.cbeg)];
+      if (d < best1) { best2 = best1; best1 = d; best_idx = j; }
+      else if (d < best2) best2 = d;
+    }
+    if (best1 <= TH_LOW && best1 < nn_ratio * best2) {
+      match_f[best_idx] = Q.qrow;
+      if (check_orientation) hist[rot_bin(KF->kps[Q.qrow].angle, F->kps[best_idx].angle)].push_back(best_idx);
+      nmatches++;
+    }
+  }
+  if (check_orientation) {
+    int cnt[HISTO], a, b, c;
+    for (int k = 0; k < HISTO; ++k) cnt[k] = (int)hist[k].size();
+    three_maxima(cnt, a, b, c);
+    for (int k = 0; k < HISTO; ++k) {
+      if (k == a || k == b || k == c) continue;
+      for (int j : hist[k]) { match_f[j] = -1; nmatches--; }
+    }
+  }
+  *n_matches = nmatches;
+  return ASD_OK;
+}
+
+int asd_match_triangulate(asd_ctx* ctx, int32_t slot1, int32_t slot2, const asd_feature_vector* fv1,
+                          const asd_feature_vector* fv2, const uint8_t* has_mp1, const uint8_t* has_mp2, const float* F12,
+                          float ex, float ey, int32_t check_orientation, int32_t* matches12, int32_t* n_matches) {
+  AsdFrameSlot *K1 = slot_of(ctx, slot1), *K2 = slot_of(ctx, slot2);
+  if (!K1 || !K2 || !has_mp1 || !has_mp2 || !F12 || !matches12 || !n_matches || !fv_valid(fv1, K1->n) || !fv_valid(fv2, K2->n))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  std::fill(matches12, matches12 + K1->n, -1);
+  *n_matches = 0;
+  std::vector<ListQuery> lq;
+  const float* dist = nullptr;
+  int rc = list_search(ctx, m, *K1, *K2, fv1, fv2, has_mp1, /*skip_if_set=*/true, lq, &dist);
+  if (rc != ASD_OK) return rc;
+  int nmatches = 0;
+  std::vector<int> hist[HISTO];
+  for (const ListQuery& Q : lq) {
+    const asd_keypoint& kp1 = K1->kps[Q.qrow];
+    // epipolar line of kp1 in image 2 (CheckDistEpipolarLine, ORBmatcher.cc:136-153)
+    const float la = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float lb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float lc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float den = la * la + lb * lb;
+    float best = TH_LOW;
+    int best_idx = -1;
+    for (int t = Q.cbeg; t < Q.cend; ++t) {
+      const int idx2 = fv2->idx[t];
+      if (has_mp2[idx2]) continue;  // vbMatched2 is never set by the reference (:688, :729)
+      const float d = dist[Q.ooff + (t - Q.cbeg)];
+      if (d > TH_LOW || d > best) continue;
+      const asd_keypoint& kp2 = K2->kps[idx2];
+      const float dex = ex - kp2.x, dey = ey - kp2.y;
+      if (dex * dex + dey * dey < 100 * ctx->scale[kp2.octave]) continue;
+      const float num = la * kp2.x + lb * kp2.y + lc;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (dsqr < 3.84 * ctx->sigma2[kp2.octave]) { best_idx = idx2; best = d; }
+    }
+    if (best_idx >= 0) {
+      matches12[Q.qrow] = best_idx;
+      nmatches++;
+      if (check_orientation) hist[rot_bin(kp1.angle, K2->kps[best_idx].angle)].push_back(Q.qrow);
+    }
+  }
+  if (check_orientation) {
+    int cnt[HISTO], a, b, c;
+    for (int k = 0; k < HISTO; ++k) cnt[k] = (int)hist[k].size();
+    three_maxima(cnt, a, b, c);
+    for (int k = 0; k < HISTO; ++k) {
+      if (k == a || k == b || k == c) continue;
+      for (int i1 : hist[k]) { matches12[i1] = -1; nmatches--; }
     }
   }
   *n_matches = nmatches;

@@ -203,6 +203,35 @@ int asd_frustum(asd_ctx* ctx, int32_t slot_cur, int32_t n, const float* Xw, cons
 int asd_match_init(asd_ctx* ctx, int32_t slot1, int32_t slot2, float* prev_matched, int32_t window,
                    float nn_ratio, int32_t check_orientation, int32_t* matches12, int32_t* n_matches);
 
+/* DBoW2::FeatureVector of a frame (node id at `levelsup` = 4 -> keypoint indices; Frame::ComputeBoW,
+ * Frame.cc:289-296).  The vocabulary transform itself stays on the host (the
+ * vocabulary file is absent from the reference tree); the matchers below only consume its output.
+ * node_id ascending (std::map order), start has n_nodes+1 entries into idx. */
+typedef struct asd_feature_vector {
+  int32_t n_nodes;
+  const int32_t* node_id;
+  const int32_t* start;
+  const int32_t* idx;
+} asd_feature_vector;
+
+/* M3: ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
+ * (ORBmatcher.cc:156-297): slot_kf / slot_f hold the two frames, has_mp_kf[i] = pKF has a good map
+ * point at keypoint i.  Output match_f[n_f] = keypoint index in pKF whose map point was assigned
+ * to F's keypoint, or -1; *n_matches = return value. */
+int asd_match_bow(asd_ctx* ctx, int32_t slot_kf, int32_t slot_f, const asd_feature_vector* fv_kf,
+                  const asd_feature_vector* fv_f, const uint8_t* has_mp_kf, float nn_ratio,
+                  int32_t check_orientation, int32_t* match_f, int32_t* n_matches);
+
+/* M4: ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo=false)
+ * (ORBmatcher.cc:669-822): has_mp1 / has_mp2 mark keypoints that already hold a map point,
+ * F12[9] row-major f32 fundamental matrix, epipole (ex, ey) of camera 1 in image 2 as computed at
+ * :675-683, sigma2 level table of pKF2 comes from the ctx.  Output matches12[n1] = index in
+ * KF2 or -1; *n_matches = return value. */
+int asd_match_triangulate(asd_ctx* ctx, int32_t slot1, int32_t slot2, const asd_feature_vector* fv1,
+                          const asd_feature_vector* fv2, const uint8_t* has_mp1, const uint8_t* has_mp2,
+                          const float* F12, float ex, float ey, int32_t check_orientation,
+                          int32_t* matches12, int32_t* n_matches);
+
 /* ---- optimizer (P1, B1-B5, C1) ------------------------------------------------------- */
 /* Optimizer::PoseOptimization (Optimizer.cc:239-413) on g2o's EdgeSE3ProjectXYZOnlyPose
  * (types_six_dof_expmap.h:194-222, .cpp:372-394) with Levenberg

@@ -375,4 +375,135 @@ int orc_match_init(const orc_frame* F1, const orc_frame* F2, float* vbPrevMatche
   return nmatches;
 }
 
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)  (ORBmatcher.cc:156-297)
+int orc_match_bow(const orc_frame* KF, const orc_frame* F, int nn_kf, const int32_t* node_kf, const int32_t* start_kf,
+                  const int32_t* idx_kf, int nn_f, const int32_t* node_f, const int32_t* start_f, const int32_t* idx_f,
+                  const uint8_t* has_mp_kf, float nn_ratio, int check_ori, int32_t* match_f) {
+  for (int j = 0; j < F->N; ++j) match_f[j] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < nn_kf && b < nn_f) {
+    if (node_kf[a] == node_f[b]) {
+      for (int iKF = start_kf[a]; iKF < start_kf[a + 1]; iKF++) {
+        const int realIdxKF = idx_kf[iKF];
+        if (!has_mp_kf[realIdxKF]) continue;  // !pMP || pMP->isBad()
+        const float* dKF = KF->desc.data() + (size_t)realIdxKF * 128;
+        float bestDist1 = 256, bestDist2 = 256;
+        int bestIdxF = -1;
+        for (int iF = start_f[b]; iF < start_f[b + 1]; iF++) {
+          const int realIdxF = idx_f[iF];
+          if (match_f[realIdxF] >= 0) continue;
+          const float dist = DescriptorDistance(dKF, F->desc.data() + (size_t)realIdxF * 128);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < nn_ratio * static_cast<float>(bestDist2)) {
+            match_f[bestIdxF] = realIdxKF;
+            if (check_ori) {
+              float rot = KF->kps[realIdxKF].angle - F->kps[bestIdxF].angle;
+              if (rot < 0.0) rot += 360.0f;
+              int bin = (int)std::round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back(bestIdxF);
+            }
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (node_kf[a] < node_f[b]) {
+      a = (int)(std::lower_bound(node_kf, node_kf + nn_kf, node_f[b]) - node_kf);
+    } else {
+      b = (int)(std::lower_bound(node_f, node_f + nn_f, node_kf[a]) - node_f);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { match_f[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:669-822) + CheckDistEpipolarLine (:136-153)
+int orc_match_triangulate(const orc_frame* KF1, const orc_frame* KF2, int nn1, const int32_t* node1, const int32_t* start1,
+                          const int32_t* idx1v, int nn2, const int32_t* node2, const int32_t* start2, const int32_t* idx2v,
+                          const uint8_t* has_mp1, const uint8_t* has_mp2, const float* F12, float ex, float ey,
+                          int check_ori, int32_t* vMatches12) {
+  int nmatches = 0;
+  std::vector<bool> vbMatched2(KF2->N, false);  // never set by the reference either
+  for (int i = 0; i < KF1->N; ++i) vMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  std::vector<float> sigma2(KF2->mnScaleLevels);
+  for (int l = 0; l < KF2->mnScaleLevels; ++l) sigma2[l] = KF2->mvScaleFactors[l] * KF2->mvScaleFactors[l];
+  int a = 0, b = 0;
+  while (a < nn1 && b < nn2) {
+    if (node1[a] == node2[b]) {
+      for (int i1 = start1[a]; i1 < start1[a + 1]; i1++) {
+        const int idx1 = idx1v[i1];
+        if (has_mp1[idx1]) continue;
+        const orc_keypoint& kp1 = KF1->kps[idx1];
+        const float* d1 = KF1->desc.data() + (size_t)idx1 * 128;
+        float bestDist = TH_LOW;
+        int bestIdx2 = -1;
+        for (int i2 = start2[b]; i2 < start2[b + 1]; i2++) {
+          const int idx2 = idx2v[i2];
+          if (vbMatched2[idx2] || has_mp2[idx2]) continue;
+          const float dist = DescriptorDistance(d1, KF2->desc.data() + (size_t)idx2 * 128);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const orc_keypoint& kp2 = KF2->kps[idx2];
+          {
+            const float distex = ex - kp2.x;
+            const float distey = ey - kp2.y;
+            if (distex * distex + distey * distey < 100 * KF2->mvScaleFactors[kp2.octave]) continue;
+          }
+          // CheckDistEpipolarLine
+          const float la = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+          const float lb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+          const float lc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+          const float num = la * kp2.x + lb * kp2.y + lc;
+          const float den = la * la + lb * lb;
+          if (den == 0) continue;
+          const float dsqr = num * num / den;
+          if (dsqr < 3.84 * sigma2[kp2.octave]) { bestIdx2 = idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          const orc_keypoint& kp2 = KF2->kps[bestIdx2];
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (check_ori) {
+            float rot = kp1.angle - kp2.angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = (int)std::round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back(idx1);
+          }
+        }
+      }
+      a++; b++;
+    } else if (node1[a] < node2[b]) {
+      a = (int)(std::lower_bound(node1, node1 + nn1, node2[b]) - node1);
+    } else {
+      b = (int)(std::lower_bound(node2, node2 + nn2, node1[a]) - node2);
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"

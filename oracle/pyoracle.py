@@ -138,6 +138,36 @@ class Oracle:
         n = self.lib.orc_match_init(f1.h, f2.h, _p(pm), window, C.c_float(nn_ratio), int(check_ori), _p(out))
         return out, n, pm
 
+    @staticmethod
+    def _fv(node_of_kp):
+        node_of_kp = np.asarray(node_of_kp)
+        ids = np.unique(node_of_kp[node_of_kp >= 0]).astype(np.int32)
+        start = np.zeros(len(ids) + 1, np.int32)
+        idx = []
+        for k, nid in enumerate(ids):
+            members = np.nonzero(node_of_kp == nid)[0]
+            idx.append(members)
+            start[k + 1] = start[k] + len(members)
+        idx = (np.concatenate(idx) if idx else np.zeros(0)).astype(np.int32)
+        return ids, start, idx
+
+    def match_bow(self, kf, f, nodes_kf, nodes_f, has_mp_kf, nn_ratio=0.7, check_ori=True):
+        a, b = self._fv(nodes_kf), self._fv(nodes_f)
+        has = _c(has_mp_kf, np.uint8)
+        out = np.empty(f.n, np.int32)
+        n = self.lib.orc_match_bow(kf.h, f.h, len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), len(b[0]), _p(b[0]), _p(b[1]),
+                                   _p(b[2]), _p(has), C.c_float(nn_ratio), int(check_ori), _p(out))
+        return out, n
+
+    def match_triangulate(self, kf1, kf2, nodes1, nodes2, has_mp1, has_mp2, F12, ex, ey, check_ori=False):
+        a, b = self._fv(nodes1), self._fv(nodes2)
+        h1, h2, F = _c(has_mp1, np.uint8), _c(has_mp2, np.uint8), _c(F12, np.float32)
+        out = np.empty(kf1.n, np.int32)
+        n = self.lib.orc_match_triangulate(kf1.h, kf2.h, len(a[0]), _p(a[0]), _p(a[1]), _p(a[2]), len(b[0]), _p(b[0]),
+                                           _p(b[1]), _p(b[2]), _p(h1), _p(h2), _p(F), C.c_float(ex), C.c_float(ey),
+                                           int(check_ori), _p(out))
+        return out, n
+
     # ---- optimizer
     def pose_optimize(self, pose7, Xw, obs, inv_sigma2, K):
         pose = _c(pose7, np.float64).copy()

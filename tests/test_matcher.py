@@ -306,3 +306,78 @@ def test_cpp_host_mirror_example(synth, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "matches=" in p.stdout
+
+
+# ------------------------------------------------------------------ BoW-guided matchers (M3, M4 triangulation)
+def _bow_nodes(desc, nbits=6):
+    """stand-in for the DBoW2 transform (vocabulary file absent): node = sign pattern of the first dims, so that
+    true matches mostly share a node"""
+    bits = (desc[:, :nbits] > 0).astype(np.int64)
+    return (bits * (1 << np.arange(nbits))).sum(1).astype(np.int32)
+
+
+def _two_views(n, seed):
+    k1, d1 = make_frame(n, seed)
+    rng = np.random.default_rng(seed + 1)
+    perm = rng.permutation(n)
+    k2 = k1[perm].copy()
+    # pure horizontal translation between the cameras -> epipolar lines are image rows: F = [t]_x with t = (1,0,0)
+    k2["x"] = np.clip(k2["x"] + rng.uniform(5, 60, n).astype(np.float32), 19, 1221)
+    k2["y"] += rng.normal(0, 0.3, n).astype(np.float32)
+    k2["angle"] = (k2["angle"] + rng.normal(0, 3, n)).astype(np.float32) % np.float32(360)
+    d2 = perturbed_descriptors(d1[perm], 0.03, seed + 2)
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    return k1, d1, k2, d2, perm, F12
+
+
+def test_oracle_bow_and_triangulation_recover_matches(oracle):
+    k1, d1, k2, d2, perm, F12 = _two_views(1500, 201)
+    n1, n2 = _bow_nodes(d1), _bow_nodes(d2)
+    has = np.ones(1500, np.uint8)
+    f1, f2 = oracle.frame(k1, d1, BOUNDS), oracle.frame(k2, d2, BOUNDS)
+    m, n = oracle.match_bow(f1, f2, n1, n2, has, 0.7, True)
+    inv = np.empty_like(perm); inv[perm] = np.arange(1500)
+    good = sum(1 for j in range(1500) if m[j] >= 0 and m[j] == perm[j])
+    assert n == (m >= 0).sum() and good > 0.4 * 1500 and good >= 0.98 * n
+    none = np.zeros(1500, np.uint8)
+    m12, nt = oracle.match_triangulate(f1, f2, n1, n2, none, none, F12, -5000.0, 188.0, False)
+    good = sum(1 for i in range(1500) if m12[i] >= 0 and perm[m12[i]] == i)
+    assert nt == (m12 >= 0).sum() and good > 0.4 * 1500 and good >= 0.95 * nt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ori", [(2000, True), (300, False)])
+def test_match_bow(hip, oracle, n, ori):
+    k1, d1, k2, d2, perm, _ = _two_views(n, 210 + n)
+    n1, n2 = _bow_nodes(d1), _bow_nodes(d2)
+    n1[::17] = -1  # keypoints the vocabulary did not place
+    rng = np.random.default_rng(5)
+    has = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+    hip.frame_set(4, k1, d1, BOUNDS)
+    hip.frame_set(5, k2, d2, BOUNDS)
+    got, ng = hip.match_bow(4, 5, n, n1, n2, has, 0.7, ori)
+    exp, ne = oracle.match_bow(oracle.frame(k1, d1, BOUNDS), oracle.frame(k2, d2, BOUNDS), n1, n2, has, 0.7, ori)
+    np.testing.assert_array_equal(got, exp)
+    assert ng == ne and ng > 0.3 * has.sum()
+    # disjoint node sets -> nothing to match
+    got, ng = hip.match_bow(4, 5, n, n1 * 0 + 1, n2 * 0 + 2, has, 0.7, ori)
+    assert ng == 0 and (got == -1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ori", [(2000, False), (500, True)])
+def test_match_triangulate(hip, oracle, n, ori):
+    k1, d1, k2, d2, perm, F12 = _two_views(n, 230 + n)
+    n1, n2 = _bow_nodes(d1), _bow_nodes(d2)
+    rng = np.random.default_rng(6)
+    has1 = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    has2 = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    hip.frame_set(4, k1, d1, BOUNDS)
+    hip.frame_set(5, k2, d2, BOUNDS)
+    for ex, ey in ((-5000.0, 188.0), (600.0, 188.0)):  # far epipole; epipole inside the image (rejects close points)
+        got, ng = hip.match_triangulate(4, 5, n, n1, n2, has1, has2, F12, ex, ey, ori)
+        exp, ne = oracle.match_triangulate(oracle.frame(k1, d1, BOUNDS), oracle.frame(k2, d2, BOUNDS), n1, n2, has1, has2,
+                                           F12, ex, ey, ori)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne
+    assert (got[has1 > 0] == -1).all()
