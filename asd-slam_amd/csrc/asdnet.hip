@@ -72,6 +72,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
   const int patch = blockIdx.x / BANDS, band = blockIdx.x % BANDS;
   const int r0 = band * ROWS;
 
+#ifdef ASD_DESYNC
+  // experiment: de-phase the first generation of workgroups by quarters of a workgroup lifetime
+  if (blockIdx.x < ASD_DESYNC_FIRST) {
+    const int q = (blockIdx.x * 2654435761u >> 20) & 3;
+    for (int i = 0; i < q * ASD_DESYNC; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+#endif
   if constexpr (FUSE1) {
     static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1), "conv1 fusion is for conv2 only");
     // extra LDS behind the weight ring: normalised input rows r0-2 .. r0+ROWS+1 (34 wide, zero padded),
@@ -106,6 +113,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
     __syncthreads();
     // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding)
     constexpr int NPIX = C::INROWS * C::INCOLS;
+    if (ABL != 1)
     for (int item = t; item < NPIX * 8; item += 256) {
       const int q = item & 7, pix = item >> 3;
       const int i = pix % C::INCOLS, j = pix / C::INCOLS;
@@ -581,14 +589,16 @@ int asdnet_profile_collect(asd_ctx* ctx) {
 // mode 0 = full, 1 = no activation staging, 2 = no MFMA, 3 = no epilogue stores
 extern "C" int asd_debug_conv2_ablate(asd_ctx* ctx, int n, int mode, int reps, float* ms) {
   hipStream_t st = ctx->stream;
-  float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
+  float* a1 = ctx->d_act[1];
   using C = ConvCfg<L2_CFG>;
-  auto k0 = k_conv_mfma<L2_CFG, 0>; auto k1 = k_conv_mfma<L2_CFG, 1>; auto k2 = k_conv_mfma<L2_CFG, 2>; auto k3 = k_conv_mfma<L2_CFG, 3>;
+  constexpr int lds = C::LDS_BYTES + ((4 + 4) * 36 + 320 + 8) * 4;
+  auto k0 = k_conv_mfma<L2_CFG, 0, true>; auto k1 = k_conv_mfma<L2_CFG, 1, true>; auto k2 = k_conv_mfma<L2_CFG, 2, true>; auto k3 = k_conv_mfma<L2_CFG, 3, true>;
   decltype(k0) ks[4] = {k0, k1, k2, k3};
-  for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(ks[mode], dim3(n * (32 / 4)), dim3(256), C::LDS_BYTES, st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, (const float*)nullptr, (const float*)nullptr);
+  for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const int grid = n * (C::HO / 4);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(ks[mode], dim3(grid), dim3(256), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0]);
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[mode], dim3(n * (32 / 4)), dim3(256), C::LDS_BYTES, st, a0, ctx->d_wimg[1], ctx->d_bias[1], a1, (const float*)nullptr, (const float*)nullptr);
+  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[mode], dim3(grid), dim3(256), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0]);
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
   ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));

@@ -977,7 +977,7 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   a.flags_g = s->po_level.as<uint8_t>();
   a.io = s->po_pose.as<double>();
   const size_t lds = (size_t)n * 64 + (size_t)2 * n + 16;
-  a.use_lds = lds <= 150 * 1024 ? 1 : 0;
+  a.use_lds = (lds <= 150 * 1024 && !getenv("ASD_POSE_NO_LDS")) ? 1 : 0;
   static bool attr_set = false;
   if (!attr_set) {
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
