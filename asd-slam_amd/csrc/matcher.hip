@@ -238,6 +238,8 @@ struct MatcherState {
   int* h_idx = nullptr;
   float* h_dist = nullptr;
   float *d_qdesc = nullptr, *h_qdesc = nullptr;
+  float* d_bank = nullptr;  // device-resident descriptor bank (MapPoint::mDescriptor rows)
+  int bank_cap = 0;
 };
 
 MatcherState* mstate(asd_ctx* ctx) {
@@ -277,6 +279,21 @@ int ensure_qdesc(asd_ctx* ctx, MatcherState* m, int n) {
   ASD_HIP_CHECK(ctx, hipMalloc(&m->d_qdesc, (size_t)cap * 512));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_qdesc, (size_t)cap * 512));
   m->qdesc_cap = cap;
+  return ASD_OK;
+}
+
+int ensure_bank(asd_ctx* ctx, MatcherState* m, int rows) {
+  if (rows <= m->bank_cap) return ASD_OK;
+  const int cap = std::max(rows * 3 / 2, 16384);
+  float* nb = nullptr;
+  ASD_HIP_CHECK(ctx, hipMalloc(&nb, (size_t)cap * 512));
+  if (m->d_bank) {
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(nb, m->d_bank, (size_t)m->bank_cap * 512, hipMemcpyDeviceToDevice, ctx->stream));
+    ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(m->d_bank);
+  }
+  m->d_bank = nb;
+  m->bank_cap = cap;
   return ASD_OK;
 }
 
@@ -352,7 +369,7 @@ void matcher_free(asd_ctx* ctx) {
   }
   if (ctx->matcher) {
     MatcherState* m = static_cast<MatcherState*>(ctx->matcher);
-    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_qdesc};
+    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_qdesc, m->d_bank};
     for (void* p : dev) if (p) (void)hipFree(p);
     void* host[] = {m->h_queries, m->h_q, m->h_idx, m->h_dist, m->h_qdesc};
     for (void* p : host) if (p) (void)hipHostFree(p);
@@ -490,11 +507,14 @@ int asd_distinctive_descriptor(asd_ctx* ctx, const float* desc, int32_t n, int32
   return ASD_OK;
 }
 
-int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
-                            const float* mp_desc, const float* Tcw, const float* K, float th,
+}  // extern "C"
+
+// mp_desc: host table indexed like the last frame's keypoints, or NULL with mp_rows = bank rows
+static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
+                            const float* mp_desc, const int32_t* mp_rows, const float* Tcw, const float* K, float th,
                             int32_t check_orientation, int32_t* match_cur, int32_t* n_matches) {
   AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
-  if (!C || !L || !has_mp || !Xw || !mp_desc || !Tcw || !K || !match_cur || !n_matches) return ASD_ERR_INVALID;
+  if (!C || !L || !has_mp || !Xw || (!mp_desc && !mp_rows) || !Tcw || !K || !match_cur || !n_matches) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   MatcherState* m = mstate(ctx);
   std::fill(match_cur, match_cur + C->n, -1);
@@ -502,7 +522,11 @@ int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
   if (L->n == 0 || C->n == 0) return ASD_OK;
   int rc = ensure_queries(ctx, m, L->n);
   if (rc != ASD_OK) return rc;
-  if ((rc = upload_qdesc(ctx, m, mp_desc, L->n)) != ASD_OK) return rc;
+  if (mp_desc) { if ((rc = upload_qdesc(ctx, m, mp_desc, L->n)) != ASD_OK) return rc; }
+  else {
+    for (int i = 0; i < L->n; ++i)
+      if (has_mp[i] && (mp_rows[i] < 0 || mp_rows[i] >= m->bank_cap)) { ctx->set_error("bank row %d out of range", mp_rows[i]); return ASD_ERR_INVALID; }
+  }
   const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
   for (int i = 0; i < L->n; ++i) {  // projection, ORBmatcher.cc:1343-1368
     WinQuery& Q = m->h_queries[i];
@@ -517,10 +541,10 @@ int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
     if (u < C->min_x || u > C->max_x) continue;
     if (v < C->min_y || v > C->max_y) continue;
     const int oct = L->kps[i].octave;
-    Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, i};
+    Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, mp_desc ? i : mp_rows[i]};
   }
   SearchResult R;
-  if ((rc = window_search(ctx, m, *C, L->n, m->d_qdesc, &R)) != ASD_OK) return rc;
+  if ((rc = window_search(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, &R)) != ASD_OK) return rc;
   int nmatches = 0;
   std::vector<int> hist[HISTO];
   for (int i = 0; i < L->n; ++i) {
@@ -550,11 +574,11 @@ int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
   return ASD_OK;
 }
 
-int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
-                             const int32_t* level, const float* view_cos, const float* desc, const uint8_t* occupied,
-                             float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
+static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
+                             const int32_t* level, const float* view_cos, const float* desc, const int32_t* rows,
+                             const uint8_t* occupied, float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
   AsdFrameSlot* F = slot_of(ctx, slot_cur);
-  if (!F || n_mp < 0 || !match_cur || !n_matches || (n_mp > 0 && (!in_view || !proj || !level || !view_cos || !desc)) ||
+  if (!F || n_mp < 0 || !match_cur || !n_matches || (n_mp > 0 && (!in_view || !proj || !level || !view_cos || (!desc && !rows))) ||
       (F->n > 0 && !occupied))
     return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
@@ -573,11 +597,12 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
     if (lvl < 0 || lvl >= ctx->cfg.n_levels) { ctx->set_error("map point %d: level %d out of range", q, lvl); return ASD_ERR_INVALID; }
     float r = view_cos[q] > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
     if (bFactor) r *= th;
-    Q = WinQuery{proj[2 * q], proj[2 * q + 1], r * ctx->scale[lvl], lvl - 1, lvl, q};
+    if (!desc && (rows[q] < 0 || rows[q] >= m->bank_cap)) { ctx->set_error("bank row %d out of range", rows[q]); return ASD_ERR_INVALID; }
+    Q = WinQuery{proj[2 * q], proj[2 * q + 1], r * ctx->scale[lvl], lvl - 1, lvl, desc ? q : rows[q]};
   }
-  if ((rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  if (desc && (rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
   SearchResult R;
-  if ((rc = window_search(ctx, m, *F, n_mp, m->d_qdesc, &R)) != ASD_OK) return rc;
+  if ((rc = window_search(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, &R)) != ASD_OK) return rc;
   int nmatches = 0;
   for (int q = 0; q < n_mp; ++q) {
     if (R.cnt[q] == 0) continue;
@@ -603,6 +628,63 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
     }
   }
   *n_matches = nmatches;
+  return ASD_OK;
+}
+
+extern "C" {
+
+int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
+                            const float* mp_desc, const float* Tcw, const float* K, float th,
+                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches) {
+  if (!mp_desc) return ASD_ERR_INVALID;
+  return match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, nullptr, Tcw, K, th, check_orientation, match_cur, n_matches);
+}
+
+int asd_match_project_frame_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
+                                 const int32_t* mp_rows, const float* Tcw, const float* K, float th,
+                                 int32_t check_orientation, int32_t* match_cur, int32_t* n_matches) {
+  if (!mp_rows) return ASD_ERR_INVALID;
+  return match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, nullptr, mp_rows, Tcw, K, th, check_orientation, match_cur, n_matches);
+}
+
+int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
+                             const int32_t* level, const float* view_cos, const float* desc, const uint8_t* occupied,
+                             float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
+  if (n_mp > 0 && !desc) return ASD_ERR_INVALID;
+  return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, nullptr, occupied, th, nn_ratio, match_cur, n_matches);
+}
+
+int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
+                                  const int32_t* level, const float* view_cos, const int32_t* rows, const uint8_t* occupied,
+                                  float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
+  if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
+  return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, occupied, th, nn_ratio, match_cur, n_matches);
+}
+
+// MapPoint::mDescriptor rows kept on the device: written when a map point's descriptor changes
+// (MapPoint::ComputeDistinctiveDescriptors, once per keyframe), read by the matchers every frame.
+int asd_bank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* desc) {
+  if (!ctx || first_row < 0 || n < 0 || (n > 0 && !desc)) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  int rc = ensure_bank(ctx, m, first_row + n);
+  if (rc != ASD_OK || n == 0) return rc;
+  if ((rc = ensure_qdesc(ctx, m, n)) != ASD_OK) return rc;
+  memcpy(m->h_qdesc, desc, (size_t)n * 512);
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_bank + (size_t)first_row * 128, m->h_qdesc, (size_t)n * 512, hipMemcpyHostToDevice, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return ASD_OK;
+}
+
+// bank[first_row + i] = descriptor of keypoint i of frame `slot` (device to device), i in [0, n)
+int asd_bank_put_from_frame(asd_ctx* ctx, int32_t slot, int32_t first_row, int32_t n) {
+  AsdFrameSlot* F = slot_of(ctx, slot);
+  if (!F || first_row < 0 || n < 0 || n > F->n) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  int rc = ensure_bank(ctx, m, first_row + n);
+  if (rc != ASD_OK || n == 0) return rc;
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_bank + (size_t)first_row * 128, F->d_desc, (size_t)n * 512, hipMemcpyDeviceToDevice, ctx->stream));
   return ASD_OK;
 }
 

@@ -72,18 +72,24 @@ ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
     s = 0.5 / s;
     ex = (R[7] - R[5]) * s; ey = (R[2] - R[6]) * s; ez = (R[3] - R[1]) * s;
   } else {
+    // largest diagonal element first (Eigen quaternionbase_assign_impl); written out per case so every
+    // index is static (a runtime-indexed R[] would live in scratch memory on the GPU)
     int i = 0;
     if (R[4] > R[0]) i = 1;
-    if (R[8] > R[i * 4]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double s = sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
-    double v[3];
-    v[i] = 0.5 * s;
-    s = 0.5 / s;
-    ew = (R[k * 3 + j] - R[j * 3 + k]) * s;
-    v[j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
-    v[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
-    ex = v[0]; ey = v[1]; ez = v[2];
+    if (R[8] > (i == 0 ? R[0] : R[4])) i = 2;
+    if (i == 0) {
+      double s = sqrt(R[0] - R[4] - R[8] + 1.0);
+      ex = 0.5 * s; s = 0.5 / s;
+      ew = (R[7] - R[5]) * s; ey = (R[3] + R[1]) * s; ez = (R[6] + R[2]) * s;
+    } else if (i == 1) {
+      double s = sqrt(R[4] - R[8] - R[0] + 1.0);
+      ey = 0.5 * s; s = 0.5 / s;
+      ew = (R[2] - R[6]) * s; ez = (R[7] + R[5]) * s; ex = (R[1] + R[3]) * s;
+    } else {
+      double s = sqrt(R[8] - R[0] - R[4] + 1.0);
+      ez = 0.5 * s; s = 0.5 / s;
+      ew = (R[3] - R[1]) * s; ex = (R[2] + R[6]) * s; ey = (R[5] + R[7]) * s;
+    }
   }
   quat_normalize(ex, ey, ez, ew);
   const double et[3] = {V[0] * u[3] + V[1] * u[4] + V[2] * u[5], V[3] * u[3] + V[4] * u[4] + V[5] * u[5],

@@ -139,6 +139,9 @@ def track_step(be, wl, image_handle, last, do_ba, next_handle=None):
         uv = predicted_uv(lk)
         Xw = backproject_identity(wl.K32, uv, 20.0)
         has = np.ones(len(lk), np.uint8)
+        # map point descriptors: the HIP backend keeps them in the device-resident bank (rows 0..n-1 = the last
+        # frame's descriptors, rows n..2n-1 = the same again for the jittered copy), the CPU backend gets the table
+        be.set_map_descriptors(lframe, ld)
         m1, n1 = be.match_frame(cur, lframe, len(kps), has, Xw, ld, wl.T, wl.K32, 15.0)
         j = np.nonzero(m1 >= 0)[0]
         stats["m1"] = int(n1)
@@ -147,7 +150,7 @@ def track_step(be, wl, image_handle, last, do_ba, next_handle=None):
             be.pose_opt(wl.pose0, Xw[m1[j]].astype(np.float64), obs, wl.inv_sigma2[kps["octave"][j]], wl.K64)
         # local map: the last frame's points plus a second, jittered copy (~2x keypoints, like a local map)
         Xw2 = np.concatenate([Xw, Xw + np.float32(0.02)])
-        d2 = np.concatenate([ld, ld])
+        d2 = (ld, ld)
         n = Xw2 / np.linalg.norm(Xw2, axis=1, keepdims=True)
         dist = np.linalg.norm(Xw2, axis=1).astype(np.float32)
         lv = np.concatenate([lk["octave"], lk["octave"]])
@@ -204,8 +207,14 @@ class HipBackend:
         self.hip.frame_set(self.slot, kps, None, BOUNDS)   # adopts the device-resident descriptors
         return self.slot
 
+    def set_map_descriptors(self, last_slot, ld):
+        n = len(ld)
+        self.hip.bank_put_from_frame(last_slot, 0, n)      # device to device, no PCIe
+        self.hip.bank_put_from_frame(last_slot, n, n)
+        self.rows = np.arange(2 * n, dtype=np.int32)
+
     def match_frame(self, cur, last, n_cur, has, Xw, mp_desc, T, K, th):
-        return self.hip.match_project_frame(cur, last, n_cur, has, Xw, mp_desc, T, K, th, True)
+        return self.hip.match_project_frame_bank(cur, last, n_cur, has, Xw, self.rows[:len(has)], T, K, th, True)
 
     def pose_opt(self, pose, Xw, obs, info, K):
         return self.hip.pose_optimize(pose, Xw, obs, info, K)
@@ -214,7 +223,7 @@ class HipBackend:
         return self.hip.frustum(cur, Xw, normal, mind, maxd, T, K)
 
     def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
-        return self.hip.match_project_points(cur, n_cur, fr[0], fr[1], fr[2], fr[3], desc, occ, th, ratio)
+        return self.hip.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], occ, th, ratio)
 
     def local_ba(self, prob):
         return self.hip.local_ba(prob)
@@ -266,8 +275,11 @@ class CpuBackend:
     def frustum(self, cur, Xw, normal, mind, maxd, T, K):
         return self.orc.frustum(cur, Xw, normal, mind, maxd, T, K)
 
+    def set_map_descriptors(self, last, ld):
+        pass
+
     def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
-        return self.orc.match_project_points(cur, fr[0], fr[1], fr[2], fr[3], desc, occ, th, ratio)
+        return self.orc.match_project_points(cur, fr[0], fr[1], fr[2], fr[3], np.concatenate(desc), occ, th, ratio)
 
     def local_ba(self, prob):
         return (self.ref or self.orc).local_ba(prob)

@@ -189,6 +189,24 @@ int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
                              const float* desc, const uint8_t* occupied, float th, float nn_ratio,
                              int32_t* match_cur, int32_t* n_matches);
 
+/* Device-resident descriptor bank.  The reference reads MapPoint::GetDescriptor() for every query of
+ * every frame (ORBmatcher.cc:72, :1371) but only rewrites it once per keyframe
+ * (MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:330-337).  An integration that gives each
+ * MapPoint a bank row uploads a descriptor when it changes and passes row ids per frame instead of
+ * 512-byte descriptors: asd_match_project_frame_bank / asd_match_project_points_bank are
+ * asd_match_project_frame / _points with `rows` in place of the descriptor table. */
+int asd_bank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* desc);
+/* bank[first_row + i] = descriptor of keypoint i of frame `slot`, i in [0, n): device to device */
+int asd_bank_put_from_frame(asd_ctx* ctx, int32_t slot, int32_t first_row, int32_t n);
+int asd_match_project_frame_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last,
+                                 const uint8_t* has_mp, const float* Xw, const int32_t* mp_rows,
+                                 const float* Tcw, const float* K, float th, int32_t check_orientation,
+                                 int32_t* match_cur, int32_t* n_matches);
+int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view,
+                                  const float* proj, const int32_t* level, const float* view_cos,
+                                  const int32_t* rows, const uint8_t* occupied, float th, float nn_ratio,
+                                  int32_t* match_cur, int32_t* n_matches);
+
 /* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
  * n map points: Xw[n][3], normal[n][3] (GetNormal), min_dist[n] / max_dist[n] = the map
  * point's raw mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors of

@@ -381,3 +381,34 @@ def test_match_triangulate(hip, oracle, n, ori):
         np.testing.assert_array_equal(got, exp)
         assert ng == ne
     assert (got[has1 > 0] == -1).all()
+
+
+@pytest.mark.gpu
+def test_descriptor_bank_variants(hip, oracle, synth):
+    """row ids into the device-resident descriptor bank give the same matches as passing the descriptors"""
+    n = 1500
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 311)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    rng = np.random.default_rng(3)
+    rows = rng.permutation(5000)[:n].astype(np.int32)      # scattered bank rows
+    bank = np.zeros((5000, 128), np.float32)
+    bank[rows] = mp_desc
+    hip.bank_put(0, bank)
+    a, na = hip.match_project_frame(0, 1, n, has, Xw, mp_desc, T, K, 15.0, True)
+    b, nb = hip.match_project_frame_bank(0, 1, n, has, Xw, rows, T, K, 15.0, True)
+    np.testing.assert_array_equal(a, b)
+    assert na == nb
+    # M2 through the bank, with the bank filled device-to-device from a frame
+    hip.bank_put_from_frame(1, 6000, n)
+    in_view = np.ones(n, np.uint8)
+    proj = np.stack([kc["x"], kc["y"]], 1)[rng.permutation(n)]
+    level = rng.integers(0, 8, n).astype(np.int32)
+    vc = rng.uniform(0.9, 1.0, n).astype(np.float32)
+    occ = np.zeros(n, np.uint8)
+    a, na = hip.match_project_points(0, n, in_view, proj, level, vc, dl, occ, 1.0, 0.8)
+    b, nb = hip.match_project_points_bank(0, n, in_view, proj, level, vc, np.arange(6000, 6000 + n, dtype=np.int32), occ, 1.0, 0.8)
+    np.testing.assert_array_equal(a, b)
+    assert na == nb
+    with pytest.raises(Exception):
+        hip.match_project_frame_bank(0, 1, n, has, Xw, rows + 10_000_000, T, K, 15.0, True)
