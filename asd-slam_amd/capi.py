@@ -274,6 +274,17 @@ class AsdHip:
                                                     C.c_float(nn_ratio), _p(out), C.byref(n)))
         return out, n.value
 
+    def fuse_search(self, slot_kf, valid, Xw, normal, min_dist, max_dist, desc, Tcw, K, th=3.0):
+        valid, Xw, normal = _c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32)
+        min_dist, max_dist, desc = _c(min_dist, np.float32), _c(max_dist, np.float32), _c(desc, np.float32)
+        Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
+        n = len(valid)
+        bi = np.empty(n, np.int32)
+        bd = np.empty(n, np.float32)
+        self._chk(self.lib.asd_fuse_search(self.ctx, slot_kf, n, _p(valid), _p(Xw), _p(normal), _p(min_dist), _p(max_dist),
+                                           _p(desc), _p(Tcw), _p(K), C.c_float(th), _p(bi), _p(bd)))
+        return bi, bd
+
     def bank_put(self, first_row, desc):
         desc = _c(desc, np.float32)
         self._chk(self.lib.asd_bank_put(self.ctx, first_row, desc.shape[0], _p(desc)))

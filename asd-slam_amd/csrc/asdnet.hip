@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
     __syncthreads();
     // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding)
     constexpr int NPIX = C::INROWS * C::INCOLS;
-    if (ABL != 1)
+    if (!(ABL & 1))
     for (int item = t; item < NPIX * 8; item += 256) {
       const int q = item & 7, pix = item >> 3;
       const int i = pix % C::INCOLS, j = pix / C::INCOLS;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
     const float* inp = static_cast<const float*>(in_) + (size_t)patch * HIN * HIN * CIN;
     // ---- stage the zero-padded input band (NHWC rows are contiguous: coalesced 16-B loads)
     constexpr int C4 = CIN / 4;
-    if (ABL != 1)
+    if (!(ABL & 1))
     for (int idx = t; idx < C::INROWS * C::INCOLS * C4; idx += 256) {
       const int c4 = idx % C4, pix = idx / C4;
       const int i = pix % C::INCOLS, j = pix / C::INCOLS;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < C::NT; ++nt)
-            if (ABL != 2) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
+            if (!(ABL & 2)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
             else { asm volatile("" :: "v"(a[mt][jj]), "v"(b[nt][jj])); }
     }
     if (s + 1 < C::NSTAGE) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
       for (int r = 0; r < 16; ++r) {
         const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         float v = acc[mt][nt][r] + bv;
-        if (ABL != 3) op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
+        if (!(ABL & 4)) op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
         else { asm volatile("" :: "v"(v)); }
       }
   }
@@ -587,21 +587,54 @@ int asdnet_profile_collect(asd_ctx* ctx) {
 
 // debug / tuning aid (not part of the C ABI header): time conv2 with parts of the kernel removed
 // mode 0 = full, 1 = no activation staging, 2 = no MFMA, 3 = no epilogue stores
-extern "C" int asd_debug_conv2_ablate(asd_ctx* ctx, int n, int mode, int reps, float* ms) {
+template <int ABL>
+static int ablate_one(asd_ctx* ctx, int layer, int n, int reps, float* ms) {
   hipStream_t st = ctx->stream;
-  float* a1 = ctx->d_act[1];
-  using C = ConvCfg<L2_CFG>;
-  constexpr int lds = C::LDS_BYTES + ((4 + 4) * 36 + 320 + 8) * 4;
-  auto k0 = k_conv_mfma<L2_CFG, 0, true>; auto k1 = k_conv_mfma<L2_CFG, 1, true>; auto k2 = k_conv_mfma<L2_CFG, 2, true>; auto k3 = k_conv_mfma<L2_CFG, 3, true>;
-  decltype(k0) ks[4] = {k0, k1, k2, k3};
-  for (int i = 0; i < 4; ++i) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ks[i]), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  const int grid = n * (C::HO / 4);
-  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(ks[mode], dim3(grid), dim3(256), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0]);
+  float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
+  hipError_t e = hipSuccess;
+  auto run = [&](int count) {
+    for (int r = 0; r < count; ++r) {
+      if (layer == 2) {
+        using C = ConvCfg<L2_CFG>;
+        constexpr int lds = C::LDS_BYTES + ((4 + 4) * 36 + 320 + 8) * 4;
+        auto k = k_conv_mfma<L2_CFG, ABL, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k, dim3(n * (C::HO / 4)), dim3(256), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0]);
+      } else if (layer == 4) {
+        using C = ConvCfg<L4_CFG>;
+        auto k = k_conv_mfma<L4_CFG, ABL, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipLaunchKernelGGL(k, dim3(n * (C::HO / 8)), dim3(256), C::LDS_BYTES, st, (const void*)a0, ctx->d_wimg[3], ctx->d_bias[3], a1, (const float*)nullptr, (const float*)nullptr);
+      } else {
+        using C = ConvCfg<L6_CFG>;
+        auto k = k_conv_mfma<L6_CFG, ABL, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipLaunchKernelGGL(k, dim3(n * (C::HO / 8)), dim3(256), C::LDS_BYTES, st, (const void*)a0, ctx->d_wimg[5], ctx->d_bias[5], a1, (const float*)nullptr, (const float*)nullptr);
+      }
+    }
+  };
+  run(3);
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(ks[mode], dim3(grid), dim3(256), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0]);
+  run(reps);
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
   ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   *ms /= reps;
+  (void)e;
   return ASD_OK;
+}
+
+// debug / tuning aid (not part of the C ABI header): time conv2 (fused) / conv4 / conv6 with parts removed.
+// mode bits: 1 = no input staging, 2 = no MFMA, 4 = no epilogue stores
+extern "C" int asd_debug_conv_ablate(asd_ctx* ctx, int layer, int n, int mode, int reps, float* ms) {
+  switch (mode) {
+    case 0: return ablate_one<0>(ctx, layer, n, reps, ms);
+    case 1: return ablate_one<1>(ctx, layer, n, reps, ms);
+    case 2: return ablate_one<2>(ctx, layer, n, reps, ms);
+    case 3: return ablate_one<3>(ctx, layer, n, reps, ms);
+    case 4: return ablate_one<4>(ctx, layer, n, reps, ms);
+    case 5: return ablate_one<5>(ctx, layer, n, reps, ms);
+    case 6: return ablate_one<6>(ctx, layer, n, reps, ms);
+    default: return ablate_one<7>(ctx, layer, n, reps, ms);
+  }
 }

@@ -661,6 +661,74 @@ int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, 
   return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, occupied, th, nn_ratio, match_cur, n_matches);
 }
 
+// ORBmatcher::Fuse, search half (ORBmatcher.cc:825-936): the Replace / AddObservation side effects
+// (:938-956) do not feed back into the search, so every map point is an independent window query.
+int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* valid, const float* Xw, const float* normal,
+                    const float* min_dist, const float* max_dist, const float* desc, const float* Tcw, const float* K,
+                    float th, int32_t* best_idx, float* best_dist) {
+  AsdFrameSlot* KF = slot_of(ctx, slot_kf);
+  if (!KF || n_mp < 0 || !Tcw || !K || (n_mp > 0 && (!valid || !Xw || !normal || !min_dist || !max_dist || !desc || !best_idx || !best_dist)))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  for (int i = 0; i < n_mp; ++i) { best_idx[i] = -1; best_dist[i] = 256.f; }
+  if (n_mp == 0 || KF->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, n_mp);
+  if (rc != ASD_OK) return rc;
+  const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  const float log_scale = std::log(ctx->cfg.scale_factor);
+  float Ow[3];  // KeyFrame::SetPose: Ow = -Rwc*tcw with Rwc materialised (gemm small-matrix path, f32 sums)
+  for (int i = 0; i < 3; ++i) {
+    const float t0 = Tcw[0 * 4 + i] * Tcw[3] + Tcw[1 * 4 + i] * Tcw[7] + Tcw[2 * 4 + i] * Tcw[11];
+    Ow[i] = (float)((double)t0 * -1.0);
+  }
+  std::vector<int> pred(n_mp, 0);
+  std::vector<float> pu(n_mp), pv(n_mp);
+  for (int i = 0; i < n_mp; ++i) {
+    WinQuery& Q = m->h_queries[i];
+    Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+    if (!valid[i]) continue;
+    const float* P = Xw + 3 * i;
+    float Pc[3];
+    transform(Tcw, P, Pc);
+    if (Pc[2] < 0.0f) continue;
+    const float invz = 1 / Pc[2];
+    const float u = fx * (Pc[0] * invz) + cx, v = fy * (Pc[1] * invz) + cy;
+    if (!(u >= KF->min_x && u < KF->max_x && v >= KF->min_y && v < KF->max_y)) continue;  // KeyFrame::IsInImage
+    const float maxD = 1.2f * max_dist[i], minD = 0.8f * min_dist[i];
+    const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
+    const float dist3D = (float)std::sqrt(nn);
+    if (dist3D < minD || dist3D > maxD) continue;
+    const float* Pn = normal + 3 * i;
+    const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+    if (dot < 0.5 * dist3D) continue;
+    int lvl = (int)std::ceil(std::log(max_dist[i] / dist3D) / log_scale);
+    if (lvl < 0) lvl = 0;
+    else if (lvl >= ctx->cfg.n_levels) lvl = ctx->cfg.n_levels - 1;
+    pred[i] = lvl; pu[i] = u; pv[i] = v;
+    Q = WinQuery{u, v, th * ctx->scale[lvl], -1, -1, i};  // KeyFrame::GetFeaturesInArea: no level filter
+  }
+  if ((rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *KF, n_mp, m->d_qdesc, &R)) != ASD_OK) return rc;
+  for (int i = 0; i < n_mp; ++i) {
+    if (R.cnt[i] == 0) continue;
+    float best = 256;
+    int bi = -1;
+    for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
+      const asd_keypoint& kp = KF->kps[R.idx[t]];
+      if (kp.octave < pred[i] - 1 || kp.octave > pred[i]) continue;
+      const float ex = pu[i] - kp.x, ey = pv[i] - kp.y;
+      const float e2 = ex * ex + ey * ey;
+      if (e2 * ctx->inv_sigma2[kp.octave] > 5.99) continue;
+      if (R.dist[t] < best) { best = R.dist[t]; bi = R.idx[t]; }
+    }
+    if (best <= TH_LOW) { best_idx[i] = bi; best_dist[i] = best; }
+  }
+  return ASD_OK;
+}
+
 // MapPoint::mDescriptor rows kept on the device: written when a map point's descriptor changes
 // (MapPoint::ComputeDistinctiveDescriptors, once per keyframe), read by the matchers every frame.
 int asd_bank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* desc) {

@@ -250,6 +250,17 @@ int asd_match_triangulate(asd_ctx* ctx, int32_t slot1, int32_t slot2, const asd_
                           const float* F12, float ex, float ey, int32_t check_orientation,
                           int32_t* matches12, int32_t* n_matches);
 
+/* ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, float th) (ORBmatcher.cc:825-960),
+ * search half: for every candidate map point (valid[i] = pMP && !isBad() && !IsInKeyFrame(pKF)) project into
+ * the keyframe, apply the depth / viewing-angle / scale gates, search the window and return the keypoint
+ * with the smallest descriptor distance among those passing the level and 5.99-chi2 gates.  best_idx[i] = -1
+ * when nothing qualifies (bestDist > TH_LOW).  The caller performs the pointer-graph side effects
+ * (Replace / AddObservation / AddMapPoint, :938-956) in map point order; they do not influence the search.
+ * min_dist / max_dist are the raw mfMinDistance / mfMaxDistance like asd_frustum. */
+int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* valid, const float* Xw,
+                    const float* normal, const float* min_dist, const float* max_dist, const float* desc,
+                    const float* Tcw, const float* K, float th, int32_t* best_idx, float* best_dist);
+
 /* ---- optimizer (P1, B1-B5, C1) ------------------------------------------------------- */
 /* Optimizer::PoseOptimization (Optimizer.cc:239-413) on g2o's EdgeSE3ProjectXYZOnlyPose
  * (types_six_dof_expmap.h:194-222, .cpp:372-394) with Levenberg

@@ -506,4 +506,71 @@ int orc_match_triangulate(const orc_frame* KF1, const orc_frame* KF2, int nn1, c
   return nmatches;
 }
 
+
+// ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, float th), search half (ORBmatcher.cc:825-936)
+void orc_fuse_search(const orc_frame* KF, int n_mp, const uint8_t* valid, const float* Xw, const float* normal,
+                     const float* min_dist, const float* max_dist, const float* desc, const float* Tcw, const float* K,
+                     float th, int32_t* best_idx, float* best_dist) {
+  const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  // KeyFrame::SetPose (KeyFrame.cc): Rwc = Rcw.t() materialised, Ow = -Rwc*tcw through gemm's small-matrix path
+  float Ow[3];
+  for (int i = 0; i < 3; ++i) {
+    const float t0 = Tcw[0 * 4 + i] * Tcw[3] + Tcw[1 * 4 + i] * Tcw[7] + Tcw[2 * 4 + i] * Tcw[11];
+    Ow[i] = (float)((double)t0 * -1.0);
+  }
+  std::vector<float> invSigma2(KF->mnScaleLevels);
+  for (int l = 0; l < KF->mnScaleLevels; ++l) invSigma2[l] = 1.0f / (KF->mvScaleFactors[l] * KF->mvScaleFactors[l]);
+  for (int i = 0; i < n_mp; i++) {
+    best_idx[i] = -1;
+    best_dist[i] = 256;
+    if (!valid[i]) continue;
+    const float* p3Dw = Xw + 3 * i;
+    float p3Dc[3];
+    transform(Tcw, p3Dw, p3Dc);
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = 1 / p3Dc[2];
+    const float x = p3Dc[0] * invz;
+    const float y = p3Dc[1] * invz;
+    const float u = fx * x + cx;
+    const float v = fy * y + cy;
+    if (!(u >= KF->mnMinX && u < KF->mnMaxX && v >= KF->mnMinY && v < KF->mnMaxY)) continue;  // IsInImage
+    const float maxDistance = 1.2f * max_dist[i];
+    const float minDistance = 0.8f * min_dist[i];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    double nn = 0;
+    for (int k = 0; k < 3; ++k) nn += (double)PO[k] * (double)PO[k];
+    const float dist3D = (float)std::sqrt(nn);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const float* Pn = normal + 3 * i;
+    double dot = 0;
+    for (int k = 0; k < 3; ++k) dot += (double)PO[k] * (double)Pn[k];
+    if (dot < 0.5 * dist3D) continue;
+    const float ratio = max_dist[i] / dist3D;  // PredictScale(dist3D, pKF)
+    int nPredictedLevel = (int)std::ceil(std::log(ratio) / KF->mfLogScaleFactor);
+    if (nPredictedLevel < 0) nPredictedLevel = 0;
+    else if (nPredictedLevel >= KF->mnScaleLevels) nPredictedLevel = KF->mnScaleLevels - 1;
+    const float radius = th * KF->mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KF->GetFeaturesInArea(u, v, radius, -1, -1);  // KeyFrame.cc:839-878: no level filter
+    if (vIndices.empty()) continue;
+    const float* dMP = desc + (size_t)i * 128;
+    float bestDist = 256;
+    int bestIdx = -1;
+    for (size_t k = 0; k < vIndices.size(); ++k) {
+      const size_t idx = vIndices[k];
+      const orc_keypoint& kp = KF->kps[idx];
+      const int kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      {
+        const float ex = u - kp.x;
+        const float ey = v - kp.y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * invSigma2[kpLevel] > 5.99) continue;
+      }
+      const float dist = DescriptorDistance(dMP, KF->desc.data() + idx * 128);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    if (bestDist <= TH_LOW) { best_idx[i] = bestIdx; best_dist[i] = bestDist; }
+  }
+}
+
 }  // extern "C"

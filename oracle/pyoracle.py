@@ -138,6 +138,17 @@ class Oracle:
         n = self.lib.orc_match_init(f1.h, f2.h, _p(pm), window, C.c_float(nn_ratio), int(check_ori), _p(out))
         return out, n, pm
 
+    def fuse_search(self, kf, valid, Xw, normal, min_dist, max_dist, desc, Tcw, K, th=3.0):
+        valid, Xw, normal = _c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32)
+        min_dist, max_dist, desc = _c(min_dist, np.float32), _c(max_dist, np.float32), _c(desc, np.float32)
+        Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
+        n = len(valid)
+        bi = np.empty(n, np.int32)
+        bd = np.empty(n, np.float32)
+        self.lib.orc_fuse_search(kf.h, n, _p(valid), _p(Xw), _p(normal), _p(min_dist), _p(max_dist), _p(desc), _p(Tcw), _p(K),
+                                 C.c_float(th), _p(bi), _p(bd))
+        return bi, bd
+
     @staticmethod
     def _fv(node_of_kp):
         node_of_kp = np.asarray(node_of_kp)

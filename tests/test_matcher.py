@@ -412,3 +412,35 @@ def test_descriptor_bank_variants(hip, oracle, synth):
     assert na == nb
     with pytest.raises(Exception):
         hip.match_project_frame_bank(0, 1, n, has, Xw, rows + 10_000_000, T, K, 15.0, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mp,th", [(4000, 3.0), (50, 3.0)])
+def test_fuse_search(hip, oracle, synth, n_mp, th):
+    """ORBmatcher::Fuse search half: best keypoint per candidate map point, bit-exact ids and distances"""
+    kc, dc = make_frame(2000, 401)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(402 + n_mp)
+    src = rng.integers(0, 2000, n_mp)
+    uv = np.stack([kc["x"][src], kc["y"][src]], 1) + rng.uniform(-1.5, 1.5, (n_mp, 2)).astype(np.float32)
+    uv[: n_mp // 8] += 2500
+    Xw = backproject(T, K, uv, rng.uniform(3, 60, n_mp))
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    normal = Xw.astype(np.float64) - Ow
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    normal = (normal + rng.normal(0, 0.4, normal.shape)).astype(np.float32)
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    dist = np.linalg.norm(Xw.astype(np.float64) - Ow, axis=1)
+    maxd = (dist * SCALES[kc["octave"][src]] * rng.uniform(0.9, 1.1, n_mp)).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    desc = perturbed_descriptors(dc[src], 0.04, 403)
+    valid = (rng.uniform(size=n_mp) < 0.9).astype(np.uint8)
+    hip.frame_set(6, kc, dc, BOUNDS)
+    gi, gd = hip.fuse_search(6, valid, Xw, normal, mind, maxd, desc, T, K, th)
+    ei, ed = oracle.fuse_search(oracle.frame(kc, dc, BOUNDS), valid, Xw, normal, mind, maxd, desc, T, K, th)
+    np.testing.assert_array_equal(gi, ei)
+    np.testing.assert_array_equal(gd, ed)
+    assert (gi[valid == 0] == -1).all()
+    if n_mp > 1000:
+        assert (gi >= 0).sum() > 0.3 * n_mp
