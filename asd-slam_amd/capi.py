@@ -285,6 +285,23 @@ class AsdHip:
                                            _p(desc), _p(Tcw), _p(K), C.c_float(th), _p(bi), _p(bd)))
         return bi, bd
 
+    def triangulate_pairs(self, slot1, slot2, idx1, idx2, Tcw1, Tcw2, K1, K2):
+        idx1, idx2 = _c(idx1, np.int32), _c(idx2, np.int32)
+        Tcw1, Tcw2, K1, K2 = _c(Tcw1, np.float32), _c(Tcw2, np.float32), _c(K1, np.float32), _c(K2, np.float32)
+        n = len(idx1)
+        x = np.empty((n, 3), np.float32)
+        ok = np.empty(n, np.uint8)
+        nok = C.c_int32(0)
+        self._chk(self.lib.asd_triangulate_pairs(self.ctx, slot1, slot2, n, _p(idx1), _p(idx2), _p(Tcw1), _p(Tcw2), _p(K1), _p(K2),
+                                                 _p(x), _p(ok), C.byref(nok)))
+        return x, ok, nok.value
+
+    def svd4_null(self, A):
+        A = _c(A, np.float32).reshape(-1, 16)
+        v = np.empty((len(A), 4), np.float32)
+        self._chk(self.lib.asd_svd4_null(self.ctx, len(A), _p(A), _p(v)))
+        return v
+
     def bank_put(self, first_row, desc):
         desc = _c(desc, np.float32)
         self._chk(self.lib.asd_bank_put(self.ctx, first_row, desc.shape[0], _p(desc)))

@@ -72,6 +72,9 @@ struct asd_ctx {
   // ---- BA scratch (lazily grown)
   void* ba = nullptr;
 
+  // ---- local-mapping scratch (state private to mapping.hip)
+  void* mapping = nullptr;
+
   // ---- per-layer profiling (asd_profile_enable)
   bool prof_on = false;
   hipEvent_t prof_ev[9] = {};
@@ -102,6 +105,7 @@ void frontend_async_shutdown(asd_ctx* ctx);
 // matcher.hip / ba.hip
 void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);
+void mapping_free(asd_ctx* ctx);
 // capi.cpp
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 

@@ -261,6 +261,20 @@ int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* 
                     const float* normal, const float* min_dist, const float* max_dist, const float* desc,
                     const float* Tcw, const float* K, float th, int32_t* best_idx, float* best_dist);
 
+/* LocalMapping::CreateNewMapPoints, per-match body (LocalMapping.cc:386-519, monocular branch): for each
+ * match (idx1[i] in frame slot1 = current keyframe, idx2[i] in slot2 = neighbour) run the parallax gate
+ * (0 < cos < 0.9998), the linear triangulation (4x4 SVD, :437-453), cheirality in both cameras, the 5.991
+ * reprojection gates and the scale-consistency gate (ratioFactor = 1.5*scaleFactor).  ok[i] = 1 and x3D[i]
+ * = the new point when the reference would create a MapPoint, else ok[i] = 0 and x3D[i] = 0.  The caller
+ * keeps the pointer-graph part (new MapPoint, AddObservation, ComputeDistinctiveDescriptors ->
+ * asd_distinctive_descriptor, UpdateNormalAndDepth, :497-515).  Tcw row-major 4x4 f32, K = fx fy cx cy. */
+int asd_triangulate_pairs(asd_ctx* ctx, int32_t slot1, int32_t slot2, int32_t n_pairs, const int32_t* idx1,
+                          const int32_t* idx2, const float* Tcw1, const float* Tcw2, const float* K1,
+                          const float* K2, float* x3D, uint8_t* ok, int32_t* n_ok);
+/* vt.row(3) of cv::SVD::compute(A, w, u, vt, MODIFY_A|FULL_UV) for n row-major 4x4 f32 matrices
+ * (the call at LocalMapping.cc:444); v is [n][4].  Exposed for the parity tests of the SVD itself. */
+int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v);
+
 /* ---- optimizer (P1, B1-B5, C1) ------------------------------------------------------- */
 /* Optimizer::PoseOptimization (Optimizer.cc:239-413) on g2o's EdgeSE3ProjectXYZOnlyPose
  * (types_six_dof_expmap.h:194-222, .cpp:372-394) with Levenberg

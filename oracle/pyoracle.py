@@ -149,6 +149,25 @@ class Oracle:
                                  C.c_float(th), _p(bi), _p(bd))
         return bi, bd
 
+    def svd4_vt(self, A):
+        A = _c(A, np.float32).reshape(-1, 16)
+        vt = np.empty((len(A), 4, 4), np.float32)
+        for i in range(len(A)):
+            self.lib.orc_svd4_vt(_p(A[i]), _p(vt[i]))
+        return vt
+
+    def triangulate_pairs(self, kps1, kps2, idx1, idx2, Tcw1, Tcw2, K1, K2, scale_factor=1.2, nlevels=8):
+        idx1, idx2 = _c(idx1, np.int32), _c(idx2, np.int32)
+        Tcw1, Tcw2, K1, K2 = _c(Tcw1, np.float32), _c(Tcw2, np.float32), _c(K1, np.float32), _c(K2, np.float32)
+        k1, k2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)
+        n = len(idx1)
+        x = np.empty((n, 3), np.float32)
+        ok = np.empty(n, np.uint8)
+        self.lib.orc_triangulate_pairs.restype = C.c_int
+        nok = self.lib.orc_triangulate_pairs(_p(k1), _p(k2), n, _p(idx1), _p(idx2), _p(Tcw1), _p(Tcw2), _p(K1), _p(K2),
+                                             C.c_float(scale_factor), nlevels, _p(x), _p(ok))
+        return x, ok, nok
+
     @staticmethod
     def _fv(node_of_kp):
         node_of_kp = np.asarray(node_of_kp)
