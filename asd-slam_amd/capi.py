@@ -302,6 +302,35 @@ class AsdHip:
         self._chk(self.lib.asd_svd4_null(self.ctx, len(A), _p(A), _p(v)))
         return v
 
+    # ---- vocabulary / BoW
+    def voc_load(self, voc, weighting=0, scoring=0):
+        cs, ci = _c(voc["child_start"], np.int32), _c(voc["child_ids"], np.int32)
+        w, wid, d = _c(voc["weight"], np.float64), _c(voc["word_id"], np.int32), _c(voc["desc"], np.float32)
+        self._chk(self.lib.asd_voc_load(self.ctx, int(voc["n_nodes"]), int(voc["k"]), int(voc["L"]), weighting, scoring,
+                                        _p(cs), _p(ci), _p(w), _p(wid), _p(d)))
+
+    def bow_descend(self, desc=None, slot=-1, n=None, levelsup=4):
+        if desc is not None:
+            desc = _c(desc, np.float32)
+            n = len(desc)
+        word, node, weight = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
+        self._chk(self.lib.asd_bow_descend(self.ctx, slot, _p(desc) if desc is not None else None, n, levelsup,
+                                           _p(word), _p(node), _p(weight)))
+        return word, node, weight
+
+    def compute_bow(self, desc=None, slot=-1, n=None, levelsup=4):
+        """-> (bow_id, bow_val), (fv_node, fv_start, fv_idx)"""
+        if desc is not None:
+            desc = _c(desc, np.float32)
+            n = len(desc)
+        bid, bval = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.float64)
+        fnode, fstart, fidx = np.empty(max(n, 1), np.int32), np.empty(n + 1, np.int32), np.empty(max(n, 1), np.int32)
+        nw, nn = C.c_int32(0), C.c_int32(0)
+        self._chk(self.lib.asd_compute_bow(self.ctx, slot, _p(desc) if desc is not None else None, n, levelsup, _p(bid), _p(bval),
+                                           C.byref(nw), _p(fnode), _p(fstart), _p(fidx), C.byref(nn)))
+        return (bid[:nw.value].copy(), bval[:nw.value].copy()), \
+               (fnode[:nn.value].copy(), fstart[:nn.value + 1].copy(), fidx[:fstart[nn.value]].copy())
+
     def bank_put(self, first_row, desc):
         desc = _c(desc, np.float32)
         self._chk(self.lib.asd_bank_put(self.ctx, first_row, desc.shape[0], _p(desc)))

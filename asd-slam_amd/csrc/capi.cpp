@@ -11,6 +11,7 @@ void frontend_free(asd_ctx* ctx);
 void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);
 void mapping_free(asd_ctx* ctx);
+void bow_free(asd_ctx* ctx);
 
 namespace {
 inline int cv_round(double v) { return (int)std::lrint(v); }  // cvRound: round-half-to-even
@@ -122,6 +123,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   matcher_free(ctx);
   ba_free(ctx);
   mapping_free(ctx);
+  bow_free(ctx);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);

@@ -75,6 +75,9 @@ struct asd_ctx {
   // ---- local-mapping scratch (state private to mapping.hip)
   void* mapping = nullptr;
 
+  // ---- vocabulary + BoW scratch (state private to bow.hip)
+  void* bow = nullptr;
+
   // ---- per-layer profiling (asd_profile_enable)
   bool prof_on = false;
   hipEvent_t prof_ev[9] = {};
@@ -106,6 +109,7 @@ void frontend_async_shutdown(asd_ctx* ctx);
 void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);
 void mapping_free(asd_ctx* ctx);
+void bow_free(asd_ctx* ctx);
 // capi.cpp
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 

@@ -222,8 +222,7 @@ int asd_match_init(asd_ctx* ctx, int32_t slot1, int32_t slot2, float* prev_match
                    float nn_ratio, int32_t check_orientation, int32_t* matches12, int32_t* n_matches);
 
 /* DBoW2::FeatureVector of a frame (node id at `levelsup` = 4 -> keypoint indices; Frame::ComputeBoW,
- * Frame.cc:289-296).  The vocabulary transform itself stays on the host (the
- * vocabulary file is absent from the reference tree); the matchers below only consume its output.
+ * Frame.cc:289-296), as produced by asd_compute_bow below or by the caller's own DBoW2.
  * node_id ascending (std::map order), start has n_nodes+1 entries into idx. */
 typedef struct asd_feature_vector {
   int32_t n_nodes;
@@ -231,6 +230,32 @@ typedef struct asd_feature_vector {
   const int32_t* start;
   const int32_t* idx;
 } asd_feature_vector;
+
+/* ---- vocabulary ----
+ * ORBVocabulary = TemplatedVocabulary<FSift::TDescriptor, FSift> (ORBVocabulary.h:34).  The tree is handed
+ * over as flat arrays indexed by DBoW2 node id (0 = root, as in m_nodes): children of node i are
+ * child_ids[child_start[i] .. child_start[i+1]) in m_nodes[i].children order (= file order,
+ * TemplatedVocabulary.h:1455-1497), weight[i] = m_nodes[i].weight, word_id[i] = m_nodes[i].word_id for
+ * leaves and -1 for inner nodes, desc[i] = m_nodes[i].descriptor (128 f32; row 0 unused).
+ * weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY; scoring: 0 L1, 1 L2, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA,
+ * 5 DOT_PRODUCT (BowVector.h enums).  ASD_ERR_INVALID unless the arrays describe a tree rooted at 0 whose
+ * leaves all carry a word id; ASD_ERR_CAPACITY for a branching factor above 64. */
+int asd_voc_load(asd_ctx* ctx, int32_t n_nodes, int32_t k, int32_t L, int32_t weighting, int32_t scoring,
+                 const int32_t* child_start, const int32_t* child_ids, const double* weight,
+                 const int32_t* word_id, const float* desc);
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) (TemplatedVocabulary.h:1219-1260)
+ * for n descriptors: desc != NULL -> host descriptors [n][128]; desc == NULL -> the descriptors resident in
+ * frame slot `slot` (n must equal the slot's keypoint count).  Any of word / node / weight may be NULL.
+ * A leaf met above level L - levelsup reports itself as node (the reference leaves *nid unset there). */
+int asd_bow_descend(asd_ctx* ctx, int32_t slot, const float* desc, int32_t n, int32_t levelsup, int32_t* word,
+                    int32_t* node, double* weight);
+/* Frame::ComputeBoW (Frame.cc:289-296) = transform(features, BowVector, FeatureVector, levelsup)
+ * (TemplatedVocabulary.h:1125-1197).  Outputs (caller-owned, capacity n, fv_start n+1): BowVector as
+ * (bow_id ascending, bow_val) with *n_words entries, FeatureVector as CSR over *n_fv_nodes nodes in the
+ * asd_feature_vector layout. */
+int asd_compute_bow(asd_ctx* ctx, int32_t slot, const float* desc, int32_t n, int32_t levelsup, int32_t* bow_id,
+                    double* bow_val, int32_t* n_words, int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx,
+                    int32_t* n_fv_nodes);
 
 /* M3: ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)
  * (ORBmatcher.cc:156-297): slot_kf / slot_f hold the two frames, has_mp_kf[i] = pKF has a good map

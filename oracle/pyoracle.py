@@ -168,6 +168,9 @@ class Oracle:
                                              C.c_float(scale_factor), nlevels, _p(x), _p(ok))
         return x, ok, nok
 
+    def vocabulary(self, voc, weighting=0, scoring=0):
+        return OracleVocabulary(self.lib, voc, weighting, scoring)
+
     @staticmethod
     def _fv(node_of_kp):
         node_of_kp = np.asarray(node_of_kp)
@@ -345,3 +348,35 @@ class OracleFrame:
         n = self.lib.orc_features_in_area(self.h, C.c_float(x), C.c_float(y), C.c_float(r), min_level, max_level,
                                           cap, _p(out))
         return out[:n].copy()
+
+
+class OracleVocabulary:
+    def __init__(self, lib, voc, weighting=0, scoring=0):
+        self.lib = lib
+        cs, ci = _c(voc["child_start"], np.int32), _c(voc["child_ids"], np.int32)
+        w, wid, d = _c(voc["weight"], np.float64), _c(voc["word_id"], np.int32), _c(voc["desc"], np.float32)
+        lib.orc_voc_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib.orc_voc_create(int(voc["n_nodes"]), int(voc["k"]), int(voc["L"]), weighting, scoring,
+                                               _p(cs), _p(ci), _p(w), _p(wid), _p(d)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.orc_voc_destroy(self.h)
+            self.h = None
+
+    def descend(self, desc, levelsup=4):
+        desc = _c(desc, np.float32)
+        n = len(desc)
+        word, node, weight = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.float64)
+        self.lib.orc_bow_descend(self.h, _p(desc), n, levelsup, _p(word), _p(node), _p(weight))
+        return word, node, weight
+
+    def transform(self, desc, levelsup=4):
+        desc = _c(desc, np.float32)
+        n = len(desc)
+        bid, bval = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.float64)
+        fnode, fstart, fidx = np.empty(max(n, 1), np.int32), np.empty(n + 1, np.int32), np.empty(max(n, 1), np.int32)
+        nn = C.c_int32(0)
+        self.lib.orc_bow_transform.restype = C.c_int
+        nw = self.lib.orc_bow_transform(self.h, _p(desc), n, levelsup, _p(bid), _p(bval), _p(fnode), _p(fstart), _p(fidx), C.byref(nn))
+        return (bid[:nw].copy(), bval[:nw].copy()), (fnode[:nn.value].copy(), fstart[:nn.value + 1].copy(), fidx[:fstart[nn.value]].copy())
