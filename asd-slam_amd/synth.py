@@ -229,41 +229,63 @@ def pose_problem(n=300, seed=2, outlier_frac=0.1, pose_sigma=0.02):
 
 def vocabulary(k=10, L=3, seed=0, stop_frac=0.05, ragged=False):
     """Synthetic DBoW2-style vocabulary tree for 128-D unit descriptors (the reference's vocabulary file is not
-    part of its tree): node descriptor = normalise(parent + noise whose norm halves per level), idf-like leaf weights with a
-    few stopped words (weight 0).  Node ids are assigned breadth-first, children lists in creation order.
-    ragged=True prunes random subtrees so that leaves sit at different depths and branching varies.
+    part of its tree): node descriptor = normalise(parent + noise whose norm halves per level), idf-like leaf
+    weights with a few stopped words (weight 0).  Node ids are assigned breadth-first, children lists in creation
+    order.  ragged=True prunes random subtrees so that leaves sit at different depths and branching varies.
     Returns a dict of the flat arrays asd_voc_load / orc_voc_create take."""
     rng = np.random.default_rng(seed)
-    desc = [np.zeros(128, np.float32)]
-    children = [[]]
-    level = [0]
-    frontier = [0]
-    for lv in range(1, L + 1):
-        nxt = []
-        for p in frontier:
-            nk = k if not ragged else int(rng.integers(2, k + 1))
-            if ragged and lv > 1 and rng.uniform() < 0.15:
-                continue  # p stays a leaf
-            for _ in range(nk):
-                d = desc[p] + rng.standard_normal(128).astype(np.float32) * np.float32(1.0 if lv == 1 else 0.7 * 0.5 ** (lv - 2) / 11.3)
-                d /= np.linalg.norm(d)
-                desc.append(d.astype(np.float32))
-                children.append([])
-                level.append(lv)
-                children[p].append(len(desc) - 1)
-                nxt.append(len(desc) - 1)
-        frontier = nxt
-    n = len(desc)
-    child_start = np.zeros(n + 1, np.int32)
-    for i in range(n):
-        child_start[i + 1] = child_start[i] + len(children[i])
-    child_ids = np.array([c for ch in children for c in ch], np.int32)
+
+    def spread(lv):
+        return np.float32(1.0 if lv == 1 else 0.7 * 0.5 ** (lv - 2) / 11.3)
+
+    if not ragged:  # level-at-a-time (a k=10, L=6 tree has 1.1 M nodes)
+        descs = [np.zeros((1, 128), np.float32)]
+        counts = [1]
+        for lv in range(1, L + 1):
+            par = descs[-1]
+            d = par[:, None, :] + rng.standard_normal((len(par), k, 128), dtype=np.float32) * spread(lv)
+            d /= np.linalg.norm(d, axis=2, keepdims=True)
+            descs.append(d.reshape(-1, 128).astype(np.float32))
+            counts.append(len(par) * k)
+        n = int(sum(counts))
+        desc = np.concatenate(descs)
+        level = np.repeat(np.arange(L + 1, dtype=np.int32), counts)
+        n_inner = n - counts[-1]
+        child_start = np.concatenate([np.arange(n_inner + 1) * k, np.full(counts[-1], n_inner * k)]).astype(np.int32)
+        child_ids = np.arange(1, n, dtype=np.int32)
+        leaves = np.arange(n_inner, n)
+    else:
+        desc_l = [np.zeros(128, np.float32)]
+        children = [[]]
+        level_l = [0]
+        frontier = [0]
+        for lv in range(1, L + 1):
+            nxt = []
+            for p in frontier:
+                nk = int(rng.integers(2, k + 1))
+                if lv > 1 and rng.uniform() < 0.15:
+                    continue  # p stays a leaf
+                for _ in range(nk):
+                    d = desc_l[p] + rng.standard_normal(128).astype(np.float32) * spread(lv)
+                    d /= np.linalg.norm(d)
+                    desc_l.append(d.astype(np.float32))
+                    children.append([])
+                    level_l.append(lv)
+                    children[p].append(len(desc_l) - 1)
+                    nxt.append(len(desc_l) - 1)
+            frontier = nxt
+        n = len(desc_l)
+        desc = np.stack(desc_l)
+        level = np.array(level_l, np.int32)
+        child_start = np.zeros(n + 1, np.int32)
+        for i in range(n):
+            child_start[i + 1] = child_start[i] + len(children[i])
+        child_ids = np.array([c for ch in children for c in ch], np.int32)
+        leaves = np.array([i for i in range(1, n) if not children[i]])
     word_id = np.full(n, -1, np.int32)
-    leaves = [i for i in range(1, n) if not children[i]]
     word_id[leaves] = np.arange(len(leaves), dtype=np.int32)
     weight = np.zeros(n, np.float64)
     weight[leaves] = rng.uniform(0.5, 9.0, len(leaves))
-    stopped = rng.uniform(size=len(leaves)) < stop_frac
-    weight[np.array(leaves)[stopped]] = 0.0
+    weight[leaves[rng.uniform(size=len(leaves)) < stop_frac]] = 0.0
     return dict(n_nodes=n, k=k, L=L, child_start=child_start, child_ids=child_ids, weight=weight, word_id=word_id,
-                desc=np.ascontiguousarray(np.stack(desc), dtype=np.float32), level=np.array(level, np.int32))
+                desc=np.ascontiguousarray(desc, dtype=np.float32), level=level)
