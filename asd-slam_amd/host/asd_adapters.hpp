@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/asd_slam.h"
@@ -199,6 +200,68 @@ class ORBmatcher {
     return n;
   }
 
+  // DBoW2::FeatureVector as the matchers read it (node id -> keypoint indices), CSR over ascending node ids
+  struct FeatVec {
+    std::vector<int32_t> node, start{0}, idx;
+    asd_feature_vector view() const { return asd_feature_vector{(int32_t)node.size(), node.data(), start.data(), idx.data()}; }
+  };
+
+  // int SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)  (:156)
+  // vpMapPointMatches[j] = pKF's map point id matched to F's keypoint j, -1 = NULL
+  int SearchByBoW(const FrameView& KF, const FeatVec& fvKF, const FrameView& F, const FeatVec& fvF,
+                  std::vector<int32_t>& vpMapPointMatches) {
+    std::vector<uint8_t> has(KF.N(), 0);
+    for (int i = 0; i < KF.N(); ++i) has[i] = KF.mvpMapPoints.size() == (size_t)KF.N() && KF.mvpMapPoints[i] >= 0;
+    std::vector<int32_t> m(F.N(), -1);
+    int32_t n = 0;
+    const asd_feature_vector a = fvKF.view(), b = fvF.view();
+    if (asd_match_bow(c_.get(), KF.slot, F.slot, &a, &b, has.data(), mfNNratio, mbCheckOrientation, m.data(), &n) != ASD_OK) return 0;
+    vpMapPointMatches.assign(F.N(), -1);
+    for (int j = 0; j < F.N(); ++j)
+      if (m[j] >= 0) vpMapPointMatches[j] = KF.mvpMapPoints[m[j]];
+    return n;
+  }
+
+  // int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t,size_t>>& vMatchedPairs,
+  //                            bool bOnlyStereo)  (:669).  (ex, ey) = epipole of camera 1 in image 2 (:675-683).
+  int SearchForTriangulation(const FrameView& KF1, const FeatVec& fv1, const FrameView& KF2, const FeatVec& fv2, const float F12[9],
+                             float ex, float ey, std::vector<std::pair<size_t, size_t>>& vMatchedPairs) {
+    std::vector<uint8_t> h1(KF1.N(), 0), h2(KF2.N(), 0);
+    for (int i = 0; i < KF1.N(); ++i) h1[i] = KF1.mvpMapPoints.size() == (size_t)KF1.N() && KF1.mvpMapPoints[i] >= 0;
+    for (int i = 0; i < KF2.N(); ++i) h2[i] = KF2.mvpMapPoints.size() == (size_t)KF2.N() && KF2.mvpMapPoints[i] >= 0;
+    std::vector<int32_t> m(KF1.N(), -1);
+    int32_t n = 0;
+    const asd_feature_vector a = fv1.view(), b = fv2.view();
+    vMatchedPairs.clear();
+    if (asd_match_triangulate(c_.get(), KF1.slot, KF2.slot, &a, &b, h1.data(), h2.data(), F12, ex, ey, mbCheckOrientation, m.data(), &n) != ASD_OK)
+      return 0;
+    for (int i = 0; i < KF1.N(); ++i)
+      if (m[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m[i]);   // :809-816: ascending idx1
+    return n;
+  }
+
+  // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, float th)  (:825): search half.  bestIdx[i] = keypoint
+  // of pKF that map point i should be fused into (-1 = none); the caller then runs the Replace / AddObservation loop
+  // (:938-956).  valid[i] = pMP && !pMP->isBad() && !pMP->IsInKeyFrame(pKF).
+  int Fuse(const FrameView& KF, const std::vector<MapPointView>& vpMapPoints, const std::vector<uint8_t>& valid, const Camera& K,
+           std::vector<int32_t>& bestIdx, float th = 3.f) {
+    const int n = (int)vpMapPoints.size();
+    std::vector<float> Xw((size_t)n * 3), nrm((size_t)n * 3), mind(n), maxd(n), desc((size_t)n * ASD_DESC_DIM), bd(n);
+    for (int m = 0; m < n; ++m) {
+      for (int k = 0; k < 3; ++k) { Xw[3 * m + k] = vpMapPoints[m].Xw[k]; nrm[3 * m + k] = vpMapPoints[m].normal[k]; }
+      mind[m] = vpMapPoints[m].mfMinDistance; maxd[m] = vpMapPoints[m].mfMaxDistance;
+      for (int k = 0; k < ASD_DESC_DIM; ++k) desc[(size_t)m * ASD_DESC_DIM + k] = vpMapPoints[m].descriptor[k];
+    }
+    bestIdx.assign(n, -1);
+    const float Kv[4] = {K.fx, K.fy, K.cx, K.cy};
+    if (asd_fuse_search(c_.get(), KF.slot, n, valid.data(), Xw.data(), nrm.data(), mind.data(), maxd.data(), desc.data(), KF.mTcw, Kv, th,
+                        bestIdx.data(), bd.data()) != ASD_OK)
+      return 0;
+    int nFused = 0;
+    for (int m = 0; m < n; ++m) nFused += bestIdx[m] >= 0;
+    return nFused;
+  }
+
  private:
   Context& c_;
   float mfNNratio;
@@ -241,5 +304,41 @@ struct Optimizer {
     return asd_local_ba(c.get(), problem, result);
   }
 };
+
+// ---- vocabulary / local mapping (ORBVocabulary.h:34, Frame.cc:289-296, LocalMapping.cc:299-519) ---
+// void Frame::ComputeBoW(): BowVector (word id -> weight) and FeatureVector (node id at levelsup = 4 -> keypoints)
+inline int ComputeBoW(Context& c, const FrameView& F, std::vector<std::pair<int32_t, double>>& mBowVec, ORBmatcher::FeatVec& mFeatVec,
+                      int levelsup = 4) {
+  const int N = F.N();
+  std::vector<int32_t> bid(N + 1);
+  std::vector<double> bval(N + 1);
+  mFeatVec.node.assign(N + 1, 0); mFeatVec.start.assign(N + 1, 0); mFeatVec.idx.assign(N + 1, 0);
+  int32_t nw = 0, nn = 0;
+  const int rc = asd_compute_bow(c.get(), F.slot, nullptr, N, levelsup, bid.data(), bval.data(), &nw, mFeatVec.node.data(),
+                                 mFeatVec.start.data(), mFeatVec.idx.data(), &nn);
+  if (rc != ASD_OK) return rc;
+  mBowVec.clear();
+  for (int k = 0; k < nw; ++k) mBowVec.emplace_back(bid[k], bval[k]);
+  mFeatVec.node.resize(nn);
+  mFeatVec.start.resize(nn + 1);
+  mFeatVec.idx.resize(mFeatVec.start[nn]);
+  return ASD_OK;
+}
+
+// LocalMapping::CreateNewMapPoints, per-match body (:386-519): x3D[3*i..] and ok[i] for every matched pair
+inline int TriangulateMatches(Context& c, const FrameView& KF1, const FrameView& KF2, const Camera& K1, const Camera& K2,
+                              const std::vector<std::pair<size_t, size_t>>& vMatchedIndices, std::vector<float>& x3D,
+                              std::vector<uint8_t>& ok) {
+  const int n = (int)vMatchedIndices.size();
+  std::vector<int32_t> i1(n), i2(n);
+  for (int i = 0; i < n; ++i) { i1[i] = (int32_t)vMatchedIndices[i].first; i2[i] = (int32_t)vMatchedIndices[i].second; }
+  x3D.assign((size_t)3 * n, 0.f);
+  ok.assign(n, 0);
+  int32_t nnew = 0;
+  const float k1[4] = {K1.fx, K1.fy, K1.cx, K1.cy}, k2[4] = {K2.fx, K2.fy, K2.cx, K2.cy};
+  if (asd_triangulate_pairs(c.get(), KF1.slot, KF2.slot, n, i1.data(), i2.data(), KF1.mTcw, KF2.mTcw, k1, k2, x3D.data(), ok.data(), &nnew) != ASD_OK)
+    return 0;
+  return nnew;
+}
 
 }  // namespace asd

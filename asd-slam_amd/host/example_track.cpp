@@ -58,8 +58,13 @@ int main(int argc, char** argv) {
     std::vector<const asd::MapPointView*> cur_pts(F[1].N(), nullptr);
     for (int j = 0; j < F[1].N(); ++j) if (F[1].mvpMapPoints[j] >= 0) cur_pts[j] = &mps[F[1].mvpMapPoints[j]];
     const int ninl = asd::Optimizer::PoseOptimization(ctx, &F[1], cur_pts, K, extractor.GetInverseScaleSigmaSquares());  // :693
-    printf("kp0=%d kp1=%d matches=%d inliers=%d t=(%.4f %.4f %.4f)\n", F[0].N(), F[1].N(), nmatches, ninl, F[1].mTcw[3], F[1].mTcw[7], F[1].mTcw[11]);
-    return (nmatches > 100 && ninl > 50) ? 0 : 1;
+    // what LocalMapping::SearchInNeighbors does with the same points once frame 1 became a keyframe (LocalMapping.cc:557-636)
+    asd::ORBmatcher fuser(ctx);
+    std::vector<int32_t> bestIdx;
+    const int nfused = fuser.Fuse(F[1], mps, std::vector<uint8_t>(mps.size(), 1), K, bestIdx);
+    printf("kp0=%d kp1=%d matches=%d inliers=%d fused=%d t=(%.4f %.4f %.4f)\n", F[0].N(), F[1].N(), nmatches, ninl, nfused, F[1].mTcw[3],
+           F[1].mTcw[7], F[1].mTcw[11]);
+    return (nmatches > 100 && ninl > 50 && nfused > 0) ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "error: %s\n", e.what());
     return 3;
