@@ -229,3 +229,26 @@ def test_pipelined_extract_equals_sync(hip, synth):
     hip.extract_wait()
     for p in d:
         hip.device_free(p)
+
+
+@pytest.mark.gpu
+def test_extract_500_keypoint_config(hip, oracle, synth):
+    """BASELINE.json configs[0]: KITTI 00 mono at 500 keypoints / frame"""
+    kps, desc = _compare_extract(hip, oracle, synth, synth.scene_frame(5), 500, override=500)
+    assert 500 <= len(kps) <= 620
+
+
+@pytest.mark.gpu
+def test_extract_euroc_size_own_context(pkg, oracle, synth):
+    """EuRoC frames (752 x 480, BASELINE.json configs[3] resolution) through a context of their own: taller than the
+    shared KITTI context, 1000 features as in the reference's EuRoC launch files"""
+    ctx = pkg.AsdHip(n_features=1000, max_width=752, max_height=480)
+    try:
+        ctx.load_weights(synth.asdnet_weights(0))
+        img = synth.scene_frame(2, w=752, h=480)
+        kps, desc = _compare_extract(ctx, oracle, synth, img, 1000)
+        assert len(kps) >= 1000
+        with pytest.raises(Exception):
+            ctx.extract(synth.scene_frame(0))       # 1241 wide does not fit this context
+    finally:
+        ctx.close()
