@@ -34,42 +34,49 @@ const LayerSpec kLayers[7] = {{32, 1, 3, 1, 1},   {32, 32, 3, 1, 1},   {64, 32, 
 // K1: 3x3 conv (pad 1, stride S) + folded BN + ReLU as an implicit GEMM on f32 MFMA.
 // One workgroup = ROWS output rows of one patch; 4 waves as WM (pixels) x WN (channels).
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1>
 struct ConvCfg {
   static constexpr int HO = HIN / S;
   static constexpr int INROWS = (ROWS - 1) * S + 3;
   static constexpr int INCOLS = (HO - 1) * S + 3;
   static constexpr int CPAD = CIN + 4;  // 16-B aligned pixel stride, odd multiple of 4 floats -> b128 reads spread over banks
-  static constexpr int M_WG = ROWS * HO;
+  static constexpr int NW = WM * WN;    // waves per workgroup (4 or 8)
+  static constexpr int NTH = 64 * NW;
+  static constexpr int M_PATCH = ROWS * HO;   // output pixels per patch band
+  static constexpr int M_WG = PP * M_PATCH;   // PP patches share one weight ring
   static constexpr int MT = M_WG / 32 / WM;
   static constexpr int NT = COUT / 32 / WN;
   static constexpr int NCC = CIN / KC;
   static constexpr int NSTAGE = 9 * NCC;
   static constexpr int WCHUNK = KC * COUT;  // floats per weight stage
-  static constexpr int WREGS = WCHUNK / 4 / 256;
-  static constexpr int ACT_FLOATS = INROWS * INCOLS * CPAD;
-  static constexpr int LDS_BYTES = (ACT_FLOATS + 2 * WCHUNK) * 4;
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+  static constexpr int WQUADS = WCHUNK / 4;  // float4 per weight stage
+  static constexpr int WREGS = (WQUADS + NTH - 1) / NTH;
+  static constexpr int ACT_FLOATS = INROWS * INCOLS * CPAD;  // per patch band
+  static constexpr int LDS_BYTES = (PP * ACT_FLOATS + 2 * WCHUNK) * 4;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0, "tile split");
-  static_assert(WCHUNK % 1024 == 0, "weight stage must be a multiple of 256 float4");
+  static_assert(WQUADS % NTH == 0 || WQUADS < NTH, "weight stage: whole float4 rounds per thread, or a single partial round");
   static_assert(HO % ROWS == 0 && CIN % KC == 0 && KC % 8 == 0, "shape");
+  static_assert(PP == 1 || ROWS == HO, "several patches per workgroup only for whole-patch bands");
+  static_assert(M_PATCH % 32 == 0, "32-pixel MFMA tiles must not straddle patches");
 };
 
 // FUSE1: the kernel is conv2 and computes its own input (input_norm + conv1 + BN + ReLU, ASDNet.py:334-336,
 // 360-365) from the raw u8 patch while filling the LDS band, so conv1's 128 KB/patch activation never
 // exists in HBM.  `in` is then the u8 patch array and w1 / b1 the folded conv1 weights.
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int ABL = 0, bool FUSE1 = false>
-__global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_, const float* __restrict__ wimg,
-                                                   const float* __restrict__ bias, float* __restrict__ out,
-                                                   const float* __restrict__ w1, const float* __restrict__ b1) {
-  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int ABL = 0, bool FUSE1 = false>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restrict__ in_, const float* __restrict__ wimg,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1, int n) {
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP>;
+  constexpr int NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sact = smem;
-  float* sw = smem + C::ACT_FLOATS;
+  float* sw = smem + PP * C::ACT_FLOATS;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   constexpr int BANDS = C::HO / ROWS;
-  const int patch = blockIdx.x / BANDS, band = blockIdx.x % BANDS;
+  const int patch = (blockIdx.x / BANDS) * PP, band = blockIdx.x % BANDS;  // first patch of this workgroup
   const int r0 = band * ROWS;
 
 #ifdef ASD_DESYNC
@@ -80,31 +87,33 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
   }
 #endif
   if constexpr (FUSE1) {
-    static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1), "conv1 fusion is for conv2 only");
+    static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1 && PP == 1), "conv1 fusion is for conv2 only");
     // extra LDS behind the weight ring: normalised input rows r0-2 .. r0+ROWS+1 (34 wide, zero padded),
     // conv1 weights + bias, reduction scratch
     float* pin = sw + 2 * C::WCHUNK;              // [(ROWS+4)][36]
     float* wsh = pin + (ROWS + 4) * 36;           // [32*9 + 32]
     float* red = wsh + 320;                       // [8]
     const uint8_t* patches = static_cast<const uint8_t*>(in_);
-    for (int i = t; i < (ROWS + 4) * 36; i += 256) pin[i] = 0.f;
-    for (int i = t; i < 288; i += 256) wsh[i] = w1[i];
+    for (int i = t; i < (ROWS + 4) * 36; i += NTH) pin[i] = 0.f;
+    for (int i = t; i < 288; i += NTH) wsh[i] = w1[i];
     if (t < 32) wsh[288 + t] = b1[t];
-    const uchar4 v = reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t];
+    // the 1024 pixels of the patch sit in the first four waves (4 per lane); further waves only help with conv1 below
+    const bool ld = C::NW == 4 || wave < 4;
+    const uchar4 v = ld ? reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t] : make_uchar4(0, 0, 0, 0);
     const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
     float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
     float s = (x[0] + x[1]) + (x[2] + x[3]);
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) red[wave] = s;
+    if (lane == 0 && ld) red[wave] = s;
     __syncthreads();
     const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
     float d[4], ss = 0.f;
     for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0) red[4 + wave] = ss;
+    if (lane == 0 && ld) red[4 + wave] = ss;
     __syncthreads();
     const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
-    {
+    if (ld) {
       const int idx = t * 4, y = idx >> 5, x0 = idx & 31;  // this thread's 4 pixels sit in row y
       const int j = y - (r0 - 2);
       if (j >= 0 && j < ROWS + 4)
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
     // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding)
     constexpr int NPIX = C::INROWS * C::INCOLS;
     if (!(ABL & 1))
-    for (int item = t; item < NPIX * 8; item += 256) {
+    for (int item = t; item < NPIX * 8; item += NTH) {
       const int q = item & 7, pix = item >> 3;
       const int i = pix % C::INCOLS, j = pix / C::INCOLS;
       const int oy = r0 - 1 + j, ox = i - 1;
@@ -133,22 +142,25 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
     }
   } else {
     const float* inp = static_cast<const float*>(in_) + (size_t)patch * HIN * HIN * CIN;
-    // ---- stage the zero-padded input band (NHWC rows are contiguous: coalesced 16-B loads)
+    // ---- stage the zero-padded input band(s) (NHWC rows are contiguous: coalesced 16-B loads)
     constexpr int C4 = CIN / 4;
+    constexpr int NPIXB = C::INROWS * C::INCOLS;
     if (!(ABL & 1))
-    for (int idx = t; idx < C::INROWS * C::INCOLS * C4; idx += 256) {
-      const int c4 = idx % C4, pix = idx / C4;
+    for (int idx = t; idx < PP * NPIXB * C4; idx += NTH) {
+      const int c4 = idx % C4, pixg = idx / C4;
+      const int pp = pixg / NPIXB, pix = pixg % NPIXB;
       const int i = pix % C::INCOLS, j = pix / C::INCOLS;
       const int iy = r0 * S - 1 + j, ix = i - 1;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < HIN && ix >= 0 && ix < HIN)
-        v = *reinterpret_cast<const f32x4*>(inp + ((size_t)iy * HIN + ix) * CIN + c4 * 4);
-      *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + c4 * 4) = v;
+      if (iy >= 0 && iy < HIN && ix >= 0 && ix < HIN && patch + pp < n)
+        v = *reinterpret_cast<const f32x4*>(inp + (size_t)pp * HIN * HIN * CIN + ((size_t)iy * HIN + ix) * CIN + c4 * 4);
+      *reinterpret_cast<f32x4*>(sact + pp * C::ACT_FLOATS + pix * C::CPAD + c4 * 4) = v;
     }
   }
   // ---- weight stage 0
   for (int r = 0; r < C::WREGS; ++r)
-    *reinterpret_cast<f32x4*>(sw + (r * 256 + t) * 4) = *reinterpret_cast<const f32x4*>(wimg + (r * 256 + t) * 4);
+    if (C::WQUADS >= NTH || t < C::WQUADS)
+      *reinterpret_cast<f32x4*>(sw + (r * NTH + t) * 4) = *reinterpret_cast<const f32x4*>(wimg + (r * NTH + t) * 4);
   __syncthreads();
 
   f32x16 acc[C::MT][C::NT];
@@ -160,16 +172,18 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
   int abase[C::MT];
   for (int mt = 0; mt < C::MT; ++mt) {
     const int m = (wm * C::MT + mt) * 32 + li;
-    const int rr = m / C::HO, ox = m % C::HO;
-    abase[mt] = ((rr * S) * C::INCOLS + ox * S) * C::CPAD + 4 * h;
+    const int pp = PP > 1 ? m / C::M_PATCH : 0, mm = m - pp * C::M_PATCH;
+    const int rr = mm / C::HO, ox = mm % C::HO;
+    abase[mt] = pp * C::ACT_FLOATS + ((rr * S) * C::INCOLS + ox * S) * C::CPAD + 4 * h;
   }
   const int bbase = (h * COUT + wn * C::NT * 32 + li) * 4;
 
   for (int s = 0; s < C::NSTAGE; ++s) {
     f32x4 wreg[C::WREGS];
-    if (s + 1 < C::NSTAGE) {
+    if (s + 1 < C::NSTAGE && !(ABL & 16)) {
       const float* wsrc = wimg + (size_t)(s + 1) * C::WCHUNK;
-      for (int r = 0; r < C::WREGS; ++r) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * 256 + t) * 4);
+      for (int r = 0; r < C::WREGS; ++r)
+        if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
     }
     const int tap = s / C::NCC, cc = s % C::NCC;
     const int tapoff = ((tap / 3) * C::INCOLS + (tap % 3)) * C::CPAD + cc * KC;
@@ -191,11 +205,12 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
             if (!(ABL & 2)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
             else { asm volatile("" :: "v"(a[mt][jj]), "v"(b[nt][jj])); }
     }
-    if (s + 1 < C::NSTAGE) {
+    if (s + 1 < C::NSTAGE && !(ABL & 16)) {
       float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
-      for (int r = 0; r < C::WREGS; ++r) *reinterpret_cast<f32x4*>(swn + (r * 256 + t) * 4) = wreg[r];
+      for (int r = 0; r < C::WREGS; ++r)
+        if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
     }
-    __syncthreads();
+    if (!(ABL & 8)) __syncthreads();
   }
 
   // ---- epilogue: bias (folded BN) + ReLU, NHWC store.  Lane owns one cout column, 16 pixel rows.
@@ -203,13 +218,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma(const void* __restrict__ in_,
   for (int nt = 0; nt < C::NT; ++nt) {
     const int co = (wn * C::NT + nt) * 32 + li;
     const float bv = bias[co];
-    for (int mt = 0; mt < C::MT; ++mt)
+    for (int mt = 0; mt < C::MT; ++mt) {
+      const int pp = PP > 1 ? ((wm * C::MT + mt) * 32) / C::M_PATCH : 0;  // a 32-pixel tile never straddles two patches
+      if (PP > 1 && patch + pp >= n) continue;
       for (int r = 0; r < 16; ++r) {
         const int m = (wm * C::MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const size_t o = (size_t)pp * C::HO * C::HO * COUT + (size_t)(m - pp * C::M_PATCH) * COUT + co;
         float v = acc[mt][nt][r] + bv;
-        if (!(ABL & 4)) op[(size_t)m * COUT + co] = v > 0.f ? v : 0.f;
+        if (!(ABL & 4)) op[o] = v > 0.f ? v : 0.f;
         else { asm volatile("" :: "v"(v)); }
       }
+    }
   }
 }
 
@@ -225,6 +244,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
                                                      const float* __restrict__ bias, float* __restrict__ out, int ntiles) {
   using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
   static_assert(C::NSTAGE >= 2, "need two stages to hide the band prefetch");
+  static_assert(C::NW == 4, "the persistent form is written for 4 waves");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sact0 = smem;
   float* sw = smem + 2 * C::ACT_FLOATS;
@@ -410,36 +430,37 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
   desc[(size_t)p * 128 + lane + 64] = v1 / norm;
 }
 
-// layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC>
+// layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP> (L3: persistent form, no PP)
 #ifndef L2_CFG
-#define L2_CFG 32, 32, 32, 1, 4, 4, 1, 32
+#define L2_CFG 32, 32, 32, 1, 4, 4, 1, 32, 1
 #endif
 #ifndef L3_CFG
 #define L3_CFG 32, 64, 32, 2, 4, 2, 2, 16
 #endif
 #ifndef L4_CFG
-#define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32
+#define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32, 1
 #endif
 #ifndef L5_CFG
-#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 8
+#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 8, 1
 #endif
 #ifndef L6_CFG
-#define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16
+#define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16, 1
 #endif
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, bool FUSE1 = false>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, bool FUSE1 = false>
 hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const float* bias, float* out, int n,
                        const float* w1 = nullptr, const float* b1 = nullptr) {
-  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
-  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC, 0, FUSE1>;
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP>;
+  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, 0, FUSE1>;
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
+  static_assert(lds <= 160 * 1024, "band + weight ring do not fit LDS");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(n * (C::HO / ROWS)), dim3(256), lds, st, in, wimg, bias, out, w1, b1);
+  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, wimg, bias, out, w1, b1, n);
   return hipGetLastError();
 }
 
@@ -596,20 +617,21 @@ static int ablate_one(asd_ctx* ctx, int layer, int n, int reps, float* ms) {
     for (int r = 0; r < count; ++r) {
       if (layer == 2) {
         using C = ConvCfg<L2_CFG>;
-        constexpr int lds = C::LDS_BYTES + ((4 + 4) * 36 + 320 + 8) * 4;
+        constexpr int rows = C::M_PATCH / C::HO;
+        constexpr int lds = C::LDS_BYTES + ((rows + 4) * 36 + 320 + 8) * 4;
         auto k = k_conv_mfma<L2_CFG, ABL, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(k, dim3(n * (C::HO / 4)), dim3(256), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0]);
+        hipLaunchKernelGGL(k, dim3(n * (C::HO / rows)), dim3(C::NTH), lds, st, (const void*)ctx->d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, ctx->d_w1, ctx->d_bias[0], n);
       } else if (layer == 4) {
         using C = ConvCfg<L4_CFG>;
         auto k = k_conv_mfma<L4_CFG, ABL, false>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        hipLaunchKernelGGL(k, dim3(n * (C::HO / 8)), dim3(256), C::LDS_BYTES, st, (const void*)a0, ctx->d_wimg[3], ctx->d_bias[3], a1, (const float*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL(k, dim3(n * (C::HO * C::HO / C::M_PATCH)), dim3(C::NTH), C::LDS_BYTES, st, (const void*)a0, ctx->d_wimg[3], ctx->d_bias[3], a1, (const float*)nullptr, (const float*)nullptr, n);
       } else {
         using C = ConvCfg<L6_CFG>;
         auto k = k_conv_mfma<L6_CFG, ABL, false>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        hipLaunchKernelGGL(k, dim3(n * (C::HO / 8)), dim3(256), C::LDS_BYTES, st, (const void*)a0, ctx->d_wimg[5], ctx->d_bias[5], a1, (const float*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL(k, dim3(((n + C::M_WG / C::M_PATCH - 1) / (C::M_WG / C::M_PATCH)) * (C::HO * C::HO / C::M_PATCH)), dim3(C::NTH), C::LDS_BYTES, st, (const void*)a0, ctx->d_wimg[5], ctx->d_bias[5], a1, (const float*)nullptr, (const float*)nullptr, n);
       }
     }
   };
@@ -625,7 +647,7 @@ static int ablate_one(asd_ctx* ctx, int layer, int n, int reps, float* ms) {
 }
 
 // debug / tuning aid (not part of the C ABI header): time conv2 (fused) / conv4 / conv6 with parts removed.
-// mode bits: 1 = no input staging, 2 = no MFMA, 4 = no epilogue stores
+// mode bits: 1 = no input staging, 2 = no MFMA, 4 = no epilogue stores, 8 = no per-stage barrier, 16 = no weight streaming
 extern "C" int asd_debug_conv_ablate(asd_ctx* ctx, int layer, int n, int mode, int reps, float* ms) {
   switch (mode) {
     case 0: return ablate_one<0>(ctx, layer, n, reps, ms);
@@ -635,6 +657,10 @@ extern "C" int asd_debug_conv_ablate(asd_ctx* ctx, int layer, int n, int mode, i
     case 4: return ablate_one<4>(ctx, layer, n, reps, ms);
     case 5: return ablate_one<5>(ctx, layer, n, reps, ms);
     case 6: return ablate_one<6>(ctx, layer, n, reps, ms);
-    default: return ablate_one<7>(ctx, layer, n, reps, ms);
+    case 7: return ablate_one<7>(ctx, layer, n, reps, ms);
+    case 13: return ablate_one<13>(ctx, layer, n, reps, ms);   // MFMA loop, no per-stage barrier
+    case 21: return ablate_one<21>(ctx, layer, n, reps, ms);   // MFMA loop, no weight streaming
+    case 29: return ablate_one<29>(ctx, layer, n, reps, ms);   // MFMA loop, neither
+    default: return ASD_ERR_INVALID;
   }
 }
