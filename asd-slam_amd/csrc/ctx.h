@@ -37,9 +37,8 @@ struct AsdFrameSlot {
 struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
-  hipStream_t cur_stream = nullptr;  // stream the extractor / ASDNet enqueue on (stream, or stream_x for the pipelined extractor)
-  hipStream_t stream_x = nullptr;
-  hipEvent_t evx[3] = {};
+  hipStream_t cur_stream = nullptr;  // stream ASDNet enqueues on (stream, or stream_x for the pipelined extractor)
+  hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
   struct AsyncExtract* ax = nullptr;
   int num_cu = 256;
   std::string err;
@@ -57,7 +56,8 @@ struct asd_ctx {
   float* d_act[2] = {};         // ping-pong NHWC activations
   float* d_part = nullptr;      // split-K partials of the last layer
   uint8_t* d_patches = nullptr; // [max_patches][1024]
-  float* d_desc = nullptr;      // [max_patches][128] descriptors of the last extract / describe
+  float* d_desc = nullptr;      // [max_patches][128] descriptors of the last asd_extract / asd_describe
+  float* d_desc_last = nullptr; // device descriptors asd_frame_set(desc == NULL) adopts: last asd_extract or last waited submission
 
   // ---- front-end (state private to frontend.hip)
   struct FrontendState* fe = nullptr;

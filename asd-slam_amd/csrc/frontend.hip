@@ -386,6 +386,14 @@ class LevelPool {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+struct ExtractSlot {
+  uint8_t* d_patches = nullptr;
+  float* d_desc = nullptr;
+  float *d_angles = nullptr, *h_angles = nullptr, *h_desc = nullptr;  // h_* pinned
+  hipEvent_t ev_begin = nullptr, ev_front = nullptr, ev_end = nullptr;
+  bool owned = false;  // slot 0 aliases the ctx / FrontendState buffers
+};
+
 struct FrontendState {
   int cfg_w = 0, cfg_h = 0;  // size the tables are currently built for
   PyrDev pyr{};
@@ -412,6 +420,7 @@ struct FrontendState {
   std::vector<float> raw_x[ASD_MAX_LEVELS], raw_y[ASD_MAX_LEVELS], raw_r[ASD_MAX_LEVELS];
   std::vector<int> sel[ASD_MAX_LEVELS];
   LevelPool* pool = nullptr;
+  ExtractSlot slot0;  // buffers of the synchronous asd_extract (aliases ctx->d_patches / d_desc and the arrays above)
 };
 
 static void level_dims(const asd_ctx* ctx, int w, int h, int level, int* lw, int* lh) {
@@ -473,6 +482,8 @@ void frontend_free(asd_ctx* ctx) {
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {fe->h_corners, fe->h_level_start, fe->h_kps, fe->h_angles, fe->h_desc};
   for (void* p : host) if (p) (void)hipHostFree(p);
+  for (hipEvent_t* e : {&fe->slot0.ev_begin, &fe->slot0.ev_front, &fe->slot0.ev_end})
+    if (*e) (void)hipEventDestroy(*e);
   delete fe->pool;
   delete fe;
   ctx->fe = nullptr;
@@ -593,42 +604,74 @@ static int configure_size(asd_ctx* ctx, int w, int h) {
   return ASD_OK;
 }
 
-extern "C" {
+// ---- one extraction = front half (pyramid .. patch gather) + back half (ASDNet + read-back) -----------
+// The halves only share an ExtractSlot, so the front half of frame t+1 can run (own stream, host quadtree)
+// while the back half of frame t keeps the matrix cores busy.
+struct ExtractJob {
+  const uint8_t* image = nullptr;
+  bool on_device = false;
+  int w = 0, h = 0, stride = 0, nfeat = 0;
+  int n = 0, rc = ASD_OK;
+};
 
-static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device, int32_t width, int32_t height,
-                        int32_t stride, int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out,
-                        bool async_ctx = false) {
-  if (!ctx || !image || !kps || !desc || !n_out || stride < width) return ASD_ERR_INVALID;
-  if (width > ctx->cfg.max_width || height > ctx->cfg.max_height) { ctx->set_error("image %dx%d exceeds ctx capacity %dx%d", width, height, ctx->cfg.max_width, ctx->cfg.max_height); return ASD_ERR_CAPACITY; }
-  if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
-  (void)hipSetDevice(ctx->cfg.device);
+static int slot_alloc(asd_ctx* ctx, ExtractSlot& S) {
+  const size_t np = ctx->cfg.max_patches;
+  ASD_HIP_CHECK(ctx, hipMalloc(&S.d_patches, np * 1024));
+  ASD_HIP_CHECK(ctx, hipMalloc(&S.d_desc, np * 128 * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&S.d_angles, np * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_angles, np * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_desc, np * 128 * sizeof(float)));
+  S.owned = true;
+  return ASD_OK;
+}
+static int slot_events(asd_ctx* ctx, ExtractSlot& S) {
+  if (!S.ev_begin) ASD_HIP_CHECK(ctx, hipEventCreate(&S.ev_begin));
+  if (!S.ev_front) ASD_HIP_CHECK(ctx, hipEventCreate(&S.ev_front));
+  if (!S.ev_end) ASD_HIP_CHECK(ctx, hipEventCreate(&S.ev_end));
+  return ASD_OK;
+}
+static void slot_free(ExtractSlot& S) {
+  if (S.owned) {
+    if (S.d_patches) (void)hipFree(S.d_patches);
+    if (S.d_desc) (void)hipFree(S.d_desc);
+    if (S.d_angles) (void)hipFree(S.d_angles);
+    if (S.h_angles) (void)hipHostFree(S.h_angles);
+    if (S.h_desc) (void)hipHostFree(S.h_desc);
+  }
+  for (hipEvent_t* e : {&S.ev_begin, &S.ev_front, &S.ev_end})
+    if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+  S = ExtractSlot();
+}
+
+// E1-E5: pyramid, FAST, quadtree, orientation, blur, patch gather.  Fills kps (angle still 0) and leaves the
+// patches + angles in the slot; records S.ev_front on `st` after the last kernel.  Blocks the calling host
+// thread twice (corner counts, corner list) but never waits for anything outside `st`.
+static int extract_front(asd_ctx* ctx, const ExtractJob& J, ExtractSlot& S, hipStream_t st, hipEvent_t ev_corners,
+                         asd_keypoint* kps, int32_t* n_out) {
+  const int width = J.w, height = J.h, stride = J.stride;
   int rc = configure_size(ctx, width, height);
   if (rc != ASD_OK) return rc;
   FrontendState* fe = ctx->fe;
   const PyrDev& P = fe->pyr;
   const int nl = P.nlevels;
-  // the pipelined extractor runs on its own stream + events so tracking kernels on ctx->stream are not queued behind ASDNet
-  hipStream_t st = async_ctx ? ctx->stream_x : ctx->stream;
-  hipEvent_t ev_begin = async_ctx ? ctx->evx[0] : ctx->ev0, ev_end = async_ctx ? ctx->evx[1] : ctx->ev1,
-             ev_corners = async_ctx ? ctx->evx[2] : ctx->ev2;
   int quota[ASD_MAX_LEVELS];
-  const int nfeat = n_features_override > 0 ? n_features_override : ctx->cfg.n_features;
+  const int nfeat = J.nfeat > 0 ? J.nfeat : ctx->cfg.n_features;
   if (nfeat > ctx->cfg.max_patches) { ctx->set_error("n_features %d exceeds max_patches", nfeat); return ASD_ERR_CAPACITY; }
-  if (n_features_override > 0) asd_compute_quotas(nfeat, ctx->cfg.scale_factor, nl, quota);
+  if (J.nfeat > 0) asd_compute_quotas(nfeat, ctx->cfg.scale_factor, nl, quota);
   else for (int l = 0; l < nl; ++l) quota[l] = ctx->features_per_level[l];
 
   const bool timing = getenv("ASD_TIMING") != nullptr;
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
   const auto t_start = now();
-  ASD_HIP_CHECK(ctx, hipEventRecord(ev_begin, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(S.ev_begin, st));
   // E1 pyramid
-  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, image, stride, width, height,
-                                      image_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, J.image, stride, width, height,
+                                      J.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   for (int l = 1; l < nl; ++l) {
-    const LevelDev &S = P.lv[l - 1], &D = P.lv[l];
-    hipLaunchKernelGGL(k_resize, dim3((D.w + 255) / 256, (D.h + 3) / 4), dim3(256), 0, st, fe->d_pyr + S.off, S.w, S.h,
-                       S.pitch, fe->d_pyr + D.off, D.w, D.h, D.pitch, fe->d_xofs + fe->tab_x_off[l],
+    const LevelDev &Sl = P.lv[l - 1], &D = P.lv[l];
+    hipLaunchKernelGGL(k_resize, dim3((D.w + 255) / 256, (D.h + 3) / 4), dim3(256), 0, st, fe->d_pyr + Sl.off, Sl.w, Sl.h,
+                       Sl.pitch, fe->d_pyr + D.off, D.w, D.h, D.pitch, fe->d_xofs + fe->tab_x_off[l],
                        fe->d_ialpha + 2 * fe->tab_x_off[l], fe->d_yofs + fe->tab_y_off[l],
                        fe->d_ibeta + 2 * fe->tab_y_off[l]);
   }
@@ -690,27 +733,73 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
     }
   }
   *n_out = n;
-  ctx->last_n = n;
   const auto t_quad = now();
-  if (n == 0) return ASD_OK;
-  // E4 + E5b + E6
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->d_kps, fe->h_kps, (size_t)n * sizeof(short4), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(k_angle_patch, dim3((n + 3) / 4), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur, fe->d_kps, n,
-                     fe->d_angles, ctx->d_patches);
-  ASD_HIP_CHECK(ctx, hipGetLastError());
+  if (n > 0) {
+    // E4 + E5b: orientation + patch gather
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->d_kps, fe->h_kps, (size_t)n * sizeof(short4), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_angle_patch, dim3((n + 3) / 4), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur, fe->d_kps, n,
+                       S.d_angles, S.d_patches);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+  }
+  ASD_HIP_CHECK(ctx, hipEventRecord(S.ev_front, st));
+  if (timing) fprintf(stderr, "[extract front] launch+counts %.0f us, corners D2H %.0f us (%d), quadtree %.0f us\n", us(t_start, t_counts), us(t_counts, t_corners), total, us(t_corners, t_quad));
+  return ASD_OK;
+}
+
+// E6: ASDNet on the slot's patches + read-back of angles and descriptors, all enqueued on `st` behind ev_front
+static int extract_back_enqueue(asd_ctx* ctx, ExtractSlot& S, int n, hipStream_t st) {
+  ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, S.ev_front, 0));
   ctx->cur_stream = st;
-  rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc);
+  const int rc = asdnet_forward_device(ctx, S.d_patches, n, S.d_desc);
   ctx->cur_stream = nullptr;
   if (rc != ASD_OK) return rc;
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_angles, fe->d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipEventRecord(ev_end, st));
-  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  memcpy(desc, fe->h_desc, (size_t)n * 128 * sizeof(float));  // pinned staging: the caller's buffer is pageable
-  for (int i = 0; i < n; ++i) kps[i].angle = fe->h_angles[i];
-  if (timing) fprintf(stderr, "[extract] launch+counts %.0f us, corners D2H %.0f us (%d), quadtree %.0f us, tail (angle+asdnet+D2H) %.0f us\n", us(t_start, t_counts), us(t_counts, t_corners), total, us(t_corners, t_quad), us(t_quad, now()));
-  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, ev_begin, ev_end));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_angles, S.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(S.ev_end, st));
   return ASD_OK;
+}
+
+// E7: wait for the back half, hand the results over (pinned staging -> caller's pageable buffers)
+static int extract_finish(asd_ctx* ctx, ExtractSlot& S, int n, asd_keypoint* kps, float* desc) {
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(S.ev_end));
+  memcpy(desc, S.h_desc, (size_t)n * 128 * sizeof(float));
+  for (int i = 0; i < n; ++i) kps[i].angle = S.h_angles[i];
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, S.ev_begin, S.ev_end));
+  return ASD_OK;
+}
+
+static int extract_check(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride) {
+  if (!ctx || !image || stride < width) return ASD_ERR_INVALID;
+  if (width > ctx->cfg.max_width || height > ctx->cfg.max_height) { ctx->set_error("image %dx%d exceeds ctx capacity %dx%d", width, height, ctx->cfg.max_width, ctx->cfg.max_height); return ASD_ERR_CAPACITY; }
+  if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
+  return ASD_OK;
+}
+
+extern "C" {
+
+static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device, int32_t width, int32_t height,
+                        int32_t stride, int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out) {
+  if (!kps || !desc || !n_out) return ASD_ERR_INVALID;
+  int rc = extract_check(ctx, image, width, height, stride);
+  if (rc != ASD_OK) return rc;
+  (void)hipSetDevice(ctx->cfg.device);
+  FrontendState* fe = ctx->fe;
+  ExtractSlot& S = fe->slot0;
+  if (!S.d_patches) {  // slot 0 = the buffers asd_describe uses as well
+    S.d_patches = ctx->d_patches; S.d_desc = ctx->d_desc;
+    S.d_angles = fe->d_angles; S.h_angles = fe->h_angles; S.h_desc = fe->h_desc;
+  }
+  if ((rc = slot_events(ctx, S)) != ASD_OK) return rc;
+  ExtractJob J;
+  J.image = image; J.on_device = image_on_device; J.w = width; J.h = height; J.stride = stride; J.nfeat = n_features_override;
+  int32_t n = 0;
+  if ((rc = extract_front(ctx, J, S, ctx->stream, ctx->ev2, kps, &n)) != ASD_OK) return rc;
+  *n_out = n;
+  ctx->last_n = n;
+  ctx->d_desc_last = S.d_desc;
+  if (n == 0) return ASD_OK;
+  if ((rc = extract_back_enqueue(ctx, S, n, ctx->stream)) != ASD_OK) return rc;
+  return extract_finish(ctx, S, n, kps, desc);
 }
 
 int asd_extract(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride,
@@ -723,80 +812,153 @@ int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int3
   return extract_impl(ctx, d_image, true, width, height, stride, n_features_override, kps, desc, n_out);
 }
 
-// ---- pipelined extraction -------------------------------------------------------------------
 }  // extern "C"
+
+// ---- pipelined extraction ---------------------------------------------------------------------------
+// A worker thread owns two low-priority streams: front halves run on stream_f, back halves on stream_x.  Up to
+// kQueueDepth submissions may be outstanding; the worker starts the front half of the next queued frame before it
+// waits for the back half (ASDNet) of the previous one, so the GPU never idles during the host-side quadtree.
+constexpr int kQueueDepth = ASD_EXTRACT_QUEUE;
+constexpr int kSlots = kQueueDepth + 2;  // a waited frame's device descriptors stay valid for two more submissions
+
+struct AsyncJob {
+  ExtractJob job;
+  int slot = 0;
+  enum State { QUEUED, FRONT, BACK, DONE } state = QUEUED;
+  std::vector<asd_keypoint> kps;
+  std::vector<float> desc;
+};
 
 struct AsyncExtract {
   std::thread th;
   std::mutex m;
   std::condition_variable cv;
-  bool have_job = false, done = false, stop = false, in_flight = false;
-  const uint8_t* image = nullptr;
-  bool on_device = false;
-  int w = 0, h = 0, stride = 0, nfeat = 0;
-  std::vector<asd_keypoint> kps;
-  std::vector<float> desc;
-  int n = 0, rc = ASD_OK;
+  bool stop = false;
+  hipStream_t stream_f = nullptr;
+  hipEvent_t ev_corners = nullptr;
+  ExtractSlot slots[kSlots];
+  AsyncJob jobs[kSlots];     // ring: job of submission s lives in jobs[s % kSlots]
+  uint64_t submitted = 0, started = 0, waited = 0;  // counters: submitted >= started >= waited
 };
 
 static void async_worker(asd_ctx* ctx) {
   AsyncExtract* ax = ctx->ax;
   (void)hipSetDevice(ctx->cfg.device);
+  AsyncJob* inflight = nullptr;  // back half enqueued, results not yet handed over
+  auto finish = [&](AsyncJob* a) {
+    ExtractSlot& S = ax->slots[a->slot];
+    const int rc = extract_finish(ctx, S, a->job.n, a->kps.data(), a->desc.data());
+    std::lock_guard<std::mutex> l(ax->m);
+    if (rc != ASD_OK) a->job.rc = rc;
+    a->state = AsyncJob::DONE;
+  };
   for (;;) {
+    AsyncJob* next = nullptr;
     {
       std::unique_lock<std::mutex> l(ax->m);
-      ax->cv.wait(l, [&] { return ax->have_job || ax->stop; });
-      if (ax->stop) return;
-      ax->have_job = false;
+      for (;;) {
+        if (ax->stop) break;
+        if (ax->started < ax->submitted) { next = &ax->jobs[ax->started % kSlots]; ++ax->started; next->state = AsyncJob::FRONT; break; }
+        if (inflight) {
+          // nothing queued: hand the in-flight frame over as soon as its back half is done, but keep an eye on the queue
+          if (hipEventQuery(ax->slots[inflight->slot].ev_end) == hipSuccess) break;
+          ax->cv.wait_for(l, std::chrono::microseconds(40));
+        } else {
+          ax->cv.wait(l);
+        }
+      }
+      if (ax->stop) {
+        l.unlock();
+        if (inflight) finish(inflight);
+        ax->cv.notify_all();
+        return;
+      }
     }
+    if (!next) {  // in-flight frame finished, queue empty
+      finish(inflight);
+      inflight = nullptr;
+      ax->cv.notify_all();
+      continue;
+    }
+    ExtractSlot& S = ax->slots[next->slot];
     int32_t n = 0;
-    const int rc = extract_impl(ctx, ax->image, ax->on_device, ax->w, ax->h, ax->stride, ax->nfeat, ax->kps.data(),
-                                ax->desc.data(), &n, true);
-    {
-      std::lock_guard<std::mutex> l(ax->m);
-      ax->n = n; ax->rc = rc; ax->done = true;
+    int rc = extract_front(ctx, next->job, S, ax->stream_f, ax->ev_corners, next->kps.data(), &n);
+    next->job.n = n;
+    if (inflight) {  // the previous frame's ASDNet ran underneath this front half
+      finish(inflight);
+      inflight = nullptr;
+      ax->cv.notify_all();
     }
-    ax->cv.notify_all();
+    if (rc == ASD_OK && n > 0) rc = extract_back_enqueue(ctx, S, n, ctx->stream_x);
+    if (rc != ASD_OK || n == 0) {
+      { std::lock_guard<std::mutex> l(ax->m); next->job.rc = rc; next->state = AsyncJob::DONE; }
+      ax->cv.notify_all();
+    } else {
+      std::lock_guard<std::mutex> l(ax->m);
+      next->state = AsyncJob::BACK;
+      inflight = next;
+    }
   }
 }
 
 void frontend_async_shutdown(asd_ctx* ctx) {
   if (!ctx->ax) return;
-  { std::lock_guard<std::mutex> l(ctx->ax->m); ctx->ax->stop = true; }
-  ctx->ax->cv.notify_all();
-  if (ctx->ax->th.joinable()) ctx->ax->th.join();
-  delete ctx->ax;
+  AsyncExtract* ax = ctx->ax;
+  { std::lock_guard<std::mutex> l(ax->m); ax->stop = true; }
+  ax->cv.notify_all();
+  if (ax->th.joinable()) ax->th.join();
+  if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
+  if (ax->stream_f) (void)hipStreamSynchronize(ax->stream_f);
+  for (auto& S : ax->slots) slot_free(S);
+  if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
+  if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
+  delete ax;
   ctx->ax = nullptr;
   if (ctx->stream_x) { (void)hipStreamDestroy(ctx->stream_x); ctx->stream_x = nullptr; }
-  for (auto& e : ctx->evx) if (e) { (void)hipEventDestroy(e); e = nullptr; }
 }
 
 extern "C" {
 
 int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width, int32_t height,
                        int32_t stride, int32_t n_features_override) {
-  if (!ctx || !image) return ASD_ERR_INVALID;
+  int rc = extract_check(ctx, image, width, height, stride);
+  if (rc != ASD_OK) return rc;
   (void)hipSetDevice(ctx->cfg.device);
   if (!ctx->ax) {
-    // lowest stream priority: the latency-critical tracking kernels on ctx->stream go first.
-    // (Masking a few CUs off this stream with hipExtStreamCreateWithCUMask was tried and measured
+    // lowest stream priority for ASDNet: the latency-critical tracking kernels on ctx->stream go first; the small
+    // front-half kernels get the middle priority so they slot in between the conv workgroups.
+    // (Masking a few CUs off these streams with hipExtStreamCreateWithCUMask was tried and measured
     //  slower: extraction 2.0 -> 3.1 ms, no gain for the tracking kernels.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_x, hipStreamDefault, prio_least));
-    for (auto& e : ctx->evx) ASD_HIP_CHECK(ctx, hipEventCreate(&e));
-    ctx->ax = new AsyncExtract();
-    ctx->ax->kps.resize(ctx->cfg.max_patches);
-    ctx->ax->desc.resize((size_t)ctx->cfg.max_patches * 128);
-    ctx->ax->th = std::thread(async_worker, ctx);
+    AsyncExtract* ax = new AsyncExtract();
+    ctx->ax = ax;
+    const int prio_mid = prio_least + (prio_greatest - prio_least) / 2;
+    ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_mid));
+    ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners));
+    for (int i = 0; i < kSlots; ++i) {
+      if ((rc = slot_alloc(ctx, ax->slots[i])) != ASD_OK) return rc;
+      if ((rc = slot_events(ctx, ax->slots[i])) != ASD_OK) return rc;
+      ax->jobs[i].slot = i;
+      ax->jobs[i].kps.resize(ctx->cfg.max_patches);
+      ax->jobs[i].desc.resize((size_t)ctx->cfg.max_patches * 128);
+    }
+    ax->th = std::thread(async_worker, ctx);
   }
   AsyncExtract* ax = ctx->ax;
   {
     std::lock_guard<std::mutex> l(ax->m);
-    if (ax->in_flight) { ctx->set_error("asd_extract_submit: a submission is already in flight"); return ASD_ERR_INVALID; }
-    ax->image = image; ax->on_device = device_resident != 0; ax->w = width; ax->h = height; ax->stride = stride;
-    ax->nfeat = n_features_override;
-    ax->have_job = true; ax->done = false; ax->in_flight = true;
+    if (ax->submitted - ax->waited >= (uint64_t)kQueueDepth) {
+      ctx->set_error("asd_extract_submit: %d submissions are already outstanding", kQueueDepth);
+      return ASD_ERR_CAPACITY;
+    }
+    AsyncJob& a = ax->jobs[ax->submitted % kSlots];
+    a.job = ExtractJob();
+    a.job.image = image; a.job.on_device = device_resident != 0; a.job.w = width; a.job.h = height; a.job.stride = stride;
+    a.job.nfeat = n_features_override;
+    a.state = AsyncJob::QUEUED;
+    ++ax->submitted;
   }
   ax->cv.notify_all();
   return ASD_OK;
@@ -806,13 +968,18 @@ int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_ou
   if (!ctx || !ctx->ax || !kps || !desc || !n_out) return ASD_ERR_INVALID;
   AsyncExtract* ax = ctx->ax;
   std::unique_lock<std::mutex> l(ax->m);
-  if (!ax->in_flight) { ctx->set_error("asd_extract_wait: nothing was submitted"); return ASD_ERR_INVALID; }
-  ax->cv.wait(l, [&] { return ax->done; });
-  ax->in_flight = false;
-  if (ax->rc != ASD_OK) return ax->rc;
-  memcpy(kps, ax->kps.data(), (size_t)ax->n * sizeof(asd_keypoint));
-  memcpy(desc, ax->desc.data(), (size_t)ax->n * 128 * sizeof(float));
-  *n_out = ax->n;
+  if (ax->waited == ax->submitted) { ctx->set_error("asd_extract_wait: nothing was submitted"); return ASD_ERR_INVALID; }
+  AsyncJob& a = ax->jobs[ax->waited % kSlots];
+  ax->cv.wait(l, [&] { return a.state == AsyncJob::DONE; });
+  ++ax->waited;
+  if (a.job.rc != ASD_OK) return a.job.rc;
+  const int n = a.job.n;
+  l.unlock();
+  memcpy(kps, a.kps.data(), (size_t)n * sizeof(asd_keypoint));
+  memcpy(desc, a.desc.data(), (size_t)n * 128 * sizeof(float));
+  *n_out = n;
+  ctx->last_n = n;
+  ctx->d_desc_last = ax->slots[a.slot].d_desc;
   return ASD_OK;
 }
 

@@ -385,6 +385,7 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   AsdFrameSlot* F = slot_of(ctx, slot);
   if (!F || n < 0 || (n > 0 && !kps) || !(max_x > min_x) || !(max_y > min_y)) return ASD_ERR_INVALID;
   if (n > ctx->cfg.max_patches) { ctx->set_error("frame has %d keypoints, capacity %d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
+  if (!desc && !ctx->d_desc_last) { ctx->set_error("desc == NULL: no extraction has completed on this context yet"); return ASD_ERR_INVALID; }
   if (!desc && n != ctx->last_n) { ctx->set_error("desc == NULL adopts the last extract (%d keypoints), got n=%d", ctx->last_n, n); return ASD_ERR_INVALID; }
   (void)hipSetDevice(ctx->cfg.device);
   const size_t cap = ctx->cfg.max_patches;
@@ -398,7 +399,7 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   hipStream_t st = ctx->stream;
   if (n > 0) {
     if (desc) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, desc, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, st));
-    else ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, ctx->d_desc_last, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   F->n = n;
   F->min_x = min_x; F->max_x = max_x; F->min_y = min_y; F->max_y = max_y;

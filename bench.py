@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 KF_INTERVAL = 15
+LOOKAHEAD = 2          # frames of read-ahead for the pipelined extractor (asd_extract_submit queue)
 N_FRAMES = 30          # distinct synthetic frames kept resident in HBM, cycled
 BOUNDS = (0.0, 1241.0, 0.0, 376.0)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense f32 matrix)
@@ -123,16 +124,17 @@ class Workload:
         self.frames = [synth.scene_frame(t + 3 * seed_offset) for t in range(N_FRAMES)]
 
 
-def track_step(be, wl, image_handle, last, do_ba, next_handle=None):
+def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
     """One frame through extract -> M1 -> P1 -> frustum/M2 -> P1 (-> LocalBA).  `be` is a backend
     (HIP or CPU restatement) exposing the same operations.  ExtractDesc of the NEXT frame does not depend
-    on this frame's tracking, so the HIP backend starts it (asd_extract_submit, second stream) as soon as
-    this frame's descriptors are adopted; every frame still goes through every stage."""
+    on this frame's tracking, so the HIP backend reads ahead (asd_extract_submit, own streams + worker thread: the
+    replay knows its next images, Examples/Monocular/kitti.cc:116-155) as soon as this frame's descriptors are
+    adopted; every frame still goes through every stage."""
     kps, desc = be.extract(image_handle)
     cur = be.make_frame(kps, desc)
     kps, desc = kps.copy(), desc.copy()
-    if next_handle is not None:
-        be.prefetch(next_handle)
+    if next_handles:
+        be.prefetch(next_handles)
     stats = {"n_kp": len(kps)}
     if last is not None:
         lk, ld, lframe = last
@@ -182,25 +184,35 @@ class HipBackend:
             self.hip.h2d(p, f)
             self.d_frames.append(p)
         self.slot = 0
-        self.pending = None
+        self.pending = []          # handles of submitted, not yet waited extractions (in order)
         self.pipeline = pipeline
 
     def image(self, t):
         return self.d_frames[t % len(self.d_frames)]
 
     def extract(self, h):
-        if self.pending is not None and self.pending.value == h.value:
-            self.pending = None
+        if self.pending and self.pending[0].value == h.value:
+            self.pending.pop(0)
             return self.hip.extract_wait()
-        if self.pending is not None:      # a different frame was prefetched: drain it first
-            self.hip.extract_wait()
-            self.pending = None
+        self.drain()                      # something else was read ahead: drop it
         return self.hip.extract_device(h, 1241, 376, 1241)
 
-    def prefetch(self, h):
-        if self.pipeline:
+    def drain(self):
+        while self.pending:
+            self.hip.extract_wait()
+            self.pending.pop(0)
+
+    def prefetch(self, handles):
+        """keep the extractions of the next frames queued (read-ahead depth = len(handles) <= LOOKAHEAD)"""
+        if not self.pipeline:
+            return
+        have = [p.value for p in self.pending]
+        if have != [h.value for h in handles[:len(have)]]:
+            self.drain()
+            have = []
+        for h in handles[len(have):]:
             self.hip.extract_submit(h, 1241, 376, 1241, device_resident=True)
-            self.pending = h
+            self.pending.append(h)
 
     def make_frame(self, kps, desc):
         self.slot ^= 1
@@ -229,9 +241,7 @@ class HipBackend:
         return self.hip.local_ba(prob)
 
     def close(self):
-        if self.pending is not None:
-            self.hip.extract_wait()
-            self.pending = None
+        self.drain()
         self.hip.close()
 
 
@@ -286,13 +296,14 @@ class CpuBackend:
 
 
 def run_steps(be, wl, t0, n, last, prefetch_beyond=False):
-    """n frames t0 .. t0+n-1.  The extraction of frame t+1 is started during frame t; the frame after the
-    last one is only prefetched when the caller will consume it (prefetch_beyond)."""
+    """n frames t0 .. t0+n-1.  The extractions of frames t+1 .. t+LOOKAHEAD are queued during frame t; frames after
+    the last one are only read ahead when the replay continues (prefetch_beyond) -- the timed region does, so that
+    it starts and ends in the same pipeline state and contains n frames' worth of every stage."""
     stats = {}
     for i in range(n):
         t = t0 + i
-        nxt = be.image(t + 1) if (i + 1 < n or prefetch_beyond) else None
-        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1), next_handle=nxt)
+        nxt = [be.image(t + k) for k in range(1, LOOKAHEAD + 1) if (i + k < n or prefetch_beyond)]
+        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1), next_handles=nxt)
     return last, stats
 
 
@@ -338,7 +349,9 @@ def main():
     be.hip.profile_enable(True)
     be.hip.sync(); device_sync(); dist.barrier()
     t0 = time.perf_counter()
-    last, stats = run_steps(be, wl, args.warmup, args.steps, last)  # EXACTLY K timed steps
+    # EXACTLY K timed steps; the replay keeps reading ahead across both ends of the timed region (steady state);
+    # the device-wide synchronize below also waits for whatever read-ahead work is in flight
+    last, stats = run_steps(be, wl, args.warmup, args.steps, last, prefetch_beyond=True)
     be.hip.sync(); device_sync(); dist.barrier()
     dt = time.perf_counter() - t0
     tmax = dist.max(dt)
@@ -372,7 +385,7 @@ def main():
                                    "(24+12 KF, 6000 MP, ~29k edges) every 15 frames",
                        "keypoints": int(stats.get("n_kp", 0)), "kf_interval": KF_INTERVAL,
                        "parallelism": f"replicas x{world} (independent sequences, no collective)",
-                       "pipeline": "ExtractDesc(t+1) overlapped with tracking(t) on a second HIP stream" if not args.no_pipeline else "none (sequential)"},
+                       "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t)" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

@@ -114,11 +114,15 @@ int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int3
                        int32_t n_features_override, asd_keypoint* kps, float* desc, int32_t* n_out);
 
 /* Pipelined extraction.  ExtractDesc of frame t+1 does not depend on the tracking of frame t, and a
- * replay reads its images from disk (Examples/Monocular/kitti.cc:116-155), so the two can overlap:
- * asd_extract_submit starts the extraction on a second HIP stream driven by a worker thread and
- * returns at once; asd_extract_wait blocks until it has finished and hands back the same results
- * asd_extract would.  One submission in flight per ctx; `image` must stay valid until the wait;
- * do not call asd_extract / asd_describe between submit and wait (they share the ASDNet buffers). */
+ * replay reads its images from disk (Examples/Monocular/kitti.cc:116-155), so they can overlap:
+ * asd_extract_submit queues an extraction for a worker thread with its own HIP streams and returns at
+ * once; asd_extract_wait blocks until the OLDEST outstanding submission has finished and hands back the
+ * same results asd_extract would.  Up to ASD_EXTRACT_QUEUE submissions may be outstanding; the worker runs
+ * the front half (pyramid .. patch gather) of the next queued frame underneath the ASDNet pass of the
+ * previous one.  `image` must stay valid until its wait; do not call asd_extract / asd_describe while
+ * submissions are outstanding (they share the ASDNet and front-end buffers).  The device-resident
+ * descriptors of a waited frame (asd_frame_set with desc == NULL) stay valid for two further submissions. */
+#define ASD_EXTRACT_QUEUE 3
 int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width,
                        int32_t height, int32_t stride, int32_t n_features_override);
 int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out);

@@ -202,31 +202,75 @@ def test_extract_deterministic(hip, synth):
 
 @pytest.mark.gpu
 def test_pipelined_extract_equals_sync(hip, synth):
-    """asd_extract_submit / asd_extract_wait (second stream + worker thread) return exactly what asd_extract does,
-    also while the main stream is busy with other work."""
-    imgs = [synth.scene_frame(t) for t in (5, 6)]
+    """asd_extract_submit / asd_extract_wait (own streams + worker thread, front half of the next frame under the
+    ASDNet pass of the previous one) return exactly what asd_extract does, in submission order, also while the
+    main stream is busy with other work and with the queue full."""
+    frames = (5, 6, 7, 8, 9)
+    imgs = [synth.scene_frame(t) for t in frames]
     ref = [hip.extract(im) for im in imgs]
     d = []
     for im in imgs:
         p = hip.device_alloc(im.nbytes)
         hip.h2d(p, im)
         d.append(p)
+    # depth 1: submit / wait alternate
     for k in range(2):
         hip.extract_submit(d[k], 1241, 376, 1241, device_resident=True)
-        # unrelated work on the main stream while the extraction runs
-        a = synth.unit_descriptors(300, seed=k)
+        a = synth.unit_descriptors(300, seed=k)       # unrelated work on the main stream while the extraction runs
         M = hip.dist_matrix(a, a)
         assert (np.diag(M) == 0).all()
         kps, desc = hip.extract_wait()
         np.testing.assert_array_equal(kps, ref[k][0])
         np.testing.assert_array_equal(desc, ref[k][1])
-    # protocol errors are reported, not crashed on
-    with pytest.raises(Exception):
+    # full queue, refilled as results are taken (the replay's steady state), frames of different content
+    q = 3
+    order = [0, 1, 2, 3, 4, 2, 0, 4, 1, 3, 3, 0]
+    for k in order[:q]:
+        hip.extract_submit(d[k], 1241, 376, 1241, device_resident=True)
+    with pytest.raises(Exception):                    # a 4th outstanding submission is refused, nothing is lost
+        hip.extract_submit(d[0], 1241, 376, 1241, device_resident=True)
+    for i, k in enumerate(order):
+        kps, desc = hip.extract_wait()
+        np.testing.assert_array_equal(kps, ref[k][0], err_msg=f"submission {i} (frame {frames[k]})")
+        np.testing.assert_array_equal(desc, ref[k][1], err_msg=f"submission {i} (frame {frames[k]})")
+        # the waited frame's descriptors are adoptable on the device while later frames are still in flight
+        hip.frame_set(2, kps, None, (0.0, 1241.0, 0.0, 376.0))
+        if i + q < len(order):
+            hip.extract_submit(d[order[i + q]], 1241, 376, 1241, device_resident=True)
+    with pytest.raises(Exception):                    # nothing outstanding any more
         hip.extract_wait()
-    hip.extract_submit(d[0], 1241, 376, 1241, device_resident=True)
-    with pytest.raises(Exception):
-        hip.extract_submit(d[1], 1241, 376, 1241, device_resident=True)
-    hip.extract_wait()
+    # the synchronous path still works afterwards and agrees
+    kps, desc = hip.extract(imgs[1])
+    np.testing.assert_array_equal(kps, ref[1][0])
+    np.testing.assert_array_equal(desc, ref[1][1])
+    for p in d:
+        hip.device_free(p)
+
+
+@pytest.mark.gpu
+def test_pipelined_extract_device_descriptors_adoptable(hip, oracle, synth):
+    """asd_frame_set(desc=NULL) after asd_extract_wait adopts THAT frame's device descriptors even though the next
+    frames' ASDNet passes are already running: checked through a matcher that reads the slot's descriptors"""
+    imgs = [synth.scene_frame(t) for t in (11, 12, 13)]
+    ref = [hip.extract(im) for im in imgs]
+    d = []
+    for im in imgs:
+        p = hip.device_alloc(im.nbytes)
+        hip.h2d(p, im)
+        d.append(p)
+    for p in d:
+        hip.extract_submit(p, 1241, 376, 1241, device_resident=True)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    for k in range(3):
+        kps, desc = hip.extract_wait()
+        hip.frame_set(3, kps, None, bounds)            # device-resident descriptors of frame k
+        hip.frame_set(4, ref[k][0], ref[k][1], bounds)  # the same frame uploaded from the host
+        # SearchForInitialization-style self match: identical descriptors on both sides -> identical results
+        prev = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+        m_dev, n_dev, _ = hip.match_init(3, 4, prev.copy(), 30, 0.9, True)
+        m_host, n_host, _ = hip.match_init(4, 4, prev.copy(), 30, 0.9, True)
+        np.testing.assert_array_equal(m_dev, m_host)
+        assert n_dev == n_host and n_dev > 100
     for p in d:
         hip.device_free(p)
 
