@@ -24,6 +24,7 @@
 //   k_ba_backsub    landmark-parallel xl = Dinv (bl - B^T xp), point update, gain-ratio partials
 // The Levenberg accept/reject logic (scalars only) runs on the host between launches.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -530,15 +531,25 @@ __global__ __launch_bounds__(256) void k_ba_point_dinv(BaDev d, double lambda) {
   double dbv[3];
   for (int r = 0; r < 3; ++r) dbv[r] = I[r * 3] * bl[0] + I[r * 3 + 1] * bl[1] + I[r * 3 + 2] * bl[2];
   for (int r = 0; r < 3; ++r) d.db[(size_t)h * 3 + r] = dbv[r];
-  for (int k = d.pt_start[h]; k < d.pt_start[h + 1]; ++k) {
-    if (d.pose_h[d.e_ps[d.act[k]]] < 0) continue;
-    const double* B = d.Bk + (size_t)k * 18;
-    double* Y = d.Yk + (size_t)k * 18;
-    double* cc = d.ck + (size_t)k * 6;
-    for (int r = 0; r < 6; ++r) {
-      for (int q = 0; q < 3; ++q) Y[r * 3 + q] = B[r * 3] * I[q] + B[r * 3 + 1] * I[3 + q] + B[r * 3 + 2] * I[6 + q];
-      cc[r] = B[r * 3] * dbv[0] + B[r * 3 + 1] * dbv[1] + B[r * 3 + 2] * dbv[2];
-    }
+}
+
+// Y_k = B_k Dinv_l and c_k = B_k (Dinv_l bl) for every active edge to a free pose: one lane per edge (the per-landmark
+// loop this replaces ran on 24 workgroups only and read its edges with an 18-double stride between lanes)
+__global__ __launch_bounds__(256) void k_ba_edge_y(BaDev d) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= d.Ea) return;
+  const int e = d.act[k];
+  if (d.pose_h[d.e_ps[e]] < 0) return;
+  const int h = d.pt_h[d.e_pt[e]];
+  const double* Di = d.Dinv + (size_t)h * 6;
+  const double I[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
+  const double dbv[3] = {d.db[(size_t)h * 3], d.db[(size_t)h * 3 + 1], d.db[(size_t)h * 3 + 2]};
+  const double* B = d.Bk + (size_t)k * 18;
+  double* Y = d.Yk + (size_t)k * 18;
+  double* cc = d.ck + (size_t)k * 6;
+  for (int r = 0; r < 6; ++r) {
+    for (int q = 0; q < 3; ++q) Y[r * 3 + q] = B[r * 3] * I[q] + B[r * 3 + 1] * I[3 + q] + B[r * 3 + 2] * I[6 + q];
+    cc[r] = B[r * 3] * dbv[0] + B[r * 3 + 1] * dbv[1] + B[r * 3 + 2] * dbv[2];
   }
 }
 
@@ -594,46 +605,75 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb, doubl
 
 // Dense SPD solve with the matrix resident in LDS: lower triangle packed by 6x6 blocks
 // (block (I,J), J <= I at ((I(I+1)/2 + J) * 36), up to 32 pose blocks = 152 KB).  Right-looking
-// block Cholesky, then block forward / backward substitution.  One workgroup, 1024 threads.
-__global__ __launch_bounds__(1024) void k_ba_chol_lds(const double* __restrict__ A, const double* __restrict__ bs,
-                                                      double* __restrict__ x, int n, int* status) {
+// block Cholesky with the right-hand side carried along as one more block row (so the forward
+// substitution costs no extra barriers), then block backward substitution.  One workgroup.
+// The chain of barriers and the serial 6x6 factorisations bound this kernel, not its 1 MFLOP: divisions are
+// replaced by one reciprocal per pivot and the triangular block index comes from a table, not from sqrt().
+constexpr int kCholThreads = 1024;
+__global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __restrict__ A, const double* __restrict__ bs,
+                                                              double* __restrict__ x, int n, int* status) {
   // all LDS in the dynamic region (a static in front of it would shift its base off 16-B alignment)
   extern __shared__ __attribute__((aligned(16))) double L[];
   const int t = threadIdx.x, nt = blockDim.x, nb = n / 6;
   const int nblk = nb * (nb + 1) / 2;
-  double* xs = L + (size_t)nblk * 36;
-  int& ok = *reinterpret_cast<int*>(xs + 192);
+  double* xs = L + (size_t)nblk * 36;   // [192] right-hand side / solution
+  double* invd = xs + 192;              // [192] reciprocals of the Cholesky pivots
+  int& ok = *reinterpret_cast<int*>(invd + 192);
+  short2* tri = reinterpret_cast<short2*>(invd + 194);  // [nblk] packed lower-triangle index -> (I, J)
 #define LB(I, J) (L + ((size_t)((I) * ((I) + 1) / 2 + (J))) * 36)
-  for (int idx = t; idx < nblk * 36; idx += nt) {
-    const int blk = idx / 36, e = idx % 36;
-    int I = (int)((sqrt(8.0 * blk + 1.0) - 1.0) * 0.5);
-    while ((I + 1) * (I + 2) / 2 <= blk) ++I;
-    while (I * (I + 1) / 2 > blk) --I;
-    const int J = blk - I * (I + 1) / 2;
-    L[idx] = A[(size_t)(6 * I + e / 6) * n + 6 * J + e % 6];
-  }
-  for (int i = t; i < n; i += nt) xs[i] = bs[i];
+  for (int I = t; I < nb; I += nt)
+    for (int J = 0; J <= I; ++J) tri[I * (I + 1) / 2 + J] = make_short2((short)I, (short)J);
   if (t == 0) ok = 1;
   __syncthreads();
+  for (int idx = t; idx < nblk * 36; idx += nt) {
+    const int blk = idx / 36, e = idx % 36;
+    const short2 ij = tri[blk];
+    L[idx] = A[(size_t)(6 * ij.x + e / 6) * n + 6 * ij.y + e % 6];
+  }
+  for (int i = t; i < n; i += nt) xs[i] = bs[i];
+  __syncthreads();
   for (int jb = 0; jb < nb; ++jb) {
-    if (t == 0) {  // factor the diagonal block in place
-      double* a = LB(jb, jb);
+    if (t == 0) {  // factor the diagonal block, forward-substitute its slice of the right-hand side: in registers
+      double* ap = LB(jb, jb);
+      double a[36], y[6], iv[6];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) a[q] = ap[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) y[q] = xs[6 * jb + q];
+      bool good = true;
+#pragma unroll
       for (int j = 0; j < 6; ++j) {
         double dgl = a[j * 6 + j];
+#pragma unroll
         for (int k = 0; k < j; ++k) dgl -= a[j * 6 + k] * a[j * 6 + k];
-        if (!(dgl > 0)) { ok = 0; dgl = 1.0; }
+        if (!(dgl > 0)) { good = false; dgl = 1.0; }
         dgl = sqrt(dgl);
+        const double inv = 1.0 / dgl;
         a[j * 6 + j] = dgl;
+        iv[j] = inv;
+#pragma unroll
         for (int i = j + 1; i < 6; ++i) {
           double s = a[i * 6 + j];
+#pragma unroll
           for (int k = 0; k < j; ++k) s -= a[i * 6 + k] * a[j * 6 + k];
-          a[i * 6 + j] = s / dgl;
+          a[i * 6 + j] = s * inv;
         }
+#pragma unroll
         for (int c = j + 1; c < 6; ++c) a[j * 6 + c] = 0.0;
+        double s = y[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= a[j * 6 + k] * y[k];
+        y[j] = s * inv;
       }
+#pragma unroll
+      for (int q = 0; q < 36; ++q) ap[q] = a[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { xs[6 * jb + q] = y[q]; invd[6 * jb + q] = iv[q]; }
+      if (!good) ok = 0;
     }
     __syncthreads();
     const double* Ljj = LB(jb, jb);
+    const double* iv = invd + 6 * jb;
     // panel: every row below solves against Ljj^T
     for (int row = t; row < (nb - jb - 1) * 6; row += nt) {
       const int I = jb + 1 + row / 6, r = row % 6;
@@ -643,57 +683,52 @@ __global__ __launch_bounds__(1024) void k_ba_chol_lds(const double* __restrict__
       for (int c = 0; c < 6; ++c) {
         double s = v[c];
         for (int k = 0; k < c; ++k) s -= v[k] * Ljj[c * 6 + k];
-        v[c] = s / Ljj[c * 6 + c];
+        v[c] = s * iv[c];
       }
       for (int c = 0; c < 6; ++c) a[c] = v[c];
     }
     __syncthreads();
-    // trailing update: block (I,K), I >= K > jb
+    // trailing update: block (I,K), I >= K > jb, and the right-hand side rows below
     const int m = nb - jb - 1, mblk = m * (m + 1) / 2;
-    for (int idx = t; idx < mblk * 36; idx += nt) {
-      const int bq = idx / 36, e = idx % 36;
-      int Ii = (int)((sqrt(8.0 * bq + 1.0) - 1.0) * 0.5);
-      while ((Ii + 1) * (Ii + 2) / 2 <= bq) ++Ii;
-      while (Ii * (Ii + 1) / 2 > bq) --Ii;
-      const int Ki = bq - Ii * (Ii + 1) / 2;
-      const int I = jb + 1 + Ii, K = jb + 1 + Ki, r = e / 6, c = e % 6;
-      const double* li = LB(I, jb) + r * 6;
-      const double* lk = LB(K, jb) + c * 6;
-      double s = 0.0;
-      for (int k = 0; k < 6; ++k) s += li[k] * lk[k];
-      LB(I, K)[e] -= s;
-    }
-    __syncthreads();
-  }
-  // forward substitution
-  for (int jb = 0; jb < nb; ++jb) {
-    if (t == 0) {
-      const double* a = LB(jb, jb);
-      for (int r = 0; r < 6; ++r) {
-        double s = xs[6 * jb + r];
-        for (int k = 0; k < r; ++k) s -= a[r * 6 + k] * xs[6 * jb + k];
-        xs[6 * jb + r] = s / a[r * 6 + r];
+    for (int idx = t; idx < mblk * 36 + m * 6; idx += nt) {
+      if (idx < mblk * 36) {
+        const int bq = idx / 36, e = idx % 36;
+        const short2 ik = tri[bq];
+        const int I = jb + 1 + ik.x, K = jb + 1 + ik.y, r = e / 6, c = e % 6;
+        const double* li = LB(I, jb) + r * 6;
+        const double* lk = LB(K, jb) + c * 6;
+        double s = 0.0;
+        for (int k = 0; k < 6; ++k) s += li[k] * lk[k];
+        LB(I, K)[e] -= s;
+      } else {
+        const int row = idx - mblk * 36;
+        const int I = jb + 1 + row / 6, r = row % 6;
+        const double* a = LB(I, jb) + r * 6;
+        double s = 0.0;
+        for (int c = 0; c < 6; ++c) s += a[c] * xs[6 * jb + c];
+        xs[6 * I + r] -= s;
       }
-    }
-    __syncthreads();
-    for (int row = t; row < (nb - jb - 1) * 6; row += nt) {
-      const int I = jb + 1 + row / 6, r = row % 6;
-      const double* a = LB(I, jb) + r * 6;
-      double s = 0.0;
-      for (int c = 0; c < 6; ++c) s += a[c] * xs[6 * jb + c];
-      xs[6 * I + r] -= s;
     }
     __syncthreads();
   }
   // backward substitution (L^T)
   for (int jb = nb - 1; jb >= 0; --jb) {
     if (t == 0) {
-      const double* a = LB(jb, jb);
+      const double* ap = LB(jb, jb);
+      double a[36], y[6], iv[6];
+#pragma unroll
+      for (int q = 0; q < 36; ++q) a[q] = ap[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { y[q] = xs[6 * jb + q]; iv[q] = invd[6 * jb + q]; }
+#pragma unroll
       for (int r = 5; r >= 0; --r) {
-        double s = xs[6 * jb + r];
-        for (int k = r + 1; k < 6; ++k) s -= a[k * 6 + r] * xs[6 * jb + k];
-        xs[6 * jb + r] = s / a[r * 6 + r];
+        double s = y[r];
+#pragma unroll
+        for (int k = r + 1; k < 6; ++k) s -= a[k * 6 + r] * y[k];
+        y[r] = s * iv[r];
       }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) xs[6 * jb + q] = y[q];
     }
     __syncthreads();
     for (int row = t; row < jb * 6; row += nt) {
@@ -1066,11 +1101,15 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
   d.partial = s->partial.as<double>();
 
   std::vector<uint8_t> level(E, 0);
-  std::vector<int> act, pose_h(P), pt_h(L), pose_of_h, pt_of_h, pt_start, ps_start, ps_edges, blk_i, blk_j, pair_start;
+  std::vector<int> act, pose_h(P), pt_h(L), pose_of_h, pt_of_h, pt_start, ps_start, ps_edges, blk_i, blk_j, pair_start, ph_of_k, cursor,
+      row_off;
   std::vector<int2> pairs;
 
   // one g2o initializeOptimization(level 0) + optimize(iterations) round
+  const bool timing = getenv("ASD_TIMING") != nullptr;
   auto run_round = [&](int iterations, bool robust, double* chi_out, int* iters_out) -> int {
+    const auto t_round = std::chrono::steady_clock::now();
+    int n_trials = 0;
     // ---- active structure (sparse_optimizer.cpp:206-267, 166-190), on the host
     std::vector<uint8_t> pa(P, 0), la(L, 0);
     for (int e = 0; e < E; ++e)
@@ -1085,53 +1124,62 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
     for (int h = 0; h < nLa; ++h) pt_start[h + 1] += pt_start[h];
     const int Ea = pt_start[nLa];
     act.assign(Ea, 0);
+    ph_of_k.assign(std::max(Ea, 1), -1);  // pose h-index of the k-th active edge (-1 = fixed pose)
     {
-      std::vector<int> cur(pt_start.begin(), pt_start.end() - 1);
-      for (int e = 0; e < E; ++e) if (!level[e]) act[cur[pt_h[pr->e_point[e]]]++] = e;
-      for (int h = 0; h < nLa; ++h)
-        std::stable_sort(act.begin() + pt_start[h], act.begin() + pt_start[h + 1],
-                         [&](int a, int b) { return pose_h[pr->e_pose[a]] < pose_h[pr->e_pose[b]]; });
+      cursor.assign(pt_start.begin(), pt_start.end() - 1);
+      for (int e = 0; e < E; ++e) if (!level[e]) act[cursor[pt_h[pr->e_point[e]]]++] = e;
+      for (int h = 0; h < nLa; ++h) {  // stable insertion sort: a landmark has a handful of observations
+        const int s0 = pt_start[h], s1 = pt_start[h + 1];
+        for (int a = s0; a < s1; ++a) ph_of_k[a] = pose_h[pr->e_pose[act[a]]];
+        for (int a = s0 + 1; a < s1; ++a) {
+          const int ea = act[a], pa_ = ph_of_k[a];
+          int b = a - 1;
+          while (b >= s0 && ph_of_k[b] > pa_) { act[b + 1] = act[b]; ph_of_k[b + 1] = ph_of_k[b]; --b; }
+          act[b + 1] = ea; ph_of_k[b + 1] = pa_;
+        }
+      }
     }
     // per free pose: its edges (k indices) in k order
     ps_start.assign(nPf + 1, 0);
-    for (int k = 0; k < Ea; ++k) { const int ph = pose_h[pr->e_pose[act[k]]]; if (ph >= 0) ++ps_start[ph + 1]; }
+    for (int k = 0; k < Ea; ++k) if (ph_of_k[k] >= 0) ++ps_start[ph_of_k[k] + 1];
     for (int h = 0; h < nPf; ++h) ps_start[h + 1] += ps_start[h];
     ps_edges.assign(std::max(ps_start[nPf], 1), 0);
     {
-      std::vector<int> cur(ps_start.begin(), ps_start.end() - 1);
-      for (int k = 0; k < Ea; ++k) { const int ph = pose_h[pr->e_pose[act[k]]]; if (ph >= 0) ps_edges[cur[ph]++] = k; }
+      cursor.assign(ps_start.begin(), ps_start.end() - 1);
+      for (int k = 0; k < Ea; ++k) if (ph_of_k[k] >= 0) ps_edges[cursor[ph_of_k[k]]++] = k;
     }
-    // Schur pair lists per upper block (bi <= bj)
+    // Schur pair lists per upper block (bi <= bj), blocks numbered row-major over the upper triangle.  Every upper
+    // block gets a workgroup, also those no landmark connects: the in-place Cholesky leaves fill-in in A, so blocks
+    // without pairs must be rewritten (to zero) on every trial.
     const int nblk_all = nPf * (nPf + 1) / 2;
-    auto blk_id = [&](int i, int j) { return i * nPf - i * (i - 1) / 2 + (j - i); };
-    std::vector<int> cnt(nblk_all + 1, 0);
-    for (int h = 0; h < nLa; ++h)
-      for (int a = pt_start[h]; a < pt_start[h + 1]; ++a) {
-        const int pi = pose_h[pr->e_pose[act[a]]];
-        if (pi < 0) continue;
-        for (int b = a; b < pt_start[h + 1]; ++b) ++cnt[blk_id(pi, pose_h[pr->e_pose[act[b]]]) + 1];
+    row_off.assign(std::max(nPf, 1), 0);
+    for (int i = 0; i < nPf; ++i) row_off[i] = i * nPf - i * (i - 1) / 2 - i;  // block id = row_off[i] + j
+    pair_start.assign(nblk_all + 1, 0);
+    for (int h = 0; h < nLa; ++h) {
+      const int s1 = pt_start[h + 1];
+      int a = pt_start[h];
+      while (a < s1 && ph_of_k[a] < 0) ++a;  // fixed poses sort first
+      for (; a < s1; ++a) {
+        const int ro = row_off[ph_of_k[a]];
+        for (int b = a; b < s1; ++b) ++pair_start[ro + ph_of_k[b] + 1];
       }
-    blk_i.clear(); blk_j.clear(); pair_start.assign(1, 0);
-    std::vector<int> blk_slot(nblk_all, -1);
-    for (int i = 0; i < nPf; ++i)
-      for (int j = i; j < nPf; ++j) {
-        const int id = blk_id(i, j);
-        // every upper block gets a workgroup, also those no landmark connects: the in-place Cholesky
-        // leaves fill-in in A, so blocks without pairs must be rewritten (to zero) on every trial
-        blk_slot[id] = (int)blk_i.size();
-        blk_i.push_back(i); blk_j.push_back(j);
-        pair_start.push_back(pair_start.back() + cnt[id + 1]);
-      }
-    pairs.assign(std::max(pair_start.back(), 1), make_int2(0, 0));
+    }
+    for (int q = 0; q < nblk_all; ++q) pair_start[q + 1] += pair_start[q];
+    blk_i.resize(nblk_all); blk_j.resize(nblk_all);
+    for (int i = 0, q = 0; i < nPf; ++i)
+      for (int j = i; j < nPf; ++j, ++q) { blk_i[q] = i; blk_j[q] = j; }
+    pairs.resize(std::max(pair_start[nblk_all], 1));
     {
-      std::vector<int> cur(pair_start.begin(), pair_start.end() - 1);
-      for (int h = 0; h < nLa; ++h)
-        for (int a = pt_start[h]; a < pt_start[h + 1]; ++a) {
-          const int pi = pose_h[pr->e_pose[act[a]]];
-          if (pi < 0) continue;
-          for (int b = a; b < pt_start[h + 1]; ++b)
-            pairs[cur[blk_slot[blk_id(pi, pose_h[pr->e_pose[act[b]]])]]++] = make_int2(a, b);
+      cursor.assign(pair_start.begin(), pair_start.end() - 1);
+      for (int h = 0; h < nLa; ++h) {
+        const int s1 = pt_start[h + 1];
+        int a = pt_start[h];
+        while (a < s1 && ph_of_k[a] < 0) ++a;
+        for (; a < s1; ++a) {
+          const int ro = row_off[ph_of_k[a]];
+          for (int b = a; b < s1; ++b) pairs[cursor[ro + ph_of_k[b]]++] = make_int2(a, b);
         }
+      }
     }
     const int nblk = (int)blk_i.size();
     int r2;
@@ -1148,6 +1196,7 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
     UP(pair_start, pair_start); UP(pairs, pairs);
 #undef UP
     d.Ea = Ea; d.nPf = nPf; d.nLa = nLa;
+    const auto t_prep = std::chrono::steady_clock::now();
     SchurBlocks sb{s->blk_i.as<int>(), s->blk_j.as<int>(), s->pair_start.as<int>(), s->pairs.as<int2>()};
     *iters_out = 0;
     *chi_out = 0;
@@ -1169,7 +1218,10 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
     int nBad = 0, done = 0;
     double currentChi = 0;
     for (int it = 0; it < iterations; ++it) {
-      if ((r2 = active_chi2(&currentChi)) != ASD_OK) return r2;
+      // computeActiveErrors + activeRobustChi2 (levenberg.cpp:70-76).  After the first iteration the loop is only
+      // re-entered behind an ACCEPTED trial, whose k_ba_error pass already left the edge errors and their robust
+      // sum at exactly this estimate (same kernel, same state, same reduction order): reuse it.
+      if (it == 0 && (r2 = active_chi2(&currentChi)) != ASD_OK) return r2;
       const double iniChi = currentChi;
       // buildSystem
       if (it == 0) ASD_HIP_CHECK(ctx, hipMemsetAsync(s->misc.p, 0, 64, st));
@@ -1192,15 +1244,17 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
         // setLambda + solve (Schur) + update + computeActiveErrors, all enqueued back to back
         hipLaunchKernelGGL(k_ba_point_dinv, dim3(gL), dim3(256), 0, st, d, lambda);
         if (nPf > 0) {
+          hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
           hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, st, d, sb, lambda);
           if (nPf <= 32) {
-            const size_t lds = (size_t)(nPf * (nPf + 1) / 2) * 36 * sizeof(double) + 192 * sizeof(double) + 16;
+            const size_t nbk = (size_t)(nPf * (nPf + 1) / 2);
+            const size_t lds = nbk * 36 * sizeof(double) + (2 * 192 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
             static bool chol_attr = false;
             if (!chol_attr) {
               ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
               chol_attr = true;
             }
-            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(1024), lds, st, d.A, d.bs, d.x, n, d.status);
+            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(kCholThreads), lds, st, d.A, d.bs, d.x, n, d.status);
           } else {
             hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, d.A, d.bs, d.x, n, d.status);
           }
@@ -1234,6 +1288,7 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
           hipLaunchKernelGGL(k_ba_restore, dim3(std::max(gL, gP)), dim3(256), 0, st, d);  // _optimizer->pop()
         }
         qmax++;
+        ++n_trials;
       } while (rho < 0 && qmax < 10);
       ++done;
       if (qmax == 10 || rho == 0) break;
@@ -1248,6 +1303,12 @@ int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
     double sum = 0;
     for (int i = 0; i < gE; ++i) sum += s->h_partial[i];
     *chi_out = sum;
+    if (timing) {
+      const auto t_end = std::chrono::steady_clock::now();
+      fprintf(stderr, "[ba round] structure %.0f us (Ea=%d nPf=%d nLa=%d pairs=%zu), %d iterations / %d trials in %.0f us\n",
+              std::chrono::duration<double, std::micro>(t_prep - t_round).count(), Ea, nPf, nLa, pairs.size(), done, n_trials,
+              std::chrono::duration<double, std::micro>(t_end - t_prep).count());
+    }
     return ASD_OK;
   };
 

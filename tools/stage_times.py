@@ -14,12 +14,12 @@ def wrap(name):
     def g(*a, **k):
         t = time.perf_counter(); r = f(*a, **k); acc[name] += time.perf_counter() - t; cnt[name] += 1; return r
     setattr(be, name, g)
-for n in ('extract', 'make_frame', 'match_frame', 'pose_opt', 'frustum', 'match_points', 'local_ba'):
+for n in ('extract', 'prefetch', 'set_map_descriptors', 'make_frame', 'match_frame', 'pose_opt', 'frustum', 'match_points', 'local_ba'):
     wrap(n)
 last, _ = bench.run_steps(be, wl, 0, 15, None, prefetch_beyond=True)
 acc.clear(); cnt.clear()
 t0 = time.perf_counter()
-last, st = bench.run_steps(be, wl, 15, 30, last)
+last, st = bench.run_steps(be, wl, 15, 30, last, prefetch_beyond=True)
 tot = time.perf_counter() - t0
 print('total ms/frame', 1e3 * tot / 30, 'host cores', bench.host_cores(), 'cpu_count', os.cpu_count())
 for k in acc: print(f'{k:14s} {1e3*acc[k]/30:8.3f} ms/frame  ({cnt[k]} calls, {1e3*acc[k]/cnt[k]:.3f} ms/call)')
