@@ -52,11 +52,38 @@ __device__ inline void rs_step(double (&v)[2 * M], double (&o)[M], int off, bool
     o[k] = keep + __shfl_xor(send, off);
   }
 }
+// The two widest steps (partner 32 and 16 lanes away) are exactly what gfx950's v_permlane32_swap / v_permlane16_swap
+// do: swap the upper half (odd 16-lane rows) of one register with the lower half (even rows) of another.  After the
+// swap both registers hold "my value + partner's value" operands lane by lane, so a step is 2 swaps + 1 add per double
+// instead of 4 selects + 2 ds_bpermute + 1 add, and the sums are bit-identical (a + b == b + a).
+template <int M, int OFF>
+__device__ inline void rs_step_swap(double (&v)[2 * M], double (&o)[M]) {
+  static_assert(OFF == 32 || OFF == 16, "swap steps exist for 32 and 16 lanes");
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    const unsigned alo = (unsigned)__double2loint(v[k]), ahi = (unsigned)__double2hiint(v[k]);
+    const unsigned blo = (unsigned)__double2loint(v[k + M]), bhi = (unsigned)__double2hiint(v[k + M]);
+    double x, y;
+    if constexpr (OFF == 32) {
+      const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+      const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+      x = __hiloint2double((int)hi[0], (int)lo[0]);
+      y = __hiloint2double((int)hi[1], (int)lo[1]);
+    } else {
+      const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+      const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+      x = __hiloint2double((int)hi[0], (int)lo[0]);
+      y = __hiloint2double((int)hi[1], (int)lo[1]);
+    }
+    o[k] = x + y;
+  }
+}
+
 __device__ inline double wave_reduce_scatter32(double (&v)[32]) {
   const int lane = threadIdx.x & 63;
   double a[16], b[8], c[4], d[2], e[1];
-  rs_step<16>(v, a, 32, (lane & 32) != 0);
-  rs_step<8>(a, b, 16, (lane & 16) != 0);
+  rs_step_swap<16, 32>(v, a);
+  rs_step_swap<8, 16>(a, b);
   rs_step<4>(b, c, 8, (lane & 8) != 0);
   rs_step<2>(c, d, 4, (lane & 4) != 0);
   rs_step<1>(d, e, 2, (lane & 2) != 0);
@@ -66,8 +93,8 @@ __device__ inline double wave_reduce_scatter32(double (&v)[32]) {
 __device__ inline double wave_reduce_scatter64(double (&v)[64]) {  // lane l ends with the total of value l
   const int lane = threadIdx.x & 63;
   double z[32], a[16], b[8], c[4], d[2], e[1];
-  rs_step<32>(v, z, 32, (lane & 32) != 0);
-  rs_step<16>(z, a, 16, (lane & 16) != 0);
+  rs_step_swap<32, 32>(v, z);
+  rs_step_swap<16, 16>(z, a);
   rs_step<8>(a, b, 8, (lane & 8) != 0);
   rs_step<4>(b, c, 4, (lane & 4) != 0);
   rs_step<2>(c, d, 2, (lane & 2) != 0);
@@ -129,9 +156,8 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
     double d = A[j * 6 + j];
     for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
     if (!(d > 0)) return false;
-    d = sqrt(d);
-    A[j * 6 + j] = d;
-    inv[j] = 1.0 / d;
+    inv[j] = asd_rsqrt(d);
+    A[j * 6 + j] = d * inv[j];
     for (int i = j + 1; i < 6; ++i) {
       double s = A[i * 6 + j];
       for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
@@ -159,12 +185,13 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 // (g2o recomputes both at the same estimate: identical values, one pass instead of three).
 struct PoseOptArgs {
   int n;
-  const double* edges;  // [n][6]
+  const double* edges;  // [n][6] as uploaded: Xw, obs, inv_sigma2
   double fx, fy, cx, cy;
-  double* err_g;        // [n][2] global scratch (used when the problem does not fit LDS)
+  double* soa_g;        // [8][n] global scratch (used when the problem does not fit LDS)
   uint8_t* flags_g;     // [2n] global scratch: level, outlier
   double* io;           // in: pose[7]; out: pose[7], n_bad (as double), then outlier bytes at io + 8
   int use_lds;
+  int debug;  // ASD_POSE_DEBUG: thread 0 prints passes / iterations per round
 };
 
 constexpr int kPoseThreads = 256, kPoseWaves = kPoseThreads / 64;
@@ -174,61 +201,107 @@ struct PoseShared {
   double sums[29];
   double red[kPoseWaves * 32];
   double lambda, ni, currentChi, iniChi, rho;
-  int qmax, cont, ok, sys_valid, stop, pad[1];
+  int qmax, cont, ok, sys_valid, stop, npass;
+  long long cyc[4];  // debug: edge loop, reduction, solve+oplus, LM bookkeeping
+  long long wend[16], dbg[4];
 };
 static_assert(sizeof(PoseShared) % 16 == 0, "keeps the dynamic LDS region 16-B aligned");
 
 // one pass over the active edges at pose T: sums[0..20] = upper H, [21..26] = b, [27] = robust chi2, [28] = #active
-__device__ inline void pose_pass(const PoseOptArgs& a, const double* ed, double* er, const uint8_t* lvl, PoseShared& S,
-                                 bool robust) {
+// 1/x and 1/sqrt(x) from the hardware seeds plus two Newton steps (error ~1 ulp for the well-scaled operands here:
+// depths, chi2 values).  The IEEE-exact expansions of `1.0 / z`, `sqrt(c)` and `hd / s` cost ~45 fp64 issue slots per
+// edge, a quarter of the loop; results move by an ulp, far inside the 1e-8 pose tolerance.
+__device__ inline double nr_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ inline double nr_rsqrt(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  return r;
+}
+
+// soa = [X | Y | Z | u | v | inv_sigma2 | e0 | e1], each [n]: consecutive lanes read consecutive doubles (the [n][6]
+// records this replaces put 8 lanes on every LDS bank pair)
+__device__ inline void pose_pass(const PoseOptArgs& a, double* soa, const uint8_t* lvl, PoseShared& S, bool robust) {
   // fp64 issue on ONE CU bounds this loop (a wave64 fp64 op takes 4 cycles, a division ~35 ops), so the
   // arithmetic is kept lean: rotation matrix instead of the quaternion sandwich, one reciprocal per
   // edge, weighted Jacobian rows shared by all 27 accumulators.
   const Pose7 T = S.T;
   double R[9];
   quat_to_rot(T, R);
+  // wave-uniform: keep the pose in scalar registers (it comes out of LDS, which the compiler cannot prove uniform)
+  auto uni = [](double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
+#pragma unroll
+  for (int q = 0; q < 9; ++q) R[q] = uni(R[q]);
+  const double ttx = uni(T.tx), tty = uni(T.ty), ttz = uni(T.tz);
   const double hd = huber_delta(), hd2 = hd * hd;
   double acc[29];
 #pragma unroll
   for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-  for (int i = threadIdx.x; i < a.n; i += kPoseThreads) {
-    if (lvl[i]) continue;
-    const double* e = ed + 6 * i;
-    const double X = e[0], Y = e[1], Z = e[2];
-    const double x = R[0] * X + R[1] * Y + R[2] * Z + T.tx;
-    const double y = R[3] * X + R[4] * Y + R[5] * Z + T.ty;
-    const double z = R[6] * X + R[7] * Y + R[8] * Z + T.tz;
-    const double iz = 1.0 / z;
+  const int n = a.n;
+  const long long c0 = a.debug ? clock64() : 0;
+  // Branch-free body (inactive or out-of-range lanes run with weight 0 and keep their stored error), unrolled by
+  // two so the scheduler can interleave two independent edges: with one wave per SIMD nothing else hides the
+  // fp64 dependency chains.  J0[4] = J1[3] = 0 by construction: the products they would enter are left out.
+  const int iters = (n + kPoseThreads - 1) / kPoseThreads;
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    const int i0 = threadIdx.x + it * kPoseThreads;
+    const int i = min(i0, n - 1);
+    const bool act = i0 < n && !lvl[i];
+    const double X = soa[i], Y = soa[n + i], Z = soa[2 * n + i];
+    const double ou = soa[3 * n + i], ov = soa[4 * n + i], isg = soa[5 * n + i];
+    const double x = R[0] * X + R[1] * Y + R[2] * Z + ttx;
+    const double y = R[3] * X + R[4] * Y + R[5] * Z + tty;
+    const double z = R[6] * X + R[7] * Y + R[8] * Z + ttz;
+    const double iz = act ? nr_rcp(z) : 0.0;
     const double xz = x * iz, yz = y * iz;
-    const double e0 = e[3] - (xz * a.fx + a.cx);
-    const double e1 = e[4] - (yz * a.fy + a.cy);
-    er[2 * i] = e0; er[2 * i + 1] = e1;
-    const double c = (e0 * e0 + e1 * e1) * e[5];
-    double r0 = c, w = 1.0;
-    if (robust && c > hd2) {  // Huber (robust_kernel_impl.cpp:78-91)
-      const double s = sqrt(c);
-      r0 = 2 * s * hd - hd2;
-      w = hd / s;
-    }
+    const double e0 = ou - (xz * a.fx + a.cx);
+    const double e1 = ov - (yz * a.fy + a.cy);
+    if (act) { soa[6 * n + i] = e0; soa[7 * n + i] = e1; }
+    const double c = (e0 * e0 + e1 * e1) * isg;
+    // Huber (robust_kernel_impl.cpp:78-91); a wave of 64 edges practically always holds an outlier, so no branch
+    const bool hub = robust && c > hd2;
+    const double rs = nr_rsqrt(hub ? c : hd2);  // 1/sqrt(chi2); the operand is >= hd2 > 0 on every lane
+    const double r0 = hub ? 2 * (c * rs) * hd - hd2 : c;
+    const double w = hub ? hd * rs : 1.0;
     const double fiz = a.fx * iz, giz = a.fy * iz;
-    // Jacobian rows (types_six_dof_expmap.cpp:382-394), [omega | upsilon]
-    const double J0[6] = {xz * yz * a.fx, -(1 + xz * xz) * a.fx, yz * a.fx, -fiz, 0.0, xz * fiz};
-    const double J1[6] = {(1 + yz * yz) * a.fy, -xz * yz * a.fy, -xz * a.fy, 0.0, -giz, yz * giz};
-    const double om = e[5] * w;
-    double W0[6], W1[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) { W0[r] = om * J0[r]; W1[r] = om * J1[r]; }
-    int k = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int cc = r; cc < 6; ++cc) acc[k++] += W0[r] * J0[cc] + W1[r] * J1[cc];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc[21 + r] -= W0[r] * e0 + W1[r] * e1;
-    acc[27] += r0;
-    acc[28] += 1.0;
+    // Jacobian rows (types_six_dof_expmap.cpp:382-394), [omega | upsilon]: J0 = (a0 a1 a2 a3 0 a5), J1 = (b0 b1 b2 0 b4 b5)
+    const double a0 = xz * yz * a.fx, a1 = -(1 + xz * xz) * a.fx, a2 = yz * a.fx, a3 = -fiz, a5 = xz * fiz;
+    const double b0 = (1 + yz * yz) * a.fy, b1 = -xz * yz * a.fy, b2 = -xz * a.fy, b4 = -giz, b5 = yz * giz;
+    const double om = act ? isg * w : 0.0;
+    const double w0 = om * a0, w1 = om * a1, w2 = om * a2, w3 = om * a3, w5 = om * a5;
+    const double v0 = om * b0, v1 = om * b1, v2 = om * b2, v4 = om * b4, v5 = om * b5;
+    acc[0] += w0 * a0 + v0 * b0;  acc[1] += w0 * a1 + v0 * b1;  acc[2] += w0 * a2 + v0 * b2;
+    acc[3] += w0 * a3;            acc[4] += v0 * b4;            acc[5] += w0 * a5 + v0 * b5;
+    acc[6] += w1 * a1 + v1 * b1;  acc[7] += w1 * a2 + v1 * b2;  acc[8] += w1 * a3;
+    acc[9] += v1 * b4;            acc[10] += w1 * a5 + v1 * b5;
+    acc[11] += w2 * a2 + v2 * b2; acc[12] += w2 * a3;           acc[13] += v2 * b4;
+    acc[14] += w2 * a5 + v2 * b5;
+    acc[15] += w3 * a3;           /* acc[16]: H(3,4) = 0 */     acc[17] += w3 * a5;
+    acc[18] += v4 * b4;           acc[19] += v4 * b5;
+    acc[20] += w5 * a5 + v5 * b5;
+    acc[21] -= w0 * e0 + v0 * e1; acc[22] -= w1 * e0 + v1 * e1; acc[23] -= w2 * e0 + v2 * e1;
+    acc[24] -= w3 * e0;           acc[25] -= v4 * e1;           acc[26] -= w5 * e0 + v5 * e1;
+    acc[27] += act ? r0 : 0.0;
+    acc[28] += act ? 1.0 : 0.0;
   }
+  const long long c1 = a.debug ? clock64() : 0;
+  if (a.debug && (threadIdx.x & 63) == 0) S.wend[threadIdx.x >> 6] = c1 - c0;
   block_reduce<29, kPoseWaves>(acc, S.red, S.sums);
+  if (threadIdx.x == 0) {
+    ++S.npass;
+    if (a.debug) {
+      S.cyc[0] += c1 - c0; S.cyc[1] += clock64() - c1;
+      long long mx = 0;
+      for (int w = 0; w < kPoseWaves; ++w) mx = S.wend[w] > mx ? S.wend[w] : mx;
+      S.dbg[0] += mx;
+    }
+  }
 }
 
 __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H, b
@@ -238,22 +311,25 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
   for (int r = 0; r < 6; ++r) S.b[r] = S.sums[21 + r];
 }
 
+// USE_LDS is a template parameter, not a run-time switch: with a pointer that may be LDS or global the compiler
+// falls back to FLAT loads, whose latency dominated the edge loop.
+template <bool USE_LDS>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
   __shared__ PoseShared S;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   const int t = threadIdx.x;
-  const double* ed = a.edges;
-  double* er = a.err_g;
-  uint8_t* lvl = a.flags_g;
-  uint8_t* outl = a.flags_g + a.n;
-  if (a.use_lds) {
-    double* led = dyn;
-    er = dyn + (size_t)6 * a.n;
+  double* soa;
+  uint8_t *lvl, *outl;
+  if constexpr (USE_LDS) {
+    soa = dyn;
     lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)8 * a.n);
     outl = lvl + a.n;
-    for (int i = t; i < 6 * a.n; i += kPoseThreads) led[i] = a.edges[i];
-    ed = led;
+  } else {
+    soa = a.soa_g;
+    lvl = a.flags_g;
+    outl = a.flags_g + a.n;
   }
+  for (int i = t; i < 6 * a.n; i += kPoseThreads) soa[(size_t)(i % 6) * a.n + i / 6] = a.edges[i];  // coalesced read, transposed write
   for (int i = t; i < a.n; i += kPoseThreads) { lvl[i] = 0; outl[i] = 0; }
   if (t == 0) {
     Pose7 T0{a.io[0], a.io[1], a.io[2], a.io[3], a.io[4], a.io[5], a.io[6]};
@@ -265,9 +341,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
   bool robust = true;
   int nBad = 0;
   for (int round = 0; round < 4; ++round) {
-    if (t == 0) S.T = S.T0;  // every round restarts from the input pose (Optimizer.cc:337)
+    if (t == 0) { S.T = S.T0; S.npass = 0; for (int q = 0; q < 4; ++q) { S.cyc[q] = 0; S.dbg[q] = 0; } }  // every round restarts from the input pose (Optimizer.cc:337)
     __syncthreads();
-    pose_pass(a, ed, er, lvl, S, robust);
+    pose_pass(a, soa, lvl, S, robust);
     const bool any_active = S.sums[28] > 0.5;
     if (any_active) {
       // ---- g2o optimize(10): Levenberg (optimization_algorithm_levenberg.cpp:61-189)
@@ -275,7 +351,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
       if (t == 0) S.sys_valid = 1;
       __syncthreads();
       for (int it = 0; it < 10; ++it) {
-        if (!S.sys_valid) pose_pass(a, ed, er, lvl, S, robust);  // only after a non-finite trial
+        if (!S.sys_valid) pose_pass(a, soa, lvl, S, robust);  // only after a non-finite trial
         if (t == 0) {
           S.currentChi = S.sums[27];
           S.iniChi = S.sums[27];
@@ -292,14 +368,17 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
         __syncthreads();
         do {
           if (t == 0) {
+            const long long c0 = a.debug ? clock64() : 0;
             S.Tbak = S.T;
             for (int j = 0; j < 6; ++j) S.x[j] = 0;
             S.ok = chol6_solve(S.H, S.lambda, S.b, S.x) ? 1 : 0;
             if (S.ok) S.T = pose_oplus(S.T, S.x);
+            if (a.debug) S.cyc[2] += clock64() - c0;
           }
           __syncthreads();
-          pose_pass(a, ed, er, lvl, S, robust);
+          pose_pass(a, soa, lvl, S, robust);
           if (t == 0) {
+            const long long c0 = a.debug ? clock64() : 0;
             double tempChi = S.sums[27];
             if (!S.ok) tempChi = 1.7976931348623157e308;
             double rho = S.currentChi - tempChi;
@@ -324,6 +403,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
             S.rho = rho;
             S.qmax++;
             S.cont = (rho < 0 && S.qmax < 10) ? 1 : 0;
+            if (a.debug) S.cyc[3] += clock64() - c0;
           }
           __syncthreads();
         } while (S.cont);
@@ -344,16 +424,17 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
     double nb[1] = {0.0};
     {
       const Pose7 T = S.T;
-      for (int i = t; i < a.n; i += kPoseThreads) {
-        const double* e = ed + 6 * i;
+      const int n = a.n;
+      for (int i = t; i < n; i += kPoseThreads) {
         if (outl[i]) {  // e->computeError()
+          const double Xw[3] = {soa[i], soa[n + i], soa[2 * n + i]};
           double Xc[3];
-          pose_map(T, e, Xc);
-          er[2 * i] = e[3] - (Xc[0] / Xc[2] * a.fx + a.cx);
-          er[2 * i + 1] = e[4] - (Xc[1] / Xc[2] * a.fy + a.cy);
+          pose_map(T, Xw, Xc);
+          soa[6 * n + i] = soa[3 * n + i] - (Xc[0] / Xc[2] * a.fx + a.cx);
+          soa[7 * n + i] = soa[4 * n + i] - (Xc[1] / Xc[2] * a.fy + a.cy);
         }
-        const double e0 = er[2 * i], e1 = er[2 * i + 1];
-        const float chi2 = (float)((e0 * e0 + e1 * e1) * e[5]);
+        const double e0 = soa[6 * n + i], e1 = soa[7 * n + i];
+        const float chi2 = (float)((e0 * e0 + e1 * e1) * soa[5 * n + i]);
         if (chi2 > kChi2Mono) { outl[i] = 1; lvl[i] = 1; nb[0] += 1.0; }
         else { outl[i] = 0; lvl[i] = 0; }
       }
@@ -362,6 +443,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
     block_reduce<1, kPoseWaves>(nb, S.red, S.sums);
     nBad = (int)(S.sums[0] + 0.5);
     __syncthreads();
+    if (a.debug && t == 0)
+      printf("[pose_opt] round %d: %d passes, nBad %d; cycles/pass: edges %lld (slowest wave %lld) reduce %lld solve+oplus %lld accept %lld\n", round, S.npass,
+             nBad, S.cyc[0] / S.npass, S.dbg[0] / S.npass, S.cyc[1] / S.npass, S.cyc[2] / S.npass, S.cyc[3] / S.npass);
     if (round == 2) robust = false;  // e->setRobustKernel(0)
     if (a.n < 10) break;             // optimizer.edges().size() < 10
   }
@@ -984,7 +1068,7 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   BaState* s = ba_state(ctx);
   int rc;
   const size_t in_bytes = (size_t)n * 48 + 64, io_bytes = 64 + (size_t)n + 64;
-  if ((rc = s->po_Xw.ensure(ctx, in_bytes)) || (rc = s->po_err.ensure(ctx, (size_t)n * 16)) ||
+  if ((rc = s->po_Xw.ensure(ctx, in_bytes)) || (rc = s->po_err.ensure(ctx, (size_t)n * 64)) ||
       (rc = s->po_level.ensure(ctx, (size_t)2 * n)) || (rc = s->po_pose.ensure(ctx, io_bytes)))
     return rc;
   if (s->h_po_cap < in_bytes + io_bytes) {
@@ -1008,18 +1092,20 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   a.n = n;
   a.edges = s->po_Xw.as<double>();
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
-  a.err_g = s->po_err.as<double>();
+  a.soa_g = s->po_err.as<double>();
   a.flags_g = s->po_level.as<uint8_t>();
   a.io = s->po_pose.as<double>();
   const size_t lds = (size_t)n * 64 + (size_t)2 * n + 16;
   a.use_lds = (lds <= 150 * 1024 && !getenv("ASD_POSE_NO_LDS")) ? 1 : 0;
+  a.debug = getenv("ASD_POSE_DEBUG") ? 1 : 0;
   static bool attr_set = false;
   if (!attr_set) {
-    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(kPoseThreads), a.use_lds ? lds : 0, st, a);
+  if (a.use_lds) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kPoseThreads), lds, st, a);
+  else hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(kPoseThreads), 0, st, a);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(hio, s->po_pose.p, 64 + (size_t)n, hipMemcpyDeviceToHost, st));

@@ -8,14 +8,28 @@
 
 #define ASD_HD __host__ __device__ inline
 
+// 1/sqrt(x) for the pose kernels.  On the device: hardware seed + two Newton steps (~1 ulp) -- PoseOptimization runs
+// its 6x6 solves and pose updates on ONE lane, where every dependent fp64 instruction costs ~44 cycles and the IEEE
+// expansions of sqrt and division are chains of 12-17 of them.  On the host: the plain expression.
+ASD_HD double asd_rsqrt(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  double r = __builtin_amdgcn_rsq(x);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+  return r;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 struct Pose7 {  // unit quaternion (x,y,z,w), translation: world -> camera
   double qx, qy, qz, qw, tx, ty, tz;
 };
 
 ASD_HD void quat_normalize(double& x, double& y, double& z, double& w) {  // normalizeRotation
   if (w < 0) { x = -x; y = -y; z = -z; w = -w; }
-  const double n = sqrt(x * x + y * y + z * z + w * w);
-  x /= n; y /= n; z /= n; w /= n;
+  const double inv = asd_rsqrt(x * x + y * y + z * z + w * w);  // Eigen's `/= norm()` multiplies by the reciprocal
+  x *= inv; y *= inv; z *= inv; w *= inv;
 }
 
 ASD_HD void quat_to_rot(const Pose7& T, double R[9]) {
@@ -43,7 +57,9 @@ ASD_HD void pose_map(const Pose7& T, const double X[3], double out[3]) {  // SE3
 // VertexSE3Expmap::oplusImpl: T <- SE3Quat::exp(u) * T, u = (omega, upsilon)
 ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
   const double wx = u[0], wy = u[1], wz = u[2];
-  const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+  const double theta2 = wx * wx + wy * wy + wz * wz;
+  const double itheta = theta2 > 0 ? asd_rsqrt(theta2) : 0.0;
+  const double theta = theta2 * itheta;
   const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
   double O2[9];
   for (int i = 0; i < 3; ++i)
@@ -54,7 +70,7 @@ ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
   } else {
     double sn, cs;
     sincos(theta, &sn, &cs);
-    const double it = 1.0 / theta, it2 = it * it;
+    const double it = itheta, it2 = it * it;
     const double a = sn * it, b = (1 - cs) * it2;
     const double c = (theta - sn) * it2 * it;
     for (int i = 0; i < 9; ++i) {
@@ -67,9 +83,9 @@ ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
   double ex, ey, ez, ew;
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0) {
-    double s = sqrt(tr + 1.0);
-    ew = 0.5 * s;
-    s = 0.5 / s;
+    const double rs = asd_rsqrt(tr + 1.0);
+    ew = 0.5 * ((tr + 1.0) * rs);
+    const double s = 0.5 * rs;
     ex = (R[7] - R[5]) * s; ey = (R[2] - R[6]) * s; ez = (R[3] - R[1]) * s;
   } else {
     // largest diagonal element first (Eigen quaternionbase_assign_impl); written out per case so every
