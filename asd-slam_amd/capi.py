@@ -194,12 +194,21 @@ class AsdHip:
     def extract_submit(self, image, w, h, stride, device_resident=True, n_features_override=0):
         self._chk(self.lib.asd_extract_submit(self.ctx, image, int(device_resident), w, h, stride, n_features_override))
 
-    def extract_wait(self):
+    def extract_wait(self, view=False):
+        """view=True: zero-copy numpy views of the library's result buffers (valid for two further submissions)"""
+        n = C.c_int32()
+        if view:
+            pk, pd = C.c_void_p(), C.c_void_p()
+            self._chk(self.lib.asd_extract_wait_view(self.ctx, C.byref(pk), C.byref(pd), C.byref(n)))
+            if n.value == 0:
+                return np.zeros(0, KP_DTYPE), np.zeros((0, 128), np.float32)
+            kb = (C.c_char * (n.value * KP_DTYPE.itemsize)).from_address(pk.value)
+            db = (C.c_float * (n.value * 128)).from_address(pd.value)
+            return np.frombuffer(kb, dtype=KP_DTYPE, count=n.value), np.frombuffer(db, dtype=np.float32).reshape(n.value, 128)
         cap = self.cfg.max_patches
         if not hasattr(self, "_kps_buf"):
             self._kps_buf = np.zeros(cap, KP_DTYPE)
             self._desc_buf = np.empty((cap, 128), np.float32)
-        n = C.c_int32()
         self._chk(self.lib.asd_extract_wait(self.ctx, _p(self._kps_buf), _p(self._desc_buf), C.byref(n)))
         return self._kps_buf[:n.value], self._desc_buf[:n.value]
 

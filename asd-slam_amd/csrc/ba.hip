@@ -315,6 +315,9 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
 // falls back to FLAT loads, whose latency dominated the edge loop.
 template <bool USE_LDS>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
+  // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
+  // the read-ahead extractor: ask the SIMD arbiters to issue its waves first
+  __builtin_amdgcn_s_setprio(3);
   __shared__ PoseShared S;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   const int t = threadIdx.x;

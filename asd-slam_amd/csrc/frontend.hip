@@ -762,7 +762,7 @@ static int extract_back_enqueue(asd_ctx* ctx, ExtractSlot& S, int n, hipStream_t
 // E7: wait for the back half, hand the results over (pinned staging -> caller's pageable buffers)
 static int extract_finish(asd_ctx* ctx, ExtractSlot& S, int n, asd_keypoint* kps, float* desc) {
   ASD_HIP_CHECK(ctx, hipEventSynchronize(S.ev_end));
-  memcpy(desc, S.h_desc, (size_t)n * 128 * sizeof(float));
+  if (desc) memcpy(desc, S.h_desc, (size_t)n * 128 * sizeof(float));  // else: the consumer reads the pinned staging itself
   for (int i = 0; i < n; ++i) kps[i].angle = S.h_angles[i];
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, S.ev_begin, S.ev_end));
   return ASD_OK;
@@ -826,7 +826,6 @@ struct AsyncJob {
   int slot = 0;
   enum State { QUEUED, FRONT, BACK, DONE } state = QUEUED;
   std::vector<asd_keypoint> kps;
-  std::vector<float> desc;
 };
 
 struct AsyncExtract {
@@ -847,7 +846,7 @@ static void async_worker(asd_ctx* ctx) {
   AsyncJob* inflight = nullptr;  // back half enqueued, results not yet handed over
   auto finish = [&](AsyncJob* a) {
     ExtractSlot& S = ax->slots[a->slot];
-    const int rc = extract_finish(ctx, S, a->job.n, a->kps.data(), a->desc.data());
+    const int rc = extract_finish(ctx, S, a->job.n, a->kps.data(), nullptr);
     std::lock_guard<std::mutex> l(ax->m);
     if (rc != ASD_OK) a->job.rc = rc;
     a->state = AsyncJob::DONE;
@@ -942,7 +941,6 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
       if ((rc = slot_events(ctx, ax->slots[i])) != ASD_OK) return rc;
       ax->jobs[i].slot = i;
       ax->jobs[i].kps.resize(ctx->cfg.max_patches);
-      ax->jobs[i].desc.resize((size_t)ctx->cfg.max_patches * 128);
     }
     ax->th = std::thread(async_worker, ctx);
   }
@@ -964,22 +962,41 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   return ASD_OK;
 }
 
-int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out) {
-  if (!ctx || !ctx->ax || !kps || !desc || !n_out) return ASD_ERR_INVALID;
+// oldest outstanding submission: blocks until it is DONE, returns its job (nullptr + error code on failure)
+static AsyncJob* wait_oldest(asd_ctx* ctx, int* rc) {
   AsyncExtract* ax = ctx->ax;
   std::unique_lock<std::mutex> l(ax->m);
-  if (ax->waited == ax->submitted) { ctx->set_error("asd_extract_wait: nothing was submitted"); return ASD_ERR_INVALID; }
+  if (ax->waited == ax->submitted) { ctx->set_error("asd_extract_wait: nothing was submitted"); *rc = ASD_ERR_INVALID; return nullptr; }
   AsyncJob& a = ax->jobs[ax->waited % kSlots];
   ax->cv.wait(l, [&] { return a.state == AsyncJob::DONE; });
   ++ax->waited;
-  if (a.job.rc != ASD_OK) return a.job.rc;
-  const int n = a.job.n;
-  l.unlock();
-  memcpy(kps, a.kps.data(), (size_t)n * sizeof(asd_keypoint));
-  memcpy(desc, a.desc.data(), (size_t)n * 128 * sizeof(float));
-  *n_out = n;
-  ctx->last_n = n;
+  if (a.job.rc != ASD_OK) { *rc = a.job.rc; return nullptr; }
+  ctx->last_n = a.job.n;
   ctx->d_desc_last = ax->slots[a.slot].d_desc;
+  *rc = ASD_OK;
+  return &a;
+}
+
+int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out) {
+  if (!ctx || !ctx->ax || !kps || !desc || !n_out) return ASD_ERR_INVALID;
+  int rc;
+  AsyncJob* a = wait_oldest(ctx, &rc);
+  if (!a) return rc;
+  const int n = a->job.n;
+  memcpy(kps, a->kps.data(), (size_t)n * sizeof(asd_keypoint));
+  memcpy(desc, ctx->ax->slots[a->slot].h_desc, (size_t)n * 128 * sizeof(float));
+  *n_out = n;
+  return ASD_OK;
+}
+
+int asd_extract_wait_view(asd_ctx* ctx, const asd_keypoint** kps, const float** desc, int32_t* n_out) {
+  if (!ctx || !ctx->ax || !kps || !desc || !n_out) return ASD_ERR_INVALID;
+  int rc;
+  AsyncJob* a = wait_oldest(ctx, &rc);
+  if (!a) return rc;
+  *kps = a->kps.data();
+  *desc = ctx->ax->slots[a->slot].h_desc;
+  *n_out = a->job.n;
   return ASD_OK;
 }
 

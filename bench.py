@@ -130,9 +130,8 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
     on this frame's tracking, so the HIP backend reads ahead (asd_extract_submit, own streams + worker thread: the
     replay knows its next images, Examples/Monocular/kitti.cc:116-155) as soon as this frame's descriptors are
     adopted; every frame still goes through every stage."""
-    kps, desc = be.extract(image_handle)
+    kps, desc = be.extract(image_handle)   # results stay valid through the next step (own arrays / library views)
     cur = be.make_frame(kps, desc)
-    kps, desc = kps.copy(), desc.copy()
     if next_handles:
         be.prefetch(next_handles)
     stats = {"n_kp": len(kps)}
@@ -193,9 +192,12 @@ class HipBackend:
     def extract(self, h):
         if self.pending and self.pending[0].value == h.value:
             self.pending.pop(0)
-            return self.hip.extract_wait()
+            # zero-copy views of the library's buffers for this submission: valid for two further submissions,
+            # the tracker needs them for one (the "last frame" of the next step)
+            return self.hip.extract_wait(view=True)
         self.drain()                      # something else was read ahead: drop it
-        return self.hip.extract_device(h, 1241, 376, 1241)
+        k, d = self.hip.extract_device(h, 1241, 376, 1241)
+        return k.copy(), d.copy()
 
     def drain(self):
         while self.pending:

@@ -126,6 +126,11 @@ int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int3
 int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width,
                        int32_t height, int32_t stride, int32_t n_features_override);
 int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out);
+/* Same without the copy: *kps / *desc point into the library's own result buffers of that submission (the
+ * descriptors sit in pinned host memory) and stay valid until two further submissions have been made -- e.g. to
+ * wrap them as the Frame's mvKeys / mDescriptors (cv::Mat header over foreign data) for the frame's lifetime in
+ * the tracker, which is two frames. */
+int asd_extract_wait_view(asd_ctx* ctx, const asd_keypoint** kps, const float** desc, int32_t* n_out);
 
 /* Intermediate products of the last asd_extract, for tests and for callers that read
  * ORBextractor::mvImagePyramid (ORBextractor.h:87).  Level images are returned WITHOUT

@@ -229,8 +229,16 @@ def test_pipelined_extract_equals_sync(hip, synth):
         hip.extract_submit(d[k], 1241, 376, 1241, device_resident=True)
     with pytest.raises(Exception):                    # a 4th outstanding submission is refused, nothing is lost
         hip.extract_submit(d[0], 1241, 376, 1241, device_resident=True)
+    held = []
     for i, k in enumerate(order):
-        kps, desc = hip.extract_wait()
+        kps, desc = hip.extract_wait(view=(i % 2 == 0))   # copies and zero-copy views alternate
+        if i % 2 == 0:
+            held.append((i, k, kps, desc))
+        # a view stays intact while the next two submissions are made and processed
+        for (j, kj, vk, vd) in held:
+            if i - j <= 2:
+                np.testing.assert_array_equal(vk, ref[kj][0], err_msg=f"view of submission {j} read at {i}")
+                np.testing.assert_array_equal(vd, ref[kj][1], err_msg=f"view of submission {j} read at {i}")
         np.testing.assert_array_equal(kps, ref[k][0], err_msg=f"submission {i} (frame {frames[k]})")
         np.testing.assert_array_equal(desc, ref[k][1], err_msg=f"submission {i} (frame {frames[k]})")
         # the waited frame's descriptors are adoptable on the device while later frames are still in flight
