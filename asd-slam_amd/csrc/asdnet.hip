@@ -34,7 +34,12 @@ const LayerSpec kLayers[7] = {{32, 1, 3, 1, 1},   {32, 32, 3, 1, 1},   {64, 32, 
 // K1: 3x3 conv (pad 1, stride S) + folded BN + ReLU as an implicit GEMM on f32 MFMA.
 // One workgroup = ROWS output rows of one patch; 4 waves as WM (pixels) x WN (channels).
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1>
+// RING = weight ring depth of k_conv_mfma.  3 = software-pipelined form: the stage written at the end of stage s is s+2, so the
+// slot of stage s+1 has been complete since the previous barrier and the first operands of the next stage can be
+// fetched from LDS BEFORE the barrier that ends the current one (with depth 2 every stage began with an exposed
+// LDS round trip: 7-13 % of the MFMA loop).  2 = one slot less LDS; measured per layer: 3 wins for conv5/conv6
+// (-22 us on conv6), 2 for conv2/conv4 where the extra slot costs a resident workgroup or nothing is gained.
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int RING = 2>
 struct ConvCfg {
   static constexpr int HO = HIN / S;
   static constexpr int INROWS = (ROWS - 1) * S + 3;
@@ -52,7 +57,8 @@ struct ConvCfg {
   static constexpr int WQUADS = WCHUNK / 4;  // float4 per weight stage
   static constexpr int WREGS = (WQUADS + NTH - 1) / NTH;
   static constexpr int ACT_FLOATS = INROWS * INCOLS * CPAD;  // per patch band
-  static constexpr int LDS_BYTES = (PP * ACT_FLOATS + 2 * WCHUNK) * 4;
+  static constexpr int LDS_BYTES = (PP * ACT_FLOATS + RING * WCHUNK) * 4;
+  static_assert(RING == 2 || RING == 3, "weight ring depth");
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0, "tile split");
   static_assert(WQUADS % NTH == 0 || WQUADS < NTH, "weight stage: whole float4 rounds per thread, or a single partial round");
@@ -64,11 +70,11 @@ struct ConvCfg {
 // FUSE1: the kernel is conv2 and computes its own input (input_norm + conv1 + BN + ReLU, ASDNet.py:334-336,
 // 360-365) from the raw u8 patch while filling the LDS band, so conv1's 128 KB/patch activation never
 // exists in HBM.  `in` is then the u8 patch array and w1 / b1 the folded conv1 weights.
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int ABL = 0, bool FUSE1 = false>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int RING = 2, int ABL = 0, bool FUSE1 = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restrict__ in_, const float* __restrict__ wimg,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            const float* __restrict__ w1, const float* __restrict__ b1, int n) {
-  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP>;
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING>;
   constexpr int NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sact = smem;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
     static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1 && PP == 1), "conv1 fusion is for conv2 only");
     // extra LDS behind the weight ring: normalised input rows r0-2 .. r0+ROWS+1 (34 wide, zero padded),
     // conv1 weights + bias, reduction scratch
-    float* pin = sw + 2 * C::WCHUNK;              // [(ROWS+4)][36]
+    float* pin = sw + RING * C::WCHUNK;           // [(ROWS+4)][36]
     float* wsh = pin + (ROWS + 4) * 36;           // [32*9 + 32]
     float* red = wsh + 320;                       // [8]
     const uint8_t* patches = static_cast<const uint8_t*>(in_);
@@ -157,10 +163,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       *reinterpret_cast<f32x4*>(sact + pp * C::ACT_FLOATS + pix * C::CPAD + c4 * 4) = v;
     }
   }
-  // ---- weight stage 0
-  for (int r = 0; r < C::WREGS; ++r)
-    if (C::WQUADS >= NTH || t < C::WQUADS)
-      *reinterpret_cast<f32x4*>(sw + (r * NTH + t) * 4) = *reinterpret_cast<const f32x4*>(wimg + (r * NTH + t) * 4);
+  // ---- weight stage 0 (and 1 for the 3-deep ring)
+  constexpr int NPRE = RING == 3 ? 2 : 1;
+  for (int ps = 0; ps < NPRE && ps < C::NSTAGE; ++ps)
+    for (int r = 0; r < C::WREGS; ++r)
+      if (C::WQUADS >= NTH || t < C::WQUADS)
+        *reinterpret_cast<f32x4*>(sw + ps * C::WCHUNK + (r * NTH + t) * 4) =
+            *reinterpret_cast<const f32x4*>(wimg + (size_t)ps * C::WCHUNK + (r * NTH + t) * 4);
   __syncthreads();
 
   f32x16 acc[C::MT][C::NT];
@@ -177,40 +186,86 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
     abase[mt] = pp * C::ACT_FLOATS + ((rr * S) * C::INCOLS + ox * S) * C::CPAD + 4 * h;
   }
   const int bbase = (h * COUT + wn * C::NT * 32 + li) * 4;
+  constexpr int STEPS = KC / 8;
 
-  for (int s = 0; s < C::NSTAGE; ++s) {
-    f32x4 wreg[C::WREGS];
-    if (s + 1 < C::NSTAGE && !(ABL & 16)) {
-      const float* wsrc = wimg + (size_t)(s + 1) * C::WCHUNK;
-      for (int r = 0; r < C::WREGS; ++r)
-        if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
-    }
+  // operands of k-step (stage s, chunk c8): A from the band at the tap's offset, B from the stage's ring slot
+  auto load_ops = [&](int s, int c8, f32x4 (&a)[C::MT], f32x4 (&b)[C::NT]) {
     const int tap = s / C::NCC, cc = s % C::NCC;
     const int tapoff = ((tap / 3) * C::INCOLS + (tap % 3)) * C::CPAD + cc * KC;
-    const float* swb = sw + (s & 1) * C::WCHUNK;
+    const float* swb = sw + (s % RING) * C::WCHUNK;
 #pragma unroll
-    for (int c8 = 0; c8 < KC / 8; ++c8) {
-      f32x4 a[C::MT], b[C::NT];
+    for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sact + abase[mt] + tapoff + c8 * 8);
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(sact + abase[mt] + tapoff + c8 * 8);
+    for (int nt = 0; nt < C::NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(swb + bbase + c8 * 2 * COUT * 4 + nt * 128);
+  };
+  auto mfma_step = [&](const f32x4 (&a)[C::MT], const f32x4 (&b)[C::NT]) {
 #pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt)
-        b[nt] = *reinterpret_cast<const f32x4*>(swb + bbase + c8 * 2 * COUT * 4 + nt * 128);
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj)
+      for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt)
+        for (int nt = 0; nt < C::NT; ++nt)
+          if (!(ABL & 2)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
+          else { asm volatile("" :: "v"(a[mt][jj]), "v"(b[nt][jj])); }
+  };
+
+  if constexpr (RING == 3) {
+    f32x4 a0[C::MT], b0[C::NT], a1[C::MT], b1[C::NT];
+    load_ops(0, 0, a0, b0);
+    for (int s = 0; s < C::NSTAGE; ++s) {
+      f32x4 wreg[C::WREGS];
+      const bool pre = s + 2 < C::NSTAGE && !(ABL & 16);
+      if (pre) {
+        const float* wsrc = wimg + (size_t)(s + 2) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
+      }
+      // k-steps of this stage, operands always one step ahead (the last step fetches the next stage's first operands:
+      // its ring slot was completed before the previous barrier)
 #pragma unroll
-          for (int nt = 0; nt < C::NT; ++nt)
-            if (!(ABL & 2)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][jj], b[nt][jj], acc[mt][nt], 0, 0, 0);
-            else { asm volatile("" :: "v"(a[mt][jj]), "v"(b[nt][jj])); }
+      for (int c8 = 0; c8 < STEPS; c8 += 2) {
+        if (c8 + 1 < STEPS) load_ops(s, c8 + 1, a1, b1);
+        else if (s + 1 < C::NSTAGE) load_ops(s + 1, 0, a1, b1);
+        mfma_step(a0, b0);
+        if (c8 + 1 < STEPS) {
+          if (c8 + 2 < STEPS) load_ops(s, c8 + 2, a0, b0);
+          else if (s + 1 < C::NSTAGE) load_ops(s + 1, 0, a0, b0);
+          mfma_step(a1, b1);
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) a0[mt] = a1[mt];
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt) b0[nt] = b1[nt];
+        }
+      }
+      if (pre) {
+        float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+      }
+      if (!(ABL & 8)) __syncthreads();
     }
-    if (s + 1 < C::NSTAGE && !(ABL & 16)) {
-      float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
-      for (int r = 0; r < C::WREGS; ++r)
-        if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+  } else {
+    for (int s = 0; s < C::NSTAGE; ++s) {
+      f32x4 wreg[C::WREGS];
+      if (s + 1 < C::NSTAGE && !(ABL & 16)) {
+        const float* wsrc = wimg + (size_t)(s + 1) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
+      }
+#pragma unroll
+      for (int c8 = 0; c8 < STEPS; ++c8) {
+        f32x4 a[C::MT], b[C::NT];
+        load_ops(s, c8, a, b);
+        mfma_step(a, b);
+      }
+      if (s + 1 < C::NSTAGE && !(ABL & 16)) {
+        float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+      }
+      if (!(ABL & 8)) __syncthreads();
     }
-    if (!(ABL & 8)) __syncthreads();
   }
 
   // ---- epilogue: bias (folded BN) + ReLU, NHWC store.  Lane owns one cout column, 16 pixel rows.
@@ -233,7 +288,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// K1p: the same implicit GEMM as a PERSISTENT workgroup with a double-buffered input band: while the
+// K1p (conv3 only; a 3-deep ring with operand prefetch as in K1 was measured here too: 221 vs 202 us):
+// the same implicit GEMM as a PERSISTENT workgroup with a double-buffered input band: while the
 // MFMAs of tile i run, the band of tile i+gridDim.x is fetched from HBM into registers (issued in
 // stage 0 behind that stage's weight prefetch, so the counted vmcnt of the weight write does not
 // drain it) and written to the other LDS buffer at the end of stage 1; the epilogue stores of tile i
@@ -430,28 +486,28 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
   desc[(size_t)p * 128 + lane + 64] = v1 / norm;
 }
 
-// layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP> (L3: persistent form, no PP)
+// layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING> (L3: persistent form, no PP / RING)
 #ifndef L2_CFG
-#define L2_CFG 32, 32, 32, 1, 4, 4, 1, 32, 1
+#define L2_CFG 32, 32, 32, 1, 4, 4, 1, 16, 1, 3
 #endif
 #ifndef L3_CFG
 #define L3_CFG 32, 64, 32, 2, 4, 2, 2, 16
 #endif
 #ifndef L4_CFG
-#define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32, 1
+#define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32, 1, 2
 #endif
 #ifndef L5_CFG
-#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 8, 1
+#define L5_CFG 64, 128, 16, 2, 4, 1, 4, 16, 1, 3
 #endif
 #ifndef L6_CFG
-#define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16, 1
+#define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16, 1, 3
 #endif
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, bool FUSE1 = false>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int RING = 2, bool FUSE1 = false>
 hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const float* bias, float* out, int n,
                        const float* w1 = nullptr, const float* b1 = nullptr) {
-  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP>;
-  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, 0, FUSE1>;
+  using C = ConvCfg<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING>;
+  auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING, 0, FUSE1>;
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds <= 160 * 1024, "band + weight ring do not fit LDS");
   static bool attr_set = false;
@@ -573,7 +629,11 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
   ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);
+#ifdef L3_NP_CFG  // tuning: conv3 through the non-persistent kernel
+  ASD_HIP_CHECK(ctx, (launch_conv<L3_NP_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
+#else
   ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
+#endif
   PROF_MARK(3);
   ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);
