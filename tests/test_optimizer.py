@@ -144,6 +144,23 @@ def test_hip_pose_optimization_full_size(hip, oracle, synth):
 
 
 @pytest.mark.gpu
+def test_hip_pose_optimization_edge_cases(hip, oracle, synth):
+    """fewer than 10 edges (one round only, Optimizer.cc:402), majority outliers, points behind / on the camera plane"""
+    cases = []
+    cases.append(synth.pose_problem(9, seed=31, outlier_frac=0.2))
+    cases.append(synth.pose_problem(600, seed=32, outlier_frac=0.6))
+    behind = synth.pose_problem(300, seed=33, outlier_frac=0.1)
+    behind["Xw"][:20] *= -1.0                      # negative depth: large residuals, gated as outliers
+    cases.append(behind)
+    for pp in cases:
+        got = hip.pose_optimize(pp["pose"], pp["Xw"], pp["obs"], pp["info"], pp["K"])
+        exp = oracle.pose_optimize(pp["pose"], pp["Xw"], pp["obs"], pp["info"], pp["K"])
+        np.testing.assert_allclose(got[0], exp[0], atol=POSE_ATOL, rtol=0)
+        np.testing.assert_array_equal(got[1], exp[1])
+        assert got[2] == exp[2]
+
+
+@pytest.mark.gpu
 def test_hip_local_ba_nominal_vs_oracle(hip, oracle, synth):
     """SURVEY 8(d) nominal LocalBA: 24 free + 12 fixed poses, 6000 points, ~29k edges."""
     prob = synth.ba_problem()
