@@ -926,8 +926,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   if (!ctx->ax) {
     // lowest stream priority for ASDNet: the latency-critical tracking kernels on ctx->stream go first; the small
     // front-half kernels get the middle priority so they slot in between the conv workgroups.
-    // (Masking a few CUs off these streams with hipExtStreamCreateWithCUMask was tried and measured
-    //  slower: extraction 2.0 -> 3.1 ms, no gain for the tracking kernels.)
+    // (Keeping 8 / 16 / 32 CUs out of these streams with hipExtStreamCreateWithCUMask, so that the tracking kernels
+    //  always find a free one, was measured twice: the masked streams lose a third of their throughput whatever
+    //  the mask (extraction 3.2 -> 4.3 ms device time under load) and k_pose_opt gains under 10 %.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_x, hipStreamDefault, prio_least));

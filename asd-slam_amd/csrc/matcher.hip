@@ -231,6 +231,7 @@ inline void transform(const float* T, const float* X, float* out) {
 
 struct MatcherState {
   int q_cap = 0, cand_cap = 0, qdesc_cap = 0;
+  int last_total[4] = {1 << 15, 1 << 15, 1 << 15, 1 << 15};  // candidates the previous search of each kind produced
   WinQuery *d_queries = nullptr, *h_queries = nullptr;   // h_* pinned
   int *d_q_off = nullptr, *d_q_cnt = nullptr, *d_total = nullptr, *d_idx = nullptr;
   float* d_dist = nullptr;
@@ -302,14 +303,17 @@ int ensure_bank(asd_ctx* ctx, MatcherState* m, int rows) {
 struct SearchResult { const int* off; const int* cnt; const int* idx; const float* dist; };
 
 // queries are already in m->h_queries[0..nq); d_q = query descriptor table on the device
-int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, SearchResult* res) {
+// kind: 0 frame-to-frame, 1 local map, 2 fuse, 3 other -- only sizes the speculative read-back
+int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, SearchResult* res, int kind = 3) {
   int rc = ensure_cands(ctx, m, 1);
   if (rc != ASD_OK) return rc;
   hipStream_t st = ctx->stream;
+  // off | cnt | total packed for THIS query count, so one small copy brings all three back
   int* d_off = m->d_q_off;
-  int* d_cnt = m->d_q_off + m->q_cap;
-  int* d_total = m->d_q_off + 2 * m->q_cap;
-  const int optimistic = std::min(m->cand_cap, 1 << 16);  // copied back together with the counts
+  int* d_cnt = m->d_q_off + nq;
+  int* d_total = m->d_q_off + 2 * nq;
+  // candidates copied back together with the counts: a little more than the last search produced
+  const int optimistic = std::min(m->cand_cap, std::max(4096, m->last_total[kind] + m->last_total[kind] / 4));
   for (int attempt = 0; attempt < 2; ++attempt) {
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_queries, m->h_queries, (size_t)nq * sizeof(WinQuery), hipMemcpyHostToDevice, st));
     ASD_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(int), st));
@@ -319,11 +323,12 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
                        d_total, m->cand_cap, m->d_idx, m->d_dist);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
-    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_q, d_off, ((size_t)2 * m->q_cap + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_q, d_off, ((size_t)2 * nq + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_idx, m->d_idx, (size_t)optimistic * sizeof(int), hipMemcpyDeviceToHost, st));
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_dist, m->d_dist, (size_t)optimistic * sizeof(float), hipMemcpyDeviceToHost, st));
     ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const int total = m->h_q[2 * m->q_cap];
+    const int total = m->h_q[2 * nq];
+    m->last_total[kind] = total;
     if (total > m->cand_cap) {  // segment reservation overflowed the buffers: grow and run again
       if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
       continue;
@@ -337,7 +342,7 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
   }
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
   res->off = m->h_q;
-  res->cnt = m->h_q + m->q_cap;
+  res->cnt = m->h_q + nq;
   res->idx = m->h_idx;
   res->dist = m->h_dist;
   return ASD_OK;
@@ -545,7 +550,7 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
     Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, mp_desc ? i : mp_rows[i]};
   }
   SearchResult R;
-  if ((rc = window_search(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, &R)) != ASD_OK) return rc;
+  if ((rc = window_search(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, &R, 0)) != ASD_OK) return rc;
   int nmatches = 0;
   std::vector<int> hist[HISTO];
   for (int i = 0; i < L->n; ++i) {
@@ -603,7 +608,7 @@ static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_m
   }
   if (desc && (rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
   SearchResult R;
-  if ((rc = window_search(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, &R)) != ASD_OK) return rc;
+  if ((rc = window_search(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, &R, 1)) != ASD_OK) return rc;
   int nmatches = 0;
   for (int q = 0; q < n_mp; ++q) {
     if (R.cnt[q] == 0) continue;
@@ -712,7 +717,7 @@ int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* 
   }
   if ((rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
   SearchResult R;
-  if ((rc = window_search(ctx, m, *KF, n_mp, m->d_qdesc, &R)) != ASD_OK) return rc;
+  if ((rc = window_search(ctx, m, *KF, n_mp, m->d_qdesc, &R, 2)) != ASD_OK) return rc;
   for (int i = 0; i < n_mp; ++i) {
     if (R.cnt[i] == 0) continue;
     float best = 256;
