@@ -283,6 +283,12 @@ class AsdHip:
                                                     C.c_float(nn_ratio), _p(out), C.byref(n)))
         return out, n.value
 
+    def distinctive_descriptor_batch(self, set_start, desc):
+        set_start, desc = _c(set_start, np.int32), _c(desc, np.float32)
+        out = np.empty(len(set_start) - 1, np.int32)
+        self._chk(self.lib.asd_distinctive_descriptor_batch(self.ctx, len(out), _p(set_start), _p(desc), _p(out)))
+        return out
+
     def fuse_search(self, slot_kf, valid, Xw, normal, min_dist, max_dist, desc, Tcw, K, th=3.0):
         valid, Xw, normal = _c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32)
         min_dist, max_dist, desc = _c(min_dist, np.float32), _c(max_dist, np.float32), _c(desc, np.float32)

@@ -140,6 +140,62 @@ __global__ __launch_bounds__(256) void k_list_dist(const ListQuery* __restrict__
   }
 }
 
+// MapPoint::ComputeDistinctiveDescriptors for many map points at once: one workgroup per map point (<= 64
+// observations), descriptors staged in LDS, all-pairs distances in the exact summation order, then the row medians by
+// rank counting (the k-th order statistic is the element that k others precede; ties ordered by index, which does not
+// change the VALUE found) and the first row with the smallest median (strict `<`, MapPoint.cc:318-331).
+constexpr int kDistinctMax = 64;
+__global__ __launch_bounds__(256) void k_distinctive(const float* __restrict__ desc, const int* __restrict__ set_start, int* __restrict__ best_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem_d[];
+  const int s0 = set_start[blockIdx.x], n = set_start[blockIdx.x + 1] - s0;
+  float* sd = smem_d;                       // [n][132] (padded rows)
+  float* D = smem_d + kDistinctMax * 132;   // [n][n + 1]
+  float* med = D + kDistinctMax * (kDistinctMax + 1);
+  const int t = threadIdx.x;
+  for (int idx = t; idx < n * 32; idx += 256) {
+    const int r = idx >> 5, c = idx & 31;
+    *reinterpret_cast<float4*>(sd + r * 132 + c * 4) = reinterpret_cast<const float4*>(desc + (size_t)(s0 + r) * 128)[c];
+  }
+  __syncthreads();
+  for (int p = t; p < n * n; p += 256) {
+    const int i = p / n, j = p % n;
+    float acc = 0.f;
+    if (i != j) {
+      const float4* x = reinterpret_cast<const float4*>(sd + i * 132);
+      const float4* y = reinterpret_cast<const float4*>(sd + j * 132);
+      for (int k = 0; k < 32; ++k) {
+        const float4 a = x[k], b = y[k];
+        float d;
+        d = a.x - b.x; acc = acc + d * d;
+        d = a.y - b.y; acc = acc + d * d;
+        d = a.z - b.z; acc = acc + d * d;
+        d = a.w - b.w; acc = acc + d * d;
+      }
+    }
+    D[i * (n + 1) + j] = acc;
+  }
+  __syncthreads();
+  const int kth = (int)(0.5 * (n - 1));
+  for (int p = t; p < n * n; p += 256) {
+    const int i = p / n, j = p % n;
+    const float v = D[i * (n + 1) + j];
+    int rank = 0;
+    for (int l = 0; l < n; ++l) {
+      const float u = D[i * (n + 1) + l];
+      rank += (u < v || (u == v && l < j)) ? 1 : 0;
+    }
+    if (rank == kth) med[i] = v;  // exactly one j per row has this rank
+  }
+  __syncthreads();
+  if (t == 0) {
+    float best_median = 100;
+    int best = 0;
+    for (int i = 0; i < n; ++i)
+      if (med[i] < best_median) { best_median = med[i]; best = i; }
+    best_out[blockIdx.x] = best;
+  }
+}
+
 // all-pairs: block = 256 columns (b rows) x 16 a rows; a tile broadcast from LDS, b row in VGPRs.
 __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a, int na, const float* __restrict__ b,
                                                      int nb, float* __restrict__ out) {
@@ -510,6 +566,56 @@ int asd_distinctive_descriptor(asd_ctx* ctx, const float* desc, int32_t n, int32
     if (median < best_median) { best_median = median; best = i; }
   }
   *best_idx = best;
+  return ASD_OK;
+}
+
+int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t* set_start, const float* desc, int32_t* best_idx) {
+  if (!ctx || n_sets < 0 || (n_sets > 0 && (!set_start || !desc || !best_idx))) return ASD_ERR_INVALID;
+  if (n_sets == 0) return ASD_OK;
+  if (set_start[0] != 0) { ctx->set_error("asd_distinctive_descriptor_batch: set_start[0] must be 0"); return ASD_ERR_INVALID; }
+  bool any_big = false;
+  for (int s = 0; s < n_sets; ++s) {
+    const int n = set_start[s + 1] - set_start[s];
+    if (n < 1) { ctx->set_error("asd_distinctive_descriptor_batch: set %d is empty", s); return ASD_ERR_INVALID; }
+    any_big |= n > kDistinctMax;
+  }
+  (void)hipSetDevice(ctx->cfg.device);
+  hipStream_t st = ctx->stream;
+  const int total = set_start[n_sets];
+  float* dd = nullptr;
+  int *ds = nullptr, *db = nullptr;
+  auto release = [&] { if (dd) (void)hipFree(dd); if (ds) (void)hipFree(ds); if (db) (void)hipFree(db); };
+  hipError_t e = hipMalloc(&dd, (size_t)total * 512);
+  if (e == hipSuccess) e = hipMalloc(&ds, (size_t)(n_sets + 1) * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&db, (size_t)n_sets * sizeof(int));
+  if (e == hipSuccess) e = hipMemcpyAsync(dd, desc, (size_t)total * 512, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(ds, set_start, (size_t)(n_sets + 1) * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)n_sets * sizeof(int), st);
+  if (e == hipSuccess) {
+    static bool attr = false;
+    const size_t lds = (size_t)(kDistinctMax * 132 + kDistinctMax * (kDistinctMax + 1) + kDistinctMax) * sizeof(float);
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    // one launch per run of map points that fit a workgroup (normally a single launch over all of them)
+    for (int s = 0; s < n_sets;) {
+      if (set_start[s + 1] - set_start[s] > kDistinctMax) { ++s; continue; }
+      int r = s;
+      while (r < n_sets && set_start[r + 1] - set_start[r] <= kDistinctMax) ++r;
+      hipLaunchKernelGGL(k_distinctive, dim3(r - s), dim3(256), lds, st, dd, ds + s, db + s);
+      s = r;
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(best_idx, db, (size_t)n_sets * sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  release();
+  if (e != hipSuccess) { ctx->set_error("asd_distinctive_descriptor_batch: %s", hipGetErrorString(e)); return ASD_ERR_HIP; }
+  if (any_big)  // map points with more observations than one workgroup stages: through the all-pairs kernel, one by one
+    for (int s = 0; s < n_sets; ++s) {
+      const int n = set_start[s + 1] - set_start[s];
+      if (n <= kDistinctMax) continue;
+      const int rc = asd_distinctive_descriptor(ctx, desc + (size_t)set_start[s] * 128, n, best_idx + s);
+      if (rc != ASD_OK) return rc;
+    }
   return ASD_OK;
 }
 

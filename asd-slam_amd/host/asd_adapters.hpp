@@ -305,6 +305,19 @@ struct Optimizer {
   }
 };
 
+// MapPoint::ComputeDistinctiveDescriptors for a batch of map points (MapPoint.cc:271-338): observations[s] = the
+// descriptors (128 f32 each) of map point s's observations; returns the chosen observation index per map point
+inline int ComputeDistinctiveDescriptors(Context& c, const std::vector<std::vector<const float*>>& observations, std::vector<int32_t>& best) {
+  std::vector<int32_t> start(observations.size() + 1, 0);
+  for (size_t s = 0; s < observations.size(); ++s) start[s + 1] = start[s] + (int32_t)observations[s].size();
+  std::vector<float> desc((size_t)start.back() * ASD_DESC_DIM);
+  for (size_t s = 0; s < observations.size(); ++s)
+    for (size_t k = 0; k < observations[s].size(); ++k)
+      for (int q = 0; q < ASD_DESC_DIM; ++q) desc[((size_t)start[s] + k) * ASD_DESC_DIM + q] = observations[s][k][q];
+  best.assign(observations.size(), 0);
+  return asd_distinctive_descriptor_batch(c.get(), (int32_t)observations.size(), start.data(), desc.data(), best.data());
+}
+
 // ---- vocabulary / local mapping (ORBVocabulary.h:34, Frame.cc:289-296, LocalMapping.cc:299-519) ---
 // void Frame::ComputeBoW(): BowVector (word id -> weight) and FeatureVector (node id at levelsup = 4 -> keypoints)
 inline int ComputeBoW(Context& c, const FrameView& F, std::vector<std::pair<int32_t, double>>& mBowVec, ORBmatcher::FeatVec& mFeatVec,

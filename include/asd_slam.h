@@ -169,6 +169,11 @@ int asd_dist_matrix(asd_ctx* ctx, const float* a, int32_t na, const float* b, in
  * n observations' descriptors [n][128] -> index of the descriptor with the least median
  * distance to the others. */
 int asd_distinctive_descriptor(asd_ctx* ctx, const float* desc, int32_t n, int32_t* best_idx);
+/* The same for many map points in one call (LocalMapping::ProcessNewKeyFrame / SearchInNeighbors update hundreds
+ * per keyframe, LocalMapping.cc:245, 535, 628): set s holds the observation descriptors
+ * desc[set_start[s] .. set_start[s+1]) (row-major [.][128], set_start[0] = 0); best_idx[s] = index inside set s. */
+int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t* set_start, const float* desc,
+                                     int32_t* best_idx);
 
 /* M1: ORBmatcher::SearchByProjection(Frame& cur, const Frame& last, th, bMono=true)
  * (ORBmatcher.cc:1318-1452).  Inputs mirror what the method reads:

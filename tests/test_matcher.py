@@ -444,3 +444,25 @@ def test_fuse_search(hip, oracle, synth, n_mp, th):
     assert (gi[valid == 0] == -1).all()
     if n_mp > 1000:
         assert (gi >= 0).sum() > 0.3 * n_mp
+
+
+@pytest.mark.gpu
+def test_distinctive_descriptor_batch(hip, oracle, synth):
+    """many map points in one call: same pick as MapPoint::ComputeDistinctiveDescriptors per point, including sets
+    larger than one workgroup stages (> 64 observations), singletons, pairs and exact duplicates (median ties)"""
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 3, 2, 30, 64, 65, 7, 100, 5, 64, 1] + list(rng.integers(1, 40, 300))
+    base = synth.unit_descriptors(len(sizes), seed=78)
+    sets = []
+    for k, n in enumerate(sizes):
+        d = perturbed_descriptors(np.repeat(base[k:k + 1], n, 0), 0.08, 79 + k)
+        if n >= 4 and k % 5 == 0:
+            d[1] = d[0]                       # identical observations -> equal rows / medians
+            d[3] = d[2]
+        sets.append(d)
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    got = hip.distinctive_descriptor_batch(start, np.concatenate(sets))
+    exp = np.array([oracle.distinctive_descriptor(d) for d in sets], np.int32)
+    np.testing.assert_array_equal(got, exp)
+    with pytest.raises(Exception):
+        hip.distinctive_descriptor_batch(np.array([0, 3, 3], np.int32), np.concatenate(sets)[:3])   # empty set

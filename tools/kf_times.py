@@ -111,6 +111,17 @@ def main():
     assert hip.distinctive_descriptor(obs) == orc.distinctive_descriptor(obs)
     out["distinctive_descriptor"] = dict(gpu_ms=timeit(lambda: hip.distinctive_descriptor(obs), a.reps),
                                          cpu_ms=timeit(lambda: orc.distinctive_descriptor(obs), a.cpu_reps), note="30 observations")
+    # the same for a keyframe's worth of updated map points in one call
+    rng = np.random.default_rng(9)
+    sizes = rng.integers(2, 16, 600)
+    sets = [perturbed_descriptors(np.repeat(dc[k:k + 1], n, 0), 0.05, 100 + k) for k, n in enumerate(sizes)]
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    alld = np.concatenate(sets)
+    exp = [orc.distinctive_descriptor(d) for d in sets]
+    assert np.array_equal(hip.distinctive_descriptor_batch(start, alld), exp)
+    out["distinctive_descriptor_batch"] = dict(gpu_ms=timeit(lambda: hip.distinctive_descriptor_batch(start, alld), a.reps),
+                                               cpu_ms=timeit(lambda: [orc.distinctive_descriptor(d) for d in sets], a.cpu_reps),
+                                               note=f"600 map points, {int(sizes.sum())} observations, one call")
     for v in out.values():
         v["gpu_ms"] = round(v["gpu_ms"], 4)
         v["cpu_ms"] = round(v["cpu_ms"], 4)
