@@ -283,6 +283,42 @@ class AsdHip:
                                                     C.c_float(nn_ratio), _p(out), C.byref(n)))
         return out, n.value
 
+    def match_project_keyframe(self, slot_cur, n_cur, valid, Xw, min_dist, max_dist, desc, kf_angle, occupied, Tcw, K, th, orb_dist,
+                               check_ori=True):
+        a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32), _c(desc, np.float32),
+             _c(kf_angle, np.float32), _c(occupied, np.uint8), _c(Tcw, np.float32), _c(K, np.float32)]
+        out = np.empty(n_cur, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_project_keyframe(self.ctx, slot_cur, len(a[0]), *[_p(x) for x in a], C.c_float(th), C.c_float(orb_dist),
+                                                      int(check_ori), _p(out), C.byref(n)))
+        return out, n.value
+
+    def match_project_sim3(self, slot_kf, Scw, valid, Xw, normal, min_dist, max_dist, desc, K, th, matched_kp):
+        a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32),
+             _c(desc, np.float32), _c(K, np.float32)]
+        Scw = _c(Scw, np.float32)
+        mk = _c(matched_kp, np.int32).copy()
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_project_sim3(self.ctx, slot_kf, _p(Scw), len(a[0]), *[_p(x) for x in a], int(th), _p(mk), C.byref(n)))
+        return mk, n.value
+
+    def fuse_search_sim3(self, slot_kf, Scw, valid, Xw, normal, min_dist, max_dist, desc, K, th=3.0):
+        a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32),
+             _c(desc, np.float32), _c(K, np.float32)]
+        Scw = _c(Scw, np.float32)
+        bi, bd = np.empty(len(a[0]), np.int32), np.empty(len(a[0]), np.float32)
+        self._chk(self.lib.asd_fuse_search_sim3(self.ctx, slot_kf, _p(Scw), len(a[0]), *[_p(x) for x in a], C.c_float(th), _p(bi), _p(bd)))
+        return bi, bd
+
+    def match_sim3(self, slot1, slot2, n1, has1, has2, Xw1, Xw2, mind1, maxd1, mind2, maxd2, desc1, desc2, T1w, T2w, s12, R12, t12, K, th):
+        a = [_c(has1, np.uint8), _c(has2, np.uint8)] + [_c(x, np.float32) for x in (Xw1, Xw2, mind1, maxd1, mind2, maxd2, desc1, desc2, T1w, T2w)]
+        R12, t12, K = _c(R12, np.float32), _c(t12, np.float32), _c(K, np.float32)
+        out = np.empty(n1, np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_match_sim3(self.ctx, slot1, slot2, *[_p(x) for x in a], C.c_float(s12), _p(R12), _p(t12), _p(K), C.c_float(th),
+                                          _p(out), C.byref(n)))
+        return out, n.value
+
     def distinctive_descriptor_batch(self, set_start, desc):
         set_start, desc = _c(set_start, np.int32), _c(desc, np.float32)
         out = np.empty(len(set_start) - 1, np.int32)

@@ -841,6 +841,304 @@ int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* 
   return ASD_OK;
 }
 
+// ---- relocalisation / loop-closing variants of the projection searches -----------------------
+// Same split as M1 / M2: the host evaluates the per-point gates in the reference's f32 arithmetic, k_window_search
+// walks the keyframe grid and evaluates the candidates' distances, the host replays best / claim / histogram logic.
+namespace {
+// -Rcw.t()*tcw: gemm with the transpose flag = general path, double accumulation (as Frame.cc:157)
+void centre_gemm_t(const float* R, const float* t, float* Ow) {
+  for (int i = 0; i < 3; ++i) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (double)R[k * 3 + i] * (double)t[k];
+    Ow[i] = (float)(-1.0 * s);
+  }
+}
+// Scw -> Rcw = sRcw / scw, tcw = Scw.col(3) / scw (ORBmatcher.cc:310-313; Mat / scalar = convertTo with a float scale)
+void decompose_sim3(const float* Scw, float* Rcw, float* tcw) {
+  double d = 0;
+  for (int k = 0; k < 3; ++k) d += (double)Scw[k] * (double)Scw[k];
+  const float scw = (float)std::sqrt(d);
+  const float inv = (float)(1.0 / (double)scw);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Rcw[r * 3 + c] = Scw[r * 4 + c] * inv + 0.0f;
+    tcw[r] = Scw[r * 4 + 3] * inv + 0.0f;
+  }
+}
+inline void rot_add(const float* R, const float* t, const float* X, float* out) {
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = R[r * 3 + 0] * X[0] + R[r * 3 + 1] * X[1] + R[r * 3 + 2] * X[2];
+    out[r] = (float)((double)t0 + (double)t[r]);
+  }
+}
+inline float norm3f(const float* p) {
+  return (float)std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
+}
+inline int predict_scale(const asd_ctx* ctx, float maxd_raw, float dist) {  // MapPoint::PredictScale (MapPoint.cc:438-453)
+  int s = (int)std::ceil(std::log(maxd_raw / dist) / std::log(ctx->cfg.scale_factor));
+  if (s < 0) s = 0;
+  else if (s >= ctx->cfg.n_levels) s = ctx->cfg.n_levels - 1;
+  return s;
+}
+// front half shared by the two Scw searches (:300-366, :963-1010)
+bool sim3_project(const asd_ctx* ctx, const AsdFrameSlot& KF, const float* Rcw, const float* tcw, const float* Ow, const float* K,
+                  const float* P, const float* Pn, float mind_raw, float maxd_raw, bool double_invz, float* u, float* v, int* level) {
+  float Pc[3];
+  rot_add(Rcw, tcw, P, Pc);
+  if (Pc[2] < 0.0f) return false;
+  const float invz = double_invz ? (float)(1.0 / Pc[2]) : 1 / Pc[2];
+  *u = K[0] * (Pc[0] * invz) + K[2];
+  *v = K[1] * (Pc[1] * invz) + K[3];
+  if (!(*u >= KF.min_x && *u < KF.max_x && *v >= KF.min_y && *v < KF.max_y)) return false;
+  const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+  const float dist = norm3f(PO);
+  if (dist < 0.8f * mind_raw || dist > 1.2f * maxd_raw) return false;
+  const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+  if (dot < 0.5 * dist) return false;
+  *level = predict_scale(ctx, maxd_raw, dist);
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+// ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, float th, float ORBdist) (:1455-1582)
+int asd_match_project_keyframe(asd_ctx* ctx, int32_t slot_cur, int32_t n_kf, const uint8_t* valid, const float* Xw, const float* min_dist,
+                               const float* max_dist, const float* desc, const float* kf_angle, const uint8_t* occupied, const float* Tcw,
+                               const float* K, float th, float orb_dist, int32_t check_orientation, int32_t* match_cur,
+                               int32_t* n_matches) {
+  AsdFrameSlot* C = slot_of(ctx, slot_cur);
+  if (!C || n_kf < 0 || !Tcw || !K || !match_cur || !n_matches || (C->n > 0 && !occupied) ||
+      (n_kf > 0 && (!valid || !Xw || !min_dist || !max_dist || !desc || !kf_angle)))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  std::fill(match_cur, match_cur + C->n, -1);
+  *n_matches = 0;
+  if (n_kf == 0 || C->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, n_kf);
+  if (rc != ASD_OK) return rc;
+  float Rcw[9], tcw[3], Ow[3];
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+  centre_gemm_t(Rcw, tcw, Ow);
+  for (int i = 0; i < n_kf; ++i) {
+    WinQuery& Q = m->h_queries[i];
+    Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+    if (!valid[i]) continue;
+    const float* P = Xw + 3 * i;
+    float Pc[3];
+    rot_add(Rcw, tcw, P, Pc);
+    const float invzc = 1.0 / Pc[2];
+    const float u = K[0] * Pc[0] * invzc + K[2];
+    const float v = K[1] * Pc[1] * invzc + K[3];
+    if (!(u >= C->min_x && u <= C->max_x && v >= C->min_y && v <= C->max_y)) continue;  // also drops NaN (z == 0)
+    const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    const float dist3D = norm3f(PO);
+    if (dist3D < 0.8f * min_dist[i] || dist3D > 1.2f * max_dist[i]) continue;
+    const int lvl = predict_scale(ctx, max_dist[i], dist3D);
+    Q = WinQuery{u, v, th * ctx->scale[lvl], lvl - 1, lvl + 1, i};
+  }
+  if ((rc = upload_qdesc(ctx, m, desc, n_kf)) != ASD_OK) return rc;
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *C, n_kf, m->d_qdesc, &R)) != ASD_OK) return rc;
+  std::vector<uint8_t> occ(occupied, occupied + C->n);
+  std::vector<int> hist[HISTO];
+  int nmatches = 0;
+  for (int i = 0; i < n_kf; ++i) {
+    if (R.cnt[i] == 0) continue;
+    float best = 256;
+    int best_idx = -1;
+    for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
+      const int j = R.idx[t];
+      if (occ[j]) continue;
+      if (R.dist[t] < best) { best = R.dist[t]; best_idx = j; }
+    }
+    if (best <= orb_dist) {
+      occ[best_idx] = 1;
+      match_cur[best_idx] = i;
+      nmatches++;
+      if (check_orientation) hist[rot_bin(kf_angle[i], C->kps[best_idx].angle)].push_back(best_idx);
+    }
+  }
+  if (check_orientation) {
+    int cnt[HISTO], i1, i2, i3;
+    for (int b = 0; b < HISTO; ++b) cnt[b] = (int)hist[b].size();
+    three_maxima(cnt, i1, i2, i3);
+    for (int b = 0; b < HISTO; ++b)
+      if (b != i1 && b != i2 && b != i3)
+        for (int j : hist[b]) { match_cur[j] = -1; nmatches--; }
+  }
+  *n_matches = nmatches;
+  return ASD_OK;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>& vpMatched, int th) (:300-413)
+int asd_match_project_sim3(asd_ctx* ctx, int32_t slot_kf, const float* Scw, int32_t n_mp, const uint8_t* valid, const float* Xw,
+                           const float* normal, const float* min_dist, const float* max_dist, const float* desc, const float* K,
+                           int32_t th, int32_t* matched_kp, int32_t* n_matches) {
+  AsdFrameSlot* KF = slot_of(ctx, slot_kf);
+  if (!KF || !Scw || n_mp < 0 || !K || !n_matches || (KF->n > 0 && !matched_kp) ||
+      (n_mp > 0 && (!valid || !Xw || !normal || !min_dist || !max_dist || !desc)))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  *n_matches = 0;
+  if (n_mp == 0 || KF->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, n_mp);
+  if (rc != ASD_OK) return rc;
+  float Rcw[9], tcw[3], Ow[3];
+  decompose_sim3(Scw, Rcw, tcw);
+  centre_gemm_t(Rcw, tcw, Ow);
+  std::vector<int> pred(n_mp, 0);
+  for (int i = 0; i < n_mp; ++i) {
+    WinQuery& Q = m->h_queries[i];
+    Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+    if (!valid[i]) continue;
+    float u, v;
+    if (!sim3_project(ctx, *KF, Rcw, tcw, Ow, K, Xw + 3 * i, normal + 3 * i, min_dist[i], max_dist[i], false, &u, &v, &pred[i])) continue;
+    Q = WinQuery{u, v, (float)th * ctx->scale[pred[i]], -1, -1, i};
+  }
+  if ((rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *KF, n_mp, m->d_qdesc, &R)) != ASD_OK) return rc;
+  int nmatches = 0;
+  for (int i = 0; i < n_mp; ++i) {
+    if (R.cnt[i] == 0) continue;
+    float best = 256;
+    int best_idx = -1;
+    for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
+      const int j = R.idx[t];
+      if (matched_kp[j] != -1) continue;  // vpMatched[idx] already holds a map point
+      const int lv = KF->kps[j].octave;
+      if (lv < pred[i] - 1 || lv > pred[i]) continue;
+      if (R.dist[t] < best) { best = R.dist[t]; best_idx = j; }
+    }
+    if (best <= TH_LOW) { matched_kp[best_idx] = i; nmatches++; }
+  }
+  *n_matches = nmatches;
+  return ASD_OK;
+}
+
+// ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, float th, vector<MapPoint*>& vpReplacePoint) (:963-1086)
+int asd_fuse_search_sim3(asd_ctx* ctx, int32_t slot_kf, const float* Scw, int32_t n_mp, const uint8_t* valid, const float* Xw,
+                         const float* normal, const float* min_dist, const float* max_dist, const float* desc, const float* K, float th,
+                         int32_t* best_idx, float* best_dist) {
+  AsdFrameSlot* KF = slot_of(ctx, slot_kf);
+  if (!KF || !Scw || n_mp < 0 || !K || (n_mp > 0 && (!valid || !Xw || !normal || !min_dist || !max_dist || !desc || !best_idx || !best_dist)))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  for (int i = 0; i < n_mp; ++i) { best_idx[i] = -1; best_dist[i] = 100.f; }
+  if (n_mp == 0 || KF->n == 0) return ASD_OK;
+  int rc = ensure_queries(ctx, m, n_mp);
+  if (rc != ASD_OK) return rc;
+  float Rcw[9], tcw[3], Ow[3];
+  decompose_sim3(Scw, Rcw, tcw);
+  centre_gemm_t(Rcw, tcw, Ow);
+  std::vector<int> pred(n_mp, 0);
+  for (int i = 0; i < n_mp; ++i) {
+    WinQuery& Q = m->h_queries[i];
+    Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+    if (!valid[i]) continue;
+    float u, v;
+    if (!sim3_project(ctx, *KF, Rcw, tcw, Ow, K, Xw + 3 * i, normal + 3 * i, min_dist[i], max_dist[i], true, &u, &v, &pred[i])) continue;
+    Q = WinQuery{u, v, th * ctx->scale[pred[i]], -1, -1, i};
+  }
+  if ((rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  SearchResult R;
+  if ((rc = window_search(ctx, m, *KF, n_mp, m->d_qdesc, &R, 2)) != ASD_OK) return rc;
+  for (int i = 0; i < n_mp; ++i) {
+    if (R.cnt[i] == 0) continue;
+    float best = 100;
+    int bi = -1;
+    for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
+      const int lv = KF->kps[R.idx[t]].octave;
+      if (lv < pred[i] - 1 || lv > pred[i]) continue;
+      if (R.dist[t] < best) { best = R.dist[t]; bi = R.idx[t]; }
+    }
+    if (best <= TH_LOW) { best_idx[i] = bi; best_dist[i] = best; }
+  }
+  return ASD_OK;
+}
+
+// ORBmatcher::SearchBySim3 (:1090-1314)
+int asd_match_sim3(asd_ctx* ctx, int32_t slot1, int32_t slot2, const uint8_t* has1, const uint8_t* has2, const float* Xw1, const float* Xw2,
+                   const float* min_dist1, const float* max_dist1, const float* min_dist2, const float* max_dist2, const float* desc1,
+                   const float* desc2, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12, const float* K,
+                   float th, int32_t* match12, int32_t* n_matches) {
+  AsdFrameSlot *KF1 = slot_of(ctx, slot1), *KF2 = slot_of(ctx, slot2);
+  if (!KF1 || !KF2 || !T1w || !T2w || !R12 || !t12 || !K || !n_matches || (KF1->n > 0 && (!has1 || !Xw1 || !min_dist1 || !max_dist1 || !desc1 || !match12)) ||
+      (KF2->n > 0 && (!has2 || !Xw2 || !min_dist2 || !max_dist2 || !desc2)))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  *n_matches = 0;
+  std::fill(match12, match12 + KF1->n, -1);
+  if (KF1->n == 0 || KF2->n == 0) return ASD_OK;
+  float R1w[9], t1w[3], R2w[9], t2w[3], sR12[9], sR21[9], t21[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) { R1w[r * 3 + c] = T1w[r * 4 + c]; R2w[r * 3 + c] = T2w[r * 4 + c]; }
+    t1w[r] = T1w[r * 4 + 3]; t2w[r] = T2w[r * 4 + 3];
+  }
+  const float a12 = (float)(double)s12, a21 = (float)(1.0 / (double)s12);  // scaled Mat = convertTo with a float scale
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) { sR12[r * 3 + c] = R12[r * 3 + c] * a12 + 0.0f; sR21[r * 3 + c] = R12[c * 3 + r] * a21 + 0.0f; }
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = sR21[r * 3 + 0] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+    t21[r] = (float)((double)t0 * -1.0);
+  }
+  auto one_way = [&](AsdFrameSlot& A, AsdFrameSlot& B, const uint8_t* has, const float* Xw, const float* mind, const float* maxd,
+                     const float* desc, const float* Raw, const float* taw, const float* sRba, const float* tba, std::vector<int>& out) -> int {
+    int rc = ensure_queries(ctx, m, A.n);
+    if (rc != ASD_OK) return rc;
+    std::vector<int> pred(A.n, 0);
+    for (int i = 0; i < A.n; ++i) {
+      WinQuery& Q = m->h_queries[i];
+      Q = WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
+      if (!has[i]) continue;
+      float pA[3], pB[3];
+      rot_add(Raw, taw, Xw + 3 * i, pA);
+      rot_add(sRba, tba, pA, pB);
+      if (pB[2] < 0.0) continue;
+      const float invz = 1.0 / pB[2];
+      const float u = K[0] * (pB[0] * invz) + K[2], v = K[1] * (pB[1] * invz) + K[3];
+      if (!(u >= B.min_x && u < B.max_x && v >= B.min_y && v < B.max_y)) continue;
+      const float dist3D = norm3f(pB);
+      if (dist3D < 0.8f * mind[i] || dist3D > 1.2f * maxd[i]) continue;
+      pred[i] = predict_scale(ctx, maxd[i], dist3D);
+      Q = WinQuery{u, v, th * ctx->scale[pred[i]], -1, -1, i};
+    }
+    if ((rc = upload_qdesc(ctx, m, desc, A.n)) != ASD_OK) return rc;
+    SearchResult R;
+    if ((rc = window_search(ctx, m, B, A.n, m->d_qdesc, &R)) != ASD_OK) return rc;
+    out.assign(A.n, -1);
+    for (int i = 0; i < A.n; ++i) {
+      if (R.cnt[i] == 0) continue;
+      float best = 100;
+      int bi = -1;
+      for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
+        const int lv = B.kps[R.idx[t]].octave;
+        if (lv < pred[i] - 1 || lv > pred[i]) continue;
+        if (R.dist[t] < best) { best = R.dist[t]; bi = R.idx[t]; }
+      }
+      if (best <= TH_HIGH) out[i] = bi;
+    }
+    return ASD_OK;
+  };
+  std::vector<int> m1, m2;
+  int rc = one_way(*KF1, *KF2, has1, Xw1, min_dist1, max_dist1, desc1, R1w, t1w, sR21, t21, m1);
+  if (rc != ASD_OK) return rc;
+  if ((rc = one_way(*KF2, *KF1, has2, Xw2, min_dist2, max_dist2, desc2, R2w, t2w, sR12, t12, m2)) != ASD_OK) return rc;
+  int found = 0;
+  for (int i1 = 0; i1 < KF1->n; ++i1) {
+    const int i2 = m1[i1];
+    if (i2 >= 0 && m2[i2] == i1) { match12[i1] = i2; ++found; }
+  }
+  *n_matches = found;
+  return ASD_OK;
+}
+
+}  // extern "C"
+
 // MapPoint::mDescriptor rows kept on the device: written when a map point's descriptor changes
 // (MapPoint::ComputeDistinctiveDescriptors, once per keyframe), read by the matchers every frame.
 int asd_bank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* desc) {

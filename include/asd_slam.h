@@ -245,6 +245,44 @@ typedef struct asd_feature_vector {
   const int32_t* idx;
 } asd_feature_vector;
 
+/* ---- relocalisation / loop-closing variants of the projection searches ----
+ * Flat-array forms of the remaining ORBmatcher overloads.  min_dist / max_dist are the raw mfMinDistance /
+ * mfMaxDistance (the 0.8 / 1.2 factors of Get{Min,Max}DistanceInvariance are applied inside), K = fx fy cx cy,
+ * poses row-major 4x4 f32.  Pointer-graph side effects stay with the caller. */
+
+/* ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th,
+ * float ORBdist) (ORBmatcher.cc:1455-1582, Tracking::Relocalization).  Arrays over pKF's keypoints (n_kf):
+ * valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP); kf_angle[i] = pKF->mvKeysUn[i].angle;
+ * occupied[j] = CurrentFrame.mvpMapPoints[j] != NULL on entry.  match_cur[j] = i (pKF's map point assigned to the
+ * current frame's keypoint j) or -1; *n_matches = return value. */
+int asd_match_project_keyframe(asd_ctx* ctx, int32_t slot_cur, int32_t n_kf, const uint8_t* valid, const float* Xw,
+                               const float* min_dist, const float* max_dist, const float* desc, const float* kf_angle,
+                               const uint8_t* occupied, const float* Tcw, const float* K, float th, float orb_dist,
+                               int32_t check_orientation, int32_t* match_cur, int32_t* n_matches);
+
+/* ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+ * vector<MapPoint*>& vpMatched, int th) (:300-413, LoopClosing).  valid[i] = !isBad() && !spAlreadyFound.count(pMP).
+ * matched_kp[j] in/out over pKF's keypoints: -1 = vpMatched[j] is NULL, anything else = occupied on entry; the call
+ * writes the index i of the point it assigns.  *n_matches = return value. */
+int asd_match_project_sim3(asd_ctx* ctx, int32_t slot_kf, const float* Scw, int32_t n_mp, const uint8_t* valid,
+                           const float* Xw, const float* normal, const float* min_dist, const float* max_dist,
+                           const float* desc, const float* K, int32_t th, int32_t* matched_kp, int32_t* n_matches);
+
+/* ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, float th,
+ * vector<MapPoint*>& vpReplacePoint) (:963-1086), search half like asd_fuse_search (no chi2 gate in this overload). */
+int asd_fuse_search_sim3(asd_ctx* ctx, int32_t slot_kf, const float* Scw, int32_t n_mp, const uint8_t* valid,
+                         const float* Xw, const float* normal, const float* min_dist, const float* max_dist,
+                         const float* desc, const float* K, float th, int32_t* best_idx, float* best_dist);
+
+/* ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) (:1090-1314).  Arrays over each keyframe's
+ * keypoints: has[i] = map point present, not bad and not already matched (vbAlreadyMatched1/2); T1w / T2w the
+ * keyframe poses; R12 row-major 3x3, t12[3].  match12[i1] = i2 for mutually consistent pairs, else -1. */
+int asd_match_sim3(asd_ctx* ctx, int32_t slot1, int32_t slot2, const uint8_t* has1, const uint8_t* has2, const float* Xw1,
+                   const float* Xw2, const float* min_dist1, const float* max_dist1, const float* min_dist2,
+                   const float* max_dist2, const float* desc1, const float* desc2, const float* T1w, const float* T2w,
+                   float s12, const float* R12, const float* t12, const float* K, float th, int32_t* match12,
+                   int32_t* n_matches);
+
 /* ---- vocabulary ----
  * ORBVocabulary = TemplatedVocabulary<FSift::TDescriptor, FSift> (ORBVocabulary.h:34).  The tree is handed
  * over as flat arrays indexed by DBoW2 node id (0 = root, as in m_nodes): children of node i are

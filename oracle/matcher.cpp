@@ -573,4 +573,268 @@ void orc_fuse_search(const orc_frame* KF, int n_mp, const uint8_t* valid, const 
   }
 }
 
+
+// ---- relocalisation / loop-closing variants (row M4 of SURVEY 8(a)) ---------------------------------------------
+
+namespace {
+// -Rcw.t()*tcw with the transpose flag on the gemm: general path, double accumulation (Frame.cc:157 idiom)
+void centre_gemm_t(const float* R /*[3][3]*/, const float* t, float* Ow) {
+  for (int i = 0; i < 3; ++i) {
+    double s = 0;
+    for (int k = 0; k < 3; ++k) s += (double)R[k * 3 + i] * (double)t[k];
+    Ow[i] = (float)(-1.0 * s);
+  }
+}
+// Scw -> Rcw = sRcw / scw, tcw = Scw.col(3) / scw (ORBmatcher.cc:310-313): Mat / scalar = convertTo with float scale
+void decompose_sim3(const float* Scw, float* Rcw, float* tcw) {
+  double d = 0;
+  for (int k = 0; k < 3; ++k) d += (double)Scw[k] * (double)Scw[k];
+  const float scw = (float)std::sqrt(d);
+  const float inv = (float)(1.0 / (double)scw);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Rcw[r * 3 + c] = Scw[r * 4 + c] * inv + 0.0f;
+    tcw[r] = Scw[r * 4 + 3] * inv + 0.0f;
+  }
+}
+inline void rot_add(const float* R, const float* t, const float* X, float* out) {  // R*X + t, gemm small path + MatExpr add
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = R[r * 3 + 0] * X[0] + R[r * 3 + 1] * X[1] + R[r * 3 + 2] * X[2];
+    out[r] = (float)((double)t0 + (double)t[r]);
+  }
+}
+inline int predict_scale(float maxd_raw, float dist, float logsf, int nlevels) {  // MapPoint::PredictScale
+  const float ratio = maxd_raw / dist;
+  int s = (int)std::ceil(std::log(ratio) / logsf);
+  if (s < 0) s = 0;
+  else if (s >= nlevels) s = nlevels - 1;
+  return s;
+}
+inline float norm3f(const float* p) {
+  double nn = 0;
+  for (int k = 0; k < 3; ++k) nn += (double)p[k] * (double)p[k];
+  return (float)std::sqrt(nn);
+}
+}  // namespace
+
+// ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, float th,
+// float ORBdist) (ORBmatcher.cc:1455-1582).  valid[i] = pMP && !isBad() && !sAlreadyFound.count(pMP);
+// occupied_in[j] = CurrentFrame.mvpMapPoints[j] != NULL on entry.  match_cur[j] = index i into pKF's map points.
+int orc_match_project_keyframe(const orc_frame* cur, int n_kf, const uint8_t* valid, const float* Xw, const float* min_dist,
+                               const float* max_dist, const float* desc, const float* kf_angle, const uint8_t* occupied_in,
+                               const float* Tcw, const float* K, float th, float ORBdist, int check_ori, int32_t* match_cur) {
+  int nmatches = 0;
+  float Rcw[9], tcw[3], Ow[3];
+  for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) Rcw[r * 3 + c] = Tcw[r * 4 + c]; tcw[r] = Tcw[r * 4 + 3]; }
+  centre_gemm_t(Rcw, tcw, Ow);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+  std::vector<uint8_t> occ(occupied_in, occupied_in + cur->N);
+  for (int j = 0; j < cur->N; ++j) match_cur[j] = -1;
+  for (int i = 0; i < n_kf; i++) {
+    if (!valid[i]) continue;
+    const float* x3Dw = Xw + 3 * i;
+    float x3Dc[3];
+    rot_add(Rcw, tcw, x3Dw, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = 1.0 / x3Dc[2];
+    const float u = fx * xc * invzc + cx;
+    const float v = fy * yc * invzc + cy;
+    if (u < cur->mnMinX || u > cur->mnMaxX) continue;
+    if (v < cur->mnMinY || v > cur->mnMaxY) continue;
+    const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+    const float dist3D = norm3f(PO);
+    const float maxDistance = 1.2f * max_dist[i], minDistance = 0.8f * min_dist[i];
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const int nPredictedLevel = predict_scale(max_dist[i], dist3D, cur->mfLogScaleFactor, cur->mnScaleLevels);
+    const float radius = th * cur->mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices2 = cur->GetFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+    if (vIndices2.empty()) continue;
+    const float* dMP = desc + (size_t)i * 128;
+    float bestDist = 256;
+    int bestIdx2 = -1;
+    for (size_t k = 0; k < vIndices2.size(); ++k) {
+      const size_t i2 = vIndices2[k];
+      if (occ[i2]) continue;
+      const float dist = DescriptorDistance(dMP, cur->desc.data() + i2 * 128);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= ORBdist) {
+      occ[bestIdx2] = 1;
+      match_cur[bestIdx2] = i;
+      nmatches++;
+      if (check_ori) {
+        float rot = kf_angle[i] - cur->kps[bestIdx2].angle;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == HISTO_LENGTH) bin = 0;
+        rotHist[bin].push_back(bestIdx2);
+      }
+    }
+  }
+  if (check_ori) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { match_cur[rotHist[i][j]] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+// shared front part of the two Scw searches (ORBmatcher.cc:300-366 and :963-1010): returns false if the point is gated out
+static bool sim3_project(const orc_frame* KF, const float* Rcw, const float* tcw, const float* Ow, const float* K, const float* p3Dw,
+                         const float* Pn, float mind_raw, float maxd_raw, bool double_invz, float* u, float* v, int* level) {
+  float p3Dc[3];
+  rot_add(Rcw, tcw, p3Dw, p3Dc);
+  if (p3Dc[2] < 0.0f) return false;
+  const float invz = double_invz ? (float)(1.0 / p3Dc[2]) : 1 / p3Dc[2];  // :993 `1.0/z`, :331 `1/z`
+  const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+  *u = K[0] * x + K[2];
+  *v = K[1] * y + K[3];
+  if (!(*u >= KF->mnMinX && *u < KF->mnMaxX && *v >= KF->mnMinY && *v < KF->mnMaxY)) return false;  // IsInImage
+  const float maxDistance = 1.2f * maxd_raw, minDistance = 0.8f * mind_raw;
+  const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+  const float dist = norm3f(PO);
+  if (dist < minDistance || dist > maxDistance) return false;
+  double dot = 0;
+  for (int k = 0; k < 3; ++k) dot += (double)PO[k] * (double)Pn[k];
+  if (dot < 0.5 * dist) return false;
+  *level = predict_scale(maxd_raw, dist, KF->mfLogScaleFactor, KF->mnScaleLevels);
+  return true;
+}
+
+// ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+// vector<MapPoint*>& vpMatched, int th) (:300-413).  valid[i] = !isBad() && !spAlreadyFound.count(pMP);
+// matched_kp[j] in/out: -1 = vpMatched[j] NULL, >= 0 = index into vpPoints written by this call, -2 = occupied on entry.
+int orc_match_project_sim3(const orc_frame* KF, const float* Scw, int n_mp, const uint8_t* valid, const float* Xw, const float* normal,
+                           const float* min_dist, const float* max_dist, const float* desc, const float* K, int th,
+                           int32_t* matched_kp) {
+  float Rcw[9], tcw[3], Ow[3];
+  decompose_sim3(Scw, Rcw, tcw);
+  centre_gemm_t(Rcw, tcw, Ow);
+  int nmatches = 0;
+  for (int iMP = 0; iMP < n_mp; iMP++) {
+    if (!valid[iMP]) continue;
+    float u, v;
+    int nPredictedLevel;
+    if (!sim3_project(KF, Rcw, tcw, Ow, K, Xw + 3 * iMP, normal + 3 * iMP, min_dist[iMP], max_dist[iMP], false, &u, &v, &nPredictedLevel))
+      continue;
+    const float radius = th * KF->mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KF->GetFeaturesInArea(u, v, radius, -1, -1);
+    if (vIndices.empty()) continue;
+    const float* dMP = desc + (size_t)iMP * 128;
+    float bestDist = 256;
+    int bestIdx = -1;
+    for (size_t k = 0; k < vIndices.size(); ++k) {
+      const size_t idx = vIndices[k];
+      if (matched_kp[idx] != -1) continue;
+      const int kpLevel = KF->kps[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const float dist = DescriptorDistance(dMP, KF->desc.data() + idx * 128);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    if (bestDist <= TH_LOW) { matched_kp[bestIdx] = iMP; nmatches++; }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, float th, vector<MapPoint*>& vpReplacePoint)
+// (:963-1086), search half: best_idx[i] = keypoint of pKF to fuse point i into, -1 = none
+void orc_fuse_search_sim3(const orc_frame* KF, const float* Scw, int n_mp, const uint8_t* valid, const float* Xw, const float* normal,
+                          const float* min_dist, const float* max_dist, const float* desc, const float* K, float th, int32_t* best_idx,
+                          float* best_dist) {
+  float Rcw[9], tcw[3], Ow[3];
+  decompose_sim3(Scw, Rcw, tcw);
+  centre_gemm_t(Rcw, tcw, Ow);
+  for (int iMP = 0; iMP < n_mp; iMP++) {
+    best_idx[iMP] = -1;
+    best_dist[iMP] = 100;
+    if (!valid[iMP]) continue;
+    float u, v;
+    int nPredictedLevel;
+    if (!sim3_project(KF, Rcw, tcw, Ow, K, Xw + 3 * iMP, normal + 3 * iMP, min_dist[iMP], max_dist[iMP], true, &u, &v, &nPredictedLevel))
+      continue;
+    const float radius = th * KF->mvScaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices = KF->GetFeaturesInArea(u, v, radius, -1, -1);
+    if (vIndices.empty()) continue;
+    const float* dMP = desc + (size_t)iMP * 128;
+    float bestDist = 100;
+    int bestIdx = -1;
+    for (size_t k = 0; k < vIndices.size(); ++k) {
+      const size_t idx = vIndices[k];
+      const int kpLevel = KF->kps[idx].octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      const float dist = DescriptorDistance(dMP, KF->desc.data() + idx * 128);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    if (bestDist <= TH_LOW) { best_idx[iMP] = bestIdx; best_dist[iMP] = bestDist; }
+  }
+}
+
+// ORBmatcher::SearchBySim3 (:1090-1314).  has1[i] / has2[i]: map point present, not bad, not already matched
+// (vbAlreadyMatched); Xw1 / Xw2 world positions; match12[i1] = i2 of a mutually consistent pair, else -1.
+int orc_match_sim3(const orc_frame* KF1, const orc_frame* KF2, const uint8_t* has1, const uint8_t* has2, const float* Xw1,
+                   const float* Xw2, const float* mind1, const float* maxd1, const float* mind2, const float* maxd2, const float* desc1,
+                   const float* desc2, const float* T1w, const float* T2w, float s12, const float* R12, const float* t12, const float* K,
+                   float th, int32_t* match12) {
+  float R1w[9], t1w[3], R2w[9], t2w[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) { R1w[r * 3 + c] = T1w[r * 4 + c]; R2w[r * 3 + c] = T2w[r * 4 + c]; }
+    t1w[r] = T1w[r * 4 + 3]; t2w[r] = T2w[r * 4 + 3];
+  }
+  // sR12 = s12*R12 ; sR21 = (1.0/s12)*R12.t() ; t21 = -sR21*t12    (:1105-1107): scaled Mat = convertTo with float scale
+  float sR12[9], sR21[9], t21[3];
+  const float a12 = (float)(double)s12, a21 = (float)(1.0 / (double)s12);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) { sR12[r * 3 + c] = R12[r * 3 + c] * a12 + 0.0f; sR21[r * 3 + c] = R12[c * 3 + r] * a21 + 0.0f; }
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = sR21[r * 3 + 0] * t12[0] + sR21[r * 3 + 1] * t12[1] + sR21[r * 3 + 2] * t12[2];
+    t21[r] = (float)((double)t0 * -1.0);
+  }
+  const int N1 = KF1->N, N2 = KF2->N;
+  std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+  auto one_way = [&](const orc_frame* A, const orc_frame* B, const uint8_t* has, const float* Xw, const float* mind, const float* maxd,
+                     const float* desc, const float* Raw, const float* taw, const float* sRba, const float* tba, std::vector<int>& out) {
+    for (int i = 0; i < A->N; i++) {
+      if (!has[i]) continue;
+      float pA[3], pB[3];
+      rot_add(Raw, taw, Xw + 3 * i, pA);
+      rot_add(sRba, tba, pA, pB);
+      if (pB[2] < 0.0) continue;
+      const float invz = 1.0 / pB[2];
+      const float x = pB[0] * invz, y = pB[1] * invz;
+      const float u = K[0] * x + K[2], v = K[1] * y + K[3];
+      if (!(u >= B->mnMinX && u < B->mnMaxX && v >= B->mnMinY && v < B->mnMaxY)) continue;
+      const float maxDistance = 1.2f * maxd[i], minDistance = 0.8f * mind[i];
+      const float dist3D = norm3f(pB);
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      const int nPredictedLevel = predict_scale(maxd[i], dist3D, B->mfLogScaleFactor, B->mnScaleLevels);
+      const float radius = th * B->mvScaleFactors[nPredictedLevel];
+      const std::vector<size_t> vIndices = B->GetFeaturesInArea(u, v, radius, -1, -1);
+      if (vIndices.empty()) continue;
+      const float* dMP = desc + (size_t)i * 128;
+      float bestDist = 100;
+      int bestIdx = -1;
+      for (size_t k = 0; k < vIndices.size(); ++k) {
+        const size_t idx = vIndices[k];
+        const orc_keypoint& kp = B->kps[idx];
+        if (kp.octave < nPredictedLevel - 1 || kp.octave > nPredictedLevel) continue;
+        const float dist = DescriptorDistance(dMP, B->desc.data() + idx * 128);
+        if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+      }
+      if (bestDist <= TH_HIGH) out[i] = bestIdx;
+    }
+  };
+  one_way(KF1, KF2, has1, Xw1, mind1, maxd1, desc1, R1w, t1w, sR21, t21, vnMatch1);
+  one_way(KF2, KF1, has2, Xw2, mind2, maxd2, desc2, R2w, t2w, sR12, t12, vnMatch2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    match12[i1] = -1;
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0 && vnMatch2[idx2] == i1) { match12[i1] = idx2; nFound++; }
+  }
+  return nFound;
+}
+
 }  // extern "C"

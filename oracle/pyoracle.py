@@ -168,6 +168,39 @@ class Oracle:
                                              C.c_float(scale_factor), nlevels, _p(x), _p(ok))
         return x, ok, nok
 
+    def match_project_keyframe(self, cur, valid, Xw, min_dist, max_dist, desc, kf_angle, occupied, Tcw, K, th, orb_dist, check_ori=True):
+        a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32), _c(desc, np.float32),
+             _c(kf_angle, np.float32), _c(occupied, np.uint8), _c(Tcw, np.float32), _c(K, np.float32)]
+        out = np.empty(cur.n, np.int32)
+        self.lib.orc_match_project_keyframe.restype = C.c_int
+        n = self.lib.orc_match_project_keyframe(cur.h, len(a[0]), *[_p(x) for x in a], C.c_float(th), C.c_float(orb_dist), int(check_ori), _p(out))
+        return out, n
+
+    def match_project_sim3(self, kf, Scw, valid, Xw, normal, min_dist, max_dist, desc, K, th, matched_kp):
+        a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32),
+             _c(desc, np.float32), _c(K, np.float32)]
+        Scw = _c(Scw, np.float32)
+        mk = _c(matched_kp, np.int32).copy()
+        self.lib.orc_match_project_sim3.restype = C.c_int
+        n = self.lib.orc_match_project_sim3(kf.h, _p(Scw), len(a[0]), *[_p(x) for x in a], int(th), _p(mk))
+        return mk, n
+
+    def fuse_search_sim3(self, kf, Scw, valid, Xw, normal, min_dist, max_dist, desc, K, th=3.0):
+        a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32),
+             _c(desc, np.float32), _c(K, np.float32)]
+        Scw = _c(Scw, np.float32)
+        bi, bd = np.empty(len(a[0]), np.int32), np.empty(len(a[0]), np.float32)
+        self.lib.orc_fuse_search_sim3(kf.h, _p(Scw), len(a[0]), *[_p(x) for x in a], C.c_float(th), _p(bi), _p(bd))
+        return bi, bd
+
+    def match_sim3(self, kf1, kf2, has1, has2, Xw1, Xw2, mind1, maxd1, mind2, maxd2, desc1, desc2, T1w, T2w, s12, R12, t12, K, th):
+        a = [_c(has1, np.uint8), _c(has2, np.uint8)] + [_c(x, np.float32) for x in (Xw1, Xw2, mind1, maxd1, mind2, maxd2, desc1, desc2, T1w, T2w)]
+        R12, t12, K = _c(R12, np.float32), _c(t12, np.float32), _c(K, np.float32)
+        out = np.empty(kf1.n, np.int32)
+        self.lib.orc_match_sim3.restype = C.c_int
+        n = self.lib.orc_match_sim3(kf1.h, kf2.h, *[_p(x) for x in a], C.c_float(s12), _p(R12), _p(t12), _p(K), C.c_float(th), _p(out))
+        return out, n
+
     def vocabulary(self, voc, weighting=0, scoring=0):
         return OracleVocabulary(self.lib, voc, weighting, scoring)
 
