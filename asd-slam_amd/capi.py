@@ -319,6 +319,13 @@ class AsdHip:
                                           _p(out), C.byref(n)))
         return out, n.value
 
+    def stereo_match(self, right_ctx, slot_left, slot_right, n_left, mb, mbf):
+        u, d = np.empty(n_left, np.float32), np.empty(n_left, np.float32)
+        n = C.c_int32()
+        self._chk(self.lib.asd_stereo_match(self.ctx, right_ctx.ctx, slot_left, slot_right, C.c_float(mb), C.c_float(mbf), _p(u), _p(d),
+                                            C.byref(n)))
+        return u, d, n.value
+
     def distinctive_descriptor_batch(self, set_start, desc):
         set_start, desc = _c(set_start, np.int32), _c(desc, np.float32)
         out = np.empty(len(set_start) - 1, np.int32)

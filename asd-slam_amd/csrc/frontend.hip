@@ -1031,3 +1031,218 @@ int asd_get_raw_corners(asd_ctx* ctx, int32_t level, int32_t capacity, float* x,
 }
 
 }  // extern "C"
+
+// ---- stereo association -----------------------------------------------------------------------
+// Frame::ComputeStereoMatches (reference Frame.cc:360-535).  Every left keypoint is independent (no claims), so one
+// wave owns one left keypoint: lanes stride over the right keypoints of its row band, evaluate the exact-order
+// descriptor distance, the wave picks the first minimum; then the 11 SAD values of the 11x11 windows on the keypoint's
+// pyramid level are computed by the lanes together (integer arithmetic: exact in any order) and lane 0 does the
+// parabola fit in the reference's f32 operation order.  The median filter over the accepted matches (:517-531) is a
+// sort of <= N pairs and stays on the host.
+namespace {
+
+struct StereoArgs {
+  PyrDev P;
+  const uint8_t *pyr_l, *pyr_r;
+  const float4 *kp_l, *kp_r;     // (x, y, octave bits, -)
+  const float *desc_l, *desc_r;
+  const int *row_start, *row_items;
+  int n_l, n_rows;
+  float maxD, mbf;
+  float scale[ASD_MAX_LEVELS], inv_scale[ASD_MAX_LEVELS];
+  float* u_right; float* depth; int* sad;  // outputs per left keypoint
+};
+
+__global__ __launch_bounds__(256) void k_stereo_match(StereoArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (iL >= a.n_l) return;
+  const float4 kl = a.kp_l[iL];
+  const float uL = kl.x, vL = kl.y;
+  const int levelL = __float_as_int(kl.z);
+  float out_u = -1.0f, out_d = -1.0f;
+  int out_sad = -1;
+  const int row = (int)vL;
+  do {
+    if (row < 0 || row >= a.n_rows) break;
+    const int c0 = a.row_start[row], c1 = a.row_start[row + 1];
+    if (c0 == c1) break;
+    const float minU = uL - a.maxD, maxU = uL;  // minD = 0
+    if (maxU < 0) break;
+    // best right keypoint: strict `<` from TH_HIGH in candidate order == smallest (distance, position)
+    float best = 1.5f;
+    int best_pos = 0x7fffffff;
+    const float4* dl = reinterpret_cast<const float4*>(a.desc_l + (size_t)iL * 128);
+    for (int p = c0 + lane; p < c1; p += 64) {
+      const int iR = a.row_items[p];
+      const float4 kr = a.kp_r[iR];
+      const int oR = __float_as_int(kr.z);
+      if (oR < levelL - 1 || oR > levelL + 1) continue;
+      if (!(kr.x >= minU && kr.x <= maxU)) continue;
+      const float4* dr = reinterpret_cast<const float4*>(a.desc_r + (size_t)iR * 128);
+      float acc = 0.f;
+      for (int k = 0; k < 32; ++k) {
+        const float4 x = dl[k], y = dr[k];
+        float d;
+        d = x.x - y.x; acc = acc + d * d;
+        d = x.y - y.y; acc = acc + d * d;
+        d = x.z - y.z; acc = acc + d * d;
+        d = x.w - y.w; acc = acc + d * d;
+      }
+      if (acc < best) { best = acc; best_pos = p; }  // positions ascend within a lane: first minimum kept
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float ob = __shfl_xor(best, off);
+      const int op = __shfl_xor(best_pos, off);
+      if (ob < best || (ob == best && op < best_pos)) { best = ob; best_pos = op; }
+    }
+    if (!(best < 1.0f) || best_pos == 0x7fffffff) break;  // thOrbDist = int((TH_HIGH + TH_LOW) / 2) = 1 (:366)
+    const int iR = a.row_items[best_pos];
+    const float uR0 = a.kp_r[iR].x;
+    const float sf = a.inv_scale[levelL];
+    const float scaleduL = roundf(uL * sf), scaledvL = roundf(vL * sf), scaleduR0 = roundf(uR0 * sf);
+    const LevelDev Lv = a.P.lv[levelL];
+    const float iniu = scaleduR0 + 5 - 5, endu = scaleduR0 + 5 + 5 + 1;
+    if (iniu < 0 || endu >= Lv.w) break;
+    const int xl = (int)scaleduL, yl = (int)scaledvL, xr = (int)scaleduR0;
+    // 11 x 11 windows: the library's own bounds (the reference relies on cv::Mat range checks throwing)
+    if (xl - 5 < 0 || xl + 5 >= Lv.w || yl - 5 < 0 || yl + 5 >= Lv.h || xr - 10 < 0 || xr + 10 >= Lv.w) break;
+    const uint8_t* L0 = a.pyr_l + Lv.off;
+    const uint8_t* R0 = a.pyr_r + Lv.off;
+    const int cl = L0[yl * Lv.pitch + xl];
+    int sad[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) sad[s] = 0;
+    for (int q = lane; q < 121; q += 64) {
+      const int dy = q / 11 - 5, dx = q % 11 - 5;
+      const int il = (int)L0[(yl + dy) * Lv.pitch + xl + dx] - cl;
+      const uint8_t* rrow = R0 + (yl + dy) * Lv.pitch + xr + dx;
+#pragma unroll
+      for (int s = 0; s < 11; ++s) {
+        const int cr = R0[yl * Lv.pitch + xr + (s - 5)];
+        const int ir = (int)rrow[s - 5] - cr;
+        sad[s] += abs(il - ir);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+      for (int off = 32; off >= 1; off >>= 1) sad[s] += __shfl_xor(sad[s], off);
+    float bestS = 2147483648.0f;  // (float)INT_MAX
+    int bestinc = 0;
+    float vd[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+      vd[s] = (float)sad[s];
+      if (vd[s] < bestS) { bestS = vd[s]; bestinc = s - 5; }
+    }
+    if (bestinc == -5 || bestinc == 5) break;
+    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+    for (int s = 1; s < 10; ++s)
+      if (s - 5 == bestinc) { d1 = vd[s - 1]; d2 = vd[s]; d3 = vd[s + 1]; }
+    const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+    if (deltaR < -1 || deltaR > 1) break;
+    float bestuR = a.scale[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+    float disparity = uL - bestuR;
+    if (disparity >= 0.f && disparity < a.maxD) {
+      if (disparity <= 0) { disparity = 0.01; bestuR = uL - 0.01; }
+      out_d = a.mbf / disparity;
+      out_u = bestuR;
+      out_sad = (int)bestS;
+    }
+  } while (false);
+  if (lane == 0) { a.u_right[iL] = out_u; a.depth[iL] = out_d; a.sad[iL] = out_sad; }
+}
+
+}  // namespace
+
+extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t slot_left, int32_t slot_right, float mb, float mbf,
+                                float* u_right, float* depth, int32_t* n_matched) {
+  if (!ctx_left || !ctx_right || !u_right || !depth || !n_matched || slot_left < 0 || slot_left >= ASD_MAX_FRAMES || slot_right < 0 ||
+      slot_right >= ASD_MAX_FRAMES || !(mb > 0) || !(mbf > 0))
+    return ASD_ERR_INVALID;
+  asd_ctx* ctx = ctx_left;
+  if (ctx_left->cfg.device != ctx_right->cfg.device) { ctx->set_error("asd_stereo_match: both contexts must live on the same device"); return ASD_ERR_INVALID; }
+  FrontendState *fl = ctx_left->fe, *fr = ctx_right->fe;
+  if (!fl || !fr || fl->cfg_w == 0 || fl->cfg_w != fr->cfg_w || fl->cfg_h != fr->cfg_h) {
+    ctx->set_error("asd_stereo_match: extract the left and the right image (same size) on the two contexts first");
+    return ASD_ERR_INVALID;
+  }
+  const AsdFrameSlot &FL = ctx->frames[slot_left], &FR = ctx->frames[slot_right];
+  const int N = FL.n, Nr = FR.n;
+  *n_matched = 0;
+  for (int i = 0; i < N; ++i) { u_right[i] = -1.0f; depth[i] = -1.0f; }
+  if (N == 0 || Nr == 0) return ASD_OK;
+  if (!FL.d_kp || !FR.d_kp) { ctx->set_error("asd_stereo_match: frame slot not set"); return ASD_ERR_INVALID; }
+  (void)hipSetDevice(ctx->cfg.device);
+  hipStream_t st = ctx->stream;
+  // row table (:370-387): right keypoint iR is a candidate for every row within 2 * scale[octave] of its y
+  const int nRows = fl->pyr.lv[0].h;
+  std::vector<int> row_start(nRows + 1, 0);
+  std::vector<int> lo(Nr), hi(Nr);
+  for (int iR = 0; iR < Nr; ++iR) {
+    const float kpY = FR.kps[iR].y, r = 2.0f * ctx->scale[FR.kps[iR].octave];
+    lo[iR] = std::max((int)std::floor(kpY - r), 0);
+    hi[iR] = std::min((int)std::ceil(kpY + r), nRows - 1);
+    for (int y = lo[iR]; y <= hi[iR]; ++y) ++row_start[y + 1];
+  }
+  for (int y = 0; y < nRows; ++y) row_start[y + 1] += row_start[y];
+  std::vector<int> row_items(std::max(row_start[nRows], 1));
+  {
+    std::vector<int> cur(row_start.begin(), row_start.end() - 1);
+    for (int iR = 0; iR < Nr; ++iR)
+      for (int y = lo[iR]; y <= hi[iR]; ++y) row_items[cur[y]++] = iR;  // ascending iR inside a row, like push_back order
+  }
+  int *d_rs = nullptr, *d_ri = nullptr, *d_sad = nullptr;
+  float *d_u = nullptr, *d_d = nullptr;
+  auto release = [&] { for (void* p : {(void*)d_rs, (void*)d_ri, (void*)d_sad, (void*)d_u, (void*)d_d}) if (p) (void)hipFree(p); };
+  hipError_t e = hipMalloc(&d_rs, row_start.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_ri, row_items.size() * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_sad, (size_t)N * sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&d_u, (size_t)N * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&d_d, (size_t)N * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_rs, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ri, row_items.data(), row_items.size() * sizeof(int), hipMemcpyHostToDevice, st);
+  std::vector<int> sad(N);
+  if (e == hipSuccess) {
+    StereoArgs a;
+    a.P = fl->pyr;
+    a.pyr_l = fl->d_pyr; a.pyr_r = fr->d_pyr;
+    a.kp_l = FL.d_kp; a.kp_r = FR.d_kp;
+    a.desc_l = FL.d_desc; a.desc_r = FR.d_desc;
+    a.row_start = d_rs; a.row_items = d_ri;
+    a.n_l = N; a.n_rows = nRows;
+    a.maxD = mbf / mb; a.mbf = mbf;
+    for (int l = 0; l < ASD_MAX_LEVELS; ++l) { a.scale[l] = ctx->scale[l]; a.inv_scale[l] = ctx->inv_scale[l]; }
+    a.u_right = d_u; a.depth = d_d; a.sad = d_sad;
+    // the right pyramid was written on ctx_right's stream: make sure it is complete
+    e = hipStreamSynchronize(ctx_right->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(k_stereo_match, dim3((N + 3) / 4), dim3(256), 0, st, a);
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(u_right, d_u, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(depth, d_d, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(sad.data(), d_sad, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  release();
+  if (e != hipSuccess) { ctx->set_error("asd_stereo_match: %s", hipGetErrorString(e)); return ASD_ERR_HIP; }
+  // median filter on the SAD values (:517-531)
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int i = 0; i < N; ++i)
+    if (sad[i] >= 0) vDistIdx.emplace_back(sad[i], i);
+  if (vDistIdx.empty()) return ASD_OK;
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  int kept = (int)vDistIdx.size();
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; --i) {
+    if (vDistIdx[i].first < thDist) break;
+    u_right[vDistIdx[i].second] = -1;
+    depth[vDistIdx[i].second] = -1;
+    --kept;
+  }
+  *n_matched = kept;
+  return ASD_OK;
+}

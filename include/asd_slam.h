@@ -352,6 +352,16 @@ int asd_triangulate_pairs(asd_ctx* ctx, int32_t slot1, int32_t slot2, int32_t n_
  * (the call at LocalMapping.cc:444); v is [n][4].  Exposed for the parity tests of the SVD itself. */
 int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v);
 
+/* ---- stereo association (dead code in the reference: no stereo Frame constructor survives) ----
+ * Frame::ComputeStereoMatches (Frame.cc:360-535).  The reference keeps two extractors (mpORBextractorLeft / Right,
+ * Frame.h), hence two contexts here: extract the left image on ctx_left and the right image on ctx_right (same size,
+ * same device), put mvKeys + mDescriptors and mvKeysRight + mDescriptorsRight into two frame slots of ctx_left, then
+ * call this before the next extraction overwrites either pyramid.  u_right[N] / depth[N] = mvuRight / mvDepth (-1 =
+ * no stereo match); *n_matched = matches that survive the 1.5 * 1.4 * median SAD filter (:517-531).
+ * mb = baseline in metres, mbf = baseline * fx. */
+int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t slot_left, int32_t slot_right, float mb, float mbf,
+                     float* u_right, float* depth, int32_t* n_matched);
+
 /* ---- optimizer (P1, B1-B5, C1) ------------------------------------------------------- */
 /* Optimizer::PoseOptimization (Optimizer.cc:239-413) on g2o's EdgeSE3ProjectXYZOnlyPose
  * (types_six_dof_expmap.h:194-222, .cpp:372-394) with Levenberg

@@ -354,6 +354,16 @@ class OracleExtractor:
         self.lib.orc_level_image(self.h, level, int(blurred), _p(out))
         return out
 
+    def stereo_match(self, right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+        """Frame::ComputeStereoMatches on the pyramids self (left) and `right` hold after their last extract"""
+        kl, kr = _c(kps_l, KP_DTYPE), _c(kps_r, KP_DTYPE)
+        dl, dr = _c(desc_l, np.float32), _c(desc_r, np.float32)
+        u, d = np.empty(len(kl), np.float32), np.empty(len(kl), np.float32)
+        self.lib.orc_stereo_match.restype = C.c_int
+        n = self.lib.orc_stereo_match(self.h, right.h, _p(kl), _p(dl), len(kl), _p(kr), _p(dr), len(kr), C.c_float(mb), C.c_float(mbf),
+                                      _p(u), _p(d))
+        return u, d, n
+
     def raw_corners(self, level, cap=200000):
         x, y, r = (np.empty(cap, np.float32) for _ in range(3))
         n = self.lib.orc_raw_corners(self.h, level, cap, _p(x), _p(y), _p(r))

@@ -122,6 +122,26 @@ def main():
     out["distinctive_descriptor_batch"] = dict(gpu_ms=timeit(lambda: hip.distinctive_descriptor_batch(start, alld), a.reps),
                                                cpu_ms=timeit(lambda: [orc.distinctive_descriptor(d) for d in sets], a.cpu_reps),
                                                note=f"600 map points, {int(sizes.sum())} observations, one call")
+    # ---- ComputeStereoMatches: two extractor contexts, constant-disparity synthetic pair
+    wide = pkg.synth.scene_frame(1, w=1241 + 96, h=376)
+    left, right = np.ascontiguousarray(wide[:, 32:32 + 1241]), np.ascontiguousarray(wide[:, 44:44 + 1241])
+    layers = pkg.synth.asdnet_weights(0)
+    SL = pkg.capi.AsdHip(n_features=2000, max_width=1241, max_height=376)
+    SR = pkg.capi.AsdHip(n_features=2000, max_width=1241, max_height=376)
+    SL.load_weights(layers); SR.load_weights(layers)
+    kl, dl = (x.copy() for x in SL.extract(left))
+    kr, dr = (x.copy() for x in SR.extract(right))
+    SL.frame_set(0, kl, dl, BOUNDS); SL.frame_set(1, kr, dr, BOUNDS)
+    exl, exr = orc.extractor(2000), orc.extractor(2000)
+    exl.extract(left, want_patches=False); exr.extract(right, want_patches=False)
+    mb, mbf = 0.54, 0.54 * 718.856
+    gu, gz, gn = SL.stereo_match(SR, 0, 1, len(kl), mb, mbf)
+    eu, ez, en = exl.stereo_match(exr, kl, dl, kr, dr, mb, mbf)
+    assert np.array_equal(gu, eu) and np.array_equal(gz, ez) and gn == en
+    out["stereo_match"] = dict(gpu_ms=timeit(lambda: SL.stereo_match(SR, 0, 1, len(kl), mb, mbf), a.reps),
+                               cpu_ms=timeit(lambda: exl.stereo_match(exr, kl, dl, kr, dr, mb, mbf), a.cpu_reps),
+                               note=f"{len(kl)} x {len(kr)} keypoints, {gn} stereo matches")
+    SL.close(); SR.close()
     for v in out.values():
         v["gpu_ms"] = round(v["gpu_ms"], 4)
         v["cpu_ms"] = round(v["cpu_ms"], 4)
