@@ -133,7 +133,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   return ASD_OK;
 }
 
-const char* asd_last_error(const asd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+const char* asd_last_error(const asd_ctx* ctx) { return ctx ? const_cast<asd_ctx*>(ctx)->last_error() : "null context"; }
 
 int asd_get_scale_tables(const asd_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
                          int32_t* fpl) {

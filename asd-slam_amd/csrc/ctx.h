@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -91,13 +92,23 @@ struct asd_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   float ms_asdnet = 0, ms_extract = 0, ms_match = 0, ms_ba = 0;
 
+  // the extraction worker thread reports errors too: the message is written under a lock, and asd_last_error hands
+  // out a copy that stays put until the next call of asd_last_error on this context
+  std::mutex err_mutex;
+  std::string err_returned;
   void set_error(const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    std::lock_guard<std::mutex> l(err_mutex);
     err = buf;
+  }
+  const char* last_error() {
+    std::lock_guard<std::mutex> l(err_mutex);
+    err_returned = err;
+    return err_returned.c_str();
   }
 };
 
