@@ -126,25 +126,41 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         for (int k = 0; k < 4; ++k) pin[j * 36 + x0 + k + 1] = d[k] / sd;
     }
     __syncthreads();
-    // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding)
+    // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding).
+    // item = (pixel, quad of 4 couts); NTH is a multiple of 8, so a thread keeps the same quad for all its items and
+    // holds that quad's 36 weights + 4 biases in registers (they were 40 LDS reads per item before)
     constexpr int NPIX = C::INROWS * C::INCOLS;
-    if (!(ABL & 1))
-    for (int item = t; item < NPIX * 8; item += NTH) {
-      const int q = item & 7, pix = item >> 3;
-      const int i = pix % C::INCOLS, j = pix / C::INCOLS;
-      const int oy = r0 - 1 + j, ox = i - 1;
-      f32x4 r = {0.f, 0.f, 0.f, 0.f};
-      if (oy >= 0 && oy < 32 && ox >= 0 && ox < 32) {
-        float a[9];
-        for (int ky = 0; ky < 3; ++ky)
-          for (int kx = 0; kx < 3; ++kx) a[ky * 3 + kx] = pin[(j + ky) * 36 + ox + kx];  // pin row j <-> image row oy-1
-        for (int c = 0; c < 4; ++c) {
-          float acc1 = wsh[288 + 4 * q + c];
-          for (int k = 0; k < 9; ++k) acc1 += a[k] * wsh[(4 * q + c) * 9 + k];
-          r[c] = acc1 > 0.f ? acc1 : 0.f;
-        }
+    static_assert(NTH % 8 == 0, "a thread must keep its cout quad across items");
+    if (!(ABL & 1)) {
+      const int q = t & 7;
+      float wq[4][9], bq[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bq[c] = wsh[288 + 4 * q + c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wq[c][k] = wsh[(4 * q + c) * 9 + k];
       }
-      *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + 4 * q) = r;
+      for (int item = t; item < NPIX * 8; item += NTH) {
+        const int pix = item >> 3;
+        const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+        const int oy = r0 - 1 + j, ox = i - 1;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (oy >= 0 && oy < 32 && ox >= 0 && ox < 32) {
+          float a[9];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a[ky * 3 + kx] = pin[(j + ky) * 36 + ox + kx];  // pin row j <-> image row oy-1
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float acc1 = bq[c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc1 += a[k] * wq[c][k];
+            r[c] = acc1 > 0.f ? acc1 : 0.f;
+          }
+        }
+        *reinterpret_cast<f32x4*>(sact + pix * C::CPAD + 4 * q) = r;
+      }
     }
   } else {
     const float* inp = static_cast<const float*>(in_) + (size_t)patch * HIN * HIN * CIN;
