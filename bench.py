@@ -345,7 +345,9 @@ def main():
     pkg = graft.load_package()
     dist = Dist(world)
     wl = Workload(pkg.synth, seed_offset=rank)
-    be = HipBackend(pkg, wl, device=local_rank if world > 1 else 0, pipeline=not args.no_pipeline)
+    # ASD_BENCH_DEVICE pins every rank to one device: rehearsal of the N > 1 path on a single-GPU box only
+    device = int(os.environ["ASD_BENCH_DEVICE"]) if "ASD_BENCH_DEVICE" in os.environ else (local_rank if world > 1 else 0)
+    be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
 
     last, _ = run_steps(be, wl, 0, args.warmup, None, prefetch_beyond=True)            # untimed warm-up
     be.hip.profile_enable(True)
@@ -396,7 +398,7 @@ def main():
             "asdnet_layers": layers,
             "last_step": stats,
         }
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             cb = CpuBackend(pkg, wl)
             nf = args.cpu_frames
             cl, _ = run_steps(cb, wl, 0, 1, None)        # one untimed frame (torch warm-up, page-in)
