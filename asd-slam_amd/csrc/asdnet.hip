@@ -85,13 +85,6 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
   const int patch = (blockIdx.x / BANDS) * PP, band = blockIdx.x % BANDS;  // first patch of this workgroup
   const int r0 = band * ROWS;
 
-#ifdef ASD_DESYNC
-  // experiment: de-phase the first generation of workgroups by quarters of a workgroup lifetime
-  if (blockIdx.x < ASD_DESYNC_FIRST) {
-    const int q = (blockIdx.x * 2654435761u >> 20) & 3;
-    for (int i = 0; i < q * ASD_DESYNC; ++i) __builtin_amdgcn_s_sleep(100);
-  }
-#endif
   if constexpr (FUSE1) {
     static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1 && PP == 1), "conv1 fusion is for conv2 only");
     // extra LDS behind the weight ring: normalised input rows r0-2 .. r0+ROWS+1 (34 wide, zero padded),

@@ -159,3 +159,43 @@ def test_match_sim3(hip, oracle, synth):
     ok = g >= 0
     inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
     assert (g[ok] == inv[np.nonzero(ok)[0]]).mean() > 0.95
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs_do_not_crash(hip, synth):
+    """empty keyframes / empty point lists / frames without keypoints return cleanly through every newer entry point"""
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    kc, dc = make_frame(50, 601)
+    empty_k, empty_d = kc[:0], dc[:0]
+    hip.frame_set(6, kc, dc, BOUNDS)
+    hip.frame_set(7, empty_k, empty_d, BOUNDS)
+    z3, z1, zd = np.zeros((0, 3), np.float32), np.zeros(0, np.float32), np.zeros((0, 128), np.float32)
+    zu = np.zeros(0, np.uint8)
+    # no candidate points
+    m, n = hip.match_project_keyframe(6, len(kc), zu, z3, z1, z1, zd, z1, np.zeros(len(kc), np.uint8), T, K, 10.0, 1.0, True)
+    assert n == 0 and (m == -1).all()
+    mk, n = hip.match_project_sim3(6, T, zu, z3, z3, z1, z1, zd, K, 4, np.full(len(kc), -1, np.int32))
+    assert n == 0 and (mk == -1).all()
+    bi, bd = hip.fuse_search_sim3(6, T, zu, z3, z3, z1, z1, zd, K, 3.0)
+    assert len(bi) == 0
+    bi, bd = hip.fuse_search(6, zu, z3, z3, z1, z1, zd, T, K, 3.0)
+    assert len(bi) == 0
+    # keyframe without keypoints
+    mp = _map_points_for(kc, dc, T, K, 30, 602)
+    bi, bd = hip.fuse_search(7, mp["valid"], mp["Xw"], mp["normal"], mp["mind"], mp["maxd"], mp["desc"], T, K, 3.0)
+    assert (bi == -1).all()
+    mk, n = hip.match_project_sim3(7, T, mp["valid"], mp["Xw"], mp["normal"], mp["mind"], mp["maxd"], mp["desc"], K, 4, np.zeros(0, np.int32))
+    assert n == 0
+    m12, n = hip.match_sim3(6, 7, len(kc), np.ones(len(kc), np.uint8), zu, np.zeros((len(kc), 3), np.float32), z3,
+                            np.ones(len(kc), np.float32), np.ones(len(kc), np.float32), z1, z1, dc, zd, T, T, 1.0, np.eye(3, dtype=np.float32),
+                            np.zeros(3, np.float32), K, 7.5)
+    assert n == 0 and (m12 == -1).all()
+    # points on the camera plane (z == 0) and behind it are gated, not propagated as NaN
+    X0 = np.zeros((4, 3), np.float32)
+    X0[:, 2] = [0.0, -5.0, 0.0, 1e-30]
+    Xw0 = (X0 - T[:3, 3]) @ T[:3, :3]                       # camera-frame coordinates X0
+    ones = np.ones(4, np.float32)
+    m, n = hip.match_project_keyframe(6, len(kc), np.ones(4, np.uint8), Xw0.astype(np.float32), ones * 0.1, ones * 100, dc[:4], ones,
+                                      np.zeros(len(kc), np.uint8), T, K, 10.0, 1.0, False)
+    assert n == (m >= 0).sum()
