@@ -1,0 +1,40 @@
+// test_replay_io.cpp -- command-line probe for replay_io.hpp, driven by tests/test_replay_io.py (CPU only).
+//   test_replay_io cam <file> | imginfo <file> | images <sequence dir> | tum <t> <16 Tcw floats> | kftum <t> <16 Tcw floats> | pgm <file>
+#include <cstdio>
+#include <cstring>
+
+#include "replay_io.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  const std::string cmd = argv[1];
+  if (cmd == "cam") {
+    asd::CamInfo c;
+    if (!asd::ReadCamInfo(argv[2], c)) return 1;
+    printf("%.10g %.10g %.10g %.10g %.10g %.10g %.10g %.10g %d", c.fx, c.fy, c.cx, c.cy, c.distort[0], c.distort[1], c.distort[2], c.distort[3], (int)c.has_Tbc);
+    for (int k = 0; k < 12; ++k) printf(" %.10g", c.Tbc[k]);
+    printf("\n");
+  } else if (cmd == "imginfo") {
+    int w, h, lv, cnt; float sc;
+    if (!asd::ReadImageInfo(argv[2], w, h, sc, lv, cnt)) return 1;
+    printf("%d %d %d %.6g %d\n", w, h, cnt, sc, lv);
+  } else if (cmd == "images") {
+    std::vector<std::string> files; std::vector<double> times;
+    if (!asd::LoadImages(argv[2], files, times)) return 1;
+    for (size_t i = 0; i < files.size(); ++i) printf("%.9f %s\n", times[i], files[i].c_str());
+  } else if ((cmd == "tum" || cmd == "kftum") && argc == 19) {
+    float T[16], t[3], q[4];
+    for (int k = 0; k < 16; ++k) T[k] = (float)atof(argv[3 + k]);
+    asd::TcwToTumPose(T, t, q);
+    printf("%s\n", (cmd == "tum" ? asd::TumLine(atof(argv[2]), t, q) : asd::TumKeyFrameLine(atof(argv[2]), t, q)).c_str());
+  } else if (cmd == "pgm") {
+    std::vector<uint8_t> px; int w, h;
+    if (!asd::ReadPGM(argv[2], px, w, h)) return 1;
+    unsigned long long s = 0;
+    for (uint8_t v : px) s += v;
+    printf("%d %d %llu\n", w, h, s);
+  } else {
+    return 2;
+  }
+  return 0;
+}
