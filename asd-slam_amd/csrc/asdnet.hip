@@ -438,8 +438,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 // One workgroup = 32 patches x 128 couts x (8192 / SK) k; wave w owns couts [32w, 32w+32), so
 // every weight element is used by exactly one wave: B goes global -> VGPR, only A through LDS.
 // ------------------------------------------------------------------------------------------
-constexpr int FC_SK = 8;
-constexpr int FC_KCH = 128;
+#ifndef ASD_FC_SK
+#define ASD_FC_SK 16
+#endif
+#ifndef ASD_FC_KCH
+#define ASD_FC_KCH 128
+#endif
+constexpr int FC_SK = ASD_FC_SK;    // split-K factor: (n / 32) x FC_SK workgroups
+constexpr int FC_KCH = ASD_FC_KCH;  // k-chunk staged in LDS per step
 __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, const float* __restrict__ wimg,
                                                  float* __restrict__ part, int n, int npad) {
   __shared__ __attribute__((aligned(16))) float sa[32 * (FC_KCH + 4)];
@@ -646,7 +652,11 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(3);
   ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);
+#ifdef L5_P_CFG  // tuning: conv5 through the persistent double-buffered kernel
+  ASD_HIP_CHECK(ctx, (launch_conv_p<L5_P_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n, ctx->num_cu)));
+#else
   ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
+#endif
   PROF_MARK(5);
   ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
   PROF_MARK(6);
