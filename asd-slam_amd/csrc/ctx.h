@@ -19,6 +19,30 @@
     }                                                                                     \
   } while (0)
 
+// Grow-only device buffer.  asd_ctx::scratch is the per-call workspace of entry points that need temporary device
+// arrays (one API call at a time per context, so one arena is enough); carve() hands out 256-B aligned pieces.
+struct AsdDevBuf {
+  void* p = nullptr;
+  size_t cap = 0, used = 0;
+  hipError_t reserve(size_t bytes) {
+    used = 0;
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    const hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  template <typename T> T* carve(size_t count) {
+    char* q = static_cast<char*>(p) + used;
+    used += (count * sizeof(T) + 255) / 256 * 256;
+    return reinterpret_cast<T*>(q);
+  }
+  static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = used = 0; }
+};
+
 struct AsdFrameSlot {
   int n = 0;
   float min_x = 0, max_x = 0, min_y = 0, max_y = 0;
@@ -72,6 +96,9 @@ struct asd_ctx {
 
   // ---- BA scratch (lazily grown)
   void* ba = nullptr;
+
+  // ---- per-call device workspace (see AsdDevBuf)
+  AsdDevBuf scratch;
 
   // ---- local-mapping scratch (state private to mapping.hip)
   void* mapping = nullptr;

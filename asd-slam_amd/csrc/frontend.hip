@@ -1193,14 +1193,13 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
     for (int iR = 0; iR < Nr; ++iR)
       for (int y = lo[iR]; y <= hi[iR]; ++y) row_items[cur[y]++] = iR;  // ascending iR inside a row, like push_back order
   }
-  int *d_rs = nullptr, *d_ri = nullptr, *d_sad = nullptr;
-  float *d_u = nullptr, *d_d = nullptr;
-  auto release = [&] { for (void* p : {(void*)d_rs, (void*)d_ri, (void*)d_sad, (void*)d_u, (void*)d_d}) if (p) (void)hipFree(p); };
-  hipError_t e = hipMalloc(&d_rs, row_start.size() * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&d_ri, row_items.size() * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&d_sad, (size_t)N * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&d_u, (size_t)N * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&d_d, (size_t)N * sizeof(float));
+  hipError_t e = ctx->scratch.reserve(AsdDevBuf::padded(row_start.size() * sizeof(int)) + AsdDevBuf::padded(row_items.size() * sizeof(int)) +
+                                      3 * AsdDevBuf::padded((size_t)N * sizeof(float)));
+  int* d_rs = ctx->scratch.carve<int>(row_start.size());
+  int* d_ri = ctx->scratch.carve<int>(row_items.size());
+  int* d_sad = ctx->scratch.carve<int>(N);
+  float* d_u = ctx->scratch.carve<float>(N);
+  float* d_d = ctx->scratch.carve<float>(N);
   if (e == hipSuccess) e = hipMemcpyAsync(d_rs, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_ri, row_items.data(), row_items.size() * sizeof(int), hipMemcpyHostToDevice, st);
   std::vector<int> sad(N);
@@ -1226,7 +1225,6 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
   if (e == hipSuccess) e = hipMemcpyAsync(depth, d_d, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipMemcpyAsync(sad.data(), d_sad, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  release();
   if (e != hipSuccess) { ctx->set_error("asd_stereo_match: %s", hipGetErrorString(e)); return ASD_ERR_HIP; }
   // median filter on the SAD values (:517-531)
   std::vector<std::pair<int, int>> vDistIdx;

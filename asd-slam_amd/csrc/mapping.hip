@@ -309,9 +309,9 @@ int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v) {
   if (!ctx || n < 0 || (n > 0 && (!A || !v))) return ASD_ERR_INVALID;
   if (n == 0) return ASD_OK;
   (void)hipSetDevice(ctx->cfg.device);
-  float *dA = nullptr, *dv = nullptr;
-  ASD_HIP_CHECK(ctx, hipMalloc(&dA, (size_t)n * 16 * sizeof(float)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&dv, (size_t)n * 4 * sizeof(float)));
+  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)n * 64) + AsdDevBuf::padded((size_t)n * 16)));
+  float* dA = ctx->scratch.carve<float>((size_t)n * 16);
+  float* dv = ctx->scratch.carve<float>((size_t)n * 4);
   hipStream_t st = ctx->stream;
   hipError_t e = hipMemcpyAsync(dA, A, (size_t)n * 16 * sizeof(float), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) {
@@ -319,7 +319,6 @@ int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v) {
     e = hipMemcpyAsync(v, dv, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, st);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(dA); (void)hipFree(dv);
   if (e != hipSuccess) { ctx->set_error("asd_svd4_null: %s", hipGetErrorString(e)); return ASD_ERR_HIP; }
   return ASD_OK;
 }

@@ -531,10 +531,12 @@ int asd_dist_matrix(asd_ctx* ctx, const float* a, int32_t na, const float* b, in
   if (na == 0 || nb == 0) return ASD_OK;
   (void)hipSetDevice(ctx->cfg.device);
   float *da = nullptr, *db = nullptr, *dout = nullptr;
-  ASD_HIP_CHECK(ctx, hipMalloc(&da, (size_t)na * 512));
-  ASD_HIP_CHECK(ctx, hipMalloc(&db, (size_t)nb * 512));
-  ASD_HIP_CHECK(ctx, hipMalloc(&dout, (size_t)na * nb * sizeof(float)));
   hipStream_t st = ctx->stream;
+  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)na * 512) + AsdDevBuf::padded((size_t)nb * 512) +
+                                          AsdDevBuf::padded((size_t)na * nb * sizeof(float))));
+  da = ctx->scratch.carve<float>((size_t)na * 128);
+  db = ctx->scratch.carve<float>((size_t)nb * 128);
+  dout = ctx->scratch.carve<float>((size_t)na * nb);
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(da, a, (size_t)na * 512, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(db, b, (size_t)nb * 512, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
@@ -544,7 +546,6 @@ int asd_dist_matrix(asd_ctx* ctx, const float* a, int32_t na, const float* b, in
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(out, dout, (size_t)na * nb * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
-  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
   return ASD_OK;
 }
 
@@ -582,12 +583,10 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
   (void)hipSetDevice(ctx->cfg.device);
   hipStream_t st = ctx->stream;
   const int total = set_start[n_sets];
-  float* dd = nullptr;
-  int *ds = nullptr, *db = nullptr;
-  auto release = [&] { if (dd) (void)hipFree(dd); if (ds) (void)hipFree(ds); if (db) (void)hipFree(db); };
-  hipError_t e = hipMalloc(&dd, (size_t)total * 512);
-  if (e == hipSuccess) e = hipMalloc(&ds, (size_t)(n_sets + 1) * sizeof(int));
-  if (e == hipSuccess) e = hipMalloc(&db, (size_t)n_sets * sizeof(int));
+  hipError_t e = ctx->scratch.reserve(AsdDevBuf::padded((size_t)total * 512) + 2 * AsdDevBuf::padded((size_t)(n_sets + 1) * sizeof(int)));
+  float* dd = ctx->scratch.carve<float>((size_t)total * 128);
+  int* ds = ctx->scratch.carve<int>((size_t)n_sets + 1);
+  int* db = ctx->scratch.carve<int>((size_t)n_sets + 1);
   if (e == hipSuccess) e = hipMemcpyAsync(dd, desc, (size_t)total * 512, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(ds, set_start, (size_t)(n_sets + 1) * sizeof(int), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)n_sets * sizeof(int), st);
@@ -607,7 +606,6 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
   }
   if (e == hipSuccess) e = hipMemcpyAsync(best_idx, db, (size_t)n_sets * sizeof(int), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  release();
   if (e != hipSuccess) { ctx->set_error("asd_distinctive_descriptor_batch: %s", hipGetErrorString(e)); return ASD_ERR_HIP; }
   if (any_big)  // map points with more observations than one workgroup stages: through the all-pairs kernel, one by one
     for (int s = 0; s < n_sets; ++s) {
