@@ -1,0 +1,241 @@
+// track_loop.cpp -- the bench's per-frame tracking step as C++ host code over the C ABI.
+//
+// The reference's host side is C++ (Tracking.cc / LocalMapping.cc call ORBextractor, ORBmatcher, Optimizer); bench.py's
+// Python loop adds ~0.25 ms of interpreter and numpy time to a ~2 ms step that a C++ caller would not pay.  This file is
+// the same synthetic tracker step as bench.py's track_step -- extract (read-ahead queue) -> grid / frame slot ->
+// SearchByProjection(frame) -> PoseOptimization -> isInFrustum + SearchByProjection(local map) -> PoseOptimization ->
+// LocalBA every kf_interval frames -- with the same f32 / f64 arithmetic, so both hosts produce identical statistics
+// (tests/test_bench_host.py).  It touches the library only through include/asd_slam.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <vector>
+
+#include "../../include/asd_slam.h"
+
+extern "C" {
+
+typedef struct asd_track_stats {
+  int32_t n_kp, m1, m2, inliers;
+  double ba_chi2;
+  int32_t has_m1, has_m2, has_inliers, has_ba;
+} asd_track_stats;
+
+struct asd_track_handle {
+  asd_ctx* ctx;
+  std::vector<const uint8_t*> d_frames;  // frames resident in HBM (device pointers), cyclic
+  int W, H;
+  float K32[4], T[16], scale32[8];
+  double K64[4], pose0[7], inv_sigma2[8];
+  asd_ba_problem ba;  // pristine problem (host arrays owned by the caller), copied per LocalBA call
+  int kf_interval, lookahead;
+  // state
+  int slot = 0;
+  std::deque<int> pending;  // frame indices of outstanding submissions, oldest first
+  bool have_last = false;
+  std::vector<asd_keypoint> last_kps;  // copies: the previous frame's keypoints (16 B each)
+  int last_slot = 0;
+  // work buffers
+  std::vector<asd_keypoint> kps;
+  std::vector<float> desc_sync;
+  std::vector<float> uv, Xw, Xw2, nrm, dist, maxd, mind, proj, vc;
+  std::vector<uint8_t> has, in_view, occ, outl;
+  std::vector<int32_t> rows, m1, m2, level;
+  std::vector<double> Xd, obs, info;
+  std::vector<double> ba_poses, ba_points, ba_chi2;
+  std::vector<uint8_t> ba_dpos, ba_out1;
+};
+
+asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* const* d_frames, int32_t W, int32_t H, const float* K32,
+                                   const float* T, const double* pose0, const double* inv_sigma2, const float* scale32,
+                                   const asd_ba_problem* ba, int32_t kf_interval, int32_t lookahead) {
+  if (!ctx || n_frames < 1 || !d_frames || !K32 || !T || !pose0 || !inv_sigma2 || !scale32 || !ba || kf_interval < 1 || lookahead < 0 ||
+      lookahead >= ASD_EXTRACT_QUEUE)
+    return nullptr;
+  asd_track_handle* h = new asd_track_handle();
+  h->ctx = ctx;
+  for (int i = 0; i < n_frames; ++i) h->d_frames.push_back(static_cast<const uint8_t*>(d_frames[i]));
+  h->W = W; h->H = H;
+  for (int i = 0; i < 4; ++i) { h->K32[i] = K32[i]; h->K64[i] = (double)K32[i]; }
+  memcpy(h->T, T, sizeof h->T);
+  memcpy(h->pose0, pose0, sizeof h->pose0);
+  memcpy(h->inv_sigma2, inv_sigma2, sizeof h->inv_sigma2);
+  memcpy(h->scale32, scale32, sizeof h->scale32);
+  h->ba = *ba;
+  h->kf_interval = kf_interval; h->lookahead = lookahead;
+  h->kps.resize(1 << 13);
+  h->desc_sync.resize((size_t)(1 << 13) * 128);
+  return h;
+}
+
+void asd_track_destroy(asd_track_handle* h) {
+  if (!h) return;
+  while (!h->pending.empty()) {  // drain: the library still owns those submissions
+    const asd_keypoint* k; const float* d; int32_t n;
+    (void)asd_extract_wait_view(h->ctx, &k, &d, &n);
+    h->pending.pop_front();
+  }
+  delete h;
+}
+
+static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<int>& next, asd_track_stats* st) {
+  asd_ctx* ctx = h->ctx;
+  const int nf = (int)h->d_frames.size();
+  int rc;
+  // ---- ExtractDesc: take the read-ahead result if this frame is the oldest submission, else extract now
+  const asd_keypoint* kps = nullptr;
+  int32_t n = 0;
+  if (!h->pending.empty() && h->pending.front() == t) {
+    const float* d = nullptr;
+    if ((rc = asd_extract_wait_view(ctx, &kps, &d, &n)) != ASD_OK) return rc;
+    h->pending.pop_front();
+  } else {
+    while (!h->pending.empty()) {
+      const asd_keypoint* k; const float* d; int32_t nn;
+      if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
+      h->pending.pop_front();
+    }
+    if ((rc = asd_extract_device(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
+    kps = h->kps.data();
+  }
+  // ---- Frame::AssignFeaturesToGrid + adopt the device-resident descriptors
+  h->slot ^= 1;
+  const int cur = h->slot;
+  if ((rc = asd_frame_set(ctx, cur, kps, nullptr, n, 0.f, (float)h->W, 0.f, (float)h->H)) != ASD_OK) return rc;
+  // ---- read ahead
+  if (h->lookahead > 0) {
+    bool same = h->pending.size() <= next.size();
+    for (size_t i = 0; same && i < h->pending.size(); ++i) same = h->pending[i] == next[i];
+    if (!same) {
+      while (!h->pending.empty()) {
+        const asd_keypoint* k; const float* d; int32_t nn;
+        if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
+        h->pending.pop_front();
+      }
+    }
+    for (size_t i = h->pending.size(); i < next.size(); ++i) {
+      if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
+      h->pending.push_back(next[i]);
+    }
+  }
+  memset(st, 0, sizeof *st);
+  st->n_kp = n;
+  if (h->have_last) {
+    const std::vector<asd_keypoint>& lk = h->last_kps;
+    const int nl = (int)lk.size();
+    const float fx = h->K32[0], fy = h->K32[1], cx = h->K32[2], cy = h->K32[3];
+    // predicted_uv + backproject_identity (depth 20), float32 like the numpy expressions
+    const float z = 1.003f, c3 = (float)(3 * 1.003), c02 = (float)(0.2 * 1.003), depth = 20.0f;
+    h->Xw.resize((size_t)3 * nl);
+    for (int i = 0; i < nl; ++i) {
+      const float u = (lk[i].x - 620.5f) * z + 620.5f - c3;
+      const float v = (lk[i].y - 188.0f) * z + 188.0f - c02;
+      h->Xw[3 * i + 0] = (u - cx) / fx * depth;
+      h->Xw[3 * i + 1] = (v - cy) / fy * depth;
+      h->Xw[3 * i + 2] = depth;
+    }
+    h->has.assign(nl, 1);
+    // map point descriptors: rows 0..nl-1 = the last frame's descriptors, rows nl..2nl-1 the same again
+    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
+    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, nl, nl)) != ASD_OK) return rc;
+    h->rows.resize((size_t)2 * nl);
+    for (int i = 0; i < 2 * nl; ++i) h->rows[i] = i;
+    h->m1.assign(n, -1);
+    int32_t n1 = 0;
+    if ((rc = asd_match_project_frame_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1,
+                                           h->m1.data(), &n1)) != ASD_OK)
+      return rc;
+    st->m1 = n1; st->has_m1 = 1;
+    auto pose_opt = [&](const std::vector<int>& sel, auto point_of, int32_t* ninl) -> int {
+      const int m = (int)sel.size();
+      h->Xd.resize((size_t)3 * m); h->obs.resize((size_t)2 * m); h->info.resize(m); h->outl.resize(m);
+      for (int q = 0; q < m; ++q) {
+        const int j = sel[q];
+        const float* P = point_of(j);
+        for (int k = 0; k < 3; ++k) h->Xd[3 * q + k] = (double)P[k];
+        h->obs[2 * q] = (double)kps[j].x; h->obs[2 * q + 1] = (double)kps[j].y;
+        h->info[q] = h->inv_sigma2[kps[j].octave];
+      }
+      double pose[7];
+      memcpy(pose, h->pose0, sizeof pose);
+      return asd_pose_optimize(ctx, pose, m, h->Xd.data(), h->obs.data(), h->info.data(), h->K64, h->outl.data(), ninl);
+    };
+    std::vector<int> sel;
+    for (int j = 0; j < n; ++j) if (h->m1[j] >= 0) sel.push_back(j);
+    if (sel.size() >= 3) {
+      int32_t ninl = 0;
+      if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, &ninl)) != ASD_OK) return rc;
+    }
+    // local map: the last frame's points plus a jittered copy
+    const int n2p = 2 * nl;
+    h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
+    for (int i = 0; i < nl; ++i)
+      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
+    for (int i = 0; i < n2p; ++i) {
+      const float* P = &h->Xw2[3 * i];
+      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
+      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
+      h->dist[i] = nn;
+      const int lv = lk[i % nl].octave;
+      h->maxd[i] = nn * h->scale32[lv];
+      h->mind[i] = h->maxd[i] / h->scale32[7];
+    }
+    h->in_view.resize(n2p); h->proj.resize((size_t)2 * n2p); h->level.resize(n2p); h->vc.resize(n2p);
+    if ((rc = asd_frustum(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->T, h->K32, 0.5f, h->in_view.data(),
+                          h->proj.data(), h->level.data(), h->vc.data())) != ASD_OK)
+      return rc;
+    h->occ.resize(n);
+    for (int j = 0; j < n; ++j) h->occ[j] = h->m1[j] >= 0;
+    h->m2.assign(n, -1);
+    int32_t n2 = 0;
+    if ((rc = asd_match_project_points_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
+                                            h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2)) != ASD_OK)
+      return rc;
+    st->m2 = n2; st->has_m2 = 1;
+    sel.clear();
+    for (int j = 0; j < n; ++j) if (h->m1[j] >= 0 || h->m2[j] >= 0) sel.push_back(j);
+    if (sel.size() >= 3) {
+      int32_t ninl = 0;
+      if ((rc = pose_opt(sel, [&](int j) { return h->m1[j] >= 0 ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * std::max(h->m2[j], 0)]; }, &ninl)) != ASD_OK)
+        return rc;
+      st->inliers = ninl; st->has_inliers = 1;
+    }
+  }
+  if (do_ba) {
+    const asd_ba_problem& B = h->ba;
+    h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
+    h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);
+    h->ba_chi2.assign(B.n_edges, 0.0); h->ba_dpos.assign(B.n_edges, 0); h->ba_out1.assign(B.n_edges, 0);
+    asd_ba_problem p = B;
+    p.poses = h->ba_poses.data(); p.points = h->ba_points.data();
+    asd_ba_result r;
+    memset(&r, 0, sizeof r);
+    r.edge_chi2 = h->ba_chi2.data(); r.edge_depth_pos = h->ba_dpos.data(); r.edge_outlier1 = h->ba_out1.data();
+    if ((rc = asd_local_ba(ctx, &p, &r)) != ASD_OK) return rc;
+    st->ba_chi2 = r.chi2_second; st->has_ba = 1;
+  }
+  h->last_kps.assign(kps, kps + n);
+  h->last_slot = cur;
+  h->have_last = true;
+  return ASD_OK;
+}
+
+// n frames t0 .. t0+n-1; frames after the last one are read ahead only when the replay continues (prefetch_beyond)
+int asd_track_run(asd_track_handle* h, int32_t t0, int32_t n, int32_t prefetch_beyond, asd_track_stats* stats) {
+  if (!h || n < 0 || !stats) return ASD_ERR_INVALID;
+  std::vector<int> next;
+  for (int i = 0; i < n; ++i) {
+    const int t = t0 + i;
+    next.clear();
+    for (int k = 1; k <= h->lookahead; ++k)
+      if (i + k < n || prefetch_beyond) next.push_back(t + k);
+    const int rc = track_step(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats);
+    if (rc != ASD_OK) return rc;
+  }
+  return ASD_OK;
+}
+
+}  // extern "C"

@@ -121,6 +121,7 @@ class Workload:
         self.pose0[:4] /= np.linalg.norm(self.pose0[:4])
         self.ba = synth.ba_problem(seed=1 + seed_offset)
         self.inv_sigma2 = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float64)
+        self.scale32 = (np.float32(1.2) ** np.arange(8)).astype(np.float32)   # level scale table, f32 like mvScaleFactors
         self.frames = [synth.scene_frame(t + 3 * seed_offset) for t in range(N_FRAMES)]
 
 
@@ -155,8 +156,8 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
         n = Xw2 / np.linalg.norm(Xw2, axis=1, keepdims=True)
         dist = np.linalg.norm(Xw2, axis=1).astype(np.float32)
         lv = np.concatenate([lk["octave"], lk["octave"]])
-        maxd = (dist * (np.float32(1.2) ** lv)).astype(np.float32)
-        mind = (maxd / np.float32(1.2 ** 7)).astype(np.float32)
+        maxd = dist * wl.scale32[lv]            # f32 * f32, mirrored term by term in host/track_loop.cpp
+        mind = maxd / wl.scale32[7]
         fr = be.frustum(cur, Xw2, n.astype(np.float32), mind, maxd, wl.T, wl.K32)
         occ = (m1 >= 0).astype(np.uint8)
         m2, n2 = be.match_points(cur, len(kps), fr, d2, occ, 1.0, 0.8)
@@ -171,6 +172,64 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
         r = be.local_ba(wl.ba)
         stats["ba_chi2"] = float(r["chi2_second"])
     return (kps, desc, cur), stats
+
+
+class asd_track_stats(__import__("ctypes").Structure):
+    _fields_ = [("n_kp", __import__("ctypes").c_int32), ("m1", __import__("ctypes").c_int32), ("m2", __import__("ctypes").c_int32),
+                ("inliers", __import__("ctypes").c_int32), ("ba_chi2", __import__("ctypes").c_double),
+                ("has_m1", __import__("ctypes").c_int32), ("has_m2", __import__("ctypes").c_int32),
+                ("has_inliers", __import__("ctypes").c_int32), ("has_ba", __import__("ctypes").c_int32)]
+
+
+class NativeHost:
+    """The same tracking step as track_step(), run by C++ host code (asd-slam_amd/host/track_loop.cpp -> libasdtrack.so)
+    over the C ABI: the reference's host side is C++, the Python loop costs ~0.25 ms of a ~2 ms step."""
+
+    def __init__(self, pkg, be, wl, pipeline):
+        import ctypes as C
+        self.C = C
+        path = os.path.join(ROOT, "asd-slam_amd", "libasdtrack.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        self.lib = C.CDLL(path)
+        self.lib.asd_track_create.restype = C.c_void_p
+        capi = pkg.capi
+        ba = wl.ba
+        self.keep = [np.ascontiguousarray(ba["poses"], np.float64), np.ascontiguousarray(ba["fixed"], np.uint8),
+                     np.ascontiguousarray(ba["points"], np.float64), np.ascontiguousarray(ba["e_point"], np.int32),
+                     np.ascontiguousarray(ba["e_pose"], np.int32), np.ascontiguousarray(ba["e_obs"], np.float64),
+                     np.ascontiguousarray(ba["e_info"], np.float64)]
+        k = self.keep
+        self.prob = capi.asd_ba_problem(len(k[0]), len(k[2]), len(k[3]), k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data,
+                                        k[3].ctypes.data, k[4].ctypes.data, k[5].ctypes.data, k[6].ctypes.data,
+                                        (C.c_double * 4)(*[float(x) for x in ba["K"]]), 5, 10)
+        frames = (C.c_void_p * len(be.d_frames))(*[f.value for f in be.d_frames])
+        self.h = C.c_void_p(self.lib.asd_track_create(be.hip.ctx, len(be.d_frames), frames, 1241, 376,
+                                                      wl.K32.ctypes.data_as(C.c_void_p), wl.T.ctypes.data_as(C.c_void_p),
+                                                      wl.pose0.ctypes.data_as(C.c_void_p), wl.inv_sigma2.ctypes.data_as(C.c_void_p),
+                                                      wl.scale32.ctypes.data_as(C.c_void_p), C.byref(self.prob), KF_INTERVAL,
+                                                      LOOKAHEAD if pipeline else 0))
+        if not self.h:
+            raise RuntimeError("asd_track_create failed")
+        self.be = be
+
+    def run(self, t0, n, prefetch_beyond):
+        st = asd_track_stats()
+        rc = self.lib.asd_track_run(self.h, t0, n, int(prefetch_beyond), self.C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"asd_track_run failed ({rc}): {self.be.hip.lib.asd_last_error(self.be.hip.ctx).decode()}")
+        out = {"n_kp": st.n_kp}
+        for k in ("m1", "m2", "inliers"):
+            if getattr(st, "has_" + k):
+                out[k] = int(getattr(st, k))
+        if st.has_ba:
+            out["ba_chi2"] = float(st.ba_chi2)
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.asd_track_destroy(self.h)
+            self.h = None
 
 
 class HipBackend:
@@ -243,6 +302,8 @@ class HipBackend:
         return self.hip.local_ba(prob)
 
     def close(self):
+        if getattr(self, "native", None) is not None:
+            self.native.close()      # drains its own read-ahead queue
         self.drain()
         self.hip.close()
 
@@ -298,6 +359,12 @@ class CpuBackend:
 
 
 def run_steps(be, wl, t0, n, last, prefetch_beyond=False):
+    if getattr(be, "native", None) is not None:   # C++ host loop: same step, same statistics
+        return None, be.native.run(t0, n, prefetch_beyond)
+    return run_steps_python(be, wl, t0, n, last, prefetch_beyond)
+
+
+def run_steps_python(be, wl, t0, n, last, prefetch_beyond=False):
     """n frames t0 .. t0+n-1.  The extractions of frames t+1 .. t+LOOKAHEAD are queued during frame t; frames after
     the last one are only read ahead when the replay continues (prefetch_beyond) -- the timed region does, so that
     it starts and ends in the same pipeline state and contains n frames' worth of every stage."""
@@ -333,6 +400,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=15, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--selftest-dist", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
+    ap.add_argument("--host", choices=["cxx", "python"], default="cxx",
+                    help="who drives the per-frame step: C++ host code over the C ABI (default, as in the reference) or the Python loop")
     args = ap.parse_args()
     if args.selftest_dist:
         return selftest_dist(args)
@@ -341,13 +410,21 @@ def main():
     world = max(world, 1)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    graft.build() if not os.path.exists(os.path.join(ROOT, "asd-slam_amd", "libasdhip.so")) else None
+    if not all(os.path.exists(os.path.join(ROOT, "asd-slam_amd", f)) for f in ("libasdhip.so", "libasdtrack.so")):
+        graft.build()
     pkg = graft.load_package()
     dist = Dist(world)
     wl = Workload(pkg.synth, seed_offset=rank)
     # ASD_BENCH_DEVICE pins every rank to one device: rehearsal of the N > 1 path on a single-GPU box only
     device = int(os.environ["ASD_BENCH_DEVICE"]) if "ASD_BENCH_DEVICE" in os.environ else (local_rank if world > 1 else 0)
     be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
+    be.native = None
+    if args.host == "cxx":
+        try:
+            be.native = NativeHost(pkg, be, wl, pipeline=not args.no_pipeline)
+        except (OSError, FileNotFoundError) as e:   # host-side convenience library only: the Python loop drives the same C ABI
+            print(f"bench: C++ host loop unavailable ({e}); using the Python loop", file=sys.stderr)
+            args.host = "python"
 
     last, _ = run_steps(be, wl, 0, args.warmup, None, prefetch_beyond=True)            # untimed warm-up
     be.hip.profile_enable(True)
@@ -389,6 +466,7 @@ def main():
                                    "(24+12 KF, 6000 MP, ~29k edges) every 15 frames",
                        "keypoints": int(stats.get("n_kp", 0)), "kf_interval": KF_INTERVAL,
                        "parallelism": f"replicas x{world} (independent sequences, no collective)",
+                       "host": "C++ host loop over the C ABI (asd-slam_amd/host/track_loop.cpp)" if args.host == "cxx" else "Python loop (ctypes)",
                        "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t)" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

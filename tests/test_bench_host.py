@@ -1,0 +1,52 @@
+"""bench.py's two hosts -- the C++ loop over the C ABI (asd-slam_amd/host/track_loop.cpp) and the Python loop -- run the
+same tracking step: identical per-frame statistics, with and without read-ahead."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    if "asd_bench" in sys.modules:
+        return sys.modules["asd_bench"]
+    spec = importlib.util.spec_from_file_location("asd_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["asd_bench"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pipeline", [True, False])
+def test_cxx_host_equals_python_host(pkg, pipeline):
+    bench = _bench()
+    wl = bench.Workload(pkg.synth)
+    n = bench.KF_INTERVAL + 3          # crosses one LocalBA
+    py = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
+    try:
+        last, ref = None, []
+        for t in range(n):
+            last, st = bench.run_steps_python(py, wl, t, 1, last, prefetch_beyond=True)
+            ref.append(st)
+    finally:
+        py.close()
+    cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
+    cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
+    try:
+        got = [cx.native.run(t, 1, True) for t in range(n)]
+        whole = None
+    finally:
+        cx.close()
+    assert got == ref
+    assert any("ba_chi2" in s for s in got) and got[-1]["m1"] > 500 and got[-1]["inliers"] > 500
+    # one call over the whole range gives the same final state as frame-by-frame calls
+    cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
+    cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
+    try:
+        whole = cx.native.run(0, n, True)
+    finally:
+        cx.close()
+    assert whole == ref[-1]
