@@ -630,6 +630,8 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
   return ASD_OK;
 }
 
+int asdnet_profile_collect_set(asd_ctx* ctx, int set);
+
 int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc) {
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
   if (n < 0 || n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
@@ -638,8 +640,9 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
   const int npad = (n + 31) / 32 * 32;
   const bool prof = ctx->prof_on;
-  if (prof && ctx->prof_pending) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
-#define PROF_MARK(i) do { if (prof) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[i], st)); } while (0)
+  const int pset = ctx->prof_cur;
+  if (prof && ctx->prof_pending[pset]) { int rc = asdnet_profile_collect_set(ctx, pset); if (rc != ASD_OK) return rc; }  // two forwards ago
+#define PROF_MARK(i) do { if (prof) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[pset][i], st)); } while (0)
   PROF_MARK(0);
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
   ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
@@ -667,21 +670,29 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   ASD_HIP_CHECK(ctx, hipGetLastError());
   PROF_MARK(8);
 #undef PROF_MARK
-  if (prof) { ctx->prof_pending = true; ctx->prof_pending_n = n; }
+  if (prof) { ctx->prof_pending[pset] = true; ctx->prof_pending_n[pset] = n; ctx->prof_cur ^= 1; }
+  return ASD_OK;
+}
+
+int asdnet_profile_collect_set(asd_ctx* ctx, int set) {
+  if (!ctx->prof_pending[set]) return ASD_OK;
+  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->prof_ev[set][8]));
+  for (int l = 0; l < 8; ++l) {
+    float ms = 0;
+    ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[set][l], ctx->prof_ev[set][l + 1]));
+    ctx->prof_ms[l] += ms;
+    ctx->prof_calls[l] += 1;
+    ctx->prof_patches[l] += ctx->prof_pending_n[set];
+  }
+  ctx->prof_pending[set] = false;
   return ASD_OK;
 }
 
 int asdnet_profile_collect(asd_ctx* ctx) {
-  if (!ctx->prof_pending) return ASD_OK;
-  ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->prof_ev[8]));
-  for (int l = 0; l < 8; ++l) {
-    float ms = 0;
-    ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[l], ctx->prof_ev[l + 1]));
-    ctx->prof_ms[l] += ms;
-    ctx->prof_calls[l] += 1;
-    ctx->prof_patches[l] += ctx->prof_pending_n;
+  for (int set = 0; set < 2; ++set) {
+    const int rc = asdnet_profile_collect_set(ctx, set);
+    if (rc != ASD_OK) return rc;
   }
-  ctx->prof_pending = false;
   return ASD_OK;
 }
 

@@ -128,7 +128,8 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-  for (int i = 0; i < 9; ++i) if (ctx->prof_ev[i]) (void)hipEventDestroy(ctx->prof_ev[i]);
+  for (int set = 0; set < 2; ++set)
+    for (int i = 0; i < 9; ++i) if (ctx->prof_ev[set][i]) (void)hipEventDestroy(ctx->prof_ev[set][i]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ASD_OK;
@@ -211,9 +212,10 @@ int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms) {
 int asd_profile_enable(asd_ctx* ctx, int32_t on) {
   if (!ctx) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
-  if (on && !ctx->prof_ev[0])
-    for (int i = 0; i < 9; ++i) ASD_HIP_CHECK(ctx, hipEventCreate(&ctx->prof_ev[i]));
-  if (!on && ctx->prof_pending) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
+  if (on && !ctx->prof_ev[0][0])
+    for (int set = 0; set < 2; ++set)
+      for (int i = 0; i < 9; ++i) ASD_HIP_CHECK(ctx, hipEventCreate(&ctx->prof_ev[set][i]));
+  if (!on) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
   ctx->prof_on = on != 0;
   if (on) for (int l = 0; l < 8; ++l) { ctx->prof_ms[l] = 0; ctx->prof_calls[l] = 0; ctx->prof_patches[l] = 0; }
   return ASD_OK;
@@ -221,7 +223,7 @@ int asd_profile_enable(asd_ctx* ctx, int32_t on) {
 
 int asd_profile_get(asd_ctx* ctx, int32_t layer, double* total_ms, int32_t* calls, int64_t* patches) {
   if (!ctx || layer < 0 || layer >= 8 || !total_ms || !calls || !patches) return ASD_ERR_INVALID;
-  if (ctx->prof_pending) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
+  { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
   *total_ms = ctx->prof_ms[layer];
   *calls = ctx->prof_calls[layer];
   *patches = ctx->prof_patches[layer];

@@ -108,9 +108,10 @@ struct asd_ctx {
 
   // ---- per-layer profiling (asd_profile_enable)
   bool prof_on = false;
-  hipEvent_t prof_ev[9] = {};
-  bool prof_pending = false;
-  int prof_pending_n = 0;
+  hipEvent_t prof_ev[2][9] = {};   // two sets: a forward is enqueued while the previous one is still running
+  bool prof_pending[2] = {false, false};
+  int prof_pending_n[2] = {0, 0};
+  int prof_cur = 0;
   double prof_ms[8] = {};
   int prof_calls[8] = {};
   long long prof_patches[8] = {};

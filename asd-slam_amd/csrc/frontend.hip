@@ -883,12 +883,14 @@ static void async_worker(asd_ctx* ctx) {
     int32_t n = 0;
     int rc = extract_front(ctx, next->job, S, ax->stream_f, ax->ev_corners, next->kps.data(), &n);
     next->job.n = n;
+    // queue this frame's ASDNet behind the previous one (same stream: its activation buffers are free by then) BEFORE
+    // waiting for the previous frame, so the matrix cores go from one forward pass straight into the next
+    if (rc == ASD_OK && n > 0) rc = extract_back_enqueue(ctx, S, n, ctx->stream_x);
     if (inflight) {  // the previous frame's ASDNet ran underneath this front half
       finish(inflight);
       inflight = nullptr;
       ax->cv.notify_all();
     }
-    if (rc == ASD_OK && n > 0) rc = extract_back_enqueue(ctx, S, n, ctx->stream_x);
     if (rc != ASD_OK || n == 0) {
       { std::lock_guard<std::mutex> l(ax->m); next->job.rc = rc; next->state = AsyncJob::DONE; }
       ax->cv.notify_all();
