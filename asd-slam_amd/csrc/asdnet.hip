@@ -24,6 +24,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Weight-ring fill by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS at a wave-uniform base + lane * 16)
+// instead of global -> VGPR -> ds_write.  Measured (N = 2000): slower on every layer (conv2 342 -> 357, conv4 314 -> 334,
+// conv5 208 -> 216, conv6 316 -> 322 us) -- the DMA issue slots cost more than the two ds_write_b128 they replace -- so it
+// stays off; kept as a tuning knob.
+#ifndef ASD_RING_DMA
+#define ASD_RING_DMA 0
+#endif
+
 namespace {
 
 struct LayerSpec { int cout, cin, k, stride, pad; };
@@ -226,8 +234,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       const bool pre = s + 2 < C::NSTAGE && !(ABL & 16);
       if (pre) {
         const float* wsrc = wimg + (size_t)(s + 2) * C::WCHUNK;
-        for (int r = 0; r < C::WREGS; ++r)
-          if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
+        if constexpr (ASD_RING_DMA) {
+          float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
+          for (int r = 0; r < C::WREGS; ++r)
+            if (C::WQUADS >= NTH || t < C::WQUADS)
+              __builtin_amdgcn_global_load_lds(wsrc + (r * NTH + t) * 4, swn + (r * NTH + wave * 64) * 4, 16, 0, 0);
+        } else {
+          for (int r = 0; r < C::WREGS; ++r)
+            if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
+        }
       }
       // k-steps of this stage, operands always one step ahead (the last step fetches the next stage's first operands:
       // its ring slot was completed before the previous barrier)
@@ -248,9 +263,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         }
       }
       if (pre) {
-        float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
-        for (int r = 0; r < C::WREGS; ++r)
-          if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+        if constexpr (ASD_RING_DMA) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of stage s+2 has landed before the barrier publishes it
+        } else {
+          float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
+          for (int r = 0; r < C::WREGS; ++r)
+            if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+        }
       }
       if (!(ABL & 8)) __syncthreads();
     }
@@ -259,8 +278,15 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       f32x4 wreg[C::WREGS];
       if (s + 1 < C::NSTAGE && !(ABL & 16)) {
         const float* wsrc = wimg + (size_t)(s + 1) * C::WCHUNK;
-        for (int r = 0; r < C::WREGS; ++r)
-          if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
+        if constexpr (ASD_RING_DMA) {
+          float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
+          for (int r = 0; r < C::WREGS; ++r)
+            if (C::WQUADS >= NTH || t < C::WQUADS)
+              __builtin_amdgcn_global_load_lds(wsrc + (r * NTH + t) * 4, swn + (r * NTH + wave * 64) * 4, 16, 0, 0);
+        } else {
+          for (int r = 0; r < C::WREGS; ++r)
+            if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
+        }
       }
 #pragma unroll
       for (int c8 = 0; c8 < STEPS; ++c8) {
@@ -269,9 +295,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         mfma_step(a, b);
       }
       if (s + 1 < C::NSTAGE && !(ABL & 16)) {
-        float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
-        for (int r = 0; r < C::WREGS; ++r)
-          if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+        if constexpr (ASD_RING_DMA) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+          float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
+          for (int r = 0; r < C::WREGS; ++r)
+            if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
+        }
       }
       if (!(ABL & 8)) __syncthreads();
     }
