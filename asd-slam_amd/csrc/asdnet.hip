@@ -476,19 +476,24 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 #endif
 constexpr int FC_SK = ASD_FC_SK;    // split-K factor: (n / 32) x FC_SK workgroups
 constexpr int FC_KCH = ASD_FC_KCH;  // k-chunk staged in LDS per step
+#ifndef ASD_FC_MT
+#define ASD_FC_MT 1
+#endif
+constexpr int FC_MT = ASD_FC_MT;  // 32-patch tiles per workgroup (2 was measured: no gain over 1, 51 us either way)
 __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, const float* __restrict__ wimg,
                                                  float* __restrict__ part, int n, int npad) {
-  __shared__ __attribute__((aligned(16))) float sa[32 * (FC_KCH + 4)];
+  __shared__ __attribute__((aligned(16))) float sa[FC_MT * 32 * (FC_KCH + 4)];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int h = lane >> 5, li = lane & 31;
-  const int p0 = blockIdx.x * 32, sk = blockIdx.y;
+  const int p0 = blockIdx.x * 32 * FC_MT, sk = blockIdx.y;
   constexpr int KPER = 8192 / FC_SK;
-  f32x16 acc;
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  f32x16 acc[FC_MT];
+  for (int m = 0; m < FC_MT; ++m)
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   for (int st = 0; st < KPER / FC_KCH; ++st) {
     const int k0 = sk * KPER + st * FC_KCH;
     __syncthreads();
-    for (int idx = t; idx < 32 * (FC_KCH / 4); idx += 256) {
+    for (int idx = t; idx < FC_MT * 32 * (FC_KCH / 4); idx += 256) {
       const int c4 = idx % (FC_KCH / 4), row = idx / (FC_KCH / 4);
       int p = p0 + row;
       if (p >= n) p = n - 1;
@@ -499,16 +504,23 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, 
     const float* wb = wimg + ((size_t)(k0 / 8) * 2 + h) * 128 * 4 + (wave * 32 + li) * 4;
 #pragma unroll 4
     for (int c8 = 0; c8 < FC_KCH / 8; ++c8) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(sa + li * (FC_KCH + 4) + c8 * 8 + 4 * h);
       const f32x4 b = *reinterpret_cast<const f32x4*>(wb + (size_t)c8 * 2 * 128 * 4);
+      f32x4 a[FC_MT];
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jj], b[jj], acc, 0, 0, 0);
+      for (int m = 0; m < FC_MT; ++m) a[m] = *reinterpret_cast<const f32x4*>(sa + (m * 32 + li) * (FC_KCH + 4) + c8 * 8 + 4 * h);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int m = 0; m < FC_MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][jj], b[jj], acc[m], 0, 0, 0);
     }
   }
-  float* op = part + ((size_t)sk * npad + p0) * 128;
-  for (int r = 0; r < 16; ++r) {
-    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-    op[(size_t)m * 128 + wave * 32 + li] = acc[r];
+  for (int m = 0; m < FC_MT; ++m) {
+    if (p0 + m * 32 >= npad) break;
+    float* op = part + ((size_t)sk * npad + p0 + m * 32) * 128;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+      op[(size_t)row * 128 + wave * 32 + li] = acc[m][r];
+    }
   }
 }
 
@@ -693,7 +705,7 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(5);
   ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
   PROF_MARK(6);
-  hipLaunchKernelGGL(k_fc_mfma, dim3(npad / 32, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
+  hipLaunchKernelGGL(k_fc_mfma, dim3((npad / 32 + FC_MT - 1) / FC_MT, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   PROF_MARK(7);
   hipLaunchKernelGGL(k_l2norm, dim3((n + 3) / 4), dim3(256), 0, st, ctx->d_part, ctx->d_bias[6], d_desc, n, npad);
