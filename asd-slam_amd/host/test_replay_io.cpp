@@ -1,9 +1,11 @@
 // test_replay_io.cpp -- command-line probe for replay_io.hpp, driven by tests/test_replay_io.py (CPU only).
+//   test_replay_io vocdump <yaml> <out.bin> | vocwrite <in.bin> <yaml> |
 //   test_replay_io cam <file> | imginfo <file> | images <sequence dir> | tum <t> <16 Tcw floats> | kftum <t> <16 Tcw floats> | pgm <file>
 #include <cstdio>
 #include <cstring>
 
 #include "replay_io.hpp"
+#include "voc_io.hpp"
 
 int main(int argc, char** argv) {
   if (argc < 3) return 2;
@@ -33,6 +35,36 @@ int main(int argc, char** argv) {
     unsigned long long s = 0;
     for (uint8_t v : px) s += v;
     printf("%d %d %llu\n", w, h, s);
+  } else if (cmd == "vocdump" && argc == 4) {   // YAML -> flat binary: header ints, then the arrays
+    asd::VocabularyArrays V;
+    std::string err;
+    if (!asd::ReadVocabulary(argv[2], V, &err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    FILE* o = fopen(argv[3], "wb");
+    if (!o) return 1;
+    const int32_t hdr[6] = {V.k, V.L, V.scoring, V.weighting, V.n_nodes, (int32_t)V.child_ids.size()};
+    fwrite(hdr, 4, 6, o);
+    fwrite(V.child_start.data(), 4, V.child_start.size(), o);
+    fwrite(V.child_ids.data(), 4, V.child_ids.size(), o);
+    fwrite(V.word_id.data(), 4, V.word_id.size(), o);
+    fwrite(V.weight.data(), 8, V.weight.size(), o);
+    fwrite(V.desc.data(), 4, V.desc.size(), o);
+    fclose(o);
+  } else if (cmd == "vocwrite" && argc == 4) {  // flat binary -> YAML
+    FILE* in = fopen(argv[2], "rb");
+    if (!in) return 1;
+    int32_t hdr[6];
+    if (fread(hdr, 4, 6, in) != 6) return 1;
+    asd::VocabularyArrays V;
+    V.k = hdr[0]; V.L = hdr[1]; V.scoring = hdr[2]; V.weighting = hdr[3]; V.n_nodes = hdr[4];
+    V.child_start.resize(V.n_nodes + 1); V.child_ids.resize(hdr[5]); V.word_id.resize(V.n_nodes); V.weight.resize(V.n_nodes);
+    V.desc.resize((size_t)V.n_nodes * 128);
+    bool ok = fread(V.child_start.data(), 4, V.child_start.size(), in) == V.child_start.size() &&
+              fread(V.child_ids.data(), 4, V.child_ids.size(), in) == V.child_ids.size() &&
+              fread(V.word_id.data(), 4, V.word_id.size(), in) == V.word_id.size() &&
+              fread(V.weight.data(), 8, V.weight.size(), in) == V.weight.size() &&
+              fread(V.desc.data(), 4, V.desc.size(), in) == V.desc.size();
+    fclose(in);
+    if (!ok || !asd::WriteVocabulary(argv[3], V)) return 1;
   } else {
     return 2;
   }
