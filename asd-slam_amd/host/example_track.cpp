@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <fstream>
 #include <iterator>
+#include <utility>
+#include <vector>
 
 #include "asd_adapters.hpp"
 
@@ -62,9 +64,36 @@ int main(int argc, char** argv) {
     asd::ORBmatcher fuser(ctx);
     std::vector<int32_t> bestIdx;
     const int nfused = fuser.Fuse(F[1], mps, std::vector<uint8_t>(mps.size(), 1), K, bestIdx);
-    printf("kp0=%d kp1=%d matches=%d inliers=%d fused=%d t=(%.4f %.4f %.4f)\n", F[0].N(), F[1].N(), nmatches, ninl, nfused, F[1].mTcw[3],
-           F[1].mTcw[7], F[1].mTcw[11]);
-    return (nmatches > 100 && ninl > 50 && nfused > 0) ? 0 : 1;
+    // Frame::ComputeBoW + SearchByBoW(KeyFrame*, Frame&, ...) (Tracking::TrackReferenceKeyFrame, Tracking.cc:607-620) with a
+    // small random vocabulary standing in for the missing vocabulary file: k = 8, L = 2, node ids breadth-first
+    int nbow = 0;
+    {
+      const int k = 8, L = 2, n_nodes = 1 + k + k * k;
+      std::vector<int32_t> start(n_nodes + 1, 0), kids, word(n_nodes, -1);
+      std::vector<double> weight(n_nodes, 0.0);
+      std::vector<float> d((size_t)n_nodes * 128, 0.f);
+      for (int i = 0; i < n_nodes; ++i) {
+        if (i < 1 + k) for (int c = 0; c < k; ++c) kids.push_back(1 + i * k + c);
+        start[i + 1] = (int32_t)kids.size();
+      }
+      uint32_t seed = 12345u;
+      for (int i = 1; i < n_nodes; ++i) {
+        if (i > k) { word[i] = i - 1 - k; weight[i] = 1.0 + (i % 7); }
+        // children scatter around a real descriptor of frame 0 so that the words are populated
+        const float* base = &F[0].mDescriptors[(size_t)((i * 37) % F[0].N()) * ASD_DESC_DIM];
+        for (int q = 0; q < 128; ++q) { seed = seed * 1664525u + 1013904223u; d[(size_t)i * 128 + q] = base[q] + ((seed >> 8) & 0xffff) * (0.2f / 65536.f) - 0.1f; }
+      }
+      if (asd_voc_load(ctx.get(), n_nodes, k, L, 0, 0, start.data(), kids.data(), weight.data(), word.data(), d.data()) != ASD_OK) { fprintf(stderr, "%s\n", ctx.error()); return 1; }
+      std::vector<std::pair<int32_t, double>> bow0, bow1;
+      asd::ORBmatcher::FeatVec fv0, fv1;
+      if (asd::ComputeBoW(ctx, F[0], bow0, fv0, 1) != ASD_OK || asd::ComputeBoW(ctx, F[1], bow1, fv1, 1) != ASD_OK) { fprintf(stderr, "%s\n", ctx.error()); return 1; }
+      asd::ORBmatcher bowmatcher(ctx, 0.7f, true);                               // Tracking.cc:616
+      std::vector<int32_t> vpMapPointMatches;
+      nbow = bowmatcher.SearchByBoW(F[0], fv0, F[1], fv1, vpMapPointMatches);
+    }
+    printf("kp0=%d kp1=%d matches=%d inliers=%d fused=%d bow=%d t=(%.4f %.4f %.4f)\n", F[0].N(), F[1].N(), nmatches, ninl, nfused, nbow,
+           F[1].mTcw[3], F[1].mTcw[7], F[1].mTcw[11]);
+    return (nmatches > 100 && ninl > 50 && nfused > 0 && nbow > 0) ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "error: %s\n", e.what());
     return 3;
