@@ -464,6 +464,307 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------
+// K1s: the same 3x3 conv + folded BN + ReLU with f32 operands SPLIT into three bf16 terms.
+//
+// Every f32 value is written exactly as x = h + m + l, three bf16 numbers (8 significant bits each, by truncation:
+// h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m, both subtractions exact).  The product of two such
+// values is the sum of nine bf16 x bf16 products, each exact in f32; the six of relative size >= 2^-16
+// (hh, hm, mh, mm, hl, lh) go through v_mfma_f32_32x32x16_bf16 with f32 accumulation, the three dropped ones are
+// <= 2^-23 relative -- below the rounding of an f32 fma chain.  Measured (tools/ubench/split_mfma.hip, K = 288 /
+// 1152 / 8192, rms error against f64): 8.7e-8 / 3.6e-7 / 2.7e-6 for this form, 8.9e-8 / 3.4e-7 / 2.4e-6 for
+// v_mfma_f32_32x32x2_f32.  The bf16 pipe runs 16x the f32 MFMA rate, so six products cost 3/8 of the f32 MFMAs.
+//
+// Interface identical to K1 (f32 NHWC in, f32 NHWC out): the split happens while the zero-padded input band is
+// staged into LDS ([pixel][cin/8][h | m | l][8 bf16], 16 B per operand fetch); the weights are split once at upload
+// (build_wx3).  With the MFMA time cut to 3/8 the per-stage barrier of K1's weight ring would dominate, so there
+// is no weight ring: every wave fetches the B operands of its own 32-cout column straight from global memory
+// (L2-resident, two chunks ahead, registers) and runs barrier-free after the band is staged; the workgroup covers
+// M_WG >= 128 pixels so that the weight stream stays at <= 16 B/clk/CU.
+// ------------------------------------------------------------------------------------------
+#ifndef ASD_X3_ABL
+#define ASD_X3_ABL 0  // tuning: 1 = weight stream pinned to chunk 0/1 (L1 hits), 2 = no band staging, 4 = no output stores
+#endif
+#ifndef ASD_X3_PD
+#define ASD_X3_PD 2  // A-operand prefetch distance in 32-pixel tiles
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP = 1>
+struct X3Cfg {
+  static constexpr int HO = HIN / S;
+  static constexpr int INROWS = (ROWS - 1) * S + 3;
+  static constexpr int INCOLS = (HO - 1) * S + 3;
+  static constexpr int PIXB = CIN * 6 + 16;  // bytes per staged pixel: an odd multiple of 16 B -> b128 reads of 16 consecutive pixels cover all banks
+  static constexpr int NW = WM * WN;
+  static constexpr int NTH = 64 * NW;
+  static constexpr int M_PATCH = ROWS * HO;
+  static constexpr int M_WG = PP * M_PATCH;
+  static constexpr int MT = M_WG / 32 / WM;
+  static constexpr int NT = COUT / 32 / WN;
+  static constexpr int NC16 = CIN / 16;
+  static constexpr int NCHUNK = 9 * NC16;        // k-chunks of 16 cin
+  static constexpr int CHUNKB = 96 * COUT;       // bytes of weight image per chunk: [piece 3][half 2][cout][8 bf16]
+  static constexpr int ACT_BYTES = INROWS * INCOLS * PIXB;
+  static constexpr int LDS_BYTES = PP * ACT_BYTES;
+  static_assert((PIXB / 16) % 2 == 1, "pixel stride must be an odd multiple of 16 B");
+  static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0 && CIN % 16 == 0 && HO % ROWS == 0, "tile split");
+  static_assert(PP == 1 || ROWS == HO, "several patches per workgroup only for whole-patch bands");
+  static_assert(M_PATCH % 32 == 0, "32-pixel MFMA tiles must not straddle patches");
+};
+
+// exact 3-way bf16 split of 8 floats -> three packed operand quads (element j in bits 16j..16j+15 of the 128-bit value)
+__device__ inline void split8(const f32x4& v0, const f32x4& v1, u32x4& ph, u32x4& pm, u32x4& pl) {
+  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  uint32_t hu[8], mu[8], lu[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t u = __float_as_uint(x[j]);
+    const float r1 = x[j] - __uint_as_float(u & 0xffff0000u);
+    const uint32_t r1u = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(r1u & 0xffff0000u);
+    hu[j] = u; mu[j] = r1u; lu[j] = __float_as_uint(r2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // v_perm_b32: high halves of the odd (upper) and even (lower) element
+    ph[q] = __builtin_amdgcn_perm(hu[2 * q + 1], hu[2 * q], 0x07060302u);
+    pm[q] = __builtin_amdgcn_perm(mu[2 * q + 1], mu[2 * q], 0x07060302u);
+    pl[q] = __builtin_amdgcn_perm(lu[2 * q + 1], lu[2 * q], 0x07060302u);
+  }
+}
+
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false>
+__global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, int n) {
+  using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
+  constexpr int NTH = C::NTH, MT = C::MT, NT = C::NT;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem_b[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, li = lane & 31;
+  constexpr int BANDS = C::HO / ROWS;
+  const int patch = (blockIdx.x / BANDS) * PP, band = blockIdx.x % BANDS;
+  const int r0 = band * ROWS;
+
+  // ---- B operand stream: chunk c = tap * NC16 + c16, this lane's 8 k values of (piece, half h, cout)
+  const uint8_t* wl = wimg + ((size_t)h * COUT + wn * NT * 32 + li) * 16;
+  auto load_b = [&](int c, u32x4 (&b)[NT][3]) {
+    const uint8_t* wc = wl + (size_t)((ASD_X3_ABL & 1) ? (c & 1) : c) * C::CHUNKB;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[nt][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * 2 * COUT * 16 + nt * 512);
+  };
+  // B operands run RB - 1 chunks ahead through a register ring of RB slots; the chunk loop is unrolled RB times so that the
+  // slot of every chunk is a compile-time constant (no register copies)
+  constexpr int RB = 3;
+  static_assert(C::NCHUNK % RB == 0, "chunk count");
+  u32x4 br[RB][NT][3];
+#pragma unroll
+  for (int d = 0; d < RB - 1; ++d) load_b(d, br[d]);
+
+  // ---- stage the zero-padded input band(s), split into bf16 terms.  Item = (pixel, 8-cin group); a thread keeps its
+  // cin group; loads are issued SBATCH items at a time so that the HBM latency is paid once per batch, not per item
+  if constexpr (FUSE1) {
+    // conv2 computes its own input (input_norm + conv1 + BN + ReLU, ASDNet.py:334-336, 360-365) from the raw u8 patch, exactly
+    // as K1's FUSE1 path does, and splits it on the way into the band.  Extra LDS behind the band: normalised input rows
+    // r0-2 .. r0+ROWS+1 (34 wide, zero padded), conv1 weights + bias, reduction scratch
+    static_assert(!FUSE1 || (CIN == 32 && HIN == 32 && S == 1 && PP == 1 && C::NW == 4), "conv1 fusion is for conv2 only");
+    float* pin = reinterpret_cast<float*>(smem_b + C::ACT_BYTES);  // [(ROWS+4)][36]
+    float* wsh = pin + (ROWS + 4) * 36;                            // [32*9 + 32]
+    float* red = wsh + 320;                                        // [8]
+    const uint8_t* patches = static_cast<const uint8_t*>(in_);
+    for (int i = t; i < (ROWS + 4) * 36; i += NTH) pin[i] = 0.f;
+    for (int i = t; i < 288; i += NTH) wsh[i] = w1[i];
+    if (t < 32) wsh[288 + t] = b1[t];
+    const uchar4 v = reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t];
+    const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
+    float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
+    float sum = (x[0] + x[1]) + (x[2] + x[3]);
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
+    float d[4], ss = 0.f;
+    for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    if (lane == 0) red[4 + wave] = ss;
+    __syncthreads();
+    const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
+    {
+      const int idx = t * 4, y = idx >> 5, x0 = idx & 31;  // this thread's 4 pixels sit in row y
+      const int j = y - (r0 - 2);
+      if (j >= 0 && j < ROWS + 4)
+        for (int k = 0; k < 4; ++k) pin[j * 36 + x0 + k + 1] = d[k] / sd;
+    }
+    __syncthreads();
+    // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding).
+    // item = (pixel, octet of 8 couts); a thread keeps its octet and holds its 72 weights + 8 biases in registers.
+    // Same f32 operation order per output as K1 (bias, then the nine taps in order)
+    constexpr int NPIX = C::INROWS * C::INCOLS;
+    if (!(ASD_X3_ABL & 2)) {
+      const int q = t & 3;
+      float wq[8][9], bq1[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        bq1[c] = wsh[288 + 8 * q + c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wq[c][k] = wsh[(8 * q + c) * 9 + k];
+      }
+      for (int item = t; item < NPIX * 4; item += NTH) {
+        const int pix = item >> 2;
+        const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+        const int oy = r0 - 1 + j, ox = i - 1;
+        f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = {0.f, 0.f, 0.f, 0.f};
+        if (oy >= 0 && oy < 32 && ox >= 0 && ox < 32) {
+          float a[9];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) a[ky * 3 + kx] = pin[(j + ky) * 36 + ox + kx];  // pin row j <-> image row oy-1
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            float acc1 = bq1[c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc1 += a[k] * wq[c][k];
+            const float r = acc1 > 0.f ? acc1 : 0.f;
+            if (c < 4) ra[c] = r; else rb[c - 4] = r;
+          }
+        }
+        u32x4 ph, pm, pl;
+        split8(ra, rb, ph, pm, pl);
+        uint8_t* dst = smem_b + pix * C::PIXB + q * 48;
+        *reinterpret_cast<u32x4*>(dst) = ph;
+        *reinterpret_cast<u32x4*>(dst + 16) = pm;
+        *reinterpret_cast<u32x4*>(dst + 32) = pl;
+      }
+    }
+  } else
+  {
+    const float* inp = static_cast<const float*>(in_) + (size_t)patch * HIN * HIN * CIN;
+    constexpr int C8 = CIN / 8;
+    constexpr int NPIXB = C::INROWS * C::INCOLS;
+    static_assert(NTH % C8 == 0, "a thread keeps its cin group");
+    constexpr int PSTEP = NTH / C8;                          // pixels per round
+    constexpr int NROUND = (PP * NPIXB + PSTEP - 1) / PSTEP;
+    constexpr int SBATCH = 8;
+    const int c8 = t % C8, pix0 = t / C8;
+    for (int rb = 0; rb < ((ASD_X3_ABL & 2) ? 0 : NROUND); rb += SBATCH) {
+      f32x4 v0[SBATCH], v1[SBATCH];
+#pragma unroll
+      for (int b = 0; b < SBATCH; ++b) {
+        const int pixg = pix0 + (rb + b) * PSTEP;
+        const int pp = pixg / NPIXB, pix = pixg % NPIXB;
+        const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+        const int iy = r0 * S - 1 + j, ix = i - 1;
+        v0[b] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rb + b < NROUND && pixg < PP * NPIXB && iy >= 0 && iy < HIN && ix >= 0 && ix < HIN && patch + pp < n) {
+          const float* src = inp + (size_t)pp * HIN * HIN * CIN + ((size_t)iy * HIN + ix) * CIN + c8 * 8;
+          v0[b] = *reinterpret_cast<const f32x4*>(src);
+          v1[b] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < SBATCH; ++b) {
+        const int pixg = pix0 + (rb + b) * PSTEP;
+        if (rb + b < NROUND && pixg < PP * NPIXB) {
+          u32x4 ph, pm, pl;
+          split8(v0[b], v1[b], ph, pm, pl);
+          uint8_t* dst = smem_b + (pixg / NPIXB) * C::ACT_BYTES + (pixg % NPIXB) * C::PIXB + c8 * 48;
+          *reinterpret_cast<u32x4*>(dst) = ph;
+          *reinterpret_cast<u32x4*>(dst + 16) = pm;
+          *reinterpret_cast<u32x4*>(dst + 32) = pl;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[MT][NT];
+  for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  int abase[MT];
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = (wm * MT + mt) * 32 + li;
+    const int pp = PP > 1 ? m / C::M_PATCH : 0, mm = m - pp * C::M_PATCH;
+    const int rr = mm / C::HO, ox = mm % C::HO;
+    abase[mt] = pp * C::ACT_BYTES + ((rr * S) * C::INCOLS + ox * S) * C::PIXB + h * 48;
+  }
+  auto chunk_off = [&](int c) {
+    const int tap = c / C::NC16, c16 = c % C::NC16;
+    return ((tap / 3) * C::INCOLS + (tap % 3)) * C::PIXB + c16 * 96;
+  };
+  auto load_a = [&](int off, u32x4 (&a)[3]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const u32x4*>(smem_b + off + p * 16);
+  };
+  auto bf = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+
+  // A operands run PD tiles ahead of the MFMAs through a register ring of PD + 1 slots; a loop iteration covers D chunks x MT
+  // tiles, a multiple of the ring size, so every tile's slot is a compile-time constant
+  constexpr int PD = ASD_X3_PD, RS = PD + 1;
+  static_assert((RB * MT) % RS == 0, "ring slots must be static");
+  u32x4 ar[RS][3];
+#pragma unroll
+  for (int q = 0; q < PD; ++q) load_a(abase[q % MT] + chunk_off(q / MT), ar[q]);
+  for (int c0 = 0; c0 < C::NCHUNK; c0 += RB) {
+    int offs[RB + PD / MT + 2];
+#pragma unroll
+    for (int u = 0; u < RB + PD / MT + 2; ++u) offs[u] = chunk_off(c0 + u < C::NCHUNK ? c0 + u : C::NCHUNK - 1);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int c = c0 + u;
+      // past the end: a redundant re-read of the last chunk instead of a branch
+      load_b(c + RB - 1 < C::NCHUNK ? c + RB - 1 : C::NCHUNK - 1, br[(u + RB - 1) % RB]);
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NT, 0);
+      const u32x4 (&bc)[NT][3] = br[u];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int q = u * MT + mt;            // tile index within the iteration
+        const int qn = q + PD;                // the tile fetched now (past the end: re-reads the last chunk, unused)
+        load_a(abase[qn % MT] + offs[qn / MT], ar[qn % RS]);
+        const u32x4 (&ac)[3] = ar[q % RS];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[2]), bf(bc[nt][0]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[0]), bf(bc[nt][2]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[1]), bf(bc[nt][1]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[1]), bf(bc[nt][0]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[0]), bf(bc[nt][1]), acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[0]), bf(bc[nt][0]), acc[mt][nt], 0, 0, 0);
+        }
+        // issue order within the tile: one operand read behind every 2 * NT MFMAs
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias (folded BN) + ReLU, NHWC f32 store.  Lane owns one cout column, 16 pixel rows.
+  float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = (wn * NT + nt) * 32 + li;
+    const float bv = bias[co];
+    for (int mt = 0; mt < MT; ++mt) {
+      const int pp = PP > 1 ? ((wm * MT + mt) * 32) / C::M_PATCH : 0;
+      if (PP > 1 && patch + pp >= n) continue;
+      for (int r = 0; r < 16; ++r) {
+        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const size_t o = (size_t)pp * C::HO * C::HO * COUT + (size_t)(m - pp * C::M_PATCH) * COUT + co;
+        const float v = acc[mt][nt][r] + bv;
+        if (!(ASD_X3_ABL & 4) || v == 12345.f) op[o] = v > 0.f ? v : 0.f;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K2: last layer, 8x8 valid conv == GEMM [n x 8192] * [8192 x 128], split-K over gridDim.y.
 // One workgroup = 32 patches x 128 couts x (8192 / SK) k; wave w owns couts [32w, 32w+32), so
 // every weight element is used by exactly one wave: B goes global -> VGPR, only A through LDS.
@@ -559,6 +860,18 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
 #ifndef L6_CFG
 #define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16, 1, 3
 #endif
+// split-operand kernels: <CIN, COUT, HIN, S, ROWS, WM, WN, PP>
+// (two workgroups per CU each: one's band staging overlaps the other's MFMAs; whole-patch conv4 / two-patch conv6
+// workgroups at one per CU measured 189 / 168 us against 163 / 160)
+#ifndef L2S_CFG
+#define L2S_CFG 32, 32, 32, 1, 8, 4, 1, 1
+#endif
+#ifndef L4S_CFG
+#define L4S_CFG 64, 64, 16, 1, 8, 2, 2, 1
+#endif
+#ifndef L6S_CFG
+#define L6S_CFG 128, 128, 8, 1, 8, 1, 4, 1
+#endif
 
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int RING = 2, bool FUSE1 = false>
 hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const float* bias, float* out, int n,
@@ -596,6 +909,55 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
   return hipGetLastError();
 }
 
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false>
+hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
+                          const float* w1 = nullptr, const float* b1 = nullptr) {
+  using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
+  auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1>;
+  constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
+  static_assert(lds <= 160 * 1024, "band does not fit LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n);
+  return hipGetLastError();
+}
+
+// exact three-term bf16 split of one f32 (host twin of split8)
+inline void split3_host(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
+  uint32_t u, r1u, r2u;
+  memcpy(&u, &x, 4);
+  const uint32_t hu = u & 0xffff0000u;
+  float hf; memcpy(&hf, &hu, 4);
+  const float r1 = x - hf;
+  memcpy(&r1u, &r1, 4);
+  const uint32_t mu = r1u & 0xffff0000u;
+  float mf; memcpy(&mf, &mu, 4);
+  const float r2 = r1 - mf;
+  memcpy(&r2u, &r2, 4);
+  h = (uint16_t)(hu >> 16); m = (uint16_t)(mu >> 16); l = (uint16_t)(r2u >> 16);
+}
+
+// split B-operand image of a 3x3 layer: [tap][cin/16][piece][half][cout][8 bf16] with cin = 16*c16 + 8*half + j,
+// BN scale folded in f32 first (the same folded value the f32 image holds)
+void build_wx3(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<uint16_t>& img) {
+  img.assign((size_t)9 * L.cin * L.cout * 3, 0);
+  const int nc16 = L.cin / 16;
+  for (int tap = 0; tap < 9; ++tap)
+    for (int ci = 0; ci < L.cin; ++ci)
+      for (int co = 0; co < L.cout; ++co) {
+        const float v = w[((size_t)co * L.cin + ci) * 9 + tap] * inv[co];
+        uint16_t p[3];
+        split3_host(v, p[0], p[1], p[2]);
+        const int c16 = ci / 16, hh = (ci % 16) / 8, j = ci % 8;
+        for (int q = 0; q < 3; ++q)
+          img[(((((size_t)tap * nc16 + c16) * 3 + q) * 2 + hh) * L.cout + co) * 8 + j] = p[q];
+      }
+}
+
 // B-operand image of a 3x3 layer: [tap][cin/8][h][cout][jj] with cin = 8*c8 + 4*h + jj, BN scale folded.
 void build_wimg(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<float>& img) {
   img.assign((size_t)9 * L.cin * L.cout, 0.f);
@@ -630,6 +992,7 @@ void asdnet_free(asd_ctx* ctx) {
   for (int i = 0; i < 7; ++i) {
     if (ctx->d_bias[i]) (void)hipFree(ctx->d_bias[i]);
     if (ctx->d_wimg[i]) (void)hipFree(ctx->d_wimg[i]);
+    if (ctx->d_wx3[i]) (void)hipFree(ctx->d_wx3[i]);
   }
 }
 
@@ -667,6 +1030,12 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
     }
     if (!ctx->d_wimg[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wimg[l], img.size() * sizeof(float)));
     ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wimg[l], img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (l < 6) {
+      std::vector<uint16_t> x3;
+      build_wx3(L, conv_w[l], inv, x3);
+      if (!ctx->d_wx3[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wx3[l], x3.size() * sizeof(uint16_t)));
+      ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wx3[l], x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
   }
   ctx->weights_loaded = true;
   return ASD_OK;
@@ -687,7 +1056,8 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
 #define PROF_MARK(i) do { if (prof) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[pset][i], st)); } while (0)
   PROF_MARK(0);
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
-  ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
+  if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (launch_conv_x3<L2S_CFG, true>(st, d_patches, ctx->d_wx3[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
+  else ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);
 #ifdef L3_NP_CFG  // tuning: conv3 through the non-persistent kernel
   ASD_HIP_CHECK(ctx, (launch_conv<L3_NP_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
@@ -695,7 +1065,8 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
 #endif
   PROF_MARK(3);
-  ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
+  if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (launch_conv_x3<L4S_CFG>(st, a0, ctx->d_wx3[3], ctx->d_bias[3], a1, n)));
+  else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);
 #ifdef L5_P_CFG  // tuning: conv5 through the persistent double-buffered kernel
   ASD_HIP_CHECK(ctx, (launch_conv_p<L5_P_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n, ctx->num_cu)));
@@ -703,7 +1074,8 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
 #endif
   PROF_MARK(5);
-  ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
+  if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (launch_conv_x3<L6S_CFG>(st, a0, ctx->d_wx3[5], ctx->d_bias[5], a1, n)));
+  else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
   PROF_MARK(6);
   hipLaunchKernelGGL(k_fc_mfma, dim3((npad / 32 + FC_MT - 1) / FC_MT, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
   ASD_HIP_CHECK(ctx, hipGetLastError());

@@ -1,6 +1,7 @@
 // capi.cpp -- C ABI entry points of libasdhip: context, ASDNet, utilities.
 // (extractor: frontend.hip, matchers: matcher.hip, optimizer: ba.hip)
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -94,6 +95,14 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
   }
   build_tables(c);
+  // ASDNet arithmetic: split-bf16 kernels by default; ASD_ASDNET_MATH=f32 keeps every layer on the f32 MFMA kernels,
+  // ASD_ASDNET_SPLIT_LAYERS=<mask> picks layers (bit 0 = conv2 ... bit 4 = conv6, bit 5 = fc)
+  c->net_split = 0x3f;
+  if (const char* e = getenv("ASD_ASDNET_MATH")) {
+    if (!strcmp(e, "f32")) c->net_split = 0;
+    else if (strcmp(e, "split")) fprintf(stderr, "libasdhip: ASD_ASDNET_MATH=%s not understood (f32 | split); using split\n", e);
+  }
+  if (const char* e = getenv("ASD_ASDNET_SPLIT_LAYERS")) c->net_split = (int)strtol(e, nullptr, 0) & 0x3f;
   // tracking kernels (small, latency critical) outrank the pipelined extractor's stream
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <vector>
@@ -47,6 +49,8 @@ struct asd_track_handle {
   std::vector<double> Xd, obs, info;
   std::vector<double> ba_poses, ba_points, ba_chi2;
   std::vector<uint8_t> ba_dpos, ba_out1;
+  double wait_ms = 0.0, ba_ms = 0.0;  // ASD_TIMING: time blocked on the extractor / inside LocalBA
+  long steps = 0;
 };
 
 asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* const* d_frames, int32_t W, int32_t H, const float* K32,
@@ -78,6 +82,9 @@ void asd_track_destroy(asd_track_handle* h) {
     (void)asd_extract_wait_view(h->ctx, &k, &d, &n);
     h->pending.pop_front();
   }
+  if (getenv("ASD_TIMING") && h->steps)
+    fprintf(stderr, "[track_loop] steps %ld  extract wait %.3f ms/step  local BA %.3f ms/step\n", h->steps, h->wait_ms / h->steps,
+            h->ba_ms / h->steps);
   delete h;
 }
 
@@ -90,7 +97,9 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
   int32_t n = 0;
   if (!h->pending.empty() && h->pending.front() == t) {
     const float* d = nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
     if ((rc = asd_extract_wait_view(ctx, &kps, &d, &n)) != ASD_OK) return rc;
+    h->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     h->pending.pop_front();
   } else {
     while (!h->pending.empty()) {
@@ -214,12 +223,15 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     asd_ba_result r;
     memset(&r, 0, sizeof r);
     r.edge_chi2 = h->ba_chi2.data(); r.edge_depth_pos = h->ba_dpos.data(); r.edge_outlier1 = h->ba_out1.data();
+    const auto b0 = std::chrono::steady_clock::now();
     if ((rc = asd_local_ba(ctx, &p, &r)) != ASD_OK) return rc;
+    h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
     st->ba_chi2 = r.chi2_second; st->has_ba = 1;
   }
   h->last_kps.assign(kps, kps + n);
   h->last_slot = cur;
   h->have_last = true;
+  ++h->steps;
   return ASD_OK;
 }
 
