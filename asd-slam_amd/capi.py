@@ -220,6 +220,11 @@ class AsdHip:
         self._chk(self.lib.asd_profile_get(self.ctx, layer, C.byref(ms), C.byref(calls), C.byref(patches)))
         return ms.value, calls.value, patches.value
 
+    def asdnet_split_mask(self):
+        """Bit l = conv(l+2) runs on the split-operand (3 x bf16, six products) kernel; 0 = every layer on the f32 MFMA kernels."""
+        self.lib.asd_asdnet_split_mask.restype = C.c_int32
+        return int(self.lib.asd_asdnet_split_mask(self.ctx))
+
     def level_size(self, level):
         w, h = C.c_int32(), C.c_int32()
         self._chk(self.lib.asd_get_level_size(self.ctx, level, C.byref(w), C.byref(h)))

@@ -536,7 +536,8 @@ __device__ inline void split8(const f32x4& v0, const f32x4& v1, u32x4& ph, u32x4
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
-                                                         const float* __restrict__ w1, const float* __restrict__ b1, int n) {
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, int n,
+                                                         unsigned long long* __restrict__ stamps) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
   constexpr int NTH = C::NTH, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_b[];
@@ -709,6 +710,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
   u32x4 ar[RS][3];
 #pragma unroll
   for (int q = 0; q < PD; ++q) load_a(abase[q % MT] + chunk_off(q / MT), ar[q]);
+  // diagnostic only (stamps == nullptr in every product launch): shader clock and 100 MHz wall clock around the MFMA loop
+  unsigned long long st_c = 0, st_r = 0;
+  if (stamps) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
   for (int c0 = 0; c0 < C::NCHUNK; c0 += RB) {
     int offs[RB + PD / MT + 2];
 #pragma unroll
@@ -746,6 +750,11 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
     }
   }
 
+  if (stamps) {
+    asm volatile("s_nop 0" ::"v"(acc[MT - 1][NT - 1][0]));  // the last MFMA has retired before the closing stamp
+    const unsigned long long e_c = __builtin_amdgcn_s_memtime(), e_r = __builtin_amdgcn_s_memrealtime();
+    if (t == 0) { stamps[2 * blockIdx.x] = e_c - st_c; stamps[2 * blockIdx.x + 1] = e_r - st_r; }
+  }
   // ---- epilogue: bias (folded BN) + ReLU, NHWC f32 store.  Lane owns one cout column, 16 pixel rows.
   float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
   for (int nt = 0; nt < NT; ++nt) {
@@ -866,8 +875,14 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
 #ifndef L2S_CFG
 #define L2S_CFG 32, 32, 32, 1, 8, 4, 1, 1
 #endif
+#ifndef L3S_CFG
+#define L3S_CFG 32, 64, 32, 2, 4, 2, 2, 1
+#endif
 #ifndef L4S_CFG
 #define L4S_CFG 64, 64, 16, 1, 8, 2, 2, 1
+#endif
+#ifndef L5S_CFG
+#define L5S_CFG 64, 128, 16, 2, 4, 1, 4, 1
 #endif
 #ifndef L6S_CFG
 #define L6S_CFG 128, 128, 8, 1, 8, 1, 4, 1
@@ -911,7 +926,7 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
 
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false>
 hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
-                          const float* w1 = nullptr, const float* b1 = nullptr) {
+                          const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
   auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1>;
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
@@ -922,7 +937,8 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n);
+  if (grid_out) *grid_out = ((n + PP - 1) / PP) * (C::HO / ROWS);
+  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps);
   return hipGetLastError();
 }
 
@@ -1059,6 +1075,8 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (launch_conv_x3<L2S_CFG, true>(st, d_patches, ctx->d_wx3[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   else ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);
+  if (ctx->net_split & 2) ASD_HIP_CHECK(ctx, (launch_conv_x3<L3S_CFG>(st, a1, ctx->d_wx3[2], ctx->d_bias[2], a0, n)));
+  else
 #ifdef L3_NP_CFG  // tuning: conv3 through the non-persistent kernel
   ASD_HIP_CHECK(ctx, (launch_conv<L3_NP_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
 #else
@@ -1068,6 +1086,8 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (launch_conv_x3<L4S_CFG>(st, a0, ctx->d_wx3[3], ctx->d_bias[3], a1, n)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);
+  if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (launch_conv_x3<L5S_CFG>(st, a1, ctx->d_wx3[4], ctx->d_bias[4], a0, n)));
+  else
 #ifdef L5_P_CFG  // tuning: conv5 through the persistent double-buffered kernel
   ASD_HIP_CHECK(ctx, (launch_conv_p<L5_P_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n, ctx->num_cu)));
 #else
@@ -1147,6 +1167,37 @@ static int ablate_one(asd_ctx* ctx, int layer, int n, int reps, float* ms) {
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
   *ms /= reps;
   (void)e;
+  return ASD_OK;
+}
+
+// debug / tuning aid (not part of the C ABI header): in-kernel clock of a split-operand layer (MI355X_MICROARCH.md, DVFS item 6).
+// Runs the layer `reps` times back to back with stamps around the MFMA loop; returns the median over workgroups of the loop's
+// shader cycles and of shader cycles per 10 ns wall tick (x 0.1 = GHz).  Uses d_part as the stamp buffer.
+extern "C" int asd_debug_x3_clock(asd_ctx* ctx, int layer, int n, int reps, double* loop_cycles, double* ghz) {
+  hipStream_t st = ctx->stream;
+  float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(ctx->d_part);
+  int grid = 0;
+  for (int r = 0; r < reps; ++r) {
+    unsigned long long* sp = r + 1 == reps ? stamps : nullptr;
+    hipError_t e = hipErrorInvalidValue;
+    if (layer == 2) e = launch_conv_x3<L2S_CFG, true>(st, ctx->d_patches, ctx->d_wx3[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0], sp, &grid);
+    else if (layer == 3) e = launch_conv_x3<L3S_CFG>(st, a1, ctx->d_wx3[2], ctx->d_bias[2], a0, n, nullptr, nullptr, sp, &grid);
+    else if (layer == 4) e = launch_conv_x3<L4S_CFG>(st, a0, ctx->d_wx3[3], ctx->d_bias[3], a1, n, nullptr, nullptr, sp, &grid);
+    else if (layer == 5) e = launch_conv_x3<L5S_CFG>(st, a1, ctx->d_wx3[4], ctx->d_bias[4], a0, n, nullptr, nullptr, sp, &grid);
+    else if (layer == 6) e = launch_conv_x3<L6S_CFG>(st, a0, ctx->d_wx3[5], ctx->d_bias[5], a1, n, nullptr, nullptr, sp, &grid);
+    ASD_HIP_CHECK(ctx, e);
+  }
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if ((size_t)grid * 16 > (size_t)FC_SK * ((ctx->cfg.max_patches + 31) / 32 * 32) * 128 * sizeof(float)) return ASD_ERR_CAPACITY;
+  std::vector<unsigned long long> hs((size_t)grid * 2);
+  ASD_HIP_CHECK(ctx, hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<double> cyc(grid), rate(grid);
+  for (int i = 0; i < grid; ++i) { cyc[i] = (double)hs[2 * i]; rate[i] = hs[2 * i + 1] ? (double)hs[2 * i] / (double)hs[2 * i + 1] : 0.0; }
+  std::nth_element(cyc.begin(), cyc.begin() + grid / 2, cyc.end());
+  std::nth_element(rate.begin(), rate.begin() + grid / 2, rate.end());
+  *loop_cycles = cyc[grid / 2];
+  *ghz = rate[grid / 2] * 0.1;
   return ASD_OK;
 }
 

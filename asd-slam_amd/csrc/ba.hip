@@ -194,7 +194,10 @@ struct PoseOptArgs {
   int debug;  // ASD_POSE_DEBUG: thread 0 prints passes / iterations per round
 };
 
-constexpr int kPoseThreads = 256, kPoseWaves = kPoseThreads / 64;
+#ifndef ASD_POSE_THREADS
+#define ASD_POSE_THREADS 512
+#endif
+constexpr int kPoseThreads = ASD_POSE_THREADS, kPoseWaves = kPoseThreads / 64;
 struct PoseShared {
   Pose7 T, T0, Tbak;
   double H[36], b[6], x[6];

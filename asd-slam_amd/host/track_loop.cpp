@@ -50,6 +50,7 @@ struct asd_track_handle {
   std::vector<double> ba_poses, ba_points, ba_chi2;
   std::vector<uint8_t> ba_dpos, ba_out1;
   double wait_ms = 0.0, ba_ms = 0.0;  // ASD_TIMING: time blocked on the extractor / inside LocalBA
+  double seg_ms[8] = {};              // frame_set, submit, bank+M1, pose1, frustum, M2, pose2, host glue
   long steps = 0;
 };
 
@@ -83,8 +84,12 @@ void asd_track_destroy(asd_track_handle* h) {
     h->pending.pop_front();
   }
   if (getenv("ASD_TIMING") && h->steps)
+  {
     fprintf(stderr, "[track_loop] steps %ld  extract wait %.3f ms/step  local BA %.3f ms/step\n", h->steps, h->wait_ms / h->steps,
             h->ba_ms / h->steps);
+    static const char* nm[8] = {"frame_set", "submit", "bank+M1", "pose1", "frustum", "M2", "pose2", "host glue"};
+    for (int i = 0; i < 8; ++i) fprintf(stderr, "[track_loop]   %-10s %.3f ms/step\n", nm[i], h->seg_ms[i] / h->steps);
+  }
   delete h;
 }
 
@@ -92,6 +97,12 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
   asd_ctx* ctx = h->ctx;
   const int nf = (int)h->d_frames.size();
   int rc;
+  auto tp = std::chrono::steady_clock::now();
+  auto seg = [&](int i) {  // charge the time since the previous mark to segment i
+    const auto now = std::chrono::steady_clock::now();
+    h->seg_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  };
   // ---- ExtractDesc: take the read-ahead result if this frame is the oldest submission, else extract now
   const asd_keypoint* kps = nullptr;
   int32_t n = 0;
@@ -113,7 +124,9 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
   // ---- Frame::AssignFeaturesToGrid + adopt the device-resident descriptors
   h->slot ^= 1;
   const int cur = h->slot;
+  seg(7);
   if ((rc = asd_frame_set(ctx, cur, kps, nullptr, n, 0.f, (float)h->W, 0.f, (float)h->H)) != ASD_OK) return rc;
+  seg(0);
   // ---- read ahead
   if (h->lookahead > 0) {
     bool same = h->pending.size() <= next.size();
@@ -130,6 +143,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       h->pending.push_back(next[i]);
     }
   }
+  seg(1);
   memset(st, 0, sizeof *st);
   st->n_kp = n;
   if (h->have_last) {
@@ -148,6 +162,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     }
     h->has.assign(nl, 1);
     // map point descriptors: rows 0..nl-1 = the last frame's descriptors, rows nl..2nl-1 the same again
+    seg(7);
     if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
     if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, nl, nl)) != ASD_OK) return rc;
     h->rows.resize((size_t)2 * nl);
@@ -158,6 +173,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
                                            h->m1.data(), &n1)) != ASD_OK)
       return rc;
     st->m1 = n1; st->has_m1 = 1;
+    seg(2);
     auto pose_opt = [&](const std::vector<int>& sel, auto point_of, int32_t* ninl) -> int {
       const int m = (int)sel.size();
       h->Xd.resize((size_t)3 * m); h->obs.resize((size_t)2 * m); h->info.resize(m); h->outl.resize(m);
@@ -178,6 +194,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       int32_t ninl = 0;
       if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, &ninl)) != ASD_OK) return rc;
     }
+    seg(3);
     // local map: the last frame's points plus a jittered copy
     const int n2p = 2 * nl;
     h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
@@ -193,9 +210,11 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       h->mind[i] = h->maxd[i] / h->scale32[7];
     }
     h->in_view.resize(n2p); h->proj.resize((size_t)2 * n2p); h->level.resize(n2p); h->vc.resize(n2p);
+    seg(7);
     if ((rc = asd_frustum(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->T, h->K32, 0.5f, h->in_view.data(),
                           h->proj.data(), h->level.data(), h->vc.data())) != ASD_OK)
       return rc;
+    seg(4);
     h->occ.resize(n);
     for (int j = 0; j < n; ++j) h->occ[j] = h->m1[j] >= 0;
     h->m2.assign(n, -1);
@@ -204,6 +223,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
                                             h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2)) != ASD_OK)
       return rc;
     st->m2 = n2; st->has_m2 = 1;
+    seg(5);
     sel.clear();
     for (int j = 0; j < n; ++j) if (h->m1[j] >= 0 || h->m2[j] >= 0) sel.push_back(j);
     if (sel.size() >= 3) {
@@ -212,6 +232,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
         return rc;
       st->inliers = ninl; st->has_inliers = 1;
     }
+    seg(6);
   }
   if (do_ba) {
     const asd_ba_problem& B = h->ba;
@@ -228,6 +249,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
     st->ba_chi2 = r.chi2_second; st->has_ba = 1;
   }
+  seg(7);
   h->last_kps.assign(kps, kps + n);
   h->last_slot = cur;
   h->have_last = true;

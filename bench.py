@@ -31,6 +31,8 @@ LOOKAHEAD = 2          # frames of read-ahead for the pipelined extractor (asd_e
 N_FRAMES = 30          # distinct synthetic frames kept resident in HBM, cycled
 BOUNDS = (0.0, 1241.0, 0.0, 376.0)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense f32 matrix)
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (the guide's "~2.5 PF dense")
+SPLIT_PRODUCTS = 6              # bf16 MFMAs per f32 multiply-add in the split-operand kernels (asdnet.hip, K1s)
 L2_MACS = 9_437_184            # conv2 (32->32 @32x32) MACs per patch, SURVEY 8(a) E6
 
 
@@ -395,8 +397,8 @@ def selftest_dist(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=15)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=45)
     ap.add_argument("--cpu-frames", type=int, default=15, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--selftest-dist", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
@@ -447,10 +449,23 @@ def main():
     ms2, calls2, patches2 = be.hip.profile_get(1)
     achieved = (2.0 * L2_MACS * patches2) / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
     asdnet_ms = sum(be.hip.profile_get(l)[0] for l in range(8)) / max(calls2, 1)
+    split = bool(be.hip.asdnet_split_mask() & 1)   # conv2 on the split-operand kernel (default) or on the f32 MFMA kernel
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic_conv2.json")
     if os.path.exists(tp):
-        traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        tj = json.load(open(tp))
+        if ("k_conv_x3" in tj.get("kernel", "")) == split:   # PMC figure of the kernel that actually ran
+            traffic = tj.get("hbm_bytes_per_launch")
+    if split:
+        # f32 work on the bf16 pipe: the ceiling for ALGORITHMIC f32 FLOP is the dense bf16 peak / 6 products
+        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        roof_kernel = "k_conv_x3<32,32,32,1,8,4,1,1,true> (ASDNet input_norm+conv1+conv2; f32 operands split into 3 bf16 terms, 6 bf16 MFMA products per multiply-add, f32 accumulate)"
+        roof_extra = {"peak_basis": f"dense bf16 MFMA {PEAK_BF16_MFMA_TFLOPS} TFLOP/s / {SPLIT_PRODUCTS} products",
+                      "executed_bf16_tflops": SPLIT_PRODUCTS * achieved, "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+    else:
+        peak = PEAK_F32_MFMA_TFLOPS
+        roof_kernel = "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)"
+        roof_extra = {}
     be.close()
 
     out = None
@@ -465,14 +480,18 @@ def main():
                                    "isInFrustum+SearchByProjection(map)+PoseOptimization per frame, LocalBA "
                                    "(24+12 KF, 6000 MP, ~29k edges) every 15 frames",
                        "keypoints": int(stats.get("n_kp", 0)), "kf_interval": KF_INTERVAL,
+                       "asdnet_math": ("f32 results on the bf16 matrix pipe: every f32 operand = exact sum of 3 bf16 terms, 6 cross products, f32 accumulate "
+                                       "(error at the level of the f32 MFMA chain; ASD_ASDNET_MATH=f32 selects the f32 MFMA kernels)") if split
+                                      else "f32 MFMA (v_mfma_f32_32x32x2_f32)",
                        "parallelism": f"replicas x{world} (independent sequences, no collective)",
                        "host": "C++ host loop over the C ABI (asd-slam_amd/host/track_loop.cpp)" if args.host == "cxx" else "Python loop (ctypes)",
                        "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t)" if not args.no_pipeline else "none (sequential)"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": roof_kernel,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
                          "avg_launch_us": layers["conv2"]["avg_us"], "asdnet_forward_ms": asdnet_ms,
-                         "asdnet_tflops": (2.0 * 39_092_224 * layers["conv2"]["patches_per_call"]) / (asdnet_ms * 1e-3) / 1e12 if asdnet_ms > 0 else 0.0},
+                         "asdnet_tflops": (2.0 * 39_092_224 * layers["conv2"]["patches_per_call"]) / (asdnet_ms * 1e-3) / 1e12 if asdnet_ms > 0 else 0.0,
+                         **roof_extra},
             "asdnet_layers": layers,
             "last_step": stats,
         }

@@ -62,3 +62,70 @@ def test_hip_full_size_properties(hip, synth):
     out_p = hip.describe(patches[perm])
     np.testing.assert_array_equal(out_p, out[perm])
     np.testing.assert_array_equal(hip.describe(patches), out)
+
+
+# ---- the two arithmetic forms of the conv layers (asdnet.hip: K1 = f32 MFMA, K1s = f32 operands split into three bf16 terms)
+def _f64_truth(synth, patches):
+    """ASDNet.forward (ASDNet.py:334-370) in float64 on the CPU: the yardstick both kernel families are measured against."""
+    import torch
+    import torch.nn.functional as F
+    layers = synth.asdnet_weights(0)
+    x = torch.from_numpy(patches.astype(np.float32) / np.float32(255.0)).double().reshape(-1, 1, 32, 32)
+    flat = x.reshape(x.shape[0], -1)
+    x = (x - flat.mean(1).reshape(-1, 1, 1, 1)) / (flat.std(1).reshape(-1, 1, 1, 1) + 1e-7)
+    spec = [(1, 1), (1, 1), (2, 1), (1, 1), (2, 1), (1, 1), (1, 0)]
+    for l, ((w, mean, var), (stride, pad)) in enumerate(zip(layers, spec)):
+        x = F.conv2d(x, torch.from_numpy(np.asarray(w)).double(), stride=stride, padding=pad)
+        m = torch.from_numpy(np.asarray(mean)).double().reshape(1, -1, 1, 1)
+        v = torch.from_numpy(np.asarray(var)).double().reshape(1, -1, 1, 1)
+        x = (x - m) / torch.sqrt(v + 1e-5)
+        if l < 6:
+            x = torch.relu(x)
+    x = x.reshape(x.shape[0], -1)
+    return (x / torch.sqrt((x * x).sum(1, keepdim=True) + 1e-10)).numpy()
+
+
+@pytest.fixture(scope="module")
+def hip_f32(pkg):
+    """A second context with every ASDNet layer on the f32 MFMA kernels (ASD_ASDNET_MATH=f32 is read at context creation)."""
+    import os
+    old = os.environ.get("ASD_ASDNET_MATH")
+    os.environ["ASD_ASDNET_MATH"] = "f32"
+    try:
+        ctx = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096)
+    finally:
+        if old is None:
+            del os.environ["ASD_ASDNET_MATH"]
+        else:
+            os.environ["ASD_ASDNET_MATH"] = old
+    ctx.load_weights(pkg.synth.asdnet_weights(0))
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_split_mask_selection(hip, hip_f32):
+    assert hip.asdnet_split_mask() == 0x1f      # default: conv2 .. conv6 on the split-operand kernels
+    assert hip_f32.asdnet_split_mask() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 33, 257])
+def test_f32_mfma_kernels_match_oracle(hip_f32, oracle, synth, n):
+    layers = synth.asdnet_weights(0)
+    patches = synth.random_patches(n, seed=100 + n)
+    np.testing.assert_allclose(hip_f32.describe(patches), oracle.asdnet_forward(layers, patches), atol=DESC_ATOL, rtol=0)
+
+
+@pytest.mark.gpu
+def test_split_operand_kernels_are_f32_accurate(hip, hip_f32, synth, asdnet_golden):
+    """The split-operand kernels are not a reduced-precision mode: against a float64 forward their error is that of the
+    f32 MFMA kernels (both ~1e-7 on unit-norm descriptors), and the two families agree far inside the parity tolerance."""
+    patches = np.concatenate([asdnet_golden["patches"], synth.random_patches(192, seed=11)])
+    truth = _f64_truth(synth, patches)
+    d_split = hip.describe(patches).astype(np.float64)
+    d_f32 = hip_f32.describe(patches).astype(np.float64)
+    e_split, e_f32 = np.abs(d_split - truth), np.abs(d_f32 - truth)
+    assert e_f32.max() < 2e-6 and e_split.max() < 2e-6
+    assert np.sqrt((e_split ** 2).mean()) <= 1.5 * np.sqrt((e_f32 ** 2).mean()) + 1e-9
+    assert np.abs(d_split - d_f32).max() < 2e-6

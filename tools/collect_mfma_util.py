@@ -2,9 +2,10 @@
   rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_clk -o c -- python3 tools/time_asdnet.py 2000 3
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d gpurun_out/pmc_mfma -o m -- python3 tools/time_asdnet.py 2000 3
   python3 tools/collect_mfma_util.py gpurun_out/pmc_clk gpurun_out/pmc_mfma > profiles/r01_asdnet_mfma_util.json
-SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the chip (= 64 x the number of v_mfma_f32_32x32x2_f32,
-checked below); GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md), so busy / (GUI_ACTIVE / 8 x 1024 SIMDs)
-is the fraction of SIMD-cycles with the matrix pipe busy."""
+SQ_VALU_MFMA_BUSY_CYCLES counts matrix-pipe cycles summed over the chip (= 64 x the number of v_mfma_f32_32x32x2_f32, or
+32 x the number of v_mfma_f32_32x32x16_bf16 of the split-operand kernels: six per 16-deep k-chunk; checked below);
+GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md), so busy / (GUI_ACTIVE / 8 x 1024 SIMDs) is the fraction of
+SIMD-cycles with the matrix pipe busy, and GUI_ACTIVE / 8 / duration the effective clock."""
 import collections
 import csv
 import glob
@@ -13,7 +14,9 @@ import re
 import sys
 
 FLOP = {"k_conv_mfma<32, 32, 32": 2 * 9437184, "k_conv_mfma_p<32, 64": 2 * 4718592, "k_conv_mfma<64, 64": 2 * 9437184,
-        "k_conv_mfma<64, 128": 2 * 4718592, "k_conv_mfma<128, 128": 2 * 9437184, "k_fc_mfma": 2 * 1048576}
+        "k_conv_mfma<64, 128": 2 * 4718592, "k_conv_mfma<128, 128": 2 * 9437184, "k_fc_mfma": 2 * 1048576,
+        "k_conv_x3<32, 32, 32": 2 * 9437184, "k_conv_x3<32, 64": 2 * 4718592, "k_conv_x3<64, 64": 2 * 9437184,
+        "k_conv_x3<64, 128": 2 * 4718592, "k_conv_x3<128, 128": 2 * 9437184}
 
 
 def load(d, name):
@@ -31,16 +34,18 @@ def main():
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
     out = {}
     for k, v in clk.items():
-        if "mfma" not in k:
+        if "mfma" not in k and "k_conv_x3" not in k:
             continue
         v, m = v[2:], mf.get(k, [])[2:]   # drop the warm-up launches
         ga = sum(a for a, _ in v) / len(v)
         dur = sum(d for _, d in v) / len(v)
         busy = sum(a for a, _ in m) / max(len(m), 1)
         flop = [f for p, f in FLOP.items() if k.startswith(p)]
-        n_mfma = n * flop[0] / 4096 if flop else 0
+        split = "k_conv_x3" in k
+        # f32 MFMA 32x32x2: 4096 FLOP, 64 cycles; bf16 MFMA 32x32x16: 32768 FLOP, 32 cycles, six per f32-equivalent chunk
+        n_mfma = (6 * n * flop[0] / 32768 if split else n * flop[0] / 4096) if flop else 0
         out[k] = {"avg_us": dur / 1e3, "effective_clock_GHz": ga / 8 / dur, "SQ_VALU_MFMA_BUSY_CYCLES": busy,
-                  "expected_64_x_n_mfma": 64 * n_mfma, "mfma_busy_fraction": busy / (ga / 8 * 1024),
+                  "expected_busy_cycles": (32 if split else 64) * n_mfma, "mfma_busy_fraction": busy / (ga / 8 * 1024),
                   "tflops": (n * flop[0] / (dur * 1e-9) / 1e12) if flop else None}
     print(json.dumps({"n_patches": n, "kernels": out,
                       "source": "rocprofv3 --pmc GRBM_GUI_ACTIVE / --pmc SQ_VALU_MFMA_BUSY_CYCLES (separate passes), tools/time_asdnet.py"}, indent=1))
