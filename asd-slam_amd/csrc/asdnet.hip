@@ -6,9 +6,11 @@
 // the TorchScript module once per pyramid level with an H2D and a D2H copy each
 // (ORBextractor.cc:1217-1231); here all levels' patches go through one batch.
 //
-// Arithmetic: f32 in / f32 accumulate on the matrix cores (v_mfma_f32_32x32x2_f32 is an
-// exact f32 fma chain), BatchNorm (eval, affine=False) folded into the conv weights and a
-// per-channel bias at upload.  Activations are NHWC f32 so the contraction index (cin) is
+// Arithmetic: f32 results with f32 accumulation on the matrix cores, in one of two forms per layer (ctx->net_split):
+//   K1  (k_conv_mfma, k_conv_mfma_p): f32 operands on v_mfma_f32_32x32x2_f32 (an exact f32 fma chain);
+//   K1s (k_conv_x3, default): each f32 operand split exactly into three bf16 terms, six products per multiply-add on
+//        v_mfma_f32_32x32x16_bf16 -- same error level, 3/8 of the matrix-pipe time (see the comment at K1s).
+// BatchNorm (eval, affine=False) is folded into the conv weights and a per-channel bias at upload.  Activations are NHWC f32 so the contraction index (cin) is
 // contiguous; every 3x3 conv is an implicit GEMM  [pixels x 9*cin] * [9*cin x cout]:
 //   A operand  = zero-padded input band staged once per workgroup in LDS,
 //   B operand  = per-(tap, cin-chunk) weight slices streamed through a 2-deep LDS ring,
