@@ -189,7 +189,10 @@ struct PoseOptArgs {
   double fx, fy, cx, cy;
   double* soa_g;        // [8][n] global scratch (used when the problem does not fit LDS)
   uint8_t* flags_g;     // [2n] global scratch: level, outlier
-  double* io;           // in: pose[7]; out: pose[7], n_bad (as double), then outlier bytes at io + 8
+  double pose0[7];      // initial pose (by value: no read of host memory on the kernel's critical path)
+  double isg_tab[16];   // MODE 2: the distinct information values ...
+  const uint8_t* isgi;  // ... and each edge's index into them (device)
+  double* io;           // out: pose[7], n_bad (as double), then outlier bytes at io + 8
   int use_lds;
   int debug;  // ASD_POSE_DEBUG: thread 0 prints passes / iterations per round
 };
@@ -199,10 +202,12 @@ struct PoseOptArgs {
 #endif
 constexpr int kPoseThreads = ASD_POSE_THREADS, kPoseWaves = kPoseThreads / 64;
 struct PoseShared {
-  Pose7 T, T0, Tbak;
+  Pose7 T, T0, Tbak, Teval;
   double H[36], b[6], x[6];
   double sums[29];
   double red[kPoseWaves * 32];
+  double isg_tab[16];
+  double pad_;  // sizeof % 16 == 0
   double lambda, ni, currentChi, iniChi, rho;
   int qmax, cont, ok, sys_valid, stop, npass;
   long long cyc[4];  // debug: edge loop, reduction, solve+oplus, LM bookkeeping
@@ -227,13 +232,61 @@ __device__ inline double nr_rsqrt(double x) {
   return r;
 }
 
-// soa = [X | Y | Z | u | v | inv_sigma2 | e0 | e1], each [n]: consecutive lanes read consecutive doubles (the [n][6]
+// Where the solver keeps its edges.  MODE 0: [6][n] doubles in global memory (problems that do not fit LDS); MODE 1: the same
+// in LDS (50 B / edge with the flags); MODE 2: the compact LDS form, 35 B / edge -- X, Y, Z as doubles, the observation as
+// two floats and the information value as an index into a <= 16-entry table.  The host picks MODE 2 when every observation
+// is exactly representable in f32 (keypoint coordinates are f32 in the reference: cv::KeyPoint::pt) and the edges use at
+// most 16 distinct information values (one per pyramid level, Optimizer.cc:300): nothing is rounded.  2000 edges then take
+// 69 KB (130 KB with f64 observations and per-edge stored errors), so the workgroup fits on a CU beside a resident ASDNet
+// workgroup (70-78 KB) instead of waiting for a whole CU to drain (rocprof under the pipeline: PoseOptimization of the
+// local-map stage 146 us at best, 292 us median).
+// g2o keeps every edge's error "as last computed"; the solver does not store them: the re-classification at the end of a
+// round re-evaluates an inlier edge at the pose of the round's LAST pass (S.Teval) with the pass's own arithmetic
+// (pass_error), which reproduces the value the pass computed bit for bit.
+template <int MODE>
+struct EdgeStore {
+  double* soa;            // MODE 0 / 1: [6][n]
+  double* xyz;            // MODE 2: LDS [3][n]
+  float2* uv;             //         LDS [n]
+  uint8_t* isgi;          //         LDS [n]
+  const double* isg_tab;  //         LDS [16]
+  int n;
+  __device__ inline void load(int i, double& X, double& Y, double& Z, double& u, double& v, double& isg) const {
+    if constexpr (MODE == 2) {
+      X = xyz[i]; Y = xyz[n + i]; Z = xyz[2 * n + i];
+      const float2 o = uv[i];
+      u = (double)o.x; v = (double)o.y;
+      isg = isg_tab[isgi[i]];
+    } else {
+      X = soa[i]; Y = soa[n + i]; Z = soa[2 * n + i];
+      u = soa[3 * n + i]; v = soa[4 * n + i]; isg = soa[5 * n + i];
+    }
+  }
+};
+
+// residual of one edge the way a pass evaluates it: rotation matrix + translation, one Newton reciprocal (iz = 0 for an
+// inactive lane).  Shared by pose_pass and the re-classification so both produce the same bits.
+__device__ __forceinline__ void pass_error(const double (&R)[9], double ttx, double tty, double ttz, double X, double Y, double Z, double ou,
+                                           double ov, double fx, double fy, double cx, double cy, bool act, double& iz, double& xz, double& yz,
+                                           double& e0, double& e1) {
+  const double x = R[0] * X + R[1] * Y + R[2] * Z + ttx;
+  const double y = R[3] * X + R[4] * Y + R[5] * Z + tty;
+  const double z = R[6] * X + R[7] * Y + R[8] * Z + ttz;
+  iz = act ? nr_rcp(z) : 0.0;
+  xz = x * iz; yz = y * iz;
+  e0 = ou - (xz * fx + cx);
+  e1 = ov - (yz * fy + cy);
+}
+
+// soa = [X | Y | Z | u | v | inv_sigma2], each [n]: consecutive lanes read consecutive doubles (the [n][6]
 // records this replaces put 8 lanes on every LDS bank pair)
-__device__ inline void pose_pass(const PoseOptArgs& a, double* soa, const uint8_t* lvl, PoseShared& S, bool robust) {
+template <int MODE>
+__device__ inline void pose_pass(const PoseOptArgs& a, const EdgeStore<MODE>& E, const uint8_t* lvl, PoseShared& S, bool robust) {
   // fp64 issue on ONE CU bounds this loop (a wave64 fp64 op takes 4 cycles, a division ~35 ops), so the
   // arithmetic is kept lean: rotation matrix instead of the quaternion sandwich, one reciprocal per
   // edge, weighted Jacobian rows shared by all 27 accumulators.
   const Pose7 T = S.T;
+  if (threadIdx.x == 0) S.Teval = T;  // the pose the stored-error semantics refer to (see EdgeStore)
   double R[9];
   quat_to_rot(T, R);
   // wave-uniform: keep the pose in scalar registers (it comes out of LDS, which the compiler cannot prove uniform)
@@ -256,16 +309,10 @@ __device__ inline void pose_pass(const PoseOptArgs& a, double* soa, const uint8_
     const int i0 = threadIdx.x + it * kPoseThreads;
     const int i = min(i0, n - 1);
     const bool act = i0 < n && !lvl[i];
-    const double X = soa[i], Y = soa[n + i], Z = soa[2 * n + i];
-    const double ou = soa[3 * n + i], ov = soa[4 * n + i], isg = soa[5 * n + i];
-    const double x = R[0] * X + R[1] * Y + R[2] * Z + ttx;
-    const double y = R[3] * X + R[4] * Y + R[5] * Z + tty;
-    const double z = R[6] * X + R[7] * Y + R[8] * Z + ttz;
-    const double iz = act ? nr_rcp(z) : 0.0;
-    const double xz = x * iz, yz = y * iz;
-    const double e0 = ou - (xz * a.fx + a.cx);
-    const double e1 = ov - (yz * a.fy + a.cy);
-    if (act) { soa[6 * n + i] = e0; soa[7 * n + i] = e1; }
+    double X, Y, Z, ou, ov, isg;
+    E.load(i, X, Y, Z, ou, ov, isg);
+    double iz, xz, yz, e0, e1;
+    pass_error(R, ttx, tty, ttz, X, Y, Z, ou, ov, a.fx, a.fy, a.cx, a.cy, act, iz, xz, yz, e0, e1);
     const double c = (e0 * e0 + e1 * e1) * isg;
     // Huber (robust_kernel_impl.cpp:78-91); a wave of 64 edges practically always holds an outlier, so no branch
     const bool hub = robust && c > hd2;
@@ -314,9 +361,9 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
   for (int r = 0; r < 6; ++r) S.b[r] = S.sums[21 + r];
 }
 
-// USE_LDS is a template parameter, not a run-time switch: with a pointer that may be LDS or global the compiler
-// falls back to FLAT loads, whose latency dominated the edge loop.
-template <bool USE_LDS>
+// MODE (the EdgeStore form) is a template parameter, not a run-time switch: with a pointer that may be LDS or global the
+// compiler falls back to FLAT loads, whose latency dominated the edge loop.
+template <int MODE>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
   // the read-ahead extractor: ask the SIMD arbiters to issue its waves first
@@ -324,21 +371,41 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
   __shared__ PoseShared S;
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   const int t = threadIdx.x;
-  double* soa;
+  EdgeStore<MODE> E{};
+  E.n = a.n;
   uint8_t *lvl, *outl;
-  if constexpr (USE_LDS) {
-    soa = dyn;
-    lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)8 * a.n);
+  // a.edges = the [n][6] records as uploaded (coalesced read, transposed write); a.isgi = information-value index per edge
+  if constexpr (MODE == 2) {
+    E.xyz = dyn;
+    E.uv = reinterpret_cast<float2*>(dyn + (size_t)3 * a.n);
+    E.isgi = reinterpret_cast<uint8_t*>(E.uv + a.n);
+    lvl = E.isgi + a.n;
     outl = lvl + a.n;
+    E.isg_tab = S.isg_tab;
+    float* uvf = reinterpret_cast<float*>(E.uv);
+    for (int i = t; i < 6 * a.n; i += kPoseThreads) {
+      const int k = i % 6, e = i / 6;
+      const double v = a.edges[i];
+      if (k < 3) E.xyz[(size_t)k * a.n + e] = v;
+      else if (k < 5) uvf[2 * e + (k - 3)] = (float)v;  // exact: checked on the host
+    }
+    for (int i = t; i < a.n; i += kPoseThreads) E.isgi[i] = a.isgi[i];
+    if (t < 16) S.isg_tab[t] = a.isg_tab[t];
   } else {
-    soa = a.soa_g;
-    lvl = a.flags_g;
-    outl = a.flags_g + a.n;
+    if constexpr (MODE == 1) {
+      E.soa = dyn;
+      lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)6 * a.n);
+      outl = lvl + a.n;
+    } else {
+      E.soa = a.soa_g;
+      lvl = a.flags_g;
+      outl = a.flags_g + a.n;
+    }
+    for (int i = t; i < 6 * a.n; i += kPoseThreads) E.soa[(size_t)(i % 6) * a.n + i / 6] = a.edges[i];
   }
-  for (int i = t; i < 6 * a.n; i += kPoseThreads) soa[(size_t)(i % 6) * a.n + i / 6] = a.edges[i];  // coalesced read, transposed write
   for (int i = t; i < a.n; i += kPoseThreads) { lvl[i] = 0; outl[i] = 0; }
   if (t == 0) {
-    Pose7 T0{a.io[0], a.io[1], a.io[2], a.io[3], a.io[4], a.io[5], a.io[6]};
+    Pose7 T0{a.pose0[0], a.pose0[1], a.pose0[2], a.pose0[3], a.pose0[4], a.pose0[5], a.pose0[6]};
     quat_normalize(T0.qx, T0.qy, T0.qz, T0.qw);
     S.T0 = T0;
     S.T = T0;
@@ -349,7 +416,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
   for (int round = 0; round < 4; ++round) {
     if (t == 0) { S.T = S.T0; S.npass = 0; for (int q = 0; q < 4; ++q) { S.cyc[q] = 0; S.dbg[q] = 0; } }  // every round restarts from the input pose (Optimizer.cc:337)
     __syncthreads();
-    pose_pass(a, soa, lvl, S, robust);
+    pose_pass(a, E, lvl, S, robust);
     const bool any_active = S.sums[28] > 0.5;
     if (any_active) {
       // ---- g2o optimize(10): Levenberg (optimization_algorithm_levenberg.cpp:61-189)
@@ -357,7 +424,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
       if (t == 0) S.sys_valid = 1;
       __syncthreads();
       for (int it = 0; it < 10; ++it) {
-        if (!S.sys_valid) pose_pass(a, soa, lvl, S, robust);  // only after a non-finite trial
+        if (!S.sys_valid) pose_pass(a, E, lvl, S, robust);  // only after a non-finite trial
         if (t == 0) {
           S.currentChi = S.sums[27];
           S.iniChi = S.sums[27];
@@ -382,7 +449,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
             if (a.debug) S.cyc[2] += clock64() - c0;
           }
           __syncthreads();
-          pose_pass(a, soa, lvl, S, robust);
+          pose_pass(a, E, lvl, S, robust);
           if (t == 0) {
             const long long c0 = a.debug ? clock64() : 0;
             double tempChi = S.sums[27];
@@ -429,18 +496,24 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
     // ---- re-classification (Optimizer.cc:341-368)
     double nb[1] = {0.0};
     {
-      const Pose7 T = S.T;
+      const Pose7 T = S.T, Te = S.Teval;
+      double Re[9];
+      quat_to_rot(Te, Re);
       const int n = a.n;
       for (int i = t; i < n; i += kPoseThreads) {
-        if (outl[i]) {  // e->computeError()
-          const double Xw[3] = {soa[i], soa[n + i], soa[2 * n + i]};
+        double X, Y, Z, ou, ov, isg, e0, e1;
+        E.load(i, X, Y, Z, ou, ov, isg);
+        if (outl[i]) {  // e->computeError() at the current estimate
+          const double Xw[3] = {X, Y, Z};
           double Xc[3];
           pose_map(T, Xw, Xc);
-          soa[6 * n + i] = soa[3 * n + i] - (Xc[0] / Xc[2] * a.fx + a.cx);
-          soa[7 * n + i] = soa[4 * n + i] - (Xc[1] / Xc[2] * a.fy + a.cy);
+          e0 = ou - (Xc[0] / Xc[2] * a.fx + a.cx);
+          e1 = ov - (Xc[1] / Xc[2] * a.fy + a.cy);
+        } else {        // inlier: active in every pass of this round, its error is the last pass's
+          double iz, xz, yz;
+          pass_error(Re, Te.tx, Te.ty, Te.tz, X, Y, Z, ou, ov, a.fx, a.fy, a.cx, a.cy, true, iz, xz, yz, e0, e1);
         }
-        const double e0 = soa[6 * n + i], e1 = soa[7 * n + i];
-        const float chi2 = (float)((e0 * e0 + e1 * e1) * soa[5 * n + i]);
+        const float chi2 = (float)((e0 * e0 + e1 * e1) * isg);
         if (chi2 > kChi2Mono) { outl[i] = 1; lvl[i] = 1; nb[0] += 1.0; }
         else { outl[i] = 0; lvl[i] = 0; }
       }
@@ -460,8 +533,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
     a.io[4] = S.T.tx; a.io[5] = S.T.ty; a.io[6] = S.T.tz;
     a.io[7] = (double)nBad;
   }
-  uint8_t* og = reinterpret_cast<uint8_t*>(a.io + 8);
-  for (int i = t; i < a.n; i += kPoseThreads) og[i] = outl[i];
+  // outlier flags to the (pinned host) io block, eight per 8-byte store
+  unsigned long long* og8 = reinterpret_cast<unsigned long long*>(a.io + 8);
+  for (int i = t; i < (a.n + 7) / 8; i += kPoseThreads) {
+    unsigned long long w = 0;
+    for (int k = 0; k < 8; ++k)
+      if (8 * i + k < a.n) w |= (unsigned long long)outl[8 * i + k] << (8 * k);
+    og8[i] = w;
+  }
 }
 
 // ---------------------------------------------------------------- LocalBA kernels
@@ -1073,7 +1152,7 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   (void)hipSetDevice(ctx->cfg.device);
   BaState* s = ba_state(ctx);
   int rc;
-  const size_t in_bytes = (size_t)n * 48 + 64, io_bytes = 64 + (size_t)n + 64;
+  const size_t idx_off = (size_t)n * 48, in_bytes = idx_off + ((size_t)n + 63) / 64 * 64 + 64, io_bytes = 64 + (size_t)n + 64;
   if ((rc = s->po_Xw.ensure(ctx, in_bytes)) || (rc = s->po_err.ensure(ctx, (size_t)n * 64)) ||
       (rc = s->po_level.ensure(ctx, (size_t)2 * n)) || (rc = s->po_pose.ensure(ctx, io_bytes)))
     return rc;
@@ -1083,40 +1162,78 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
     ASD_HIP_CHECK(ctx, hipHostMalloc(&s->h_po, 2 * (in_bytes + io_bytes)));
     s->h_po_cap = 2 * (in_bytes + io_bytes);
   }
-  // one pinned staging buffer: [n][6] edges, then the io block
+  static const bool timing = getenv("ASD_TIMING") != nullptr;
+  static double tacc[2][4]; static long tcalls[2];
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto tp0 = now();
+  // one pinned staging buffer: [n][6] edges, the information-value index per edge, then the io block
   double* hin = reinterpret_cast<double*>(s->h_po);
+  uint8_t* hidx = reinterpret_cast<uint8_t*>(s->h_po + idx_off);
+  PoseOptArgs a;
+  int ntab = 0;
+  bool compact = true;  // observations exactly f32, <= 16 distinct information values (see EdgeStore)
   for (int i = 0; i < n; ++i) {
     hin[6 * i] = Xw[3 * i]; hin[6 * i + 1] = Xw[3 * i + 1]; hin[6 * i + 2] = Xw[3 * i + 2];
-    hin[6 * i + 3] = obs[2 * i]; hin[6 * i + 4] = obs[2 * i + 1]; hin[6 * i + 5] = inv_sigma2[i];
+    const double u = obs[2 * i], v = obs[2 * i + 1], w = inv_sigma2[i];
+    hin[6 * i + 3] = u; hin[6 * i + 4] = v; hin[6 * i + 5] = w;
+    if (compact) {
+      if ((double)(float)u != u || (double)(float)v != v) { compact = false; continue; }
+      int k = 0;
+      while (k < ntab && memcmp(&a.isg_tab[k], &w, 8) != 0) ++k;   // bit pattern: NaNs and signed zeros stay themselves
+      if (k == ntab) {
+        if (ntab == 16) { compact = false; continue; }
+        a.isg_tab[ntab++] = w;
+      }
+      hidx[i] = (uint8_t)k;
+    }
   }
+  for (int k = ntab; k < 16; ++k) a.isg_tab[k] = 0.0;
   double* hio = reinterpret_cast<double*>(s->h_po + in_bytes);
   memcpy(hio, pose7, 56);
   hipStream_t st = ctx->stream;
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_Xw.p, hin, (size_t)n * 48, hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_pose.p, hio, 56, hipMemcpyHostToDevice, st));
-  PoseOptArgs a;
+  auto tp1 = now();
+  // edges and their information-value indices travel in one copy; the pose is a kernel argument
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->po_Xw.p, hin, idx_off + (size_t)n, hipMemcpyHostToDevice, st));
   a.n = n;
   a.edges = s->po_Xw.as<double>();
+  a.isgi = s->po_Xw.as<uint8_t>() + idx_off;
+  memcpy(a.pose0, pose7, 56);
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
   a.soa_g = s->po_err.as<double>();
   a.flags_g = s->po_level.as<uint8_t>();
   a.io = s->po_pose.as<double>();
-  const size_t lds = (size_t)n * 64 + (size_t)2 * n + 16;
-  a.use_lds = (lds <= 150 * 1024 && !getenv("ASD_POSE_NO_LDS")) ? 1 : 0;
+  static const bool no_lds = getenv("ASD_POSE_NO_LDS") != nullptr, no_compact = getenv("ASD_POSE_NO_COMPACT") != nullptr;
+  const size_t lds_full = (size_t)n * 48 + (size_t)2 * n + 16, lds_compact = (size_t)n * 35 + 16;
+  int mode = 0;
+  if (!no_lds && compact && !no_compact && lds_compact <= 150 * 1024) mode = 2;
+  else if (!no_lds && lds_full <= 150 * 1024) mode = 1;
+  a.use_lds = mode;
   a.debug = getenv("ASD_POSE_DEBUG") ? 1 : 0;
   static bool attr_set = false;
   if (!attr_set) {
-    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-  if (a.use_lds) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kPoseThreads), lds, st, a);
-  else hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(kPoseThreads), 0, st, a);
+  if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
+  else if (mode == 1) hipLaunchKernelGGL(k_pose_opt<1>, dim3(1), dim3(kPoseThreads), lds_full, st, a);
+  else hipLaunchKernelGGL(k_pose_opt<0>, dim3(1), dim3(kPoseThreads), 0, st, a);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(hio, s->po_pose.p, 64 + (size_t)n, hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(hio, s->po_pose.p, 64 + (size_t)n + 8, hipMemcpyDeviceToHost, st));
+  auto tp2 = now();
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  auto tp3 = now();
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_ba, ctx->ev0, ctx->ev1));
+  if (timing) {
+    const int k = n > 1500;
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    tacc[k][0] += ms(tp0, tp1); tacc[k][1] += ms(tp1, tp2); tacc[k][2] += ms(tp2, tp3); tacc[k][3] += ctx->ms_ba;
+    if (++tcalls[k] % 200 == 0)
+      fprintf(stderr, "[pose_optimize n%s1500] pack %.3f enqueue %.3f sync %.3f kernel %.3f ms\n", k ? ">" : "<=", tacc[k][0] / tcalls[k], tacc[k][1] / tcalls[k],
+              tacc[k][2] / tcalls[k], tacc[k][3] / tcalls[k]);
+  }
   memcpy(pose7, hio, 56);
   memcpy(outlier, hio + 8, n);
   *n_inliers = n - (int)(hio[7] + 0.5);

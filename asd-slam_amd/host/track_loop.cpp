@@ -51,6 +51,7 @@ struct asd_track_handle {
   std::vector<uint8_t> ba_dpos, ba_out1;
   double wait_ms = 0.0, ba_ms = 0.0;  // ASD_TIMING: time blocked on the extractor / inside LocalBA
   double seg_ms[8] = {};              // frame_set, submit, bank+M1, pose1, frustum, M2, pose2, host glue
+  double kern_ms[4] = {};             // device time of M1, pose1, M2, pose2 (asd_last_stage_ms)
   long steps = 0;
 };
 
@@ -89,6 +90,8 @@ void asd_track_destroy(asd_track_handle* h) {
             h->ba_ms / h->steps);
     static const char* nm[8] = {"frame_set", "submit", "bank+M1", "pose1", "frustum", "M2", "pose2", "host glue"};
     for (int i = 0; i < 8; ++i) fprintf(stderr, "[track_loop]   %-10s %.3f ms/step\n", nm[i], h->seg_ms[i] / h->steps);
+    fprintf(stderr, "[track_loop]   device time: M1 %.3f pose1 %.3f M2 %.3f pose2 %.3f ms/step\n", h->kern_ms[0] / h->steps, h->kern_ms[1] / h->steps,
+            h->kern_ms[2] / h->steps, h->kern_ms[3] / h->steps);
   }
   delete h;
 }
@@ -174,6 +177,8 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       return rc;
     st->m1 = n1; st->has_m1 = 1;
     seg(2);
+    auto dev = [&](int i, const char* stage) { float ms = 0.f; if (asd_last_stage_ms(ctx, stage, &ms) == ASD_OK) h->kern_ms[i] += ms; };
+    dev(0, "match");
     auto pose_opt = [&](const std::vector<int>& sel, auto point_of, int32_t* ninl) -> int {
       const int m = (int)sel.size();
       h->Xd.resize((size_t)3 * m); h->obs.resize((size_t)2 * m); h->info.resize(m); h->outl.resize(m);
@@ -194,6 +199,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       int32_t ninl = 0;
       if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, &ninl)) != ASD_OK) return rc;
     }
+    dev(1, "ba");
     seg(3);
     // local map: the last frame's points plus a jittered copy
     const int n2p = 2 * nl;
@@ -223,6 +229,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
                                             h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2)) != ASD_OK)
       return rc;
     st->m2 = n2; st->has_m2 = 1;
+    dev(2, "match");
     seg(5);
     sel.clear();
     for (int j = 0; j < n; ++j) if (h->m1[j] >= 0 || h->m2[j] >= 0) sel.push_back(j);
@@ -232,6 +239,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
         return rc;
       st->inliers = ninl; st->has_inliers = 1;
     }
+    dev(3, "ba");
     seg(6);
   }
   if (do_ba) {

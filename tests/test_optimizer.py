@@ -144,6 +144,28 @@ def test_hip_pose_optimization_full_size(hip, oracle, synth):
 
 
 @pytest.mark.gpu
+def test_hip_pose_optimization_storage_forms(hip, oracle, synth):
+    """The solver keeps its edges in one of three forms (ba.hip, EdgeStore): compact LDS (observations exactly f32 and
+    <= 16 distinct information values: the reference's case, and every other test here), full f64 LDS, or global memory
+    (problems too large for LDS).  Inputs that are NOT f32-representable, or carry too many information values, must take
+    the f64 forms and still match the oracle; sizes on both sides of the LDS limits."""
+    rng = np.random.default_rng(5)
+    for n, seed, kind in ((1500, 41, "obs"), (1500, 42, "info"), (2300, 43, "obs"), (4300, 44, "compact"), (4500, 45, "obs")):
+        pp = synth.pose_problem(n, seed=seed, outlier_frac=0.12)
+        if kind == "obs":
+            pp["obs"] = pp["obs"] + rng.uniform(-1e-9, 1e-9, pp["obs"].shape)     # no longer exact in f32
+            assert (pp["obs"].astype(np.float32).astype(np.float64) != pp["obs"]).any()
+        elif kind == "info":
+            pp["info"] = pp["info"] * (1.0 + 1e-3 * rng.integers(0, 40, pp["info"].shape))   # > 16 distinct values
+            assert len(np.unique(pp["info"])) > 16
+        got = hip.pose_optimize(pp["pose"], pp["Xw"], pp["obs"], pp["info"], pp["K"])
+        exp = oracle.pose_optimize(pp["pose"], pp["Xw"], pp["obs"], pp["info"], pp["K"])
+        np.testing.assert_allclose(got[0], exp[0], atol=POSE_ATOL, rtol=0)
+        np.testing.assert_array_equal(got[1], exp[1])
+        assert got[2] == exp[2]
+
+
+@pytest.mark.gpu
 def test_hip_pose_optimization_edge_cases(hip, oracle, synth):
     """fewer than 10 edges (one round only, Optimizer.cc:402), majority outliers, points behind / on the camera plane"""
     cases = []
