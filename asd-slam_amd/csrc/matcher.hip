@@ -17,6 +17,7 @@
 // over the per-query (index, distance) lists.
 // The all-pairs matrix (asd_dist_matrix) uses the same exact summation, tiled through LDS.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -361,6 +362,10 @@ struct SearchResult { const int* off; const int* cnt; const int* idx; const floa
 // queries are already in m->h_queries[0..nq); d_q = query descriptor table on the device
 // kind: 0 frame-to-frame, 1 local map, 2 fuse, 3 other -- only sizes the speculative read-back
 int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, SearchResult* res, int kind = 3) {
+  static const bool timing = getenv("ASD_TIMING") != nullptr;   // per-kind host-side split, printed every 200 searches
+  static double tacc[4][3]; static long tcalls[4];
+  const auto tw0 = std::chrono::steady_clock::now();
+  auto tw1 = tw0;
   int rc = ensure_cands(ctx, m, 1);
   if (rc != ASD_OK) return rc;
   hipStream_t st = ctx->stream;
@@ -382,6 +387,7 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_q, d_off, ((size_t)2 * nq + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_idx, m->d_idx, (size_t)optimistic * sizeof(int), hipMemcpyDeviceToHost, st));
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_dist, m->d_dist, (size_t)optimistic * sizeof(float), hipMemcpyDeviceToHost, st));
+    tw1 = std::chrono::steady_clock::now();
     ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
     const int total = m->h_q[2 * nq];
     m->last_total[kind] = total;
@@ -397,6 +403,14 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
     break;
   }
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+  if (timing) {
+    const auto tw2 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    tacc[kind][0] += ms(tw0, tw1); tacc[kind][1] += ms(tw1, tw2); tacc[kind][2] += ctx->ms_match;
+    if (++tcalls[kind] % 200 == 0)
+      fprintf(stderr, "[window_search kind %d] enqueue %.3f sync %.3f kernel %.3f ms, %d candidates copied (last total %d)\n", kind,
+              tacc[kind][0] / tcalls[kind], tacc[kind][1] / tcalls[kind], tacc[kind][2] / tcalls[kind], optimistic, m->last_total[kind]);
+  }
   res->off = m->h_q;
   res->cnt = m->h_q + nq;
   res->idx = m->h_idx;
