@@ -486,6 +486,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 #ifndef ASD_X3_ABL
 #define ASD_X3_ABL 0  // tuning: 1 = weight stream pinned to chunk 0/1 (L1 hits), 2 = no band staging, 4 = no output stores
 #endif
+#ifndef ASD_X3_S16
+#define ASD_X3_S16 1  // 1 = v_mfma_f32_16x16x32_bf16 (16-row tiles, 32-deep chunks), 0 = 32x32x16: same cycles, but the chip holds a higher clock
+                      // under the 16x16x32 form (conv4 168 -> 154, conv6 165 -> 150 us)
+#endif
 #ifndef ASD_X3_PD
 #define ASD_X3_PD 2  // A-operand prefetch distance in 32-pixel tiles
 #endif
@@ -504,13 +508,14 @@ struct X3Cfg {
   static constexpr int M_WG = PP * M_PATCH;
   static constexpr int MT = M_WG / 32 / WM;
   static constexpr int NT = COUT / 32 / WN;
-  static constexpr int NC16 = CIN / 16;
-  static constexpr int NCHUNK = 9 * NC16;        // k-chunks of 16 cin
-  static constexpr int CHUNKB = 96 * COUT;       // bytes of weight image per chunk: [piece 3][half 2][cout][8 bf16]
+  static constexpr int KCH = ASD_X3_S16 ? 32 : 16;  // cin per k-chunk = K of the MFMA shape
+  static constexpr int NC16 = CIN / KCH;            // chunks per tap
+  static constexpr int NCHUNK = 9 * NC16;
+  static constexpr int CHUNKB = KCH * 6 * COUT;     // bytes of weight image per chunk: [piece 3][k-group KCH/8][cout][8 bf16]
   static constexpr int ACT_BYTES = INROWS * INCOLS * PIXB;
   static constexpr int LDS_BYTES = PP * ACT_BYTES;
   static_assert((PIXB / 16) % 2 == 1, "pixel stride must be an odd multiple of 16 B");
-  static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0 && CIN % 16 == 0 && HO % ROWS == 0, "tile split");
+  static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0 && CIN % KCH == 0 && HO % ROWS == 0, "tile split");
   static_assert(PP == 1 || ROWS == HO, "several patches per workgroup only for whole-patch bands");
   static_assert(M_PATCH % 32 == 0, "32-pixel MFMA tiles must not straddle patches");
 };
@@ -550,20 +555,26 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
   const int patch = (blockIdx.x / BANDS) * PP, band = blockIdx.x % BANDS;
   const int r0 = band * ROWS;
 
-  // ---- B operand stream: chunk c = tap * NC16 + c16, this lane's 8 k values of (piece, half h, cout)
-  const uint8_t* wl = wimg + ((size_t)h * COUT + wn * NT * 32 + li) * 16;
-  auto load_b = [&](int c, u32x4 (&b)[NT][3]) {
+  // MFMA shape: 32x32x16 -> lane = (k-half h, row/col li of 32), one sub-tile per 32x32 tile; 16x16x32 -> lane = (k-group of
+  // four, row/col of 16), SUB = 2 sub-tiles per tile side
+  constexpr bool S16 = ASD_X3_S16;
+  constexpr int SUB = S16 ? 2 : 1, KG = C::KCH / 8, TW = 32 / SUB;
+  const int kg = S16 ? lane >> 4 : h, lr = S16 ? lane & 15 : li;
+  // ---- B operand stream: chunk c = tap * NC16 + c16, this lane's 8 k values of (piece, k-group kg, cout)
+  const uint8_t* wl = wimg + ((size_t)kg * COUT + wn * NT * 32 + lr) * 16;
+  constexpr int NB = NT * SUB;  // B sub-tiles of this wave
+  auto load_b = [&](int c, u32x4 (&b)[NB][3]) {
     const uint8_t* wc = wl + (size_t)((ASD_X3_ABL & 1) ? (c & 1) : c) * C::CHUNKB;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[nt][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * 2 * COUT * 16 + nt * 512);
+      for (int p = 0; p < 3; ++p) b[nb][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * KG * COUT * 16 + nb * TW * 16);
   };
   // B operands run RB - 1 chunks ahead through a register ring of RB slots; the chunk loop is unrolled RB times so that the
   // slot of every chunk is a compile-time constant (no register copies)
   constexpr int RB = 3;
   static_assert(C::NCHUNK % RB == 0, "chunk count");
-  u32x4 br[RB][NT][3];
+  u32x4 br[RB][NB][3];
 #pragma unroll
   for (int d = 0; d < RB - 1; ++d) load_b(d, br[d]);
 
@@ -684,68 +695,75 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
   }
   __syncthreads();
 
-  f32x16 acc[MT][NT];
-  for (int mt = 0; mt < MT; ++mt)
-    for (int nt = 0; nt < NT; ++nt)
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-  int abase[MT];
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = (wm * MT + mt) * 32 + li;
+  // accumulators: [A sub-tile][B sub-tile]; a sub-tile is 32x32 (16 floats per lane) or 16x16 (4 floats per lane)
+  constexpr int NA = MT * SUB, AR = S16 ? 4 : 16;
+  typedef float accv __attribute__((ext_vector_type(S16 ? 4 : 16)));
+  accv acc[NA][NB];
+  for (int ma = 0; ma < NA; ++ma)
+    for (int nb = 0; nb < NB; ++nb)
+      for (int r = 0; r < AR; ++r) acc[ma][nb][r] = 0.f;
+  int abase[NA];
+  for (int ma = 0; ma < NA; ++ma) {
+    const int m = wm * MT * 32 + ma * TW + lr;
     const int pp = PP > 1 ? m / C::M_PATCH : 0, mm = m - pp * C::M_PATCH;
     const int rr = mm / C::HO, ox = mm % C::HO;
-    abase[mt] = pp * C::ACT_BYTES + ((rr * S) * C::INCOLS + ox * S) * C::PIXB + h * 48;
+    abase[ma] = pp * C::ACT_BYTES + ((rr * S) * C::INCOLS + ox * S) * C::PIXB + kg * 48;
   }
   auto chunk_off = [&](int c) {
     const int tap = c / C::NC16, c16 = c % C::NC16;
-    return ((tap / 3) * C::INCOLS + (tap % 3)) * C::PIXB + c16 * 96;
+    return ((tap / 3) * C::INCOLS + (tap % 3)) * C::PIXB + c16 * (KG * 48);
   };
   auto load_a = [&](int off, u32x4 (&a)[3]) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const u32x4*>(smem_b + off + p * 16);
   };
   auto bf = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+  auto mma = [&](const u32x4& x, const u32x4& y, accv& c) {
+    if constexpr (S16) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(x), bf(y), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(x), bf(y), c, 0, 0, 0);
+  };
 
-  // A operands run PD tiles ahead of the MFMAs through a register ring of PD + 1 slots; a loop iteration covers D chunks x MT
-  // tiles, a multiple of the ring size, so every tile's slot is a compile-time constant
+  // A operands run PD sub-tiles ahead of the MFMAs through a register ring of PD + 1 slots; a loop iteration covers RB chunks x
+  // NA sub-tiles, a multiple of the ring size, so every sub-tile's slot is a compile-time constant
   constexpr int PD = ASD_X3_PD, RS = PD + 1;
-  static_assert((RB * MT) % RS == 0, "ring slots must be static");
+  static_assert((RB * NA) % RS == 0, "ring slots must be static");
   u32x4 ar[RS][3];
 #pragma unroll
-  for (int q = 0; q < PD; ++q) load_a(abase[q % MT] + chunk_off(q / MT), ar[q]);
+  for (int q = 0; q < PD; ++q) load_a(abase[q % NA] + chunk_off(q / NA), ar[q]);
   // diagnostic only (stamps == nullptr in every product launch): shader clock and 100 MHz wall clock around the MFMA loop
   unsigned long long st_c = 0, st_r = 0;
   if (stamps) { st_c = __builtin_amdgcn_s_memtime(); st_r = __builtin_amdgcn_s_memrealtime(); }
   for (int c0 = 0; c0 < C::NCHUNK; c0 += RB) {
-    int offs[RB + PD / MT + 2];
+    int offs[RB + PD / NA + 2];
 #pragma unroll
-    for (int u = 0; u < RB + PD / MT + 2; ++u) offs[u] = chunk_off(c0 + u < C::NCHUNK ? c0 + u : C::NCHUNK - 1);
+    for (int u = 0; u < RB + PD / NA + 2; ++u) offs[u] = chunk_off(c0 + u < C::NCHUNK ? c0 + u : C::NCHUNK - 1);
 #pragma unroll
     for (int u = 0; u < RB; ++u) {
       const int c = c0 + u;
       // past the end: a redundant re-read of the last chunk instead of a branch
       load_b(c + RB - 1 < C::NCHUNK ? c + RB - 1 : C::NCHUNK - 1, br[(u + RB - 1) % RB]);
-      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NT, 0);
-      const u32x4 (&bc)[NT][3] = br[u];
+      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NB, 0);
+      const u32x4 (&bc)[NB][3] = br[u];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int q = u * MT + mt;            // tile index within the iteration
-        const int qn = q + PD;                // the tile fetched now (past the end: re-reads the last chunk, unused)
-        load_a(abase[qn % MT] + offs[qn / MT], ar[qn % RS]);
+      for (int ma = 0; ma < NA; ++ma) {
+        const int q = u * NA + ma;            // sub-tile index within the iteration
+        const int qn = q + PD;                // the sub-tile fetched now (past the end: re-reads the last chunk, unused)
+        load_a(abase[qn % NA] + offs[qn / NA], ar[qn % RS]);
         const u32x4 (&ac)[3] = ar[q % RS];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
+        for (int nb = 0; nb < NB; ++nb) {
           // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[2]), bf(bc[nt][0]), acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[0]), bf(bc[nt][2]), acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[1]), bf(bc[nt][1]), acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[1]), bf(bc[nt][0]), acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[0]), bf(bc[nt][1]), acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(ac[0]), bf(bc[nt][0]), acc[mt][nt], 0, 0, 0);
+          mma(ac[2], bc[nb][0], acc[ma][nb]);
+          mma(ac[0], bc[nb][2], acc[ma][nb]);
+          mma(ac[1], bc[nb][1], acc[ma][nb]);
+          mma(ac[1], bc[nb][0], acc[ma][nb]);
+          mma(ac[0], bc[nb][1], acc[ma][nb]);
+          mma(ac[0], bc[nb][0], acc[ma][nb]);
         }
-        // issue order within the tile: one operand read behind every 2 * NT MFMAs
+        // issue order within the sub-tile: one operand read behind every 2 * NB MFMAs
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
@@ -753,22 +771,24 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
   }
 
   if (stamps) {
-    asm volatile("s_nop 0" ::"v"(acc[MT - 1][NT - 1][0]));  // the last MFMA has retired before the closing stamp
+    asm volatile("s_nop 0" ::"v"(acc[NA - 1][NB - 1][0]));  // the last MFMA has retired before the closing stamp
     const unsigned long long e_c = __builtin_amdgcn_s_memtime(), e_r = __builtin_amdgcn_s_memrealtime();
     if (t == 0) { stamps[2 * blockIdx.x] = e_c - st_c; stamps[2 * blockIdx.x + 1] = e_r - st_r; }
   }
-  // ---- epilogue: bias (folded BN) + ReLU, NHWC f32 store.  Lane owns one cout column, 16 pixel rows.
+  // ---- epilogue: bias (folded BN) + ReLU, NHWC f32 store.  Lane owns one cout column and AR pixel rows of each sub-tile
+  // (32x32: rows (r & 3) + 8 (r >> 2) + 4 h; 16x16: rows 4 kg + r)
   float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = (wn * NT + nt) * 32 + li;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int co = wn * NT * 32 + nb * TW + lr;
     const float bv = bias[co];
-    for (int mt = 0; mt < MT; ++mt) {
-      const int pp = PP > 1 ? ((wm * MT + mt) * 32) / C::M_PATCH : 0;
+    for (int ma = 0; ma < NA; ++ma) {
+      const int m0 = wm * MT * 32 + ma * TW;
+      const int pp = PP > 1 ? m0 / C::M_PATCH : 0;  // a sub-tile never straddles two patches
       if (PP > 1 && patch + pp >= n) continue;
-      for (int r = 0; r < 16; ++r) {
-        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      for (int r = 0; r < AR; ++r) {
+        const int m = m0 + (S16 ? 4 * kg + r : (r & 3) + 8 * (r >> 2) + 4 * h);
         const size_t o = (size_t)pp * C::HO * C::HO * COUT + (size_t)(m - pp * C::M_PATCH) * COUT + co;
-        const float v = acc[mt][nt][r] + bv;
+        const float v = acc[ma][nb][r] + bv;
         if (!(ASD_X3_ABL & 4) || v == 12345.f) op[o] = v > 0.f ? v : 0.f;
       }
     }
@@ -959,20 +979,21 @@ inline void split3_host(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
   h = (uint16_t)(hu >> 16); m = (uint16_t)(mu >> 16); l = (uint16_t)(r2u >> 16);
 }
 
-// split B-operand image of a 3x3 layer: [tap][cin/16][piece][half][cout][8 bf16] with cin = 16*c16 + 8*half + j,
-// BN scale folded in f32 first (the same folded value the f32 image holds)
+// split B-operand image of a 3x3 layer: [tap][cin/KCH][piece][k-group][cout][8 bf16] with cin = KCH*c + 8*group + j
+// (KCH = 16 for the 32x32x16 MFMA shape, 32 for 16x16x32), BN scale folded in f32 first (the same folded value the f32 image holds)
 void build_wx3(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<uint16_t>& img) {
   img.assign((size_t)9 * L.cin * L.cout * 3, 0);
-  const int nc16 = L.cin / 16;
+  constexpr int kch = ASD_X3_S16 ? 32 : 16, kg = kch / 8;
+  const int nc16 = L.cin / kch;
   for (int tap = 0; tap < 9; ++tap)
     for (int ci = 0; ci < L.cin; ++ci)
       for (int co = 0; co < L.cout; ++co) {
         const float v = w[((size_t)co * L.cin + ci) * 9 + tap] * inv[co];
         uint16_t p[3];
         split3_host(v, p[0], p[1], p[2]);
-        const int c16 = ci / 16, hh = (ci % 16) / 8, j = ci % 8;
+        const int c16 = ci / kch, hh = (ci % kch) / 8, j = ci % 8;
         for (int q = 0; q < 3; ++q)
-          img[(((((size_t)tap * nc16 + c16) * 3 + q) * 2 + hh) * L.cout + co) * 8 + j] = p[q];
+          img[(((((size_t)tap * nc16 + c16) * 3 + q) * kg + hh) * L.cout + co) * 8 + j] = p[q];
       }
 }
 
