@@ -816,8 +816,11 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
 #pragma unroll
         for (int k = 0; k < j; ++k) dgl -= a[j * 6 + k] * a[j * 6 + k];
         if (!(dgl > 0)) { good = false; dgl = 1.0; }
-        dgl = sqrt(dgl);
-        const double inv = 1.0 / dgl;
+        // 1/sqrt from the hardware seed + two Newton steps (~1 ulp) instead of the IEEE sqrt and division expansions: this
+        // single-lane block factorisation is a chain of dependent fp64 instructions (44 cycles each), and the two expansions
+        // were ~30 of the ~45 links per column
+        const double inv = nr_rsqrt(dgl);
+        dgl = dgl * inv;
         a[j * 6 + j] = dgl;
         iv[j] = inv;
 #pragma unroll
