@@ -445,8 +445,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
             S.Tbak = S.T;
             for (int j = 0; j < 6; ++j) S.x[j] = 0;
             S.ok = chol6_solve(S.H, S.lambda, S.b, S.x) ? 1 : 0;
+            const long long c1 = a.debug ? clock64() : 0;
             if (S.ok) S.T = pose_oplus(S.T, S.x);
-            if (a.debug) S.cyc[2] += clock64() - c0;
+            if (a.debug) { S.cyc[2] += clock64() - c0; S.dbg[1] += c1 - c0; }
           }
           __syncthreads();
           pose_pass(a, E, lvl, S, robust);
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
     nBad = (int)(S.sums[0] + 0.5);
     __syncthreads();
     if (a.debug && t == 0)
-      printf("[pose_opt] round %d: %d passes, nBad %d; cycles/pass: edges %lld (slowest wave %lld) reduce %lld solve+oplus %lld accept %lld\n", round, S.npass,
-             nBad, S.cyc[0] / S.npass, S.dbg[0] / S.npass, S.cyc[1] / S.npass, S.cyc[2] / S.npass, S.cyc[3] / S.npass);
+      printf("[pose_opt] round %d: %d passes, nBad %d; cycles/pass: edges %lld (slowest wave %lld) reduce %lld solve+oplus %lld (solve %lld) accept %lld\n", round, S.npass,
+             nBad, S.cyc[0] / S.npass, S.dbg[0] / S.npass, S.cyc[1] / S.npass, S.cyc[2] / S.npass, S.dbg[1] / S.npass, S.cyc[3] / S.npass);
     if (round == 2) robust = false;  // e->setRobustKernel(0)
     if (a.n < 10) break;             // optimizer.edges().size() < 10
   }
