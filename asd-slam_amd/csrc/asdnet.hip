@@ -484,7 +484,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 // M_WG >= 128 pixels so that the weight stream stays at <= 16 B/clk/CU.
 // ------------------------------------------------------------------------------------------
 #ifndef ASD_X3_ABL
-#define ASD_X3_ABL 0  // tuning: 1 = weight stream pinned to chunk 0/1 (L1 hits), 2 = no band staging, 4 = no output stores
+#define ASD_X3_ABL 0  // tuning: 1 = weight stream pinned to chunk 0/1 (L1 hits), 2 = no band staging, 4 = no output stores,
+                      // 8 = no MFMAs, 32 = conv1 with one tap instead of nine, 64 = conv1 output written unsplit
 #endif
 // MFMA shape of the split-operand kernels: 0 = v_mfma_f32_32x32x16_bf16 (default), 1 = v_mfma_f32_16x16x32_bf16 (16-row tiles,
 // 32-deep chunks).  The 16x16x32 form takes the same cycles and lets the chip hold a higher clock (in-kernel 1.87-2.25 GHz
@@ -649,13 +650,14 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
           for (int c = 0; c < 8; ++c) {
             float acc1 = bq1[c];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc1 += a[k] * wq[c][k];
+            for (int k = 0; k < ((ASD_X3_ABL & 32) ? 1 : 9); ++k) acc1 += a[k] * wq[c][k];
             const float r = acc1 > 0.f ? acc1 : 0.f;
             if (c < 4) ra[c] = r; else rb[c - 4] = r;
           }
         }
         u32x4 ph, pm, pl;
-        split8(ra, rb, ph, pm, pl);
+        if constexpr ((ASD_X3_ABL & 64) != 0) { ph = __builtin_bit_cast(u32x4, ra); pm = __builtin_bit_cast(u32x4, rb); pl = ph; }
+        else split8(ra, rb, ph, pm, pl);
         uint8_t* dst = smem_b + pix * C::PIXB + q * 48;
         *reinterpret_cast<u32x4*>(dst) = ph;
         *reinterpret_cast<u32x4*>(dst + 16) = pm;
