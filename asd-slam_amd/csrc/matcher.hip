@@ -651,6 +651,9 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
     for (int i = 0; i < L->n; ++i)
       if (has_mp[i] && (mp_rows[i] < 0 || mp_rows[i] >= m->bank_cap)) { ctx->set_error("bank row %d out of range", mp_rows[i]); return ASD_ERR_INVALID; }
   }
+  static const bool timing = getenv("ASD_TIMING") != nullptr;
+  static double tacc[3]; static long tcalls;
+  const auto tm0 = std::chrono::steady_clock::now();
   const float fx = K[0], fy = K[1], cx = K[2], cy = K[3];
   for (int i = 0; i < L->n; ++i) {  // projection, ORBmatcher.cc:1343-1368
     WinQuery& Q = m->h_queries[i];
@@ -668,33 +671,58 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
     Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, mp_desc ? i : mp_rows[i]};
   }
   SearchResult R;
+  const auto tm1 = std::chrono::steady_clock::now();
   if ((rc = window_search(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, &R, 0)) != ASD_OK) return rc;
+  const auto tm2 = std::chrono::steady_clock::now();
   int nmatches = 0;
-  std::vector<int> hist[HISTO];
+  // rotation histogram (ORBmatcher.cc:1419-1425, 1437-1450) without per-bin vectors: a current keypoint is matched at most
+  // once, so its bin is kept per keypoint and the bins only need their counts
+  static thread_local std::vector<int8_t> bin_of;
+  int cnt[HISTO];
+  for (int b = 0; b < HISTO; ++b) cnt[b] = 0;
+  if (check_orientation) bin_of.assign(C->n, -1);
+  constexpr int kAhead = 12;  // the lists were just written by DMA: every line is a DRAM miss, and segments sit in launch order, not query order
   for (int i = 0; i < L->n; ++i) {
+    if (i + kAhead < L->n && R.cnt[i + kAhead] > 0) {
+      __builtin_prefetch(R.idx + R.off[i + kAhead]);
+      __builtin_prefetch(R.dist + R.off[i + kAhead]);
+    }
     if (R.cnt[i] == 0) continue;
     float best = 100;
     int best_idx = -1;
-    for (int t = R.off[i]; t < R.off[i] + R.cnt[i]; ++t) {
-      const int j = R.idx[t];
+    const int* idx = R.idx + R.off[i];
+    const float* dist = R.dist + R.off[i];
+    for (int t = 0, e = R.cnt[i]; t < e; ++t) {
+      const int j = idx[t];
       if (match_cur[j] >= 0) continue;  // already holds a map point with Observations() > 0
-      if (R.dist[t] < best) { best = R.dist[t]; best_idx = j; }
+      if (dist[t] < best) { best = dist[t]; best_idx = j; }
     }
     if (best <= TH_HIGH) {
       match_cur[best_idx] = i;
       nmatches++;
-      if (check_orientation) hist[rot_bin(L->kps[i].angle, C->kps[best_idx].angle)].push_back(best_idx);
+      if (check_orientation) {
+        const int b = rot_bin(L->kps[i].angle, C->kps[best_idx].angle);
+        bin_of[best_idx] = (int8_t)b;
+        ++cnt[b];
+      }
     }
   }
   if (check_orientation) {
-    int cnt[HISTO], i1, i2, i3;
-    for (int b = 0; b < HISTO; ++b) cnt[b] = (int)hist[b].size();
+    int i1, i2, i3;
     three_maxima(cnt, i1, i2, i3);
-    for (int b = 0; b < HISTO; ++b)
-      if (b != i1 && b != i2 && b != i3)
-        for (int j : hist[b]) { match_cur[j] = -1; nmatches--; }
+    for (int j = 0; j < C->n; ++j) {
+      const int b = bin_of[j];
+      if (b >= 0 && b != i1 && b != i2 && b != i3) { match_cur[j] = -1; nmatches--; }
+    }
   }
   *n_matches = nmatches;
+  if (timing) {
+    const auto tm3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    tacc[0] += ms(tm0, tm1); tacc[1] += ms(tm1, tm2); tacc[2] += ms(tm2, tm3);
+    if (++tcalls % 200 == 0)
+      fprintf(stderr, "[match_project_frame] project %.3f search %.3f select %.3f ms\n", tacc[0] / tcalls, tacc[1] / tcalls, tacc[2] / tcalls);
+  }
   return ASD_OK;
 }
 
