@@ -111,6 +111,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
     const uchar4 v = ld ? reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t] : make_uchar4(0, 0, 0, 0);
     const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
     float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
+    // the ROUNDED products are the operands of everything below: a constant patch must give mean == pixel and x - mean == 0
+    // exactly (as the reference's double-accumulated mean does); contracted into fma(v, 1/255, -mean) the difference would be
+    // the product's rounding error, which (x - mean) / (0 + 1e-7) turns into an O(0.1) input.  (HIP's __fmul_rn is a plain
+    // multiply, so the barrier is an empty asm on the value.)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(x[k]));
     float s = (x[0] + x[1]) + (x[2] + x[3]);
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0 && ld) red[wave] = s;
@@ -604,6 +610,12 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
     const uchar4 v = ld ? reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t] : make_uchar4(0, 0, 0, 0);
     const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
     float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
+    // the ROUNDED products are the operands of everything below: a constant patch must give mean == pixel and x - mean == 0
+    // exactly (as the reference's double-accumulated mean does); contracted into fma(v, 1/255, -mean) the difference would be
+    // the product's rounding error, which (x - mean) / (0 + 1e-7) turns into an O(0.1) input.  (HIP's __fmul_rn is a plain
+    // multiply, so the barrier is an empty asm on the value.)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(x[k]));
     float sum = (x[0] + x[1]) + (x[2] + x[3]);
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
     if (lane == 0 && ld) red[wave] = sum;

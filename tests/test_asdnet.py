@@ -43,6 +43,23 @@ def test_hip_matches_oracle_ragged(hip, oracle, synth, n):
 
 
 @pytest.mark.gpu
+def test_hip_constant_and_flat_patches(hip, hip_f32, oracle, synth):
+    """input_norm divides by (std + 1e-7): on a constant patch any rounding noise in x - mean would be amplified to O(0.1).
+    Both kernel families must reproduce the reference's exact zero there, and stay within tolerance on nearly flat patches."""
+    layers = synth.asdnet_weights(0)
+    p = synth.random_patches(12, seed=3)
+    p[0] = 77; p[1] = 200; p[2] = 0; p[3] = 255
+    p[4] = 77; p[4][0, 0] = 78                         # one pixel off
+    p[5] = 130; p[5][::2, ::2] = 131                   # two grey levels
+    ref = oracle.asdnet_forward(layers, p)
+    for ctx in (hip, hip_f32):
+        out = ctx.describe(p)
+        np.testing.assert_array_equal(out[0], out[1])  # every constant patch normalises to exactly zero
+        np.testing.assert_array_equal(out[0], out[3])
+        np.testing.assert_allclose(out, ref, atol=DESC_ATOL, rtol=0)
+
+
+@pytest.mark.gpu
 def test_hip_empty_and_capacity(hip, pkg):
     assert hip.describe(np.zeros((0, 32, 32), np.uint8)).shape == (0, 128)
     with pytest.raises(pkg.AsdError) as ei:
