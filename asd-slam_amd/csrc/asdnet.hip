@@ -9,7 +9,7 @@
 // Arithmetic: f32 results with f32 accumulation on the matrix cores, in one of two forms per layer (ctx->net_split):
 //   K1  (k_conv_mfma, k_conv_mfma_p): f32 operands on v_mfma_f32_32x32x2_f32 (an exact f32 fma chain);
 //   K1s (k_conv_x3, default): each f32 operand split exactly into three bf16 terms, six products per multiply-add on
-//        v_mfma_f32_32x32x16_bf16 -- same error level, 3/8 of the matrix-pipe time (see the comment at K1s).
+//        the bf16 MFMA (v_mfma_f32_16x16x32_bf16) -- same error level, 3/8 of the matrix-pipe time (see K1s).
 // BatchNorm (eval, affine=False) is folded into the conv weights and a per-channel bias at upload.  Activations are NHWC f32 so the contraction index (cin) is
 // contiguous; every 3x3 conv is an implicit GEMM  [pixels x 9*cin] * [9*cin x cout]:
 //   A operand  = zero-padded input band staged once per workgroup in LDS,
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 // Every f32 value is written exactly as x = h + m + l, three bf16 numbers (8 significant bits each, by truncation:
 // h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m, both subtractions exact).  The product of two such
 // values is the sum of nine bf16 x bf16 products, each exact in f32; the six of relative size >= 2^-16
-// (hh, hm, mh, mm, hl, lh) go through v_mfma_f32_32x32x16_bf16 with f32 accumulation, the three dropped ones are
+// (hh, hm, mh, mm, hl, lh) go through the bf16 MFMA (shape: ASD_X3_S16 below) with f32 accumulation, the three dropped ones are
 // <= 2^-23 relative -- below the rounding of an f32 fma chain.  Measured (tools/ubench/split_mfma.hip, K = 288 /
 // 1152 / 8192, rms error against f64): 8.7e-8 / 3.6e-7 / 2.7e-6 for this form, 8.9e-8 / 3.4e-7 / 2.4e-6 for
 // v_mfma_f32_32x32x2_f32.  The bf16 pipe runs 16x the f32 MFMA rate, so six products cost 3/8 of the f32 MFMAs.
@@ -493,15 +493,19 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 #define ASD_X3_ABL 0  // tuning: 1 = weight stream pinned to chunk 0/1 (L1 hits), 2 = no band staging, 4 = no output stores,
                       // 8 = no MFMAs, 32 = conv1 with one tap instead of nine, 64 = conv1 output written unsplit
 #endif
-// MFMA shape of the split-operand kernels: 0 = v_mfma_f32_32x32x16_bf16 (default), 1 = v_mfma_f32_16x16x32_bf16 (16-row tiles,
-// 32-deep chunks).  The 16x16x32 form takes the same cycles and lets the chip hold a higher clock (in-kernel 1.87-2.25 GHz
-// against 1.67-1.99; conv4 168 -> 154, conv6 165 -> 150 us, the bench 695 -> 720-745 frames/s) -- but while it runs,
-// OTHER kernels resident on the same CUs return wrong values in groups of 16 lanes (asd_dist_matrix next to the read-ahead
-// extractor: tests/test_frontend.py::test_pipelined_extract_equals_sync fails, the bench's keypoint and match counts move;
-// the same kernel built without its MFMAs, and the 32x32x16 form, are clean; its own results pass every parity test).
-// Not understood, so not used: correctness of everything else on the chip comes first.
+// MFMA shape of the split-operand kernels: 1 = v_mfma_f32_16x16x32_bf16 (16-row tiles, 32-deep chunks; default),
+// 0 = v_mfma_f32_32x32x16_bf16.  Both take the same cycles; under the 16x16x32 form the chip holds a higher clock (in-kernel
+// 1.87-2.25 GHz against 1.67-1.99: conv4 168 -> 154, conv6 165 -> 150 us, ASDNet 0.89 -> 0.82 ms, and the latency-bound
+// tracking kernels gain from the clock too: 700 -> 766 frames/s).
+// HAZARD (measured, MI355X): while a wave issues v_mfma_f32_16x16x32_bf16, waves of OTHER kernels on the same CU that
+// execute packed-f32 vector instructions (v_pk_add_f32 / v_pk_mul_f32) return wrong values in groups of 16 lanes --
+// asd_dist_matrix next to the read-ahead extractor failed tests/test_frontend.py::test_pipelined_extract_equals_sync
+// deterministically; the same ASDNet kernel without its MFMAs, the 32x32x16 shape, and victims rebuilt without packed-f32
+// instructions are all clean.  The library is therefore compiled with -fno-slp-vectorize (Makefile; `make check-isa` and
+// tests/test_isa.py verify that no packed-f32 instruction is left in any kernel).  A host application that runs its own
+// kernels with packed-f32 arithmetic on the same device concurrently with the extractor should build with ASD_X3_S16=0.
 #ifndef ASD_X3_S16
-#define ASD_X3_S16 0
+#define ASD_X3_S16 1
 #endif
 #ifndef ASD_X3_PD
 #define ASD_X3_PD 2  // A-operand prefetch distance in 32-pixel tiles
