@@ -883,6 +883,107 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, 
   }
 }
 
+// K2s: the same GEMM with split operands on the bf16 matrix pipe (see K1s).  One workgroup = 64 patches x 128 couts x
+// (8192 / FC_SK) k; the activations go through LDS in slabs of 128 k (one pixel position: 64 rows x 784 B, split while
+// staged), wave w owns couts [32w, 32w+32) as two 16-wide sub-tiles and all four 16-patch sub-tiles; B operands (the split
+// weight image [k/32][piece][k-group][cout][8]) stream from global memory through a 3-slot register ring, two chunks ahead,
+// across slab boundaries.  MFMA shape 16x16x32 only.  Partials land in the same [FC_SK][npad][128] buffer K3 sums.
+constexpr int FCS_MP = 64;              // patches per workgroup
+constexpr int FCS_SLAB = 128;           // k per LDS slab
+constexpr int FCS_ROWB = FCS_SLAB * 6 + 16;
+__global__ __launch_bounds__(256) void k_fc_x3(const float* __restrict__ act, const uint8_t* __restrict__ wimg,
+                                               float* __restrict__ part, int n, int npad) {
+  __shared__ __attribute__((aligned(16))) uint8_t sa[FCS_MP * FCS_ROWB];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int kg = lane >> 4, lr = lane & 15;
+  const int p0 = blockIdx.x * FCS_MP, sk = blockIdx.y;
+  constexpr int KPER = 8192 / FC_SK, NSLAB = KPER / FCS_SLAB, NCH = KPER / 32;  // chunks of 32 k per workgroup
+  static_assert(KPER % FCS_SLAB == 0 && NCH >= 3, "split-K slice");
+  constexpr int CHUNKB = 32 * 6 * 128;
+  const uint8_t* wl = wimg + (size_t)(sk * (KPER / 32)) * CHUNKB + ((size_t)kg * 128 + wave * 32 + lr) * 16;
+  auto load_b = [&](int c, u32x4 (&b)[2][3]) {
+    const uint8_t* wc = wl + (size_t)c * CHUNKB;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[nb][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * 4 * 128 * 16 + nb * 256);
+  };
+  auto bf = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+  u32x4 br[3][2][3];
+  load_b(0, br[0]);
+  load_b(1, br[1]);
+  f4 acc[4][2];
+  for (int ma = 0; ma < 4; ++ma)
+    for (int nb = 0; nb < 2; ++nb)
+      for (int r = 0; r < 4; ++r) acc[ma][nb][r] = 0.f;
+  int c = 0;  // chunk index within this workgroup's k range
+  for (int slab = 0; slab < NSLAB; ++slab) {
+    const int k0 = sk * KPER + slab * FCS_SLAB;
+    __syncthreads();  // the previous slab has been consumed
+    {
+      // 64 rows x 16 groups of 8 k: four items per thread, loads first
+      f32x4 v0[4], v1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int item = t + i * 256, row = item >> 4, g = item & 15;
+        int p = p0 + row;
+        if (p >= n) p = n - 1;
+        const float* src = act + (size_t)p * 8192 + k0 + g * 8;
+        v0[i] = *reinterpret_cast<const f32x4*>(src);
+        v1[i] = *reinterpret_cast<const f32x4*>(src + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int item = t + i * 256, row = item >> 4, g = item & 15;
+        u32x4 ph, pm, pl;
+        split8(v0[i], v1[i], ph, pm, pl);
+        uint8_t* dst = sa + row * FCS_ROWB + g * 48;
+        *reinterpret_cast<u32x4*>(dst) = ph;
+        *reinterpret_cast<u32x4*>(dst + 16) = pm;
+        *reinterpret_cast<u32x4*>(dst + 32) = pl;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cs = 0; cs < FCS_SLAB / 32; ++cs, ++c) {
+      // ring slot of chunk c is c % 3; NSLAB * 4 chunks in all, the slot pattern repeats every 3 chunks, so index by (c % 3)
+      // through a small switch that keeps every slot a static register
+      auto step = [&](u32x4 (&bc)[2][3], u32x4 (&bn)[2][3]) {
+        load_b(c + 2 < NCH ? c + 2 : NCH - 1, bn);  // past the end: a redundant re-read instead of a branch
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma) {
+          u32x4 a[3];
+          const uint8_t* ap = sa + (ma * 16 + lr) * FCS_ROWB + (cs * 4 + kg) * 48;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const u32x4*>(ap + p * 16);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a[2]), bf(bc[nb][0]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a[0]), bf(bc[nb][2]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a[1]), bf(bc[nb][1]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a[1]), bf(bc[nb][0]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a[0]), bf(bc[nb][1]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(a[0]), bf(bc[nb][0]), acc[ma][nb], 0, 0, 0);
+          }
+        }
+      };
+      const int slot = c % 3;
+      if (slot == 0) step(br[0], br[2]);
+      else if (slot == 1) step(br[1], br[0]);
+      else step(br[2], br[1]);
+    }
+  }
+  if (p0 >= npad) return;
+  float* op = part + ((size_t)sk * npad + p0) * 128;
+  for (int ma = 0; ma < 4; ++ma)
+    for (int nb = 0; nb < 2; ++nb)
+      for (int r = 0; r < 4; ++r) {
+        const int row = ma * 16 + 4 * kg + r;
+        if (p0 + row < npad) op[(size_t)row * 128 + wave * 32 + nb * 16 + lr] = acc[ma][nb][r];
+      }
+}
+
 // K3: sum split-K partials in fixed order (deterministic), folded BN bias, L2Norm (Utils.py:15-22).
 __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, const float* __restrict__ bias,
                                                 float* __restrict__ desc, int n, int npad) {
@@ -1099,6 +1200,20 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
     }
     if (!ctx->d_wimg[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wimg[l], img.size() * sizeof(float)));
     ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wimg[l], img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (l == 6) {
+      // split image of the 8x8 conv for K2s: k = px*128 + c, [k/32][piece][k-group 4][cout 128][8 bf16]
+      std::vector<uint16_t> x3((size_t)8192 * 128 * 3, 0);
+      for (int px = 0; px < 64; ++px)
+        for (int c = 0; c < 128; ++c)
+          for (int co = 0; co < 128; ++co) {
+            const int k = px * 128 + c, c32 = k / 32, g = (k % 32) / 8, j = k % 8;
+            uint16_t pc[3];
+            split3_host(conv_w[6][((size_t)co * 128 + c) * 64 + px] * inv[co], pc[0], pc[1], pc[2]);
+            for (int q = 0; q < 3; ++q) x3[((((size_t)c32 * 3 + q) * 4 + g) * 128 + co) * 8 + j] = pc[q];
+          }
+      if (!ctx->d_wx3[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wx3[l], x3.size() * sizeof(uint16_t)));
+      ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wx3[l], x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    }
     if (l < 6) {
       std::vector<uint16_t> x3;
       build_wx3(L, conv_w[l], inv, x3);
@@ -1150,7 +1265,10 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (launch_conv_x3<L6S_CFG>(st, a0, ctx->d_wx3[5], ctx->d_bias[5], a1, n)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
   PROF_MARK(6);
-  hipLaunchKernelGGL(k_fc_mfma, dim3((npad / 32 + FC_MT - 1) / FC_MT, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
+  if (ctx->net_split & 32)
+    hipLaunchKernelGGL(k_fc_x3, dim3((npad + FCS_MP - 1) / FCS_MP, FC_SK), dim3(256), 0, st, a1, static_cast<const uint8_t*>(ctx->d_wx3[6]), ctx->d_part, n, npad);
+  else
+    hipLaunchKernelGGL(k_fc_mfma, dim3((npad / 32 + FC_MT - 1) / FC_MT, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   PROF_MARK(7);
   hipLaunchKernelGGL(k_l2norm, dim3((n + 3) / 4), dim3(256), 0, st, ctx->d_part, ctx->d_bias[6], d_desc, n, npad);

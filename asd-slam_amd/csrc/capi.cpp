@@ -218,7 +218,7 @@ int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms) {
   return ASD_OK;
 }
 
-int32_t asd_asdnet_split_mask(const asd_ctx* ctx) { return ctx ? (ctx->net_split & 0x1f) : 0; }
+int32_t asd_asdnet_split_mask(const asd_ctx* ctx) { return ctx ? (ctx->net_split & 0x3f) : 0; }
 
 int asd_profile_enable(asd_ctx* ctx, int32_t on) {
   if (!ctx) return ASD_ERR_INVALID;

@@ -418,7 +418,7 @@ int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms);
  * 1..5 = conv2..conv6 (MFMA implicit GEMM), 6 = 8x8 conv (split-K GEMM), 7 = reduce+L2Norm. */
 int asd_profile_enable(asd_ctx* ctx, int32_t on);
 int asd_profile_get(asd_ctx* ctx, int32_t layer, double* total_ms, int32_t* calls, int64_t* patches);
-/* Which ASDNet layers run on the split-operand kernels: bit 0 = conv2 ... bit 4 = conv6 (bit 5 reserved for the 8x8 conv).
+/* Which ASDNet layers run on the split-operand kernels: bit 0 = conv2 ... bit 4 = conv6, bit 5 = the 8x8 conv.
  * Both kernel families compute in f32: the split kernels write every f32 operand exactly as the sum of three bf16 terms
  * and accumulate the six significant cross products in f32 on the bf16 matrix pipe (error at the level of the f32 MFMA chain,
  * see asdnet.hip); the others use v_mfma_f32_32x32x2_f32.  Chosen at asd_ctx_create: environment ASD_ASDNET_MATH=f32 clears

@@ -122,7 +122,7 @@ def hip_f32(pkg):
 
 @pytest.mark.gpu
 def test_split_mask_selection(hip, hip_f32):
-    assert hip.asdnet_split_mask() == 0x1f      # default: conv2 .. conv6 on the split-operand kernels
+    assert hip.asdnet_split_mask() == 0x3f      # default: conv2 .. conv6 and the 8x8 conv on the split-operand kernels
     assert hip_f32.asdnet_split_mask() == 0
 
 
