@@ -16,7 +16,7 @@ import sys
 FLOP = {"k_conv_mfma<32, 32, 32": 2 * 9437184, "k_conv_mfma_p<32, 64": 2 * 4718592, "k_conv_mfma<64, 64": 2 * 9437184,
         "k_conv_mfma<64, 128": 2 * 4718592, "k_conv_mfma<128, 128": 2 * 9437184, "k_fc_mfma": 2 * 1048576,
         "k_conv_x3<32, 32, 32": 2 * 9437184, "k_conv_x3<32, 64": 2 * 4718592, "k_conv_x3<64, 64": 2 * 9437184,
-        "k_conv_x3<64, 128": 2 * 4718592, "k_conv_x3<128, 128": 2 * 9437184}
+        "k_conv_x3<64, 128": 2 * 4718592, "k_conv_x3<128, 128": 2 * 9437184, "k_fc_x3": 2 * 1048576}
 
 
 def load(d, name):
@@ -34,14 +34,14 @@ def main():
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
     out = {}
     for k, v in clk.items():
-        if "mfma" not in k and "k_conv_x3" not in k:
+        if "mfma" not in k and "k_conv_x3" not in k and "k_fc_x3" not in k:
             continue
         v, m = v[2:], mf.get(k, [])[2:]   # drop the warm-up launches
         ga = sum(a for a, _ in v) / len(v)
         dur = sum(d for _, d in v) / len(v)
         busy = sum(a for a, _ in m) / max(len(m), 1)
         flop = [f for p, f in FLOP.items() if k.startswith(p)]
-        split = "k_conv_x3" in k
+        split = "k_conv_x3" in k or "k_fc_x3" in k
         # f32 MFMA 32x32x2: 4096 FLOP, 64 cycles; bf16 MFMA 32x32x16: 32768 FLOP, 32 cycles, six per f32-equivalent chunk
         n_mfma = (6 * n * flop[0] / 32768 if split else n * flop[0] / 4096) if flop else 0
         out[k] = {"avg_us": dur / 1e3, "effective_clock_GHz": ga / 8 / dur, "SQ_VALU_MFMA_BUSY_CYCLES": busy,

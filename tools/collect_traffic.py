@@ -33,7 +33,7 @@ def main():
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     allk = {}
     for k in fetch:
-        if "k_conv_mfma" in k or "k_conv_x3" in k or "k_fc_mfma" in k or "k_l2norm" in k:
+        if "k_conv_mfma" in k or "k_conv_x3" in k or "k_fc_mfma" in k or "k_fc_x3" in k or "k_l2norm" in k:
             f_kb, w_kb = fetch[k], write.get(k, 0.0)
             allk[short(k)] = {"FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb, "hbm_bytes_per_launch": int(2.0 * f_kb * 1024 + w_kb * 1024)}
     fused = [k for k in allk if k.startswith("k_conv_x3<32, 32, 32")] or [k for k in allk if k.startswith("k_conv_mfma<32, 32, 32")]
