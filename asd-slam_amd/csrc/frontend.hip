@@ -928,9 +928,11 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   if (!ctx->ax) {
     // lowest stream priority for ASDNet: the latency-critical tracking kernels on ctx->stream go first; the small
     // front-half kernels get the middle priority so they slot in between the conv workgroups.
-    // (Keeping 8 / 16 / 32 CUs out of these streams with hipExtStreamCreateWithCUMask, so that the tracking kernels
-    //  always find a free one, was measured twice: the masked streams lose a third of their throughput whatever
-    //  the mask (extraction 3.2 -> 4.3 ms device time under load) and k_pose_opt gains under 10 %.)
+    // (Keeping 4 / 8 / 16 / 32 CUs out of these streams with hipExtStreamCreateWithCUMask, so that the tracking kernels
+    //  always find a free one, was measured three times.  With the split-operand ASDNet: PoseOptimization of the
+    //  local-map stage drops from 0.31 to 0.18 ms device time -- its workgroup no longer waits for a CU -- but a masked
+    //  stream runs ASDNet 9 % slower whatever the mask (0.80 -> 0.88 ms), which puts the extractor back on the critical
+    //  path: 720-750 frames/s either way.)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_x, hipStreamDefault, prio_least));
