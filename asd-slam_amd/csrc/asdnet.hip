@@ -497,13 +497,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 // 0 = v_mfma_f32_32x32x16_bf16.  Both take the same cycles; under the 16x16x32 form the chip holds a higher clock (in-kernel
 // 1.87-2.25 GHz against 1.67-1.99: conv4 168 -> 154, conv6 165 -> 150 us, ASDNet 0.89 -> 0.82 ms, and the latency-bound
 // tracking kernels gain from the clock too: 700 -> 766 frames/s).
-// HAZARD (measured, MI355X): while a wave issues v_mfma_f32_16x16x32_bf16, waves of OTHER kernels on the same CU that
-// execute packed-f32 vector instructions (v_pk_add_f32 / v_pk_mul_f32) return wrong values in groups of 16 lanes --
-// asd_dist_matrix next to the read-ahead extractor failed tests/test_frontend.py::test_pipelined_extract_equals_sync
-// deterministically; the same ASDNet kernel without its MFMAs, the 32x32x16 shape, and victims rebuilt without packed-f32
-// instructions are all clean.  The library is therefore compiled with -fno-slp-vectorize (Makefile; `make check-isa` and
-// tests/test_isa.py verify that no packed-f32 instruction is left in any kernel).  A host application that runs its own
-// kernels with packed-f32 arithmetic on the same device concurrently with the extractor should build with ASD_X3_S16=0.
+// HAZARD (gfx950, measured stand-alone: tools/ubench/mfma_pk_hazard.hip, profiles/r02_mfma_pk_hazard*.txt): a packed-f32
+// instruction whose src1 takes its LOW-half operand from the HIGH register of the pair (v_pk_add_f32 ... op_sel:[0,1], what the
+// SLP vectoriser emits for "both halves use y.y") drops the low-half result in lanes 48-63 now and then while a wave that
+// issues bf16 MFMAs -- either shape, this kernel or anybody's -- is resident on the same CU.  It is a property of the device,
+// not of this kernel: the 32x32x16 shape triggers it as well (round 1 thought it did not: it is 8x rarer next to this loop),
+// a plain f32 loop does not.  The library therefore contains no packed-f32 arithmetic at all (-fno-slp-vectorize in the
+// Makefile; `make check-isa` / tests/test_isa.py), and tests/test_frontend.py runs asd_dist_matrix beside the extractor.
 #ifndef ASD_X3_S16
 #define ASD_X3_S16 1
 #endif

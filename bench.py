@@ -8,7 +8,10 @@ isInFrustum + SearchByProjection vs a local map -> PoseOptimization; every 15th 
 --max_step_KF=15, run_vslam_kitti.sh:7) also runs LocalBundleAdjustment on the SURVEY 8(d) nominal problem
 (24 free + 12 fixed keyframes, 6000 map points, ~29k edges).  Frames are resident in HBM before the timed
 region.  SLAM is sequential per trajectory, so N GPUs = N independent sequences (replicas, no collective on
-the data path; a gloo barrier brackets the timed region).
+the data path; a gloo barrier brackets the timed region).  `--gpus N` without torchrun's environment starts the N ranks
+itself (fresh child processes, before this one has made any HIP call).  `--sequences S` is BASELINE configs[4]: S
+sequences of different lengths (the 11 KITTI odometry sequences, scaled by --seq-scale) handed out longest-first to
+whichever rank is free, value = sum of frames / wall time.
 
 Prints ONE JSON line (rank 0).  `cpu_baseline` times the same step with the CPU restatement (oracle/:
 front-end, matchers, pose optimisation; PyTorch-CPU ASDNet run per level like the reference) and, when
@@ -75,9 +78,68 @@ class Dist:
         self.pg.all_reduce(t, op=self.pg.ReduceOp.SUM)
         return float(t[0])
 
+    def next_ticket(self, key="ticket"):
+        """shared counter (control plane only): the sequence queue of --sequences.  0, 1, 2, ... across all ranks."""
+        if not self.pg:
+            self._local = getattr(self, "_local", -1) + 1
+            return self._local
+        if getattr(self, "store", None) is None:
+            from torch.distributed import distributed_c10d
+            self.store = distributed_c10d._get_default_store()
+        return int(self.store.add(key, 1)) - 1
+
+    def gather_json(self, obj):
+        """every rank's small report on rank 0 (all ranks call it)"""
+        if not self.pg:
+            return [obj]
+        out = [None] * self.world
+        self.pg.all_gather_object(out, obj)
+        return out
+
     def close(self):
         if self.pg:
             self.pg.destroy_process_group()
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, rank i on GPU i (LOCAL_RANK), gloo
+    rendezvous on 127.0.0.1.  Called before this process has loaded the HIP library or asked torch about the GPU, and
+    the children are new processes (no exec of a process that has touched the GPU).  Rank 0's stdout is this
+    process's stdout (the one JSON line); the exit code is the worst child's."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is not None:
+                    pending.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        print(f"bench: rank {r} exited with {code}; stopping the others", file=sys.stderr)
+                        for q in pending:
+                            procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 def host_cores():
@@ -92,11 +154,11 @@ def host_cores():
     return max(1, min(n, 64))
 
 
-def device_sync():
+def device_sync(device=0):
     try:
         import torch
         if torch.cuda.is_available():
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(device)
     except Exception:
         pass
 
@@ -114,10 +176,34 @@ def predicted_uv(kps):
     return np.stack([(kps["x"] - 620.5) * z + 620.5 - 3 * z, (kps["y"] - 188.0) * z + 188.0 - 0.2 * z], 1).astype(np.float32)
 
 
+# BASELINE configs[4]: the 11 KITTI odometry sequences (frames in image_0, image size, intrinsics file of the reference's
+# cameraconfig/KITTI/: kitti00-02.txt, kitti03.txt, kitti04-12.txt); a replay is kitti.cc:116-155 over one of them
+KITTI_CAM = {"00-02": (1241, 376, (718.856, 718.856, 607.1928, 185.2157)),
+             "03": (1242, 375, (721.5377, 721.5377, 609.5593, 172.854)),
+             "04-12": (1226, 370, (707.0912, 707.09127, 601.8873, 183.1104))}
+KITTI_SEQUENCES = [("00", 4541, "00-02"), ("01", 1101, "00-02"), ("02", 4661, "00-02"), ("03", 801, "03"), ("04", 271, "04-12"),
+                   ("05", 2761, "04-12"), ("06", 1101, "04-12"), ("07", 1101, "04-12"), ("08", 4071, "04-12"),
+                   ("09", 1591, "04-12"), ("10", 1201, "04-12")]
+
+
+def sequence_table(n, scale):
+    """n sequences (the KITTI table, repeated if n > 11), lengths scaled, LONGEST FIRST: the order the shared queue hands
+    them out in, so the long ones start first and the short ones fill the tail (list scheduling)"""
+    seqs = []
+    for i in range(n):
+        name, frames, cam = KITTI_SEQUENCES[i % len(KITTI_SEQUENCES)]
+        seqs.append({"name": name if i < len(KITTI_SEQUENCES) else f"{name}+{i // len(KITTI_SEQUENCES)}",
+                     "frames": max(KF_INTERVAL, int(round(frames * scale))), "cam": cam})
+    return sorted(seqs, key=lambda q: (-q["frames"], q["name"]))
+
+
 class Workload:
-    def __init__(self, synth, seed_offset=0):
+    def __init__(self, synth, seed_offset=0, cams=()):
         self.K32 = np.array(synth.KITTI_K, np.float32)
         self.K64 = np.array(synth.KITTI_K, np.float64)
+        # further camera / image-size classes (--sequences): frames of each class resident in HBM too
+        self.cam_frames = {c: [synth.scene_frame(t + 3 * seed_offset, seed=21 + k, w=KITTI_CAM[c][0], h=KITTI_CAM[c][1])
+                               for t in range(N_FRAMES)] for k, c in enumerate(cams)}
         self.T = np.eye(4, dtype=np.float32)
         self.pose0 = np.array([0.002, -0.001, 0.0015, 1.0, 0.01, -0.02, 0.03])
         self.pose0[:4] /= np.linalg.norm(self.pose0[:4])
@@ -187,7 +273,7 @@ class NativeHost:
     """The same tracking step as track_step(), run by C++ host code (asd-slam_amd/host/track_loop.cpp -> libasdtrack.so)
     over the C ABI: the reference's host side is C++, the Python loop costs ~0.25 ms of a ~2 ms step."""
 
-    def __init__(self, pkg, be, wl, pipeline):
+    def __init__(self, pkg, be, wl, pipeline, cam=None):
         import ctypes as C
         self.C = C
         path = os.path.join(ROOT, "asd-slam_amd", "libasdtrack.so")
@@ -205,9 +291,14 @@ class NativeHost:
         self.prob = capi.asd_ba_problem(len(k[0]), len(k[2]), len(k[3]), k[0].ctypes.data, k[1].ctypes.data, k[2].ctypes.data,
                                         k[3].ctypes.data, k[4].ctypes.data, k[5].ctypes.data, k[6].ctypes.data,
                                         (C.c_double * 4)(*[float(x) for x in ba["K"]]), 5, 10)
-        frames = (C.c_void_p * len(be.d_frames))(*[f.value for f in be.d_frames])
-        self.h = C.c_void_p(self.lib.asd_track_create(be.hip.ctx, len(be.d_frames), frames, 1241, 376,
-                                                      wl.K32.ctypes.data_as(C.c_void_p), wl.T.ctypes.data_as(C.c_void_p),
+        d_frames, W, H, K32 = be.d_frames, 1241, 376, wl.K32
+        if cam is not None:   # a sequence of another camera class (image size + intrinsics)
+            d_frames, (W, H, K) = be.d_cam_frames[cam], KITTI_CAM[cam]
+            K32 = np.array(K, np.float32)
+        self.keep.append(K32)
+        frames = (C.c_void_p * len(d_frames))(*[f.value for f in d_frames])
+        self.h = C.c_void_p(self.lib.asd_track_create(be.hip.ctx, len(d_frames), frames, W, H,
+                                                      K32.ctypes.data_as(C.c_void_p), wl.T.ctypes.data_as(C.c_void_p),
                                                       wl.pose0.ctypes.data_as(C.c_void_p), wl.inv_sigma2.ctypes.data_as(C.c_void_p),
                                                       wl.scale32.ctypes.data_as(C.c_void_p), C.byref(self.prob), KF_INTERVAL,
                                                       LOOKAHEAD if pipeline else 0))
@@ -236,13 +327,20 @@ class NativeHost:
 
 class HipBackend:
     def __init__(self, pkg, wl, device, pipeline=True):
-        self.hip = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096, device=device)
+        mw = max([1241] + [KITTI_CAM[c][0] for c in wl.cam_frames])
+        mh = max([376] + [KITTI_CAM[c][1] for c in wl.cam_frames])
+        self.hip = pkg.AsdHip(n_features=2000, max_width=mw, max_height=mh, max_patches=4096, device=device)
         self.hip.load_weights(pkg.synth.asdnet_weights(0))
-        self.d_frames = []
-        for f in wl.frames:   # frames resident in HBM before the timed region
-            p = self.hip.device_alloc(f.nbytes)
-            self.hip.h2d(p, f)
-            self.d_frames.append(p)
+
+        def upload(frames):   # frames resident in HBM before the timed region
+            out = []
+            for f in frames:
+                p = self.hip.device_alloc(f.nbytes)
+                self.hip.h2d(p, f)
+                out.append(p)
+            return out
+        self.d_frames = upload(wl.frames)
+        self.d_cam_frames = {c: upload(fr) for c, fr in wl.cam_frames.items()}
         self.slot = 0
         self.pending = []          # handles of submitted, not yet waited extractions (in order)
         self.pipeline = pipeline
@@ -388,10 +486,74 @@ def selftest_dist(args):
     d.barrier()
     tmax = d.max(dt)
     total = d.sum(float(args.steps))
+    # the --sequences queue: every ticket 0..10 handed out exactly once across the ranks
+    seqs = sequence_table(11, 0.1)
+    mine = []
+    while True:
+        k = d.next_ticket("sequence")
+        if k >= len(seqs):
+            break
+        mine.append(k)
+        time.sleep(0.002 * (1 + d.rank))
+    tickets = d.gather_json(mine)
     if d.rank == 0:
         print(json.dumps({"selftest": "dist", "n_gpus": args.gpus, "t_max": tmax, "frames_total": total,
-                          "value": total / tmax}))
+                          "value": total / tmax, "tickets": tickets, "queue": [q["name"] for q in seqs]}))
     d.close()
+
+
+def run_sequences(args, pkg, dist, rank, world, device):
+    """BASELINE configs[4]: S independent sequences over `world` GPUs.  Every rank owns one device and one context; the
+    sequences sit in one shared queue, longest first, and a rank that finishes one takes the next (a ticket counter in the
+    rendezvous store -- control plane only, nothing on the data path).  A sequence is a replay from scratch
+    (kitti.cc:116-155): fresh tracker state, its own image size and intrinsics, read-ahead extraction inside it only."""
+    seqs = sequence_table(args.sequences, args.seq_scale)
+    cams = sorted({q["cam"] for q in seqs})
+    wl = Workload(pkg.synth, seed_offset=rank, cams=cams)
+    be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
+    be.native = None
+
+    def replay(cam, n):
+        h = NativeHost(pkg, be, wl, pipeline=not args.no_pipeline, cam=cam)
+        try:
+            return h.run(0, n, False)
+        finally:
+            h.close()
+    replay(cams[0], args.warmup)                       # untimed: code objects, clocks, allocations
+    be.hip.sync(); device_sync(device); dist.barrier()
+    t0 = time.perf_counter()
+    mine, frames = [], 0
+    while True:
+        k = dist.next_ticket("sequence")
+        if k >= len(seqs):
+            break
+        q = seqs[k]
+        ts = time.perf_counter()
+        replay(q["cam"], q["frames"])
+        mine.append({"seq": q["name"], "frames": q["frames"], "s": round(time.perf_counter() - ts, 4)})
+        frames += q["frames"]
+    be.hip.sync(); device_sync(device)
+    busy = time.perf_counter() - t0
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = dist.max(dt)
+    total = dist.sum(float(frames))
+    reports = dist.gather_json({"rank": rank, "device": device, "busy_s": round(busy, 4), "sequences": mine})
+    be.close()
+    if rank == 0:
+        assert int(total) == sum(q["frames"] for q in seqs), "a sequence was lost or run twice"
+        print(json.dumps({
+            "metric": "frames/sec end-to-end tracking+LocalBA, KITTI 00 mono @2000 keypoints",
+            "value": total / tmax, "unit": "frames/s", "n_gpus": world, "steps": int(total), "warmup": args.warmup,
+            "ms_per_step": 1e3 * tmax / total, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: {len(seqs)} independent KITTI-odometry-shaped sequences "
+                                   f"(lengths x{args.seq_scale}, image sizes / intrinsics of cameraconfig/KITTI) handed out "
+                                   f"longest-first to {world} GPU(s), one context per GPU, no RCCL; value = sum of frames / wall",
+                       "sequences": [{k: q[k] for k in ("name", "frames", "cam")} for q in seqs],
+                       "kf_interval": KF_INTERVAL, "parallelism": f"{world} rank(s), shared sequence queue, no collective"},
+            "wall_s": tmax, "ranks": reports}))
+    dist.close()
 
 
 def main():
@@ -401,24 +563,35 @@ def main():
     ap.add_argument("--warmup", type=int, default=45)
     ap.add_argument("--cpu-frames", type=int, default=15, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--selftest-dist", action="store_true")
+    ap.add_argument("--sequences", type=int, default=0,
+                    help="BASELINE configs[4]: this many independent sequences (11 = KITTI odometry 00-10) in a shared "
+                         "longest-first queue over the ranks; value = sum of frames / wall")
+    ap.add_argument("--seq-scale", type=float, default=0.1, help="--sequences: fraction of the real sequence lengths")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
     ap.add_argument("--host", choices=["cxx", "python"], default="cxx",
                     help="who drives the per-frame step: C++ host code over the C ABI (default, as in the reference) or the Python loop")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    # N > 1 without a launcher: start the ranks ourselves.  Nothing in this process has touched the GPU yet.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    rank, local_rank, world = dist_env()
+    world = max(world, 1)
+    if world != args.gpus:   # never report a GPU count that is not the one asked for
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.selftest_dist:
         return selftest_dist(args)
 
-    rank, local_rank, world = dist_env()
-    world = max(world, 1)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not all(os.path.exists(os.path.join(ROOT, "asd-slam_amd", f)) for f in ("libasdhip.so", "libasdtrack.so")):
         graft.build()
     pkg = graft.load_package()
     dist = Dist(world)
-    wl = Workload(pkg.synth, seed_offset=rank)
     # ASD_BENCH_DEVICE pins every rank to one device: rehearsal of the N > 1 path on a single-GPU box only
     device = int(os.environ["ASD_BENCH_DEVICE"]) if "ASD_BENCH_DEVICE" in os.environ else (local_rank if world > 1 else 0)
+    if args.sequences > 0:
+        return run_sequences(args, pkg, dist, rank, world, device)
+    wl = Workload(pkg.synth, seed_offset=rank)
     be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
     be.native = None
     if args.host == "cxx":
@@ -430,12 +603,12 @@ def main():
 
     last, _ = run_steps(be, wl, 0, args.warmup, None, prefetch_beyond=True)            # untimed warm-up
     be.hip.profile_enable(True)
-    be.hip.sync(); device_sync(); dist.barrier()
+    be.hip.sync(); device_sync(device); dist.barrier()
     t0 = time.perf_counter()
     # EXACTLY K timed steps; the replay keeps reading ahead across both ends of the timed region (steady state);
     # the device-wide synchronize below also waits for whatever read-ahead work is in flight
     last, stats = run_steps(be, wl, args.warmup, args.steps, last, prefetch_beyond=True)
-    be.hip.sync(); device_sync(); dist.barrier()
+    be.hip.sync(); device_sync(device); dist.barrier()
     dt = time.perf_counter() - t0
     tmax = dist.max(dt)
     frames_total = dist.sum(float(args.steps))

@@ -201,6 +201,33 @@ def test_extract_deterministic(hip, synth):
 
 
 @pytest.mark.gpu
+def test_dist_matrix_beside_readahead_extractor(hip, synth):
+    """Other kernels of the library keep returning exact values while the read-ahead extractor's bf16-MFMA kernels share
+    the CUs with them.  On gfx950 a packed-f32 instruction with op_sel:[0,1] loses results in lanes 48-63 beside ANY bf16
+    MFMA kernel (tools/ubench/mfma_pk_hazard.hip, profiles/r02_mfma_pk_hazard.txt): a library built
+    with the SLP vectoriser fails this test in 23 of 24 calls, the shipped build (no packed-f32 arithmetic, tests/test_isa.py)
+    must not fail it once."""
+    im = synth.scene_frame(5)
+    p = hip.device_alloc(im.nbytes)
+    hip.h2d(p, im)
+    n = 300
+    inputs = [synth.unit_descriptors(n, seed=k) for k in range(12)]
+    idle = [hip.dist_matrix(a, a) for a in inputs]
+    # the idle-device result is the exact-order f32 sum (ORBmatcher.cc:1629-1650), term by term
+    ref = np.zeros((n, n), np.float32)
+    for k in range(128):
+        d = inputs[0][:, None, k] - inputs[0][None, :, k]
+        ref = ref + d * d
+    np.testing.assert_array_equal(idle[0], ref)
+    for k, a in enumerate(inputs):
+        hip.extract_submit(p, 1241, 376, 1241, device_resident=True)
+        M = hip.dist_matrix(a, a)          # runs while ASDNet of the submission is in flight
+        hip.extract_wait()
+        np.testing.assert_array_equal(M, idle[k])
+    hip.device_free(p)
+
+
+@pytest.mark.gpu
 def test_pipelined_extract_equals_sync(hip, synth):
     """asd_extract_submit / asd_extract_wait (own streams + worker thread, front half of the next frame under the
     ASDNet pass of the previous one) return exactly what asd_extract does, in submission order, also while the

@@ -1,10 +1,11 @@
 """The library must not contain packed-f32 vector arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
 
-Measured on MI355X (asdnet.hip, ASD_X3_S16): a wave executing those instructions returns wrong values in groups of 16
-lanes while another wave on the same CU issues v_mfma_f32_16x16x32_bf16 -- the MFMA shape of the ASDNet kernels, which run
-concurrently with every other kernel of the library in the read-ahead pipeline.  The build therefore disables the SLP
-vectoriser; this test compiles every kernel source to device assembly with the build's flags (`make check-isa`, a
-cross-compile: no GPU needed) and fails if such an instruction appears."""
+Measured on MI355X with a stand-alone program (tools/ubench/mfma_pk_hazard.hip, profiles/r02_mfma_pk_hazard.txt): a
+v_pk_add_f32 whose src1 carries op_sel:[0,1] -- the form the SLP vectoriser emits when both halves use the same scalar --
+loses its low-half result in lanes 48-63 while a wave of ANY kernel that issues bf16 MFMAs is resident on the same CU.  The
+ASDNet kernels run concurrently with every other kernel of the library in the read-ahead pipeline, so the build disables
+the SLP vectoriser; this test compiles every kernel source to device assembly with the build's flags (`make check-isa`, a
+cross-compile: no GPU needed) and fails if a packed-f32 arithmetic instruction appears."""
 import os
 import subprocess
 
