@@ -268,24 +268,25 @@ class AsdHip:
         self._chk(self.lib.asd_distinctive_descriptor(self.ctx, _p(desc), desc.shape[0], C.byref(best)))
         return best.value
 
-    def match_project_frame(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_desc, Tcw, K, th, check_ori=True):
+    def match_project_frame(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_desc, Tcw, K, th, check_ori=True, obs_positive=None):
         has_mp, Xw, mp_desc = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(mp_desc, np.float32)
         Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
         out = np.empty(n_cur, np.int32)
         n = C.c_int32()
         self._chk(self.lib.asd_match_project_frame(self.ctx, slot_cur, slot_last, _p(has_mp), _p(Xw), _p(mp_desc),
                                                    _p(Tcw), _p(K), C.c_float(th), int(check_ori), _p(out),
-                                                   C.byref(n)))
+                                                   C.byref(n), _p(None if obs_positive is None else _c(obs_positive, np.uint8))))
         return out, n.value
 
-    def match_project_points(self, slot_cur, n_cur, in_view, proj, level, view_cos, desc, occupied, th, nn_ratio):
+    def match_project_points(self, slot_cur, n_cur, in_view, proj, level, view_cos, desc, occupied, th, nn_ratio, obs_positive=None):
         in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
         view_cos, desc, occupied = _c(view_cos, np.float32), _c(desc, np.float32), _c(occupied, np.uint8)
         out = np.empty(n_cur, np.int32)
         n = C.c_int32()
         self._chk(self.lib.asd_match_project_points(self.ctx, slot_cur, len(in_view), _p(in_view), _p(proj),
                                                     _p(level), _p(view_cos), _p(desc), _p(occupied), C.c_float(th),
-                                                    C.c_float(nn_ratio), _p(out), C.byref(n)))
+                                                    C.c_float(nn_ratio), _p(out), C.byref(n),
+                                                    _p(None if obs_positive is None else _c(obs_positive, np.uint8))))
         return out, n.value
 
     def match_project_keyframe(self, slot_cur, n_cur, valid, Xw, min_dist, max_dist, desc, kf_angle, occupied, Tcw, K, th, orb_dist,
@@ -401,23 +402,25 @@ class AsdHip:
     def bank_put_from_frame(self, slot, first_row, n):
         self._chk(self.lib.asd_bank_put_from_frame(self.ctx, slot, first_row, n))
 
-    def match_project_frame_bank(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_rows, Tcw, K, th, check_ori=True):
+    def match_project_frame_bank(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_rows, Tcw, K, th, check_ori=True, obs_positive=None):
         has_mp, Xw, mp_rows = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(mp_rows, np.int32)
         Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
         out = np.empty(n_cur, np.int32)
         n = C.c_int32()
         self._chk(self.lib.asd_match_project_frame_bank(self.ctx, slot_cur, slot_last, _p(has_mp), _p(Xw), _p(mp_rows),
-                                                        _p(Tcw), _p(K), C.c_float(th), int(check_ori), _p(out), C.byref(n)))
+                                                        _p(Tcw), _p(K), C.c_float(th), int(check_ori), _p(out), C.byref(n),
+                                                        _p(None if obs_positive is None else _c(obs_positive, np.uint8))))
         return out, n.value
 
-    def match_project_points_bank(self, slot_cur, n_cur, in_view, proj, level, view_cos, rows, occupied, th, nn_ratio):
+    def match_project_points_bank(self, slot_cur, n_cur, in_view, proj, level, view_cos, rows, occupied, th, nn_ratio, obs_positive=None):
         in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
         view_cos, rows, occupied = _c(view_cos, np.float32), _c(rows, np.int32), _c(occupied, np.uint8)
         out = np.empty(n_cur, np.int32)
         n = C.c_int32()
         self._chk(self.lib.asd_match_project_points_bank(self.ctx, slot_cur, len(in_view), _p(in_view), _p(proj), _p(level),
                                                          _p(view_cos), _p(rows), _p(occupied), C.c_float(th),
-                                                         C.c_float(nn_ratio), _p(out), C.byref(n)))
+                                                         C.c_float(nn_ratio), _p(out), C.byref(n),
+                                                         _p(None if obs_positive is None else _c(obs_positive, np.uint8))))
         return out, n.value
 
     def frustum(self, slot_cur, Xw, normal, min_dist, max_dist, Tcw, K, cos_limit=0.5):

@@ -1227,11 +1227,12 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
 
 int asdnet_profile_collect_set(asd_ctx* ctx, int set);
 
-int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc) {
+int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st) {
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
   if (n < 0 || n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
   if (n == 0) return ASD_OK;
-  hipStream_t st = ctx->cur_stream ? ctx->cur_stream : ctx->stream;
+  if (!st) st = ctx->stream;
+  std::lock_guard<std::mutex> prof_lock(ctx->prof_mutex);  // prof_* state is shared with asd_profile_enable / _get
   float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
   const int npad = (n + 31) / 32 * 32;
   const bool prof = ctx->prof_on;
@@ -1294,6 +1295,7 @@ int asdnet_profile_collect_set(asd_ctx* ctx, int set) {
 }
 
 int asdnet_profile_collect(asd_ctx* ctx) {
+  std::lock_guard<std::mutex> prof_lock(ctx->prof_mutex);
   for (int set = 0; set < 2; ++set) {
     const int rc = asdnet_profile_collect_set(ctx, set);
     if (rc != ASD_OK) return rc;

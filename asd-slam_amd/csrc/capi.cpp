@@ -171,7 +171,8 @@ int asd_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* co
 
 int asd_describe_device(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc) {
   if (!ctx || (n > 0 && (!d_patches || !d_desc))) return ASD_ERR_INVALID;
-  return asdnet_forward_device(ctx, d_patches, n, d_desc);
+  if (asd_extractor_busy(ctx, "asd_describe_device")) return ASD_ERR_INVALID;
+  return asdnet_forward_device(ctx, d_patches, n, d_desc, ctx->stream);
 }
 
 int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc) {
@@ -179,10 +180,11 @@ int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc) {
   if (n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
   if (n == 0) return ASD_OK;
+  if (asd_extractor_busy(ctx, "asd_describe")) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_patches, patches, (size_t)n * 1024, hipMemcpyHostToDevice, ctx->stream));
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc);
+  int rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc, ctx->stream);
   if (rc != ASD_OK) return rc;
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -193,10 +195,11 @@ int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc) {
 
 int asd_describe_timed(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc, int32_t reps, float* avg_ms) {
   if (!ctx || !avg_ms || reps < 1 || n < 1) return ASD_ERR_INVALID;
+  if (asd_extractor_busy(ctx, "asd_describe_timed")) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int r = 0; r < reps; ++r) {
-    int rc = asdnet_forward_device(ctx, d_patches, n, d_desc);
+    int rc = asdnet_forward_device(ctx, d_patches, n, d_desc, ctx->stream);
     if (rc != ASD_OK) return rc;
   }
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -223,10 +226,11 @@ int32_t asd_asdnet_split_mask(const asd_ctx* ctx) { return ctx ? (ctx->net_split
 int asd_profile_enable(asd_ctx* ctx, int32_t on) {
   if (!ctx) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
+  if (!on) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
+  std::lock_guard<std::mutex> prof_lock(ctx->prof_mutex);
   if (on && !ctx->prof_ev[0][0])
     for (int set = 0; set < 2; ++set)
       for (int i = 0; i < 9; ++i) ASD_HIP_CHECK(ctx, hipEventCreate(&ctx->prof_ev[set][i]));
-  if (!on) { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
   ctx->prof_on = on != 0;
   if (on) for (int l = 0; l < 8; ++l) { ctx->prof_ms[l] = 0; ctx->prof_calls[l] = 0; ctx->prof_patches[l] = 0; }
   return ASD_OK;
@@ -235,6 +239,7 @@ int asd_profile_enable(asd_ctx* ctx, int32_t on) {
 int asd_profile_get(asd_ctx* ctx, int32_t layer, double* total_ms, int32_t* calls, int64_t* patches) {
   if (!ctx || layer < 0 || layer >= 8 || !total_ms || !calls || !patches) return ASD_ERR_INVALID;
   { int rc = asdnet_profile_collect(ctx); if (rc != ASD_OK) return rc; }
+  std::lock_guard<std::mutex> prof_lock(ctx->prof_mutex);
   *total_ms = ctx->prof_ms[layer];
   *calls = ctx->prof_calls[layer];
   *patches = ctx->prof_patches[layer];

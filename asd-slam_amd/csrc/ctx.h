@@ -62,7 +62,6 @@ struct AsdFrameSlot {
 struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
-  hipStream_t cur_stream = nullptr;  // stream ASDNet enqueues on (stream, or stream_x for the pipelined extractor)
   hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
   struct AsyncExtract* ax = nullptr;
   int num_cu = 256;
@@ -108,7 +107,9 @@ struct asd_ctx {
   // ---- vocabulary + BoW scratch (state private to bow.hip)
   void* bow = nullptr;
 
-  // ---- per-layer profiling (asd_profile_enable)
+  // ---- per-layer profiling (asd_profile_enable).  The extraction worker enqueues forwards while the caller enables /
+  // reads the profile: every access to the prof_* fields below happens under prof_mutex.
+  std::mutex prof_mutex;
   bool prof_on = false;
   hipEvent_t prof_ev[2][9] = {};   // two sets: a forward is enqueued while the previous one is still running
   bool prof_pending[2] = {false, false};
@@ -146,6 +147,9 @@ struct asd_ctx {
 int frontend_alloc(asd_ctx* ctx);
 void frontend_free(asd_ctx* ctx);
 void frontend_async_shutdown(asd_ctx* ctx);
+// true while submissions of asd_extract_submit have not been waited for: the worker thread owns the shared pyramid / score /
+// blur buffers and the ASDNet activations then, and the synchronous entry points that use them must refuse to run
+bool asd_extractor_busy(asd_ctx* ctx, const char* who);
 // matcher.hip / ba.hip
 void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);
@@ -159,5 +163,7 @@ int asdnet_alloc(asd_ctx* ctx);
 void asdnet_free(asd_ctx* ctx);
 int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
                         const float* const bn_var[7], float eps);
-int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc);
+// enqueues one forward on `st` (the caller's stream or the extraction worker's); d_act / d_part are one set per context, so
+// forwards of one context must be ordered among themselves: asd_extractor_busy() guards the caller-side entry points
+int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st);
 int asdnet_profile_collect(asd_ctx* ctx);  // folds pending layer events into the totals (needs a synced stream)

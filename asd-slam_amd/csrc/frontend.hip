@@ -749,9 +749,7 @@ static int extract_front(asd_ctx* ctx, const ExtractJob& J, ExtractSlot& S, hipS
 // E6: ASDNet on the slot's patches + read-back of angles and descriptors, all enqueued on `st` behind ev_front
 static int extract_back_enqueue(asd_ctx* ctx, ExtractSlot& S, int n, hipStream_t st) {
   ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, S.ev_front, 0));
-  ctx->cur_stream = st;
-  const int rc = asdnet_forward_device(ctx, S.d_patches, n, S.d_desc);
-  ctx->cur_stream = nullptr;
+  const int rc = asdnet_forward_device(ctx, S.d_patches, n, S.d_desc, st);
   if (rc != ASD_OK) return rc;
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_angles, S.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -782,6 +780,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   if (!kps || !desc || !n_out) return ASD_ERR_INVALID;
   int rc = extract_check(ctx, image, width, height, stride);
   if (rc != ASD_OK) return rc;
+  if (asd_extractor_busy(ctx, "asd_extract")) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   FrontendState* fe = ctx->fe;
   ExtractSlot& S = fe->slot0;
@@ -918,6 +917,16 @@ void frontend_async_shutdown(asd_ctx* ctx) {
   if (ctx->stream_x) { (void)hipStreamDestroy(ctx->stream_x); ctx->stream_x = nullptr; }
 }
 
+bool asd_extractor_busy(asd_ctx* ctx, const char* who) {
+  AsyncExtract* ax = ctx->ax;
+  if (!ax) return false;
+  std::lock_guard<std::mutex> l(ax->m);
+  if (ax->submitted == ax->waited) return false;
+  ctx->set_error("%s: %llu submission(s) of asd_extract_submit are outstanding -- the worker thread owns the pyramid, score and "
+                 "activation buffers until asd_extract_wait has returned them all", who, (unsigned long long)(ax->submitted - ax->waited));
+  return true;
+}
+
 extern "C" {
 
 int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width, int32_t height,
@@ -933,20 +942,37 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     //  local-map stage drops from 0.31 to 0.18 ms device time -- its workgroup no longer waits for a CU -- but a masked
     //  stream runs ASDNet 9 % slower whatever the mask (0.80 -> 0.88 ms), which puts the extractor back on the critical
     //  path: 720-750 frames/s either way.)
+    // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
+    // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
+    // will ever take (asd_extract_wait would block forever).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_x, hipStreamDefault, prio_least));
-    AsyncExtract* ax = new AsyncExtract();
-    ctx->ax = ax;
     const int prio_mid = prio_least + (prio_greatest - prio_least) / 2;
-    ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_mid));
-    ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners));
-    for (int i = 0; i < kSlots; ++i) {
-      if ((rc = slot_alloc(ctx, ax->slots[i])) != ASD_OK) return rc;
-      if ((rc = slot_events(ctx, ax->slots[i])) != ASD_OK) return rc;
-      ax->jobs[i].slot = i;
-      ax->jobs[i].kps.resize(ctx->cfg.max_patches);
+    AsyncExtract* ax = new AsyncExtract();
+    hipStream_t sx = nullptr;
+    auto build = [&]() -> int {
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_mid));
+      ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners));
+      for (int i = 0; i < kSlots; ++i) {
+        int r;
+        if ((r = slot_alloc(ctx, ax->slots[i])) != ASD_OK) return r;
+        if ((r = slot_events(ctx, ax->slots[i])) != ASD_OK) return r;
+        ax->jobs[i].slot = i;
+        ax->jobs[i].kps.resize(ctx->cfg.max_patches);
+      }
+      return ASD_OK;
+    };
+    if ((rc = build()) != ASD_OK) {
+      for (auto& S : ax->slots) slot_free(S);
+      if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
+      if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
+      if (sx) (void)hipStreamDestroy(sx);
+      delete ax;
+      return rc;
     }
+    ctx->stream_x = sx;
+    ctx->ax = ax;
     ax->th = std::thread(async_worker, ctx);
   }
   AsyncExtract* ax = ctx->ax;
@@ -1014,6 +1040,7 @@ int asd_get_level_size(const asd_ctx* ctx, int32_t level, int32_t* width, int32_
 
 int asd_get_level_image(asd_ctx* ctx, int32_t level, int32_t blurred, uint8_t* out) {
   if (!ctx || !ctx->fe || !out || level < 0 || level >= ctx->fe->pyr.nlevels) return ASD_ERR_INVALID;
+  if (asd_extractor_busy(ctx, "asd_get_level_image")) return ASD_ERR_INVALID;
   const LevelDev& L = ctx->fe->pyr.lv[level];
   const uint8_t* src = (blurred ? ctx->fe->d_blur : ctx->fe->d_pyr) + L.off;
   ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(out, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
@@ -1023,6 +1050,7 @@ int asd_get_level_image(asd_ctx* ctx, int32_t level, int32_t blurred, uint8_t* o
 
 int asd_get_raw_corners(asd_ctx* ctx, int32_t level, int32_t capacity, float* x, float* y, float* response, int32_t* n_out) {
   if (!ctx || !ctx->fe || !n_out || level < 0 || level >= ctx->fe->pyr.nlevels) return ASD_ERR_INVALID;
+  if (asd_extractor_busy(ctx, "asd_get_raw_corners")) return ASD_ERR_INVALID;
   const FrontendState* fe = ctx->fe;
   const int n = std::min((int)fe->raw_x[level].size(), capacity);
   for (int i = 0; i < n; ++i) {
@@ -1178,6 +1206,11 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
   for (int i = 0; i < N; ++i) { u_right[i] = -1.0f; depth[i] = -1.0f; }
   if (N == 0 || Nr == 0) return ASD_OK;
   if (!FL.d_kp || !FR.d_kp) { ctx->set_error("asd_stereo_match: frame slot not set"); return ASD_ERR_INVALID; }
+  // the SAD windows are read from both contexts' pyramids: those must still hold the images the two frame slots came from
+  if (asd_extractor_busy(ctx_left, "asd_stereo_match") || asd_extractor_busy(ctx_right, "asd_stereo_match")) {
+    if (ctx != ctx_right) ctx->set_error("%s", ctx_right->last_error());
+    return ASD_ERR_INVALID;
+  }
   (void)hipSetDevice(ctx->cfg.device);
   hipStream_t st = ctx->stream;
   // row table (:370-387): right keypoint iR is a candidate for every row within 2 * scale[octave] of its y

@@ -636,7 +636,7 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
 // mp_desc: host table indexed like the last frame's keypoints, or NULL with mp_rows = bank rows
 static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
                             const float* mp_desc, const int32_t* mp_rows, const float* Tcw, const float* K, float th,
-                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches) {
+                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches, const uint8_t* obs_pos) {
   AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
   if (!C || !L || !has_mp || !Xw || (!mp_desc && !mp_rows) || !Tcw || !K || !match_cur || !n_matches) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
@@ -678,6 +678,10 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
   // rotation histogram (ORBmatcher.cc:1419-1425, 1437-1450) without per-bin vectors: a current keypoint is matched at most
   // once, so its bin is kept per keypoint and the bins only need their counts
   static thread_local std::vector<int8_t> bin_of;
+  // with map points that have no observations a keypoint can be written -- and enter the histogram -- more than once
+  // (ORBmatcher.cc:1392-1395): those calls keep the reference's per-write entries (keypoint, bin)
+  static thread_local std::vector<std::pair<int, int8_t>> writes;
+  if (obs_pos) writes.clear();
   int cnt[HISTO];
   for (int b = 0; b < HISTO; ++b) cnt[b] = 0;
   if (check_orientation) bin_of.assign(C->n, -1);
@@ -694,7 +698,7 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
     const float* dist = R.dist + R.off[i];
     for (int t = 0, e = R.cnt[i]; t < e; ++t) {
       const int j = idx[t];
-      if (match_cur[j] >= 0) continue;  // already holds a map point with Observations() > 0
+      if (match_cur[j] >= 0 && (!obs_pos || obs_pos[match_cur[j]])) continue;  // holds a map point with Observations() > 0
       if (dist[t] < best) { best = dist[t]; best_idx = j; }
     }
     if (best <= TH_HIGH) {
@@ -702,7 +706,8 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
       nmatches++;
       if (check_orientation) {
         const int b = rot_bin(L->kps[i].angle, C->kps[best_idx].angle);
-        bin_of[best_idx] = (int8_t)b;
+        if (obs_pos) writes.emplace_back(best_idx, (int8_t)b);
+        else bin_of[best_idx] = (int8_t)b;
         ++cnt[b];
       }
     }
@@ -710,9 +715,14 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
   if (check_orientation) {
     int i1, i2, i3;
     three_maxima(cnt, i1, i2, i3);
-    for (int j = 0; j < C->n; ++j) {
-      const int b = bin_of[j];
-      if (b >= 0 && b != i1 && b != i2 && b != i3) { match_cur[j] = -1; nmatches--; }
+    if (obs_pos) {
+      for (const auto& w : writes)
+        if (w.second != i1 && w.second != i2 && w.second != i3) { match_cur[w.first] = -1; nmatches--; }
+    } else {
+      for (int j = 0; j < C->n; ++j) {
+        const int b = bin_of[j];
+        if (b >= 0 && b != i1 && b != i2 && b != i3) { match_cur[j] = -1; nmatches--; }
+      }
     }
   }
   *n_matches = nmatches;
@@ -728,7 +738,8 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
 
 static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
                              const int32_t* level, const float* view_cos, const float* desc, const int32_t* rows,
-                             const uint8_t* occupied, float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
+                             const uint8_t* occupied, float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches,
+                             const uint8_t* obs_pos) {
   AsdFrameSlot* F = slot_of(ctx, slot_cur);
   if (!F || n_mp < 0 || !match_cur || !n_matches || (n_mp > 0 && (!in_view || !proj || !level || !view_cos || (!desc && !rows))) ||
       (F->n > 0 && !occupied))
@@ -762,7 +773,7 @@ static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_m
     int best_lvl = -1, best_lvl2 = -1, best_idx = -1;
     for (int t = R.off[q]; t < R.off[q] + R.cnt[q]; ++t) {
       const int j = R.idx[t];
-      if (occupied[j] || match_cur[j] >= 0) continue;
+      if (occupied[j] || (match_cur[j] >= 0 && (!obs_pos || obs_pos[match_cur[j]]))) continue;
       const float d = R.dist[t];
       if (d < best) {
         best2 = best; best = d;
@@ -787,30 +798,30 @@ extern "C" {
 
 int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
                             const float* mp_desc, const float* Tcw, const float* K, float th,
-                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches) {
+                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive) {
   if (!mp_desc) return ASD_ERR_INVALID;
-  return match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, nullptr, Tcw, K, th, check_orientation, match_cur, n_matches);
+  return match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, nullptr, Tcw, K, th, check_orientation, match_cur, n_matches, mp_obs_positive);
 }
 
 int asd_match_project_frame_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
                                  const int32_t* mp_rows, const float* Tcw, const float* K, float th,
-                                 int32_t check_orientation, int32_t* match_cur, int32_t* n_matches) {
+                                 int32_t check_orientation, int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive) {
   if (!mp_rows) return ASD_ERR_INVALID;
-  return match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, nullptr, mp_rows, Tcw, K, th, check_orientation, match_cur, n_matches);
+  return match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, nullptr, mp_rows, Tcw, K, th, check_orientation, match_cur, n_matches, mp_obs_positive);
 }
 
 int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
                              const int32_t* level, const float* view_cos, const float* desc, const uint8_t* occupied,
-                             float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
+                             float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive) {
   if (n_mp > 0 && !desc) return ASD_ERR_INVALID;
-  return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, nullptr, occupied, th, nn_ratio, match_cur, n_matches);
+  return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, nullptr, occupied, th, nn_ratio, match_cur, n_matches, mp_obs_positive);
 }
 
 int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
                                   const int32_t* level, const float* view_cos, const int32_t* rows, const uint8_t* occupied,
-                                  float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches) {
+                                  float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive) {
   if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
-  return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, occupied, th, nn_ratio, match_cur, n_matches);
+  return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, occupied, th, nn_ratio, match_cur, n_matches, mp_obs_positive);
 }
 
 // ORBmatcher::Fuse, search half (ORBmatcher.cc:825-936): the Replace / AddObservation side effects

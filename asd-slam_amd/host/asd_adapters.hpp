@@ -45,6 +45,7 @@ struct MapPointView {
   float normal[3];      // GetNormal
   float mfMinDistance, mfMaxDistance;
   const float* descriptor;  // GetDescriptor, 128 f32
+  int nObs = 1;             // Observations(): a keypoint holding a map point with nObs == 0 is not skipped (ORBmatcher.cc:86-88)
 };
 
 class Context {
@@ -139,11 +140,12 @@ class ORBmatcher {
   int SearchByProjection(FrameView& Cur, const FrameView& Last, const std::vector<const MapPointView*>& points,
                          const Camera& K, float th, bool /*bMono: the reference is monocular only*/ = true) {
     const int nl = Last.N();
-    std::vector<uint8_t> has(nl, 0);
+    std::vector<uint8_t> has(nl, 0), obs(nl, 1);
     std::vector<float> Xw((size_t)nl * 3, 0.f), desc((size_t)nl * ASD_DESC_DIM, 0.f);
     for (int i = 0; i < nl; ++i)
       if (points[i]) {
         has[i] = 1;
+        obs[i] = points[i]->nObs > 0;
         for (int k = 0; k < 3; ++k) Xw[3 * i + k] = points[i]->Xw[k];
         for (int k = 0; k < ASD_DESC_DIM; ++k) desc[(size_t)i * ASD_DESC_DIM + k] = points[i]->descriptor[k];
       }
@@ -151,7 +153,7 @@ class ORBmatcher {
     int32_t n = 0;
     const float Kv[4] = {K.fx, K.fy, K.cx, K.cy};
     if (asd_match_project_frame(c_.get(), Cur.slot, Last.slot, has.data(), Xw.data(), desc.data(), Cur.mTcw, Kv, th,
-                                mbCheckOrientation, match.data(), &n) != ASD_OK)
+                                mbCheckOrientation, match.data(), &n, obs.data()) != ASD_OK)
       return 0;
     Cur.mvpMapPoints.assign(Cur.N(), -1);
     for (int j = 0; j < Cur.N(); ++j)
@@ -170,7 +172,8 @@ class ORBmatcher {
       mind[m] = vpMapPoints[m].mfMinDistance; maxd[m] = vpMapPoints[m].mfMaxDistance;
       for (int k = 0; k < ASD_DESC_DIM; ++k) desc[(size_t)m * ASD_DESC_DIM + k] = vpMapPoints[m].descriptor[k];
     }
-    std::vector<uint8_t> in_view(n), occupied(F.N(), 0);
+    std::vector<uint8_t> in_view(n), occupied(F.N(), 0), obs(n, 1);
+    for (int m = 0; m < n; ++m) obs[m] = vpMapPoints[m].nObs > 0;
     std::vector<float> proj((size_t)n * 2), vc(n);
     std::vector<int32_t> level(n), match(F.N(), -1);
     const float Kv[4] = {K.fx, K.fy, K.cx, K.cy};
@@ -180,7 +183,7 @@ class ORBmatcher {
     for (int j = 0; j < F.N(); ++j) occupied[j] = F.mvpMapPoints.size() == (size_t)F.N() && F.mvpMapPoints[j] >= 0;
     int32_t nm = 0;
     if (asd_match_project_points(c_.get(), F.slot, n, in_view.data(), proj.data(), level.data(), vc.data(), desc.data(),
-                                 occupied.data(), th, mfNNratio, match.data(), &nm) != ASD_OK)
+                                 occupied.data(), th, mfNNratio, match.data(), &nm, obs.data()) != ASD_OK)
       return 0;
     F.mvpMapPoints.resize(F.N(), -1);
     for (int j = 0; j < F.N(); ++j)

@@ -173,7 +173,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     h->m1.assign(n, -1);
     int32_t n1 = 0;
     if ((rc = asd_match_project_frame_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1,
-                                           h->m1.data(), &n1)) != ASD_OK)
+                                           h->m1.data(), &n1, nullptr)) != ASD_OK)
       return rc;
     st->m1 = n1; st->has_m1 = 1;
     seg(2);
@@ -226,7 +226,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     h->m2.assign(n, -1);
     int32_t n2 = 0;
     if ((rc = asd_match_project_points_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
-                                            h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2)) != ASD_OK)
+                                            h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2, nullptr)) != ASD_OK)
       return rc;
     st->m2 = n2; st->has_m2 = 1;
     dev(2, "match");

@@ -119,8 +119,10 @@ int asd_extract_device(asd_ctx* ctx, const uint8_t* d_image, int32_t width, int3
  * once; asd_extract_wait blocks until the OLDEST outstanding submission has finished and hands back the
  * same results asd_extract would.  Up to ASD_EXTRACT_QUEUE submissions may be outstanding; the worker runs
  * the front half (pyramid .. patch gather) of the next queued frame underneath the ASDNet pass of the
- * previous one.  `image` must stay valid until its wait; do not call asd_extract / asd_describe while
- * submissions are outstanding (they share the ASDNet and front-end buffers).  The device-resident
+ * previous one.  `image` must stay valid until its wait.  While submissions are outstanding the worker owns the
+ * shared front-end and ASDNet buffers: asd_extract*, asd_describe*, asd_get_level_image / asd_get_raw_corners and
+ * asd_stereo_match return ASD_ERR_INVALID ("... submission(s) outstanding") instead of racing with it.  If the
+ * extractor's streams / buffers cannot be created the call fails and the next submit starts over.  The device-resident
  * descriptors of a waited frame (asd_frame_set with desc == NULL) stay valid for two further submissions. */
 #define ASD_EXTRACT_QUEUE 3
 int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_resident, int32_t width,
@@ -184,11 +186,15 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
  * Output: match_cur[n_cur] = index i of the last-frame keypoint whose map point was
  * written into CurrentFrame.mvpMapPoints[j], or -1; *n_matches = the method's return
  * value.  cur.mvpMapPoints is taken as all-NULL on entry (Tracking.cc:670).
- * check_orientation mirrors mbCheckOrientation. */
+ * check_orientation mirrors mbCheckOrientation.
+ * mp_obs_positive[i] (NULL = all non-zero): MapPoint::Observations() > 0 of last-frame map point i.  A current keypoint
+ * that received a map point WITHOUT observations earlier in the same call is not skipped by later map points
+ * (ORBmatcher.cc:1392-1395) and may be overwritten; each write counts in the return value and enters the rotation
+ * histogram, exactly as in the reference (a keypoint written twice can be removed -- and subtracted -- twice). */
 int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last,
                             const uint8_t* has_mp, const float* Xw, const float* mp_desc,
                             const float* Tcw, const float* K, float th, int32_t check_orientation,
-                            int32_t* match_cur, int32_t* n_matches);
+                            int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive);
 
 /* M2: ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>&, th)
  * (ORBmatcher.cc:44-122) after Frame::isInFrustum (Frame.cc:160-217) has filled the
@@ -196,12 +202,14 @@ int asd_match_project_frame(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last,
  * level[m] = mnTrackScaleLevel, view_cos[m], desc[m][128].  occupied[j] != 0 marks current
  * keypoints that already hold a map point with Observations()>0 on entry.
  * Output: match_cur[n_cur] = map point index m written to F.mvpMapPoints[j] or -1 (entries
- * occupied on entry stay -1 unless overwritten); *n_matches = reference return value
- * (counts each match twice, ORBmatcher.cc:116-117). */
+ * occupied on entry stay -1); *n_matches = reference return value
+ * (counts each match twice, ORBmatcher.cc:116-117).
+ * mp_obs_positive[m] (NULL = all non-zero): Observations() > 0 of map point m; a keypoint given a map point without
+ * observations earlier in this call stays available to later map points (ORBmatcher.cc:86-88). */
 int asd_match_project_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view,
                              const float* proj, const int32_t* level, const float* view_cos,
                              const float* desc, const uint8_t* occupied, float th, float nn_ratio,
-                             int32_t* match_cur, int32_t* n_matches);
+                             int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive);
 
 /* Device-resident descriptor bank.  The reference reads MapPoint::GetDescriptor() for every query of
  * every frame (ORBmatcher.cc:72, :1371) but only rewrites it once per keyframe
@@ -215,11 +223,11 @@ int asd_bank_put_from_frame(asd_ctx* ctx, int32_t slot, int32_t first_row, int32
 int asd_match_project_frame_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last,
                                  const uint8_t* has_mp, const float* Xw, const int32_t* mp_rows,
                                  const float* Tcw, const float* K, float th, int32_t check_orientation,
-                                 int32_t* match_cur, int32_t* n_matches);
+                                 int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive);
 int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view,
                                   const float* proj, const int32_t* level, const float* view_cos,
                                   const int32_t* rows, const uint8_t* occupied, float th, float nn_ratio,
-                                  int32_t* match_cur, int32_t* n_matches);
+                                  int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive);
 
 /* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
  * n map points: Xw[n][3], normal[n][3] (GetNormal), min_dist[n] / max_dist[n] = the map

@@ -166,7 +166,8 @@ int orc_distinctive_descriptor(const float* desc, int n) {
 
 int orc_match_project_frame(const orc_frame* cur, const orc_frame* last, const uint8_t* has_mp, const float* Xw,
                             const float* mp_desc, const float* Tcw, const float* K, float th, int check_ori,
-                            int32_t* match_cur) {
+                            int32_t* match_cur, const uint8_t* obs_pos) {
+  // obs_pos[i] = pMP->Observations() > 0 of last-frame map point i (NULL: all true)
   int nmatches = 0;
   std::vector<int> rotHist[HISTO_LENGTH];
   const float factor = 1.0f / HISTO_LENGTH;
@@ -192,7 +193,8 @@ int orc_match_project_frame(const orc_frame* cur, const orc_frame* last, const u
     int bestIdx2 = -1;
     for (size_t k = 0; k < vIndices2.size(); ++k) {
       const size_t i2 = vIndices2[k];
-      if (match_cur[i2] >= 0) continue;  // already holds a map point (Observations() > 0)
+      if (match_cur[i2] >= 0)                                  // if(CurrentFrame.mvpMapPoints[i2])
+        if (!obs_pos || obs_pos[match_cur[i2]]) continue;      //   if(...->Observations()>0) continue;  (:1392-1395)
       const float dist = DescriptorDistance(dMP, cur->desc.data() + i2 * 128);
       if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
     }
@@ -223,7 +225,7 @@ int orc_match_project_frame(const orc_frame* cur, const orc_frame* last, const u
 
 int orc_match_project_points(const orc_frame* F, int n_mp, const uint8_t* in_view, const float* proj,
                              const int32_t* level, const float* view_cos, const float* desc, const uint8_t* occupied,
-                             float th, float nn_ratio, int32_t* match_cur) {
+                             float th, float nn_ratio, int32_t* match_cur, const uint8_t* obs_pos) {
   int nmatches = 0;
   const bool bFactor = th != 1.0;
   for (int j = 0; j < F->N; ++j) match_cur[j] = -1;
@@ -244,7 +246,8 @@ int orc_match_project_points(const orc_frame* F, int n_mp, const uint8_t* in_vie
     int bestIdx = -1;
     for (size_t k = 0; k < vIndices.size(); ++k) {
       const size_t idx = vIndices[k];
-      if (occupied[idx] || match_cur[idx] >= 0) continue;  // F.mvpMapPoints[idx] with Observations() > 0
+      if (occupied[idx]) continue;                                  // F.mvpMapPoints[idx] with Observations() > 0 on entry
+      if (match_cur[idx] >= 0 && (!obs_pos || obs_pos[match_cur[idx]])) continue;  // given one in this call (:86-88)
       const float dist = DescriptorDistance(MPdescriptor, F->desc.data() + idx * 128);
       if (dist < bestDist) {
         bestDist2 = bestDist;

@@ -103,20 +103,22 @@ class Oracle:
         desc = _c(desc, np.float32)
         return self.lib.orc_distinctive_descriptor(_p(desc), desc.shape[0])
 
-    def match_project_frame(self, cur, last, has_mp, Xw, mp_desc, Tcw, K, th, check_ori=True):
+    def match_project_frame(self, cur, last, has_mp, Xw, mp_desc, Tcw, K, th, check_ori=True, obs_positive=None):
         has_mp, Xw, mp_desc = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(mp_desc, np.float32)
         Tcw, K = _c(Tcw, np.float32), _c(K, np.float32)
         out = np.empty(cur.n, np.int32)
         n = self.lib.orc_match_project_frame(cur.h, last.h, _p(has_mp), _p(Xw), _p(mp_desc), _p(Tcw), _p(K),
-                                             C.c_float(th), int(check_ori), _p(out))
+                                             C.c_float(th), int(check_ori), _p(out),
+                                             _p(None if obs_positive is None else _c(obs_positive, np.uint8)))
         return out, n
 
-    def match_project_points(self, cur, in_view, proj, level, view_cos, desc, occupied, th, nn_ratio):
+    def match_project_points(self, cur, in_view, proj, level, view_cos, desc, occupied, th, nn_ratio, obs_positive=None):
         in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
         view_cos, desc, occupied = _c(view_cos, np.float32), _c(desc, np.float32), _c(occupied, np.uint8)
         out = np.empty(cur.n, np.int32)
         n = self.lib.orc_match_project_points(cur.h, len(in_view), _p(in_view), _p(proj), _p(level), _p(view_cos),
-                                              _p(desc), _p(occupied), C.c_float(th), C.c_float(nn_ratio), _p(out))
+                                              _p(desc), _p(occupied), C.c_float(th), C.c_float(nn_ratio), _p(out),
+                                              _p(None if obs_positive is None else _c(obs_positive, np.uint8)))
         return out, n
 
     def frustum(self, cur, Xw, normal, min_dist, max_dist, Tcw, K, cos_limit=0.5):

@@ -120,6 +120,110 @@ def test_oracle_m1_recovers_true_matches(oracle, synth):
     assert n == (m >= 0).sum() and good > 0.9 * has.sum() * 0.9
 
 
+def _contested_m1_case(synth, n, seed):
+    """_m1_case-like input in which every map point has a twin projecting onto the same current keypoint, so the
+    'already holds a map point' branch (ORBmatcher.cc:1392-1395) decides most matches"""
+    kl, dl = make_frame(n, seed)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(seed + 1)
+    half = n // 2
+    twin = np.concatenate([np.arange(half), np.arange(half)])[:n]      # last keypoint i aims at current keypoint twin[i]
+    kc = kl[:half].copy()
+    kc["x"] += rng.uniform(-2, 2, half).astype(np.float32)
+    kc["y"] += rng.uniform(-2, 2, half).astype(np.float32)
+    kc["angle"] = (kc["angle"] + rng.normal(0, 25, half)).astype(np.float32) % np.float32(360)
+    dc = perturbed_descriptors(dl[:half], 0.03, seed + 2)
+    kl = kl.copy()
+    kl["octave"] = kc["octave"][twin]
+    kl["angle"] = (kc["angle"][twin] + rng.normal(0, 40, n)).astype(np.float32) % np.float32(360)
+    uv = np.stack([kc["x"][twin], kc["y"][twin]], 1)
+    Xw = backproject(T, K, uv, rng.uniform(5, 40, n))
+    has = (rng.uniform(size=n) < 0.9).astype(np.uint8)
+    mp_desc = perturbed_descriptors(dc[twin], 0.03, seed + 3)
+    obs = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    return kl, dl, kc, dc, Xw, has, mp_desc, T, K, obs
+
+
+def _m1_python(oracle, cur, last_kps, cur_kps, has, Xw, mp_desc, dc, T, K, th, check_ori, obs):
+    """the reference loop (ORBmatcher.cc:1318-1452) written out in Python over the oracle's grid query and distance"""
+    n_cur = len(cur_kps)
+    held = [-1] * n_cur
+    nm = 0
+    hist = [[] for _ in range(30)]
+    scale = SCALES.astype(np.float32)
+    for i in range(len(last_kps)):
+        if not has[i]:
+            continue
+        x3 = [np.float32(np.float64(np.float32(np.float32(np.float32(T[r, 0] * Xw[i, 0]) + np.float32(T[r, 1] * Xw[i, 1]))
+                                               + np.float32(T[r, 2] * Xw[i, 2]))) + np.float64(T[r, 3])) for r in range(3)]
+        invz = np.float32(1.0 / np.float64(x3[2]))
+        if invz < 0:
+            continue
+        u = np.float32(np.float32(np.float32(K[0] * x3[0]) * invz) + K[2])
+        v = np.float32(np.float32(np.float32(K[1] * x3[1]) * invz) + K[3])
+        if u < BOUNDS[0] or u > BOUNDS[1] or v < BOUNDS[2] or v > BOUNDS[3]:
+            continue
+        o = int(last_kps["octave"][i])
+        cand = cur.features_in_area(float(u), float(v), float(np.float32(th) * scale[o]), o - 1, o + 1)
+        best, bj = np.float32(100), -1
+        for j in cand:
+            if held[j] >= 0 and obs[held[j]]:
+                continue
+            d = oracle.descriptor_distance(mp_desc[i], dc[j])
+            if d < best:
+                best, bj = d, int(j)
+        if best <= np.float32(1.5):   # TH_HIGH
+            held[bj] = i
+            nm += 1
+            if check_ori:
+                rot = np.float32(last_kps["angle"][i]) - np.float32(cur_kps["angle"][bj])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360))
+                b = int(np.round(np.float32(rot * np.float32(1.0 / 30))))
+                if b == 30:
+                    b = 0
+                hist[b].append(bj)
+    if check_ori:
+        cnt = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda b: -cnt[b])
+        m1, m2, m3 = cnt[order[0]], cnt[order[1]], cnt[order[2]]
+        keep = {order[0]}
+        if m2 >= 0.1 * m1:
+            keep.add(order[1])
+            if m3 >= 0.1 * m1:
+                keep.add(order[2])
+        for b in range(30):
+            if b not in keep:
+                for j in hist[b]:
+                    held[j] = -1
+                    nm -= 1
+    return np.array(held, np.int32), nm
+
+
+@pytest.mark.parametrize("ori", [False, True])
+def test_oracle_m1_overwrites_map_points_without_observations(oracle, synth, ori):
+    """ORBmatcher.cc:1392-1395: a keypoint holding a map point with Observations() == 0 is not skipped; the later map
+    point overwrites it and both writes count.  The oracle against the loop written out in Python (ties in the top-3
+    histogram bins would be order dependent: the seed has none)."""
+    n = 160
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, obs = _contested_m1_case(synth, n, 300)
+    cur, last = oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS)
+    m_all, n_all = oracle.match_project_frame(cur, last, has, Xw, mp_desc, T, K, 15.0, check_ori=ori)
+    m_obs, n_obs = oracle.match_project_frame(cur, last, has, Xw, mp_desc, T, K, 15.0, check_ori=ori, obs_positive=obs)
+    m_one, n_one = oracle.match_project_frame(cur, last, has, Xw, mp_desc, T, K, 15.0, check_ori=ori,
+                                              obs_positive=np.ones(n, np.uint8))
+    np.testing.assert_array_equal(m_all, m_one)
+    assert n_all == n_one
+    assert not np.array_equal(m_obs, m_all)            # the flag vector changes who wins
+    if not ori:
+        assert n_obs > (m_obs >= 0).sum()              # overwritten writes still count in the return value
+        assert n_all == (m_all >= 0).sum()
+    pm, pn = _m1_python(oracle, cur, kl, kc, has, Xw, mp_desc, dc, T, K, 15.0, ori, obs)
+    np.testing.assert_array_equal(m_obs, pm)
+    assert n_obs == pn
+
+
 # ------------------------------------------------------------------ HIP vs oracle (GPU)
 @pytest.mark.gpu
 def test_dist_matrix_bit_exact(hip, oracle, synth):
@@ -238,6 +342,54 @@ def test_frustum_and_match_project_points(hip, oracle, synth, n_mp, th):
     np.testing.assert_array_equal(got, exp)
     assert ng == ne
     assert not ((got >= 0) & (occupied > 0)).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ori", [(2000, True), (2000, False), (160, True)])
+def test_match_project_frame_obs_positive(hip, oracle, synth, n, ori):
+    """mixed Observations() flags (ORBmatcher.cc:1392-1395): overwrites, double counting and double histogram entries"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, obs = _contested_m1_case(synth, n, 300 + n)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    cur, last = oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS)
+    for flags in (obs, np.zeros(n, np.uint8), None):
+        got, ng = hip.match_project_frame(0, 1, len(kc), has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=flags)
+        exp, ne = oracle.match_project_frame(cur, last, has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne
+    hip.bank_put(0, mp_desc)
+    got, ng = hip.match_project_frame_bank(0, 1, len(kc), has, Xw, np.arange(n, dtype=np.int32), T, K, 15.0, ori, obs_positive=obs)
+    exp, ne = oracle.match_project_frame(cur, last, has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=obs)
+    np.testing.assert_array_equal(got, exp)
+    assert ng == ne
+
+
+@pytest.mark.gpu
+def test_match_project_points_obs_positive(hip, oracle, synth):
+    """M2 with map points that have no observations (ORBmatcher.cc:86-88): the keypoint stays available"""
+    kc, dc = make_frame(1500, 95)
+    rng = np.random.default_rng(96)
+    n_mp = 4000
+    src = rng.integers(0, 1500, n_mp)                     # ~2.7 map points per keypoint
+    proj = np.stack([kc["x"][src], kc["y"][src]], 1) + rng.uniform(-1.5, 1.5, (n_mp, 2)).astype(np.float32)
+    level = kc["octave"][src].astype(np.int32)
+    vc = rng.uniform(0.99, 1.0, n_mp).astype(np.float32)
+    in_view = (rng.uniform(size=n_mp) < 0.9).astype(np.uint8)
+    desc = perturbed_descriptors(dc[src], 0.04, 97)
+    occupied = (rng.uniform(size=1500) < 0.1).astype(np.uint8)
+    obs = (rng.uniform(size=n_mp) < 0.5).astype(np.uint8)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    F = oracle.frame(kc, dc, BOUNDS)
+    res = []
+    for flags in (obs, None):
+        got, ng = hip.match_project_points(0, 1500, in_view, proj, level, vc, desc, occupied, 1.0, 0.8, obs_positive=flags)
+        exp, ne = oracle.match_project_points(F, in_view, proj, level, vc, desc, occupied, 1.0, 0.8, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne
+        res.append((got, ng))
+    assert not np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] > 2 * (res[0][0] >= 0).sum()         # overwritten writes are still counted (twice each)
+    assert res[1][1] == 2 * (res[1][0] >= 0).sum()
 
 
 @pytest.mark.gpu

@@ -7,10 +7,14 @@ MB, FX = 0.54, 718.856
 MBF = MB * FX
 
 
-def _stereo_pair(synth, disparity=12, seed_t=0):
-    wide = synth.scene_frame(seed_t, w=1241 + 96, h=376)
-    left = np.ascontiguousarray(wide[:, 32:32 + 1241])
-    right = np.ascontiguousarray(wide[:, 32 + disparity:32 + disparity + 1241])
+# BASELINE configs[3]: EuRoC MH stereo, 752x480, fx = 458.654 (cameraconfig/MH_EUROC/EuRoC_config.txt), baseline 0.11 m
+EUROC_W, EUROC_H, EUROC_MB, EUROC_FX = 752, 480, 0.11, 458.654
+
+
+def _stereo_pair(synth, disparity=12, seed_t=0, w=1241, h=376):
+    wide = synth.scene_frame(seed_t, w=w + 96, h=h)
+    left = np.ascontiguousarray(wide[:, 32:32 + w])
+    right = np.ascontiguousarray(wide[:, 32 + disparity:32 + disparity + w])
     return left, right
 
 
@@ -38,12 +42,16 @@ def test_oracle_stereo_recovers_constant_disparity(oracle, synth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("disparity,nfeat", [(12, 2000), (40, 1000)])
-def test_stereo_match_parity(pkg, oracle, synth, disparity, nfeat):
-    left, right = _stereo_pair(synth, disparity, seed_t=1)
+@pytest.mark.parametrize("disparity,nfeat,w,h,mb,fx", [(12, 2000, 1241, 376, MB, FX), (40, 1000, 1241, 376, MB, FX),
+                                                        (9, 2000, EUROC_W, EUROC_H, EUROC_MB, EUROC_FX)])
+def test_stereo_match_parity(pkg, oracle, synth, disparity, nfeat, w, h, mb, fx):
+    """the last case is BASELINE configs[3]'s size: two 752x480 contexts (left / right extractor), 2000 features each"""
+    left, right = _stereo_pair(synth, disparity, seed_t=1, w=w, h=h)
     layers = synth.asdnet_weights(0)
-    L = pkg.AsdHip(n_features=nfeat, max_width=1241, max_height=376)
-    R = pkg.AsdHip(n_features=nfeat, max_width=1241, max_height=376)
+    BOUNDS = (0.0, float(w), 0.0, float(h))
+    MB, MBF = mb, mb * fx
+    L = pkg.AsdHip(n_features=nfeat, max_width=w, max_height=h)
+    R = pkg.AsdHip(n_features=nfeat, max_width=w, max_height=h)
     try:
         L.load_weights(layers)
         R.load_weights(layers)
