@@ -98,6 +98,7 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
   // ASDNet arithmetic: split-bf16 kernels by default; ASD_ASDNET_MATH=f32 keeps every layer on the f32 MFMA kernels,
   // ASD_ASDNET_SPLIT_LAYERS=<mask> picks layers (bit 0 = conv2 ... bit 4 = conv6, bit 5 = fc)
   c->net_split = 0x3f;
+  if (const char* e = getenv("ASD_MATCH_REPLAY")) c->match_replay_host = !strcmp(e, "host");   // matcher.hip, k_resolve
   if (const char* e = getenv("ASD_ASDNET_MATH")) {
     if (!strcmp(e, "f32")) c->net_split = 0;
     else if (strcmp(e, "split")) fprintf(stderr, "libasdhip: ASD_ASDNET_MATH=%s not understood (f32 | split); using split\n", e);

@@ -78,6 +78,7 @@ struct asd_ctx {
   float* d_bias[7] = {};        // folded BN bias per layer
   float* d_wimg[7] = {};        // MFMA B-operand images, layers 2..7 (index 1..6)
   void* d_wx3[7] = {};          // the same weights split into three bf16 terms (asdnet.hip, split-operand kernels)
+  bool match_replay_host = false;  // ASD_MATCH_REPLAY=host (read at asd_ctx_create): matcher claim replay on the host
   int net_split = 1;            // ASD_ASDNET_MATH: 1 = split-bf16 kernels where a layer has one, 0 = f32 MFMA everywhere
   float* d_act[2] = {};         // ping-pong NHWC activations
   float* d_part = nullptr;      // split-K partials of the last layer

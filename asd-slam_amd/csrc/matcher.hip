@@ -32,7 +32,7 @@ constexpr int GC = ASD_GRID_COLS, GR = ASD_GRID_ROWS;
 // A window query = one GetFeaturesInArea call + the descriptor it is matched against.
 struct WinQuery { float x, y, r; int min_level, max_level, qrow; };
 struct GridDev {
-  const float4* kp;        // (x, y, octave as int bits, -) per keypoint
+  const float4* kp;        // (x, y, octave as int bits, angle) per keypoint
   const int* cell_start;   // [64*48+1], cell = ix*48 + iy
   const int* cell_items;
   float min_x, min_y, inv_w, inv_h;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery
                                                        const float* __restrict__ qdesc, const float* __restrict__ cdesc,
                                                        int* __restrict__ q_off, int* __restrict__ q_cnt,
                                                        int* __restrict__ total, int cap, int* __restrict__ out_idx,
-                                                       float* __restrict__ out_dist) {
+                                                       float* __restrict__ out_dist, unsigned* __restrict__ out_meta = nullptr) {
   const int lane = threadIdx.x & 63;
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= nq) return;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery
             }
             out_idx[p] = idx;
             out_dist[p] = sqd;
+            if (out_meta) out_meta[p] = ((unsigned)(p - off) << 16) | (unsigned)q;   // k_resolve: position in the list | query
           }
         }
         pos += __popcll(m);
@@ -230,6 +231,243 @@ __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a
       if (i0 + r < na) out[(size_t)(i0 + r) * nb + j] = acc[r];
 }
 
+
+// ---- claim / ratio / rotation-histogram replay on the device ------------------------------------------------------
+// The searches are order dependent: map point q (in input order) takes the best candidate that no EARLIER map point with
+// Observations() > 0 holds (ORBmatcher.cc:86-88, :1392-1395).  Written as a recurrence, pick(q) = g(picks of all q' < q):
+// a triangular system with exactly one solution, the serial walk's.  A serial walk is ~100 dependent LDS / L2 round trips
+// per map point, so the system is solved by fixed-point iteration instead: every map point recomputes its pick in parallel
+// from the claims of the previous iteration ("keypoint j is taken for q iff the smallest claimant of j is < q") until an
+// iteration changes nothing.  Correctness propagates upward from q = 0 (after k iterations the first k map points are
+// final), and a state that one more iteration leaves unchanged IS the solution of the recurrence; real frames settle in
+// 4-13 iterations of one barrier each (13: 2000 frame-to-frame queries with every candidate eligible and random distances).
+// Claims live in LDS as two tables used alternately; an entry is (iterations-left << 16 | q) so that atomicMin lets the
+// current iteration's posts overrule stale ones and nothing has to be cleared.  A keypoint held by a map point without
+// observations stays available (mp_obs_positive): such map points post no claim, and the keypoint's final holder is the
+// LAST writer = the largest q picking it.
+// KIND 0 = SearchByProjection(frame, frame) (:1318-1452): best only, TH_HIGH, rotation histogram over every write.
+// KIND 1 = SearchByProjection(frame, points) (:44-122): best / second best with levels and the ratio test; counts twice.
+struct ResolveArgs {
+  int nq, n_cur;
+  const int* q_off; const int* q_cnt; const int* idx; const float* dist;   // k_window_search output
+  const int* total; int cap;  // candidates produced / capacity of idx, dist: beyond it the lists are truncated -> no replay
+  const unsigned* meta;       // per candidate: position in its list << 16 | query (k_window_search)
+  const uint8_t* obs_pos;     // [nq] or null
+  const uint8_t* occupied;    // KIND 1: [n_cur]
+  const float4* kp_cur;       // (x, y, octave bits, angle)
+  const float4* kp_last;      // KIND 0: query q = last-frame keypoint q
+  int check_ori;
+  float nn_ratio;
+  int* pick;                  // [nq] scratch: the keypoint q writes (-1 none)
+  int* match_cur;             // out [n_cur]
+  int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations
+};
+constexpr int kResolveThreads = 512, kResolveMaxQPT = 8;   // up to 4096 queries
+// SLOTS = candidates a thread keeps in registers (template parameter: 8, 16 or 24, i.e. up to 12288 candidates register resident;
+// the launcher picks by the size of the previous search of the same kind, longer lists are read from L2 every iteration)
+
+// Shape of an iteration.  A thread per QUERY pays, per wave, for the longest candidate list among its 64 lanes (lists run
+// from 0 to ~100 entries: 12 us per iteration).  So the scan is flat over CANDIDATES: candidate c (keypoint j, query q,
+// position in q's list, distance d) is looked at by thread c % 512, which keeps it in registers for the whole kernel, and an
+// available candidate posts key = (bits of d, position, j) by a 64-bit atomicMin on its query's slot -- distances are
+// non-negative, so the bit pattern orders like the value, and the position breaks ties exactly as the reference's strict
+// `<` does (first in Frame::GetFeaturesInArea order).  The owner of q (thread q % 512) then reads the winner and posts the
+// claim.  The reference's best / second-best walk (KIND 1) equals the two smallest keys: the second best and ITS level are
+// the smallest key among the others (a candidate tying with the best lands there too; among equal values the first in list
+// order sets the level and later ones, not being `<`, leave it).  Everything the iterations touch is in registers or LDS.
+template <int KIND, int QPT, int kResolveSlots>
+__global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {   // <= 128 VGPRs: 8 waves beside one ASDNet workgroup
+  extern __shared__ unsigned long long lds_q[];
+  unsigned long long* key1 = lds_q;                                   // [nq]
+  unsigned long long* key2 = lds_q + a.nq;                            // [nq] (KIND 1)
+  unsigned* claim0 = reinterpret_cast<unsigned*>(lds_q + (KIND == 1 ? 2 : 1) * a.nq);
+  unsigned* claim[2] = {claim0, claim0 + a.n_cur};
+  uint8_t* oct_occ = reinterpret_cast<uint8_t*>(claim0 + 2 * a.n_cur);   // octave | 0x80 if occupied on entry
+  __shared__ int n_written, hist[HISTO], keep[3], n_removed;
+  const int t = threadIdx.x;
+  const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+  const int total = *a.total;
+  if (total > a.cap) {   // truncated lists: the host grows the buffers and searches again
+    if (t == 0) { a.n_matches[0] = 0; a.n_matches[1] = total; a.n_matches[2] = 0; }
+    return;
+  }
+  if (total == 0) {      // nothing in any window
+    for (int j = t; j < a.n_cur; j += kResolveThreads) a.match_cur[j] = -1;
+    if (t == 0) { a.n_matches[0] = 0; a.n_matches[1] = 0; a.n_matches[2] = 0; }
+    return;
+  }
+  constexpr unsigned long long kNone = ~0ull;
+  for (int q = t; q < (KIND == 1 ? 2 : 1) * a.nq; q += kResolveThreads) lds_q[q] = kNone;
+  for (int j = t; j < 2 * a.n_cur; j += kResolveThreads) claim0[j] = 0xffffffffu;
+  if (KIND == 1)
+    for (int j = t; j < a.n_cur; j += kResolveThreads)
+      oct_occ[j] = (uint8_t)((__float_as_int(a.kp_cur[j].z) & 0x7f) | (a.occupied[j] ? 0x80 : 0));
+  if (t == 0) { n_written = 0; n_removed = 0; }
+  if (t < HISTO) hist[t] = 0;
+  // the thread's candidates: key low word (position << 16 | keypoint), distance bits, and the query (16 bits, two per register;
+  // 0xffff = empty slot)
+  unsigned clo[kResolveSlots], cdb[kResolveSlots], cqp[kResolveSlots / 2];
+#pragma unroll
+  for (int i = 0; i < kResolveSlots / 2; ++i) cqp[i] = 0xffffffffu;
+#pragma unroll
+  for (int i = 0; i < kResolveSlots; ++i) {
+    const int c = min(t + i * kResolveThreads, total - 1);   // clamped: the loads of all slots are issued unconditionally
+    const bool v = t + i * kResolveThreads < total;
+    const unsigned meta = a.meta[c];
+    clo[i] = (meta & 0xffff0000u) | (unsigned)a.idx[c];
+    cdb[i] = __float_as_uint(a.dist[c]);
+    if (v) cqp[i / 2] = (cqp[i / 2] & ~(0xffffu << (16 * (i & 1)))) | ((meta & 0xffffu) << (16 * (i & 1)));
+  }
+#define CQ(i) ((cqp[(i) / 2] >> (16 * ((i) & 1))) & 0xffffu)
+  int pick[QPT];
+  unsigned posmask = 0;
+#pragma unroll
+  for (int k = 0; k < QPT; ++k) {
+    const int q = t + k * kResolveThreads;
+    if (q < a.nq && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
+    pick[k] = -1;
+  }
+  __syncthreads();
+  const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+  const unsigned th_bits = __float_as_uint(TH_HIGH);
+  unsigned long long ts_it0 = ts1;
+  int ph[4] = {0, 0, 0, 0};   // thread 0's view: bids, barrier, owners, closing barrier (10 ns units)
+  const int max_it = a.nq + 2;
+  int it = 0;
+  for (;; ++it) {
+    // read the claims of iteration it-1 (table it & 1, tag it), post this iteration's picks into the other table (tag it+1)
+    const unsigned* rd = claim[it & 1];
+    unsigned* wr = claim[(it + 1) & 1];
+    const unsigned tag_rd = (unsigned)(0xffff - it), tag_wr = (unsigned)(0xffff - (it + 1));
+    const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
+    // phase 1: every available candidate bids for its query.  The claim-table reads of eight candidates are in flight together
+    // (the scan is latency bound: ~100 cycles per dependent LDS access); in phase 1b (KIND 1) the query's winner is left out so
+    // that the minimum of the others comes out.  Measured and not kept: a contiguous piece of the buffers per thread with one
+    // atomic per run of equal queries (fewer atomics, but the piece's tail beyond the registers costs serial L2 round trips).
+    auto scan = [&](unsigned long long* keys, bool second) {
+      auto take = [&](unsigned q, unsigned lo, unsigned db, unsigned cl, unsigned long long w) {
+        bool ok = !((cl >> 16) == tag_rd && (cl & 0xffffu) < q);
+        if (KIND == 0) ok = ok && db <= th_bits;                       // beyond TH_HIGH it can never be picked
+        if (KIND == 1) ok = ok && !(oct_occ[lo & 0xffffu] & 0x80);
+        const unsigned long long k = ((unsigned long long)db << 32) | lo;
+        if (ok && (!second || k != w)) atomicMin(&keys[q], k);
+      };
+#pragma unroll
+      for (int g = 0; g < kResolveSlots; g += 8) {
+        unsigned cl[8];
+        unsigned long long w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          cl[i] = rd[clo[g + i] & 0xffffu];
+          w[i] = (second && CQ(g + i) != 0xffffu) ? key1[CQ(g + i)] : 0ull;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (CQ(g + i) != 0xffffu) take(CQ(g + i), clo[g + i], cdb[g + i], cl[i], w[i]);
+      }
+      for (int c0 = t + kResolveSlots * kResolveThreads; c0 < total; c0 += 4 * kResolveThreads) {   // beyond the registers: 12 loads in flight
+        unsigned meta[4], lo[4], db[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = min(c0 + i * kResolveThreads, total - 1);
+          meta[i] = a.meta[c]; lo[i] = (unsigned)a.idx[c]; db[i] = __float_as_uint(a.dist[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (c0 + i * kResolveThreads < total)
+            take(meta[i] & 0xffffu, (meta[i] & 0xffff0000u) | lo[i], db[i], rd[lo[i]], second ? key1[meta[i] & 0xffffu] : 0ull);
+      }
+    };
+    scan(key1, false);
+    const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();
+    const unsigned long long p2 = __builtin_amdgcn_s_memrealtime();
+    if (KIND == 1) {   // phase 1b: the smallest key among the others = second best (value and level)
+      scan(key2, true);
+      __syncthreads();
+    }
+    // phase 2: the owner of a query takes the winner and posts the claim
+    int changed = 0;
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int q = t + k * kResolveThreads;
+      if (q >= a.nq) continue;
+      const unsigned long long k1 = key1[q];
+      key1[q] = kNone;
+      int p = -1;
+      if (k1 != kNone) {
+        p = (int)(k1 & 0xffffu);
+        const float best = __uint_as_float((unsigned)(k1 >> 32));
+        if (KIND == 1) {
+          const unsigned long long k2 = key2[q];
+          key2[q] = kNone;
+          const float best2 = k2 != kNone ? __uint_as_float((unsigned)(k2 >> 32)) : 256.f;
+          const int lvl = oct_occ[p] & 0x7f, lvl2 = k2 != kNone ? (oct_occ[k2 & 0xffffu] & 0x7f) : -1;
+          if (!(best <= TH_HIGH) || (lvl == lvl2 && best > a.nn_ratio * best2)) p = -1;
+        }
+      }
+      changed |= p != pick[k];
+      pick[k] = p;
+      if (p >= 0 && (posmask >> k & 1)) atomicMin(&wr[p], (tag_wr << 16) | (unsigned)q);
+    }
+    const unsigned long long p3 = __builtin_amdgcn_s_memrealtime();
+    const bool more = __syncthreads_or(changed) && it < max_it;
+    ph[0] += (int)(p1 - p0); ph[1] += (int)(p2 - p1); ph[2] += (int)(p3 - p2); ph[3] += (int)(__builtin_amdgcn_s_memrealtime() - p3);
+    if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
+    if (!more) break;
+  }
+  const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+  // ---- outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
+  int* last = reinterpret_cast<int*>(claim0);
+  for (int j = t; j < a.n_cur; j += kResolveThreads) last[j] = -1;
+  __syncthreads();
+  int mine = 0;
+#pragma unroll
+  for (int k = 0; k < QPT; ++k)
+    if (pick[k] >= 0) { atomicMax(&last[pick[k]], t + k * kResolveThreads); ++mine; }
+  if (mine) atomicAdd(&n_written, mine);
+  __syncthreads();
+  for (int j = t; j < a.n_cur; j += kResolveThreads) a.match_cur[j] = last[j];
+  if (KIND == 0 && a.check_ori) {
+    int bin[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      bin[k] = -1;
+      if (pick[k] < 0) continue;
+      float rot = a.kp_last[t + k * kResolveThreads].w - a.kp_cur[pick[k]].w;   // ORBmatcher.cc:1419-1425
+      if (rot < 0.0) rot += 360.0f;
+      int b = (int)roundf(rot * (1.0f / HISTO));
+      if (b == HISTO) b = 0;
+      bin[k] = b;
+      atomicAdd(&hist[b], 1);
+    }
+    __syncthreads();   // also orders the match_cur stores above before the removals below
+    if (t == 0) {      // ComputeThreeMaxima (:1584-1625)
+      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+      for (int i = 0; i < HISTO; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+      }
+      if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+      else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+      keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
+    }
+    __syncthreads();
+    int removed = 0;
+#pragma unroll
+    for (int k = 0; k < QPT; ++k)   // every write in a discarded bin clears the keypoint and is subtracted (:1437-1450)
+      if (bin[k] >= 0 && bin[k] != keep[0] && bin[k] != keep[1] && bin[k] != keep[2]) { a.match_cur[pick[k]] = -1; ++removed; }
+    if (removed) atomicAdd(&n_removed, removed);
+  }
+  __syncthreads();
+  if (t == 0) { a.n_matches[0] = (KIND == 1 ? 2 : 1) * n_written - n_removed; a.n_matches[1] = *a.total; a.n_matches[2] = it + 1;
+    // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs -- in units of 10 ns
+    a.n_matches[3] = (int)(ts1 - ts0); a.n_matches[4] = (int)(ts2 - ts1); a.n_matches[5] = (int)(__builtin_amdgcn_s_memrealtime() - ts2); a.n_matches[6] = (int)(ts_it0 - ts1);
+    for (int i = 0; i < 4; ++i) a.n_matches[7 + i] = ph[i]; }
+}
+
 // ---- host helpers -------------------------------------------------------------------------
 inline void three_maxima(const int* cnt, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1584-1625
   int max1 = 0, max2 = 0, max3 = 0;
@@ -291,6 +529,7 @@ struct MatcherState {
   int last_total[4] = {1 << 15, 1 << 15, 1 << 15, 1 << 15};  // candidates the previous search of each kind produced
   WinQuery *d_queries = nullptr, *h_queries = nullptr;   // h_* pinned
   int *d_q_off = nullptr, *d_q_cnt = nullptr, *d_total = nullptr, *d_idx = nullptr;
+  unsigned* d_meta = nullptr;  // per candidate: position in its list << 16 | query (k_resolve)
   float* d_dist = nullptr;
   int *h_q = nullptr;      // [2*q_cap + 1]: off, cnt, total
   int* h_idx = nullptr;
@@ -298,10 +537,18 @@ struct MatcherState {
   float *d_qdesc = nullptr, *h_qdesc = nullptr;
   float* d_bank = nullptr;  // device-resident descriptor bank (MapPoint::mDescriptor rows)
   int bank_cap = 0;
+  // device-side replay (k_resolve): pinned staging for flags in / matches out
+  int* h_res = nullptr;      // [res_cap + 4] ints, then res_cap bytes of flags
+  int res_cap = 0;
+  bool replay_host = false;  // ASD_MATCH_REPLAY=host at asd_ctx_create
 };
 
 MatcherState* mstate(asd_ctx* ctx) {
-  if (!ctx->matcher) ctx->matcher = new MatcherState();
+  if (!ctx->matcher) {
+    MatcherState* m = new MatcherState();
+    m->replay_host = ctx->match_replay_host;
+    ctx->matcher = m;
+  }
   return static_cast<MatcherState*>(ctx->matcher);
 }
 
@@ -320,10 +567,11 @@ int ensure_queries(asd_ctx* ctx, MatcherState* m, int nq) {
 int ensure_cands(asd_ctx* ctx, MatcherState* m, int n) {
   if (n <= m->cand_cap) return ASD_OK;
   const int cap = std::max(n * 3 / 2, 1 << 18);
-  if (m->d_idx) { (void)hipFree(m->d_idx); (void)hipFree(m->d_dist); (void)hipHostFree(m->h_idx); (void)hipHostFree(m->h_dist); }
+  if (m->d_idx) { (void)hipFree(m->d_idx); (void)hipFree(m->d_dist); (void)hipFree(m->d_meta); (void)hipHostFree(m->h_idx); (void)hipHostFree(m->h_dist); }
   m->cand_cap = 0;
   ASD_HIP_CHECK(ctx, hipMalloc(&m->d_idx, (size_t)cap * sizeof(int)));
   ASD_HIP_CHECK(ctx, hipMalloc(&m->d_dist, (size_t)cap * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_meta, (size_t)cap * sizeof(unsigned)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_idx, (size_t)cap * sizeof(int)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_dist, (size_t)cap * sizeof(float)));
   m->cand_cap = cap;
@@ -418,6 +666,110 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
   return ASD_OK;
 }
 
+
+// where the claim / ratio / histogram replay runs: on the device (k_resolve, default) or on the host over the copied-back
+// candidate lists (ASD_MATCH_REPLAY=host in the environment of asd_ctx_create; also taken when the tables would
+// not fit the workgroup's LDS or there are more than 4096 queries)
+size_t resolve_lds_bytes(int kind, int n_cur, int nq) {
+  return (size_t)(kind == 1 ? 2 : 1) * nq * 8 + (size_t)n_cur * 2 * sizeof(int) + (size_t)(n_cur + 15) / 16 * 16;
+}
+bool replay_on_device(const MatcherState* m, int kind, int n_cur, int nq) {
+  return !m->replay_host && n_cur > 0 && n_cur < 65536 && nq <= kResolveThreads * kResolveMaxQPT && resolve_lds_bytes(kind, n_cur, nq) <= 96 * 1024;
+}
+
+// k_window_search + k_resolve<KIND> behind one synchronisation: queries are in m->h_queries[0..nq), flags (may be null) are
+// copied through pinned staging, match_cur[n_cur] / *n_matches come back.  kp_last = last frame's device keypoints (KIND 0).
+template <int KIND>
+int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, const float4* kp_last,
+                       const uint8_t* obs_pos, const uint8_t* occupied, int check_ori, float nn_ratio, int32_t* match_cur,
+                       int32_t* n_matches) {
+  int rc = ensure_cands(ctx, m, 1);
+  if (rc != ASD_OK) return rc;
+  hipStream_t st = ctx->stream;
+  const int n_cur = F.n;
+  const int need = std::max(n_cur, nq) + 32;
+  if (need > m->res_cap) {
+    if (m->h_res) (void)hipHostFree(m->h_res);
+    m->res_cap = 0;
+    const int cap = std::max(need * 3 / 2, 8192);
+    ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_res, (size_t)cap * sizeof(int) + 16 + 2 * (size_t)cap));
+    m->res_cap = cap;
+  }
+  uint8_t* h_obs = reinterpret_cast<uint8_t*>(m->h_res + m->res_cap + 4);
+  uint8_t* h_occ = h_obs + m->res_cap;
+  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4) + AsdDevBuf::padded((size_t)(n_cur + 16) * 4) + AsdDevBuf::padded(nq) +
+                                          AsdDevBuf::padded(n_cur)));
+  int* d_pick = ctx->scratch.carve<int>(nq);
+  int* d_out = ctx->scratch.carve<int>((size_t)n_cur + 16);
+  uint8_t* d_obs = ctx->scratch.carve<uint8_t>(nq);
+  uint8_t* d_occ = ctx->scratch.carve<uint8_t>(n_cur);
+  int* d_off = m->d_q_off;
+  int* d_cnt = m->d_q_off + nq;
+  int* d_total = m->d_q_off + 2 * nq;
+  if (obs_pos) { memcpy(h_obs, obs_pos, nq); ASD_HIP_CHECK(ctx, hipMemcpyAsync(d_obs, h_obs, nq, hipMemcpyHostToDevice, st)); }
+  if (KIND == 1) { memcpy(h_occ, occupied, n_cur); ASD_HIP_CHECK(ctx, hipMemcpyAsync(d_occ, h_occ, n_cur, hipMemcpyHostToDevice, st)); }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_queries, m->h_queries, (size_t)nq * sizeof(WinQuery), hipMemcpyHostToDevice, st));
+    ASD_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(int), st));
+    GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
+                       d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    ResolveArgs a{};
+    a.nq = nq; a.n_cur = n_cur;
+    a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.meta = m->d_meta;
+    a.total = d_total; a.cap = m->cand_cap;
+    a.obs_pos = obs_pos ? d_obs : nullptr;
+    a.occupied = d_occ;
+    a.kp_cur = F.d_kp; a.kp_last = kp_last;
+    a.check_ori = check_ori; a.nn_ratio = nn_ratio;
+    a.pick = d_pick; a.match_cur = d_out; a.n_matches = d_out + n_cur;
+    const size_t lds = resolve_lds_bytes(KIND, n_cur, nq);
+    auto launch = [&](auto kern) -> hipError_t {
+      static bool attr_set = false;   // per instantiation: more than 64 KB of dynamic LDS has to be asked for once
+      if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(1), dim3(kResolveThreads), lds, st, a);
+      return hipGetLastError();
+    };
+    // register-resident candidates per thread: 8, or 16 for long frame-to-frame lists (KIND 1 with 16 spills under the cap)
+    constexpr int kBig = KIND == 0 ? 16 : 8;
+    const bool small = m->last_total[KIND] <= 8 * kResolveThreads;   // (24 slots = 60 registers with the queries packed two per register)
+    if (nq <= 4 * kResolveThreads) { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, kBig>)); }
+    else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_res, d_out, ((size_t)n_cur + 16) * sizeof(int), hipMemcpyDeviceToHost, st));
+    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const int total = m->h_res[n_cur + 1];
+    m->last_total[KIND] = total;
+    if (total > m->cand_cap) {  // the candidate buffers overflowed (k_resolve did not run): grow and search again
+      if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
+      continue;
+    }
+    break;
+  }
+  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+  memcpy(match_cur, m->h_res, (size_t)n_cur * sizeof(int));
+  *n_matches = m->h_res[n_cur];
+  static const bool timing = getenv("ASD_TIMING") != nullptr;
+  if (timing) {
+    static double acc[2]; static long calls[2]; static long rounds[2]; static double st_us[2][8];
+    acc[KIND] += ctx->ms_match; rounds[KIND] += m->h_res[n_cur + 2];
+    for (int i = 0; i < 8; ++i) st_us[KIND][i] += 0.01 * m->h_res[n_cur + 3 + i];
+    if (++calls[KIND] % 200 == 0)
+      fprintf(stderr, "[search+resolve kind %d] device %.3f ms, %.1f iterations, %d candidates; k_resolve: staging %.1f us, iterations %.1f us (the first %.1f; bids %.1f barrier %.1f owners %.1f closing %.1f), outputs %.1f us\n", KIND,
+              acc[KIND] / calls[KIND], (double)rounds[KIND] / calls[KIND], m->h_res[n_cur + 1], st_us[KIND][0] / calls[KIND], st_us[KIND][1] / calls[KIND],
+              st_us[KIND][3] / calls[KIND], st_us[KIND][4] / calls[KIND], st_us[KIND][5] / calls[KIND], st_us[KIND][6] / calls[KIND],
+              st_us[KIND][7] / calls[KIND], st_us[KIND][2] / calls[KIND]);
+  }
+  return ASD_OK;
+}
+
 // query descriptors: host table -> pinned staging -> device (one async copy)
 int upload_qdesc(asd_ctx* ctx, MatcherState* m, const float* desc, int n) {
   int rc = ensure_qdesc(ctx, m, n);
@@ -444,9 +796,9 @@ void matcher_free(asd_ctx* ctx) {
   }
   if (ctx->matcher) {
     MatcherState* m = static_cast<MatcherState*>(ctx->matcher);
-    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_qdesc, m->d_bank};
+    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_meta, m->d_qdesc, m->d_bank};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {m->h_queries, m->h_q, m->h_idx, m->h_dist, m->h_qdesc};
+    void* host[] = {m->h_queries, m->h_q, m->h_idx, m->h_dist, m->h_qdesc, m->h_res};
     for (void* p : host) if (p) (void)hipHostFree(p);
     delete m;
     ctx->matcher = nullptr;
@@ -503,7 +855,7 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   for (int i = 0; i < n; ++i) {
     float ob;
     memcpy(&ob, &kps[i].octave, sizeof ob);  // octave travels as raw int bits in .z
-    hk[i] = make_float4(kps[i].x, kps[i].y, ob, 0.f);
+    hk[i] = make_float4(kps[i].x, kps[i].y, ob, kps[i].angle);  // .w = angle (rotation histogram of k_resolve)
   }
   memcpy(hs, F->cell_start.data(), (GC * GR + 1) * sizeof(int));
   if (!F->cell_items.empty()) memcpy(hi, F->cell_items.data(), F->cell_items.size() * sizeof(int));
@@ -670,6 +1022,9 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
     const int oct = L->kps[i].octave;
     Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, mp_desc ? i : mp_rows[i]};
   }
+  if (replay_on_device(m, 0, C->n, L->n))   // search + claims + rotation histogram on the device, one synchronisation, 4 B per keypoint back
+    return search_and_resolve<0>(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, L->d_kp, obs_pos, nullptr, check_orientation, 0.f,
+                                 match_cur, n_matches);
   SearchResult R;
   const auto tm1 = std::chrono::steady_clock::now();
   if ((rc = window_search(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, &R, 0)) != ASD_OK) return rc;
@@ -764,6 +1119,9 @@ static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_m
     Q = WinQuery{proj[2 * q], proj[2 * q + 1], r * ctx->scale[lvl], lvl - 1, lvl, desc ? q : rows[q]};
   }
   if (desc && (rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  if (replay_on_device(m, 1, F->n, n_mp))
+    return search_and_resolve<1>(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, nullptr, obs_pos, occupied, 0, nn_ratio, match_cur,
+                                 n_matches);
   SearchResult R;
   if ((rc = window_search(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, &R, 1)) != ASD_OK) return rc;
   int nmatches = 0;

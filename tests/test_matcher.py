@@ -365,6 +365,41 @@ def test_match_project_frame_obs_positive(hip, oracle, synth, n, ori):
 
 
 @pytest.mark.gpu
+def test_host_and_device_replay_agree(pkg, oracle, synth, monkeypatch):
+    """The claim / ratio / histogram replay runs on the device (k_resolve: the serial recurrence solved by fixed-point
+    iteration) by default and on the host over the copied-back candidate lists with ASD_MATCH_REPLAY=host (also the
+    fallback for very large inputs): both against the oracle on contested inputs, all-positive and mixed flags."""
+    monkeypatch.setenv("ASD_MATCH_REPLAY", "host")
+    H = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376)
+    monkeypatch.delenv("ASD_MATCH_REPLAY")
+    D = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376)
+    try:
+        for n, ori in ((2000, True), (700, False)):
+            kl, dl, kc, dc, Xw, has, mp_desc, T, K, obs = _contested_m1_case(synth, n, 900 + n)
+            cur, last = oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS)
+            for flags in (None, obs):
+                exp, ne = oracle.match_project_frame(cur, last, has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=flags)
+                for dev in (H, D):
+                    dev.frame_set(0, kc, dc, BOUNDS)
+                    dev.frame_set(1, kl, dl, BOUNDS)
+                    got, ng = dev.match_project_frame(0, 1, len(kc), has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=flags)
+                    np.testing.assert_array_equal(got, exp)
+                    assert ng == ne
+        # wide windows: lists of 100+ candidates, several per thread beyond the register-resident part
+        kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, 2000, 950)
+        exp, ne = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw, mp_desc, T, K, 60.0, True)
+        for dev in (H, D):
+            dev.frame_set(0, kc, dc, BOUNDS)
+            dev.frame_set(1, kl, dl, BOUNDS)
+            got, ng = dev.match_project_frame(0, 1, 2000, has, Xw, mp_desc, T, K, 60.0, True)
+            np.testing.assert_array_equal(got, exp)
+            assert ng == ne
+    finally:
+        H.close()
+        D.close()
+
+
+@pytest.mark.gpu
 def test_match_project_points_obs_positive(hip, oracle, synth):
     """M2 with map points that have no observations (ORBmatcher.cc:86-88): the keypoint stays available"""
     kc, dc = make_frame(1500, 95)
