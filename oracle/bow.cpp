@@ -6,8 +6,10 @@
 // differences accumulated in a double, ascending index), BowVector.cpp:35-85 (addWeight / addIfNotExist /
 // normalize), FeatureVector.cpp:34-48 (addFeature), ScoringObject.h:72-89 (mustNormalize table), as called
 // from Frame::ComputeBoW (src/vslam/src/Frame.cc:289-296, levelsup = 4).
-// DBoW2 is vendored in the reference but needs OpenCV to compile (cv::Mat descriptors, cv::FileStorage), and
-// the vocabulary file is not part of the tree: PARITY UNPINNED beyond known-answer cases.
+// DBoW2 is vendored in the reference; the vocabulary template and FSift need OpenCV to compile (cv::Mat descriptors,
+// cv::FileStorage) and the vocabulary file is not part of the tree: the DESCENT is PARITY UNPINNED beyond known-answer
+// cases.  BowVector.cpp / FeatureVector.cpp include only the STL: the ASSEMBLY (orc_bow_assemble) is pinned against them
+// compiled in place (oracle/ref_dbow2/Makefile -> oracle/_ref/libdbow2_ref.so).
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -93,46 +95,46 @@ void orc_bow_descend(const orc_vocabulary* V, const float* desc, int n, int leve
   }
 }
 
-// TemplatedVocabulary::transform(features, v, fv, levelsup) (:1125-1197).  Outputs: BowVector as (bow_id ascending,
-// bow_val), FeatureVector as CSR (fv_node ascending, fv_start, fv_idx); returns the number of words, *n_fv nodes.
-int orc_bow_transform(const orc_vocabulary* V, const float* desc, int n, int levelsup, int32_t* bow_id, double* bow_val,
-                      int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int32_t* n_fv) {
+// The assembly half of TemplatedVocabulary::transform(features, v, fv, levelsup) (:1141-1197) on the per-feature results
+// of the descent (word id, weight, node id): BowVector::addWeight / addIfNotExist (BowVector.cpp:35-60), the !must division
+// (:1163-1169), BowVector::normalize (:64-87) and FeatureVector::addFeature (FeatureVector.cpp:34-48).  PINNED against the
+// reference's own BowVector.cpp / FeatureVector.cpp compiled in place (oracle/ref_dbow2, tests/golden/bow_golden.npz).
+int orc_bow_assemble(int n, const int32_t* word_id, const double* weight, const int32_t* node_id, int weighting, int scoring,
+                     int32_t* bow_id, double* bow_val, int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int32_t* n_fv) {
   std::map<unsigned, double> v;
   std::map<unsigned, std::vector<unsigned>> fv;
-  if (V->nodes.size() > 1) {
-    const bool must = V->scoring != 5;      // DotProductScoring is the only one that does not normalise
-    const bool l2 = V->scoring == 1;        // L2Scoring -> L2, all others L1
-    if (V->weighting == 0 || V->weighting == 1) {  // TF_IDF, TF
-      for (int i = 0; i < n; ++i) {
-        int id, nid; double w;
-        transform_one(V, desc + (size_t)i * 128, levelsup, &id, &w, &nid);
-        if (w > 0) {
-          auto it = v.lower_bound(id);
-          if (it != v.end() && !(v.key_comp()(id, it->first))) it->second += w;
-          else v.insert(it, std::make_pair((unsigned)id, w));
-          fv[nid].push_back(i);
-        }
-      }
-      if (!v.empty() && !must) {
-        const double nd = v.size();
-        for (auto& e : v) e.second /= nd;
-      }
-    } else {  // IDF, BINARY
-      for (int i = 0; i < n; ++i) {
-        int id, nid; double w;
-        transform_one(V, desc + (size_t)i * 128, levelsup, &id, &w, &nid);
-        if (w > 0) {
-          if (v.find(id) == v.end()) v[id] = w;
-          fv[nid].push_back(i);
-        }
+  const bool must = scoring != 5;      // DotProductScoring is the only one that does not normalise (ScoringObject.h:72-89)
+  const bool l2 = scoring == 1;        // L2Scoring -> L2, all others L1
+  if (weighting == 0 || weighting == 1) {  // TF_IDF, TF
+    for (int i = 0; i < n; ++i) {
+      const double w = weight[i];
+      if (w > 0) {
+        const unsigned id = (unsigned)word_id[i];
+        auto it = v.lower_bound(id);
+        if (it != v.end() && !(v.key_comp()(id, it->first))) it->second += w;
+        else v.insert(it, std::make_pair(id, w));
+        fv[(unsigned)node_id[i]].push_back(i);
       }
     }
-    if (must) {  // BowVector::normalize
-      double norm = 0.0;
-      if (!l2) for (auto& e : v) norm += fabs(e.second);
-      else { for (auto& e : v) norm += e.second * e.second; norm = sqrt(norm); }
-      if (norm > 0.0) for (auto& e : v) e.second /= norm;
+    if (!v.empty() && !must) {
+      const double nd = v.size();
+      for (auto& e : v) e.second /= nd;
     }
+  } else {  // IDF, BINARY
+    for (int i = 0; i < n; ++i) {
+      const double w = weight[i];
+      if (w > 0) {
+        const unsigned id = (unsigned)word_id[i];
+        if (v.find(id) == v.end()) v[id] = w;
+        fv[(unsigned)node_id[i]].push_back(i);
+      }
+    }
+  }
+  if (must) {  // BowVector::normalize
+    double norm = 0.0;
+    if (!l2) for (auto& e : v) norm += fabs(e.second);
+    else { for (auto& e : v) norm += e.second * e.second; norm = sqrt(norm); }
+    if (norm > 0.0) for (auto& e : v) e.second /= norm;
   }
   int k = 0;
   for (auto& e : v) { bow_id[k] = (int)e.first; bow_val[k] = e.second; ++k; }
@@ -145,6 +147,23 @@ int orc_bow_transform(const orc_vocabulary* V, const float* desc, int n, int lev
   }
   *n_fv = m;
   return k;
+}
+
+// TemplatedVocabulary::transform(features, v, fv, levelsup) (:1125-1197): descent per feature, then the assembly above.
+// Outputs: BowVector as (bow_id ascending, bow_val), FeatureVector as CSR (fv_node ascending, fv_start, fv_idx); returns the
+// number of words, *n_fv nodes.
+int orc_bow_transform(const orc_vocabulary* V, const float* desc, int n, int levelsup, int32_t* bow_id, double* bow_val,
+                      int32_t* fv_node, int32_t* fv_start, int32_t* fv_idx, int32_t* n_fv) {
+  if (V->nodes.size() <= 1) { fv_start[0] = 0; *n_fv = 0; return 0; }   // empty(): v and fv stay cleared (:1134-1137)
+  std::vector<int32_t> word(n), node(n);
+  std::vector<double> weight(n);
+  for (int i = 0; i < n; ++i) {
+    int id, nid; double w;
+    transform_one(V, desc + (size_t)i * 128, levelsup, &id, &w, &nid);
+    word[i] = id; node[i] = nid; weight[i] = w;
+  }
+  return orc_bow_assemble(n, word.data(), weight.data(), node.data(), V->weighting, V->scoring, bow_id, bow_val, fv_node, fv_start,
+                          fv_idx, n_fv);
 }
 
 }  // extern "C"

@@ -99,6 +99,9 @@ class Oracle:
         self.lib.orc_dist_matrix(_p(a), a.shape[0], _p(b), b.shape[0], _p(out))
         return out
 
+    def bow_assemble(self, word, weight, node, weighting, scoring):
+        return _bow_assemble(self.lib.orc_bow_assemble, word, weight, node, (int(weighting), int(scoring)))
+
     def distinctive_descriptor(self, desc):
         desc = _c(desc, np.float32)
         return self.lib.orc_distinctive_descriptor(_p(desc), desc.shape[0])
@@ -274,6 +277,36 @@ class Oracle:
         T = np.zeros((4, 4), np.float32)
         self.lib.orc_pose7_to_tcw(_p(p), _p(T))
         return T
+
+
+def _bow_assemble(fn, word, weight, node, extra):
+    word, node, weight = _c(word, np.int32), _c(node, np.int32), _c(weight, np.float64)
+    n = len(word)
+    bid, bval = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.float64)
+    fnode, fstart, fidx = np.empty(max(n, 1), np.int32), np.empty(n + 1, np.int32), np.empty(max(n, 1), np.int32)
+    nn = C.c_int32()
+    fn.restype = C.c_int
+    nw = fn(n, _p(word), _p(weight), _p(node), *extra, _p(bid), _p(bval), _p(fnode), _p(fstart), _p(fidx), C.byref(nn))
+    return (bid[:nw].copy(), bval[:nw].copy()), (fnode[:nn.value].copy(), fstart[:nn.value + 1].copy(), fidx[:fstart[nn.value]].copy())
+
+
+class RefDBoW2:
+    """The reference's own DBoW2::BowVector / FeatureVector compiled in place (oracle/ref_dbow2 -> oracle/_ref/libdbow2_ref.so):
+    the assembly half of TemplatedVocabulary::transform on per-feature (word, weight, node) triples."""
+
+    def __init__(self):
+        path = os.path.join(_HERE, "_ref", "libdbow2_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libdbow2_ref.so"))
+
+    def assemble(self, word, weight, node, weighting, scoring):
+        # ScoringObject.h:72-89: every scoring normalises with L1 except L2Scoring (L2) and DotProductScoring (none)
+        return _bow_assemble(self.lib.ref_bow_assemble, word, weight, node, (int(weighting), int(scoring != 5), int(scoring == 1)))
 
 
 class RefG2O:

@@ -51,6 +51,12 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
+def oracle_mod():
+    """the oracle's Python module (RefG2O / RefDBoW2: the reference's own sources compiled in place, where present)"""
+    return load_oracle()
+
+
+@pytest.fixture(scope="session")
 def hip(pkg):
     """One HIP context shared by the GPU tests (fails loudly if libasdhip / the GPU is missing)."""
     ctx = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096)

@@ -1,5 +1,7 @@
 """DBoW2 transform for float descriptors (TemplatedVocabulary<FSift>::transform, Frame::ComputeBoW):
 oracle known-answer checks on CPU, HIP-vs-oracle parity on the GPU through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -212,3 +214,47 @@ def test_voc_load_rejects_bad_trees(hip, synth, pkg):
         hip.voc_load(bad)
     hip.voc_load(voc)                                       # a good one still loads afterwards
     assert len(hip.bow_descend(voc["desc"][1:5], levelsup=1)[0]) == 4
+
+
+# ------------------------------------------------------------------ pinned: the reference's own BowVector / FeatureVector
+def _bow_golden():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bow_golden.npz"))
+
+
+def test_oracle_bow_assembly_equals_reference_classes(oracle):
+    """BowVector::addWeight / addIfNotExist / normalize and FeatureVector::addFeature (src/dbow2/DBoW2/BowVector.cpp,
+    FeatureVector.cpp), driven like TemplatedVocabulary::transform: the oracle's assembly against fixtures produced by the
+    reference's own sources compiled in place (tests/golden/make_bow_golden.py) -- word ids, node lists and the f64
+    weights bit for bit, for every weighting x normalisation."""
+    G = _bow_golden()
+    for ci in range(int(G["n_cases"])):
+        word, weight, node = G[f"c{ci}_word"], G[f"c{ci}_weight"], G[f"c{ci}_node"]
+        for weighting in range(4):
+            w = weight if weighting in (0, 2) else (weight > 0).astype(np.float64)
+            for scoring in (0, 1, 5):
+                (bid, bval), (fnode, fstart, fidx) = oracle.bow_assemble(word, w, node, weighting, scoring)
+                k = f"c{ci}_w{weighting}_s{scoring}"
+                np.testing.assert_array_equal(bid, G[k + "_bow_id"])
+                np.testing.assert_array_equal(bval.view(np.uint64), G[k + "_bow_val"].view(np.uint64))
+                np.testing.assert_array_equal(fnode, G[k + "_fv_node"])
+                np.testing.assert_array_equal(fstart, G[k + "_fv_start"])
+                np.testing.assert_array_equal(fidx, G[k + "_fv_idx"])
+
+
+def test_reference_dbow2_live_when_built(oracle, oracle_mod):
+    """where oracle/_ref/libdbow2_ref.so exists (build container, GPU box): the same comparison live on fresh inputs"""
+    if not oracle_mod.RefDBoW2.available():
+        pytest.skip("oracle/_ref/libdbow2_ref.so not built")
+    ref = oracle_mod.RefDBoW2()
+    rng = np.random.default_rng(77)
+    for n in (0, 5, 1500):
+        word = rng.integers(0, 400, n).astype(np.int32)
+        node = (word // 13).astype(np.int32)
+        weight = np.where(rng.uniform(size=n) < 0.1, 0.0, rng.uniform(0.1, 5.0, n))
+        for weighting in range(4):
+            for scoring in range(6):
+                a = oracle.bow_assemble(word, weight, node, weighting, scoring)
+                b = ref.assemble(word, weight, node, weighting, scoring)
+                for x, y in zip(a[0] + a[1], b[0] + b[1]):
+                    np.testing.assert_array_equal(x.view(np.uint64) if x.dtype == np.float64 else x,
+                                                  y.view(np.uint64) if y.dtype == np.float64 else y)
