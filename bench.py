@@ -226,7 +226,7 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
     stats = {"n_kp": len(kps)}
     if last is not None:
         lk, ld, lframe = last
-        uv = predicted_uv(lk)
+        uv = wl.predicted_uv(lk) if hasattr(wl, "predicted_uv") else predicted_uv(lk)
         Xw = backproject_identity(wl.K32, uv, 20.0)
         has = np.ones(len(lk), np.uint8)
         # map point descriptors: the HIP backend keeps them in the device-resident bank (rows 0..n-1 = the last
@@ -502,6 +502,136 @@ def selftest_dist(args):
     d.close()
 
 
+EUROC = {"w": 752, "h": 480, "K": (458.654, 457.296, 367.215, 248.375), "mb": 0.11, "disparity": 9}
+
+
+class EurocWorkload:
+    """BASELINE configs[3]: EuRoC MH-shaped synthetic stereo stream -- 752x480 (cameraconfig/MH_EUROC/EuRoC_config.txt: fx 458.654,
+    fy 457.296, cx 367.215, cy 248.375), baseline 0.11 m, left / right = two crops of one synthetic scene 9 px apart."""
+
+    def __init__(self, synth, seed_offset=0):
+        W, H = EUROC["w"], EUROC["h"]
+        self.K32 = np.array(EUROC["K"], np.float32)
+        self.K64 = np.array(EUROC["K"], np.float64)
+        self.T = np.eye(4, dtype=np.float32)
+        self.pose0 = np.array([0.002, -0.001, 0.0015, 1.0, 0.01, -0.02, 0.03])
+        self.pose0[:4] /= np.linalg.norm(self.pose0[:4])
+        self.ba = synth.ba_problem(seed=1 + seed_offset)
+        self.inv_sigma2 = (1.0 / (np.float32(1.2) ** np.arange(8)) ** 2).astype(np.float64)
+        self.scale32 = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+        wide = [synth.scene_frame(t + 3 * seed_offset, seed=31, w=W + 96, h=H) for t in range(N_FRAMES)]
+        self.left = [np.ascontiguousarray(f[:, 32:32 + W]) for f in wide]
+        self.right = [np.ascontiguousarray(f[:, 32 + EUROC["disparity"]:32 + EUROC["disparity"] + W]) for f in wide]
+        self.bounds = (0.0, float(W), 0.0, float(H))
+
+    def predicted_uv(self, kps):
+        # the scene drifts about the centre of the WIDE render: (W + 96) / 2 - 32 in the left crop's coordinates
+        z, cx, cy = 1.003, EUROC["w"] / 2 + 16.0, EUROC["h"] / 2.0
+        return np.stack([(kps["x"] - cx) * z + cx - 3 * z, (kps["y"] - cy) * z + cy - 0.2 * z], 1).astype(np.float32)
+
+
+class StereoBackend:
+    """Two contexts = the reference's left and right extractors (Frame.cc:64-121 would take two ORBextractors in a stereo
+    build); Frame::ComputeStereoMatches after both extractions, then the monocular tracking chain on the left frame."""
+
+    def __init__(self, pkg, wl, device):
+        W, H = EUROC["w"], EUROC["h"]
+        self.W, self.H, self.wl = W, H, wl
+        self.L = pkg.AsdHip(n_features=2000, max_width=W, max_height=H, max_patches=4096, device=device)
+        self.R = pkg.AsdHip(n_features=2000, max_width=W, max_height=H, max_patches=4096, device=device)
+        for c in (self.L, self.R):
+            c.load_weights(pkg.synth.asdnet_weights(0))
+        self.hip = self.L
+        self.dL, self.dR = [], []
+        for fl, fr in zip(wl.left, wl.right):
+            for ctx, f, dst in ((self.L, fl, self.dL), (self.R, fr, self.dR)):
+                p = ctx.device_alloc(f.nbytes)
+                ctx.h2d(p, f)
+                dst.append(p)
+        self.slot = 0
+        self.native = None
+        self.stereo_matched = 0
+
+    def image(self, t):
+        return t % len(self.dL)
+
+    def prefetch(self, handles):
+        pass
+
+    def extract(self, i):
+        kl, dl = self.L.extract_device(self.dL[i], self.W, self.H, self.W)
+        kr, dr = self.R.extract_device(self.dR[i], self.W, self.H, self.W)
+        self.right = (kr.copy(), dr.copy())
+        return kl.copy(), dl.copy()
+
+    def make_frame(self, kps, desc):
+        self.slot ^= 1
+        self.L.frame_set(self.slot, kps, None, self.wl.bounds)              # left: adopts the device-resident descriptors
+        self.L.frame_set(2, self.right[0], self.right[1], self.wl.bounds)   # the right frame's keypoints + descriptors
+        mb = EUROC["mb"]
+        _, _, self.stereo_matched = self.L.stereo_match(self.R, self.slot, 2, len(kps), mb, mb * EUROC["K"][0])
+        return self.slot
+
+    def set_map_descriptors(self, last_slot, ld):
+        n = len(ld)
+        self.L.bank_put_from_frame(last_slot, 0, n)
+        self.L.bank_put_from_frame(last_slot, n, n)
+        self.rows = np.arange(2 * n, dtype=np.int32)
+
+    def match_frame(self, cur, last, n_cur, has, Xw, mp_desc, T, K, th):
+        return self.L.match_project_frame_bank(cur, last, n_cur, has, Xw, self.rows[:len(has)], T, K, th, True)
+
+    def pose_opt(self, pose, Xw, obs, info, K):
+        return self.L.pose_optimize(pose, Xw, obs, info, K)
+
+    def frustum(self, cur, Xw, normal, mind, maxd, T, K):
+        return self.L.frustum(cur, Xw, normal, mind, maxd, T, K)
+
+    def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
+        return self.L.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], occ, th, ratio)
+
+    def local_ba(self, prob):
+        return self.L.local_ba(prob)
+
+    def close(self):
+        self.L.close()
+        self.R.close()
+
+
+def run_euroc_stereo(args, pkg, dist, rank, world, device):
+    """BASELINE configs[3] (secondary bench line): stereo association + the tracking chain + LocalBA at the EuRoC image size.
+    What the reference would run in a stereo build and what it does not: the stereo optimiser edges
+    (types_six_dof_expmap.cpp:256-340, 405-470) are never constructed by this fork (Optimizer.cc:266-269, 521-528 loop over
+    empty vectors), so PoseOptimization / LocalBA run on monocular edges exactly as in the mono configs."""
+    wl = EurocWorkload(pkg.synth, seed_offset=rank)
+    be = StereoBackend(pkg, wl, device)
+    last, _ = run_steps_python(be, wl, 0, args.warmup, None)
+    be.L.sync(); be.R.sync(); device_sync(device); dist.barrier()
+    t0 = time.perf_counter()
+    last, stats = run_steps_python(be, wl, args.warmup, args.steps, last)
+    be.L.sync(); be.R.sync(); device_sync(device); dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = dist.max(dt)
+    total = dist.sum(float(args.steps))
+    stats["stereo_matched"] = int(be.stereo_matched)
+    be.close()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frames/sec end-to-end tracking+LocalBA, EuRoC MH stereo @2000 keypoints (BASELINE configs[3])",
+            "value": total / tmax, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: EuRoC-MH-shaped synthetic stereo stream 752x480, 2000 kpts per image: two "
+                                   "extractions (left / right contexts), Frame::ComputeStereoMatches (asd_stereo_match), then the left "
+                                   "frame through SearchByProjection(frame) + PoseOptimization + isInFrustum + SearchByProjection(map) + "
+                                   "PoseOptimization, LocalBA every 15 frames",
+                       "not_included": "stereo optimiser edges: dead code in the reference (Optimizer.cc:266-269, 521-528), mono edges only",
+                       "host": "Python loop (ctypes), sequential extraction (no read-ahead)", "kf_interval": KF_INTERVAL,
+                       "parallelism": f"replicas x{world}"},
+            "last_step": stats}))
+    dist.close()
+
+
 def run_sequences(args, pkg, dist, rank, world, device):
     """BASELINE configs[4]: S independent sequences over `world` GPUs.  Every rank owns one device and one context; the
     sequences sit in one shared queue, longest first, and a rank that finishes one takes the next (a ticket counter in the
@@ -567,6 +697,8 @@ def main():
                     help="BASELINE configs[4]: this many independent sequences (11 = KITTI odometry 00-10) in a shared "
                          "longest-first queue over the ranks; value = sum of frames / wall")
     ap.add_argument("--seq-scale", type=float, default=0.1, help="--sequences: fraction of the real sequence lengths")
+    ap.add_argument("--workload", choices=["kitti-mono", "euroc-stereo"], default="kitti-mono",
+                    help="kitti-mono = the headline configuration (BASELINE configs[2]); euroc-stereo = configs[3], a secondary line")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
     ap.add_argument("--host", choices=["cxx", "python"], default="cxx",
                     help="who drives the per-frame step: C++ host code over the C ABI (default, as in the reference) or the Python loop")
@@ -591,6 +723,8 @@ def main():
     device = int(os.environ["ASD_BENCH_DEVICE"]) if "ASD_BENCH_DEVICE" in os.environ else (local_rank if world > 1 else 0)
     if args.sequences > 0:
         return run_sequences(args, pkg, dist, rank, world, device)
+    if args.workload == "euroc-stereo":
+        return run_euroc_stereo(args, pkg, dist, rank, world, device)
     wl = Workload(pkg.synth, seed_offset=rank)
     be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
     be.native = None
