@@ -941,7 +941,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     //  always find a free one, was measured three times.  With the split-operand ASDNet: PoseOptimization of the
     //  local-map stage drops from 0.31 to 0.18 ms device time -- its workgroup no longer waits for a CU -- but a masked
     //  stream runs ASDNet 9 % slower whatever the mask (0.80 -> 0.88 ms), which puts the extractor back on the critical
-    //  path: 720-750 frames/s either way.)
+    //  path: 720-750 frames/s either way.  Round 2, ASDNet at 0.80 ms with 0.5 ms of slack: reserving 8 / 16 / 32 CUs gives
+    //  711 / 722 / 750 frames/s against 757 without a mask -- the masked ASDNet takes 0.87-0.88 ms and the tracking kernels
+    //  do not get faster by more than that costs.)
     // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
     // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
     // will ever take (asd_extract_wait would block forever).
