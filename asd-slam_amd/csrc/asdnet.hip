@@ -26,13 +26,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Weight-ring fill by LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS at a wave-uniform base + lane * 16)
-// instead of global -> VGPR -> ds_write.  Measured (N = 2000): slower on every layer (conv2 342 -> 357, conv4 314 -> 334,
-// conv5 208 -> 216, conv6 316 -> 322 us) -- the DMA issue slots cost more than the two ds_write_b128 they replace -- so it
-// stays off; kept as a tuning knob.
-#ifndef ASD_RING_DMA
-#define ASD_RING_DMA 0
-#endif
+// (Weight-ring fill by LDS-DMA -- global_load_lds_dwordx4 instead of global -> VGPR -> ds_write -- was measured slower on every
+// layer at N = 2000: conv2 342 -> 357, conv4 314 -> 334, conv5 208 -> 216, conv6 316 -> 322 us; the variant is gone.)
 
 namespace {
 
@@ -242,15 +237,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       const bool pre = s + 2 < C::NSTAGE && !(ABL & 16);
       if (pre) {
         const float* wsrc = wimg + (size_t)(s + 2) * C::WCHUNK;
-        if constexpr (ASD_RING_DMA) {
-          float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
-          for (int r = 0; r < C::WREGS; ++r)
-            if (C::WQUADS >= NTH || t < C::WQUADS)
-              __builtin_amdgcn_global_load_lds(wsrc + (r * NTH + t) * 4, swn + (r * NTH + wave * 64) * 4, 16, 0, 0);
-        } else {
-          for (int r = 0; r < C::WREGS; ++r)
-            if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
-        }
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
       }
       // k-steps of this stage, operands always one step ahead (the last step fetches the next stage's first operands:
       // its ring slot was completed before the previous barrier)
@@ -271,13 +259,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         }
       }
       if (pre) {
-        if constexpr (ASD_RING_DMA) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA of stage s+2 has landed before the barrier publishes it
-        } else {
-          float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
-          for (int r = 0; r < C::WREGS; ++r)
-            if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
-        }
+        float* swn = sw + ((s + 2) % 3) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
       }
       if (!(ABL & 8)) __syncthreads();
     }
@@ -286,15 +270,8 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       f32x4 wreg[C::WREGS];
       if (s + 1 < C::NSTAGE && !(ABL & 16)) {
         const float* wsrc = wimg + (size_t)(s + 1) * C::WCHUNK;
-        if constexpr (ASD_RING_DMA) {
-          float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
-          for (int r = 0; r < C::WREGS; ++r)
-            if (C::WQUADS >= NTH || t < C::WQUADS)
-              __builtin_amdgcn_global_load_lds(wsrc + (r * NTH + t) * 4, swn + (r * NTH + wave * 64) * 4, 16, 0, 0);
-        } else {
-          for (int r = 0; r < C::WREGS; ++r)
-            if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
-        }
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) wreg[r] = *reinterpret_cast<const f32x4*>(wsrc + (r * NTH + t) * 4);
       }
 #pragma unroll
       for (int c8 = 0; c8 < STEPS; ++c8) {
@@ -303,13 +280,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         mfma_step(a, b);
       }
       if (s + 1 < C::NSTAGE && !(ABL & 16)) {
-        if constexpr (ASD_RING_DMA) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
-          for (int r = 0; r < C::WREGS; ++r)
-            if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
-        }
+        float* swn = sw + ((s + 1) & 1) * C::WCHUNK;
+        for (int r = 0; r < C::WREGS; ++r)
+          if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
       }
       if (!(ABL & 8)) __syncthreads();
     }
@@ -507,9 +480,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 #ifndef ASD_X3_S16
 #define ASD_X3_S16 1
 #endif
-#ifndef ASD_X3_PD
-#define ASD_X3_PD 2  // A-operand prefetch distance in 32-pixel tiles
-#endif
+#define ASD_X3_PD 2  // A-operand prefetch distance in sub-tiles
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -827,18 +798,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
 // One workgroup = 32 patches x 128 couts x (8192 / SK) k; wave w owns couts [32w, 32w+32), so
 // every weight element is used by exactly one wave: B goes global -> VGPR, only A through LDS.
 // ------------------------------------------------------------------------------------------
-#ifndef ASD_FC_SK
-#define ASD_FC_SK 16
-#endif
-#ifndef ASD_FC_KCH
-#define ASD_FC_KCH 128
-#endif
-constexpr int FC_SK = ASD_FC_SK;    // split-K factor: (n / 32) x FC_SK workgroups
-constexpr int FC_KCH = ASD_FC_KCH;  // k-chunk staged in LDS per step
-#ifndef ASD_FC_MT
-#define ASD_FC_MT 1
-#endif
-constexpr int FC_MT = ASD_FC_MT;  // 32-patch tiles per workgroup (2 was measured: no gain over 1, 51 us either way)
+constexpr int FC_SK = 16;    // split-K factor: (n / 32) x FC_SK workgroups (8 / 32 measured: 48 + 6 / 40 + 9 us against 37 + 7)
+constexpr int FC_KCH = 128;  // k-chunk staged in LDS per step
+constexpr int FC_MT = 1;  // 32-patch tiles per workgroup (2 was measured: no gain over 1, 51 us either way)
 __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, const float* __restrict__ wimg,
                                                  float* __restrict__ part, int n, int npad) {
   __shared__ __attribute__((aligned(16))) float sa[FC_MT * 32 * (FC_KCH + 4)];
@@ -1004,39 +966,19 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
 }
 
 // layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING> (L3: persistent form, no PP / RING)
-#ifndef L2_CFG
 #define L2_CFG 32, 32, 32, 1, 4, 4, 1, 16, 1, 3
-#endif
-#ifndef L3_CFG
 #define L3_CFG 32, 64, 32, 2, 4, 2, 2, 16
-#endif
-#ifndef L4_CFG
 #define L4_CFG 64, 64, 16, 1, 8, 4, 1, 32, 1, 2
-#endif
-#ifndef L5_CFG
 #define L5_CFG 64, 128, 16, 2, 4, 1, 4, 16, 1, 3
-#endif
-#ifndef L6_CFG
 #define L6_CFG 128, 128, 8, 1, 8, 2, 2, 16, 1, 3
-#endif
 // split-operand kernels: <CIN, COUT, HIN, S, ROWS, WM, WN, PP>
 // (two workgroups per CU each: one's band staging overlaps the other's MFMAs; whole-patch conv4 / two-patch conv6
 // workgroups at one per CU measured 189 / 168 us against 163 / 160)
-#ifndef L2S_CFG
 #define L2S_CFG 32, 32, 32, 1, 8, 4, 1, 1
-#endif
-#ifndef L3S_CFG
 #define L3S_CFG 32, 64, 32, 2, 4, 2, 2, 1
-#endif
-#ifndef L4S_CFG
 #define L4S_CFG 64, 64, 16, 1, 8, 2, 2, 1
-#endif
-#ifndef L5S_CFG
 #define L5S_CFG 64, 128, 16, 2, 4, 1, 4, 1
-#endif
-#ifndef L6S_CFG
 #define L6S_CFG 128, 128, 8, 1, 8, 1, 4, 1
-#endif
 
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int RING = 2, bool FUSE1 = false>
 hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const float* bias, float* out, int n,
@@ -1079,10 +1021,7 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
                           const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
   auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1>;
-#ifndef ASD_X3_LDS_SLACK
-#define ASD_X3_LDS_SLACK 0
-#endif
-  constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0) + ASD_X3_LDS_SLACK;
+  constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds <= 160 * 1024, "band does not fit LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1246,22 +1185,14 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(2);
   if (ctx->net_split & 2) ASD_HIP_CHECK(ctx, (launch_conv_x3<L3S_CFG>(st, a1, ctx->d_wx3[2], ctx->d_bias[2], a0, n)));
   else
-#ifdef L3_NP_CFG  // tuning: conv3 through the non-persistent kernel
-  ASD_HIP_CHECK(ctx, (launch_conv<L3_NP_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n)));
-#else
   ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
-#endif
   PROF_MARK(3);
   if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (launch_conv_x3<L4S_CFG>(st, a0, ctx->d_wx3[3], ctx->d_bias[3], a1, n)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);
   if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (launch_conv_x3<L5S_CFG>(st, a1, ctx->d_wx3[4], ctx->d_bias[4], a0, n)));
   else
-#ifdef L5_P_CFG  // tuning: conv5 through the persistent double-buffered kernel
-  ASD_HIP_CHECK(ctx, (launch_conv_p<L5_P_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n, ctx->num_cu)));
-#else
   ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
-#endif
   PROF_MARK(5);
   if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (launch_conv_x3<L6S_CFG>(st, a0, ctx->d_wx3[5], ctx->d_bias[5], a1, n)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));

@@ -757,12 +757,15 @@ def main():
     achieved = (2.0 * L2_MACS * patches2) / (ms2 * 1e-3) / 1e12 if ms2 > 0 else 0.0
     asdnet_ms = sum(be.hip.profile_get(l)[0] for l in range(8)) / max(calls2, 1)
     split = bool(be.hip.asdnet_split_mask() & 1)   # conv2 on the split-operand kernel (default) or on the f32 MFMA kernel
-    traffic = None
+    # roofline.traffic is NOT measured in this run: PMC counters need their own rocprofv3 passes (tools/collect_traffic.py).  The
+    # figure is read from the committed summary of that tool for the same kernel family and labelled with its source.
+    traffic, traffic_source = None, None
     tp = os.path.join(ROOT, "profiles", "traffic_conv2.json")
     if os.path.exists(tp):
         tj = json.load(open(tp))
-        if ("k_conv_x3" in tj.get("kernel", "")) == split:   # PMC figure of the kernel that actually ran
+        if ("k_conv_x3" in tj.get("kernel", "")) == split:   # PMC figure of the kernel family that actually ran
             traffic = tj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/traffic_conv2.json (separate rocprofv3 --pmc passes via tools/collect_traffic.py; not measured in this run)"
     if split:
         # f32 work on the bf16 pipe: the ceiling for ALGORITHMIC f32 FLOP is the dense bf16 peak / 6 products
         peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
@@ -795,7 +798,7 @@ def main():
                        "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t)" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": roof_kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_us": layers["conv2"]["avg_us"], "asdnet_forward_ms": asdnet_ms,
                          "asdnet_tflops": (2.0 * 39_092_224 * layers["conv2"]["patches_per_call"]) / (asdnet_ms * 1e-3) / 1e12 if asdnet_ms > 0 else 0.0,
                          **roof_extra},

@@ -33,6 +33,31 @@ def test_hip_matches_golden(hip, asdnet_golden):
 
 
 @pytest.mark.gpu
+def test_other_mfma_shape_build_matches_golden(pkg, synth, asdnet_golden, monkeypatch):
+    """build matrix: libasdhip_s32.so = the same sources with the split-operand kernels on v_mfma_f32_32x32x16_bf16
+    (ASD_X3_S16=0; the default is 16x16x32).  Same golden descriptors, same tolerance, and within 2e-6 of the default build."""
+    import os
+    alt = os.path.join(os.path.dirname(pkg.lib_path()), "libasdhip_s32.so")
+    assert os.path.exists(alt), "libasdhip_s32.so not built: run __graft_entry__.build()"
+    monkeypatch.setenv("ASDHIP_LIB", alt)
+    other = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    monkeypatch.delenv("ASDHIP_LIB")
+    base = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    try:
+        g = asdnet_golden
+        layers = synth.asdnet_weights(int(g["weight_seed"]))
+        other.load_weights(layers)
+        base.load_weights(layers)
+        assert other.asdnet_split_mask() == 63
+        a, b = other.describe(g["patches"]), base.describe(g["patches"])
+        np.testing.assert_allclose(a, g["desc"], atol=DESC_ATOL, rtol=0)
+        np.testing.assert_allclose(a, b, atol=2e-6, rtol=0)
+    finally:
+        other.close()
+        base.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 31, 33, 257])
 def test_hip_matches_oracle_ragged(hip, oracle, synth, n):
     layers = synth.asdnet_weights(0)
