@@ -57,6 +57,7 @@ struct AsdFrameSlot {
   int32_t* d_cell_start = nullptr;
   int32_t* d_cell_items = nullptr;
   char* h_stage = nullptr;
+  hipEvent_t ev_staged = nullptr;  // recorded behind the slot's H2D copies: h_stage may be rewritten once it has completed
 };
 
 struct asd_ctx {
@@ -85,6 +86,8 @@ struct asd_ctx {
   uint8_t* d_patches = nullptr; // [max_patches][1024]
   float* d_desc = nullptr;      // [max_patches][128] descriptors of the last asd_extract / asd_describe
   float* d_desc_last = nullptr; // device descriptors asd_frame_set(desc == NULL) adopts: last asd_extract or last waited submission
+  hipEvent_t ev_adopt = nullptr;  // behind the last adoption copy out of d_desc_last (see asd_frame_set / asd_extract_submit)
+  bool adopt_pending = false;
 
   // ---- front-end (state private to frontend.hip)
   struct FrontendState* fe = nullptr;

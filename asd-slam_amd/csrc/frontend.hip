@@ -782,6 +782,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   if (rc != ASD_OK) return rc;
   if (asd_extractor_busy(ctx, "asd_extract")) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
+  ctx->adopt_pending = false;   // same stream as the adoption copy: ordered behind it
   FrontendState* fe = ctx->fe;
   ExtractSlot& S = fe->slot0;
   if (!S.d_patches) {  // slot 0 = the buffers asd_describe uses as well
@@ -934,6 +935,10 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   int rc = extract_check(ctx, image, width, height, stride);
   if (rc != ASD_OK) return rc;
   (void)hipSetDevice(ctx->cfg.device);
+  if (ctx->adopt_pending) {   // an asd_frame_set(desc == NULL) is still copying out of an extraction buffer the worker may reuse
+    ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_adopt));
+    ctx->adopt_pending = false;
+  }
   if (!ctx->ax) {
     // lowest stream priority for ASDNet: the latency-critical tracking kernels on ctx->stream go first; the small
     // front-half kernels get the middle priority so they slot in between the conv workgroups.

@@ -343,7 +343,9 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     // phase 1: every available candidate bids for its query.  The claim-table reads of eight candidates are in flight together
     // (the scan is latency bound: ~100 cycles per dependent LDS access); in phase 1b (KIND 1) the query's winner is left out so
     // that the minimum of the others comes out.  Measured and not kept: a contiguous piece of the buffers per thread with one
-    // atomic per run of equal queries (fewer atomics, but the piece's tail beyond the registers costs serial L2 round trips).
+    // atomic per run of equal queries (fewer atomics, but the piece's tail beyond the registers costs serial L2 round trips:
+    // 72 instead of 42 us of bids); folding the lanes of a run with three DPP row shifts before the atomic (63 us: the shifts
+    // and 64-bit selects cost more than the same-address atomics they save).
     auto scan = [&](unsigned long long* keys, bool second) {
       auto take = [&](unsigned q, unsigned lo, unsigned db, unsigned cl, unsigned long long w) {
         bool ok = !((cl >> 16) == tag_rd && (cl & 0xffffu) < q);
