@@ -794,6 +794,8 @@ void matcher_free(asd_ctx* ctx) {
     if (f.d_cell_start) (void)hipFree(f.d_cell_start);
     if (f.d_cell_items) (void)hipFree(f.d_cell_items);
     if (f.h_stage) (void)hipHostFree(f.h_stage);
+    if (f.ev_staged) (void)hipEventDestroy(f.ev_staged);
+    f.ev_staged = nullptr;
     f.d_desc = nullptr; f.d_kp = nullptr; f.d_cell_start = nullptr; f.d_cell_items = nullptr; f.h_stage = nullptr;
   }
   if (ctx->matcher) {
@@ -824,6 +826,10 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
     ASD_HIP_CHECK(ctx, hipMalloc(&F->d_cell_start, (GC * GR + 1) * sizeof(int)));
     ASD_HIP_CHECK(ctx, hipMalloc(&F->d_cell_items, cap * sizeof(int)));
     ASD_HIP_CHECK(ctx, hipHostMalloc(&F->h_stage, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int)));
+    ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&F->ev_staged, hipEventDisableTiming));
+  } else {
+    // the slot's pinned staging buffer is about to be rewritten: its previous copies (a frame or more ago) must have left it
+    ASD_HIP_CHECK(ctx, hipEventSynchronize(F->ev_staged));
   }
   hipStream_t st = ctx->stream;
   if (n > 0) {
@@ -865,7 +871,18 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_cell_start, hs, (GC * GR + 1) * sizeof(int), hipMemcpyHostToDevice, st));
   if (!F->cell_items.empty())
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_cell_items, hi, F->cell_items.size() * sizeof(int), hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  // desc == NULL (the per-frame path): no synchronisation -- every consumer of the slot is enqueued on this stream behind the
+  // copies; ev_staged guards the slot's pinned staging buffer, ev_adopt the extraction buffer the descriptors are copied
+  // out of (asd_extract_submit waits for it before the worker may reuse that buffer on its own streams).
+  // desc != NULL: the caller's buffer is ordinary host memory and may be freed or rewritten as soon as we return.
+  ASD_HIP_CHECK(ctx, hipEventRecord(F->ev_staged, st));
+  if (!desc && n > 0) {
+    if (!ctx->ev_adopt) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_adopt, hipEventDisableTiming));
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_adopt, st));
+    ctx->adopt_pending = true;
+  } else {
+    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
   return ASD_OK;
 }
 
