@@ -289,6 +289,37 @@ class AsdHip:
                                                     _p(None if obs_positive is None else _c(obs_positive, np.uint8))))
         return out, n.value
 
+    # ---- fused tracking chains (search + claim replay + PoseOptimization, one synchronisation)
+    def track_motion_model(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_desc_or_rows, Tcw, K, th, pose7, check_ori=True, obs_positive=None):
+        """mp_desc_or_rows: float [n][128] descriptors or int32 bank rows.  -> (match_cur, n_matches, pose7, outlier, n_inliers)"""
+        has_mp, Xw, Tcw, K = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(Tcw, np.float32), _c(K, np.float32)
+        d = np.asarray(mp_desc_or_rows)
+        bank = d.dtype.kind in "iu"
+        d = _c(d, np.int32 if bank else np.float32)
+        match, outl = np.empty(n_cur, np.int32), np.empty(max(n_cur, 1), np.uint8)
+        pose = _c(pose7, np.float64).copy()
+        n, ninl = C.c_int32(), C.c_int32()
+        fn = self.lib.asd_track_motion_model_bank if bank else self.lib.asd_track_motion_model
+        self._chk(fn(self.ctx, slot_cur, slot_last, _p(has_mp), _p(Xw), _p(d), _p(Tcw), _p(K), C.c_float(th), int(check_ori),
+                     _p(None if obs_positive is None else _c(obs_positive, np.uint8)), _p(pose), _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        return match, n.value, pose, outl[:n_cur], ninl.value
+
+    def track_local_map(self, slot_cur, n_cur, in_view, proj, level, view_cos, desc_or_rows, mp_Xw, occupied, cur_Xw, th, nn_ratio, K, pose7,
+                        obs_positive=None):
+        in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
+        view_cos, mp_Xw, occupied, cur_Xw, K = _c(view_cos, np.float32), _c(mp_Xw, np.float32), _c(occupied, np.uint8), _c(cur_Xw, np.float32), _c(K, np.float32)
+        d = np.asarray(desc_or_rows)
+        bank = d.dtype.kind in "iu"
+        d = _c(d, np.int32 if bank else np.float32)
+        match, outl = np.empty(n_cur, np.int32), np.empty(max(n_cur, 1), np.uint8)
+        pose = _c(pose7, np.float64).copy()
+        n, ninl = C.c_int32(), C.c_int32()
+        fn = self.lib.asd_track_local_map_bank if bank else self.lib.asd_track_local_map
+        self._chk(fn(self.ctx, slot_cur, len(in_view), _p(in_view), _p(proj), _p(level), _p(view_cos), _p(d), _p(mp_Xw), _p(occupied), _p(cur_Xw),
+                     C.c_float(th), C.c_float(nn_ratio), _p(None if obs_positive is None else _c(obs_positive, np.uint8)), _p(K), _p(pose),
+                     _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        return match, n.value, pose, outl[:n_cur], ninl.value
+
     def match_project_keyframe(self, slot_cur, n_cur, valid, Xw, min_dist, max_dist, desc, kf_angle, occupied, Tcw, K, th, orb_dist,
                                check_ori=True):
         a = [_c(valid, np.uint8), _c(Xw, np.float32), _c(min_dist, np.float32), _c(max_dist, np.float32), _c(desc, np.float32),

@@ -185,6 +185,7 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 // (g2o recomputes both at the same estimate: identical values, one pass instead of three).
 struct PoseOptArgs {
   int n;
+  const int* n_dev;     // fused chains: the edge count produced on the device by k_pose_edges (n then = capacity)
   const double* edges;  // [n][6] as uploaded: Xw, obs, inv_sigma2
   double fx, fy, cx, cy;
   double* soa_g;        // [8][n] global scratch (used when the problem does not fit LDS)
@@ -364,7 +365,16 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
 // MODE (the EdgeStore form) is a template parameter, not a run-time switch: with a pointer that may be LDS or global the
 // compiler falls back to FLAT loads, whose latency dominated the edge loop.
 template <int MODE>
-__global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
+__global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
+  PoseOptArgs a = a_in;
+  if (a.n_dev) {   // the matches were made on the device (asd_track_*): the edge count is only known there
+    a.n = *a.n_dev;
+    if (a.n < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
+      if (threadIdx.x < 7) a.io[threadIdx.x] = a.pose0[threadIdx.x];
+      if (threadIdx.x == 7) a.io[7] = 0.0;
+      return;
+    }
+  }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
   // the read-ahead extractor: ask the SIMD arbiters to issue its waves first
   __builtin_amdgcn_s_setprio(3);
@@ -542,6 +552,62 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a) {
       if (8 * i + k < a.n) w |= (unsigned long long)outl[8 * i + k] << (8 * k);
     og8[i] = w;
   }
+}
+
+// ---------------------------------------------------------------- fused tracking chains: edges made on the device
+// The unary edges of PoseOptimization (Optimizer.cc:272-310) straight from match results that live on the device: keypoint
+// j gets an edge when it holds a map point -- src[j] >= 0 names a row of the world-position table tab (the match k_resolve
+// wrote), or hold[j] != 0 says the keypoint already held one on entry with its position in own[j].  Edge order = keypoint
+// order, as the reference's loop over mvpMapPoints (:281): the same records, in the same order, as asd_pose_optimize
+// receives from a host that packs them -- so the fused chain returns the same bits as the two separate calls.
+// Observation = the keypoint's f32 coordinates, information = invSigma2 of its octave (both exactly representable in the
+// compact EdgeStore form: no check needed).
+struct PoseEdgesArgs {
+  int n_cur;
+  const int* src;          // [n_cur] row of tab or -1
+  const uint8_t* hold;     // [n_cur] or null
+  const float* tab;        // [.][3]
+  const float* own;        // [n_cur][3] or null
+  const float4* kp;        // (x, y, octave bits, angle)
+  float inv_sigma2[ASD_MAX_LEVELS];
+  double* edges;           // out [n][6]
+  uint8_t* isgi;           // out [n]
+  int* n_out;              // out
+};
+__global__ __launch_bounds__(1024) void k_pose_edges(PoseEdgesArgs a) {
+  __shared__ int wave_tot[16], base;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) base = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < a.n_cur; j0 += 1024) {
+    const int j = j0 + t;
+    int row = -1;
+    bool mine = false;
+    if (j < a.n_cur) {
+      if (a.hold && a.hold[j]) mine = true;
+      else row = a.src[j];
+    }
+    const bool has = mine || row >= 0;
+    const unsigned long long m = __ballot(has);
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (has) {
+      const int e = off + __popcll(m & ((1ull << lane) - 1));
+      const float* X = mine ? a.own + 3 * (size_t)j : a.tab + 3 * (size_t)row;
+      const float4 k = a.kp[j];
+      const int oct = __float_as_int(k.z);
+      double* E = a.edges + (size_t)e * 6;
+      E[0] = (double)X[0]; E[1] = (double)X[1]; E[2] = (double)X[2];
+      E[3] = (double)k.x; E[4] = (double)k.y; E[5] = (double)a.inv_sigma2[oct];
+      a.isgi[e] = (uint8_t)oct;
+    }
+    __syncthreads();
+    if (t == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wave_tot[w]; base += s; }
+    __syncthreads();
+  }
+  if (t == 0) *a.n_out = base;
 }
 
 // ---------------------------------------------------------------- LocalBA kernels
@@ -1116,6 +1182,7 @@ struct BaState {
       ps_start, ps_edges, Bk, Hc, Hl, Yk, ck, Hpp, Hll, Dinv, db, x, A, bs, misc, partial, blk_i, blk_j, pair_start,
       pairs, chi2, dpos;
   DevBuf po_Xw, po_obs, po_info, po_err, po_level, po_outlier, po_pose;
+  DevBuf pc_n;   // fused chains: edge count made on the device
   double* h_partial = nullptr;  // pinned
   size_t h_partial_cap = 0;
   int* h_misc = nullptr;        // pinned: status, maxdiag (2 ints), n_bad
@@ -1137,13 +1204,56 @@ void ba_free(asd_ctx* ctx) {
                    &s->pose_h, &s->pt_h, &s->pose_of_h, &s->pt_of_h, &s->pt_start, &s->ps_start, &s->ps_edges, &s->Bk,
                    &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc,
                    &s->partial, &s->blk_i, &s->blk_j, &s->pair_start, &s->pairs, &s->chi2, &s->dpos, &s->po_Xw,
-                   &s->po_obs, &s->po_info, &s->po_err, &s->po_level, &s->po_outlier, &s->po_pose};
+                   &s->po_obs, &s->po_info, &s->po_err, &s->po_level, &s->po_outlier, &s->po_pose, &s->pc_n};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (s->h_partial) (void)hipHostFree(s->h_partial);
   if (s->h_misc) (void)hipHostFree(s->h_misc);
   if (s->h_po) (void)hipHostFree(s->h_po);
   delete s;
   ctx->ba = nullptr;
+}
+
+// Fused tracking chains (asd_track_motion_model / asd_track_local_map, matcher.hip): PoseOptimization enqueued on the context's
+// stream directly behind the kernels that made the matches -- k_pose_edges builds the edge records from the device-resident
+// match table, k_pose_opt reads their count from the device -- so the chain needs ONE synchronisation, at its end.  The results
+// (pose, n_bad, outlier byte per edge in keypoint order) are copied to *h_io; the caller synchronises and unpacks them.
+int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
+                       const float* d_own, const double* pose7, const double* K, double* d_io) {
+  // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
+  // inside the caller's one result block: no copy is enqueued here
+  BaState* s = ba_state(ctx);
+  hipStream_t st = ctx->stream;
+  int rc;
+  const size_t idx_off = (size_t)n_cur * 48;
+  if ((rc = s->po_Xw.ensure(ctx, idx_off + ((size_t)n_cur + 63) / 64 * 64 + 64)) || (rc = s->po_err.ensure(ctx, (size_t)n_cur * 64)) ||
+      (rc = s->po_level.ensure(ctx, (size_t)2 * n_cur)) || (rc = s->pc_n.ensure(ctx, 16)))
+    return rc;
+  PoseEdgesArgs e{};
+  e.n_cur = n_cur; e.src = d_src; e.hold = d_hold; e.tab = d_tab; e.own = d_own; e.kp = d_kp;
+  for (int l = 0; l < ASD_MAX_LEVELS; ++l) e.inv_sigma2[l] = l < ctx->cfg.n_levels ? ctx->inv_sigma2[l] : 0.f;
+  e.edges = s->po_Xw.as<double>(); e.isgi = s->po_Xw.as<uint8_t>() + idx_off; e.n_out = s->pc_n.as<int>();
+  hipLaunchKernelGGL(k_pose_edges, dim3(1), dim3(1024), 0, st, e);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  PoseOptArgs a{};
+  a.n = n_cur; a.n_dev = s->pc_n.as<int>();
+  a.edges = s->po_Xw.as<double>(); a.isgi = s->po_Xw.as<uint8_t>() + idx_off;
+  for (int k = 0; k < 16; ++k) a.isg_tab[k] = k < ctx->cfg.n_levels ? (double)ctx->inv_sigma2[k] : 0.0;   // invSigma2 is a float in the reference (Optimizer.cc:300)
+  memcpy(a.pose0, pose7, 56);
+  a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
+  a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;
+  const size_t lds_compact = (size_t)n_cur * 35 + 16;
+  const int mode = (ctx->cfg.n_levels <= 16 && lds_compact <= 150 * 1024) ? 2 : 0;
+  a.use_lds = mode;
+  a.debug = 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
+  else hipLaunchKernelGGL(k_pose_opt<0>, dim3(1), dim3(kPoseThreads), 0, st, a);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  return ASD_OK;
 }
 
 extern "C" {
@@ -1173,7 +1283,7 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   // one pinned staging buffer: [n][6] edges, the information-value index per edge, then the io block
   double* hin = reinterpret_cast<double*>(s->h_po);
   uint8_t* hidx = reinterpret_cast<uint8_t*>(s->h_po + idx_off);
-  PoseOptArgs a;
+  PoseOptArgs a{};   // n_dev = nullptr: the edge count is the argument n
   int ntab = 0;
   bool compact = true;  // observations exactly f32, <= 16 distinct information values (see EdgeStore)
   for (int i = 0; i < n; ++i) {

@@ -135,6 +135,8 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   mapping_free(ctx);
   bow_free(ctx);
   ctx->scratch.release();
+  ctx->up.release();
+  ctx->down.release();
   if (ctx->ev_adopt) (void)hipEventDestroy(ctx->ev_adopt);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

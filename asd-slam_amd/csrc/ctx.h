@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -41,6 +42,36 @@ struct AsdDevBuf {
   }
   static size_t padded(size_t bytes) { return (bytes + 255) / 256 * 256; }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = used = 0; }
+};
+
+
+// One pinned host block + its device twin.  A hipMemcpyAsync costs ~15-25 us on the tracking stream (host call + the hop to
+// the copy engine), whatever its size, so everything a call uploads -- queries, flags, tables -- is packed into ONE block and
+// travels in one copy; results come back the same way (AsdXfer used in the other direction).
+struct AsdXfer {
+  char* h = nullptr;
+  char* d = nullptr;
+  size_t cap = 0, used = 0;
+  hipError_t begin(hipStream_t st, size_t bytes) {   // room for `bytes` (+ alignment slack); contents undefined
+    used = 0;
+    bytes += 4096;
+    if (bytes <= cap) return hipSuccess;
+    if (h) { (void)hipStreamSynchronize(st); (void)hipHostFree(h); (void)hipFree(d); }
+    h = nullptr; d = nullptr; cap = 0;
+    const size_t want = bytes + bytes / 2;
+    hipError_t e = hipHostMalloc(&h, want);
+    if (e == hipSuccess) e = hipMalloc(&d, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  size_t reserve(size_t bytes) { const size_t off = used; used += (bytes + 255) / 256 * 256; return off; }
+  size_t add(const void* src, size_t bytes) { const size_t off = reserve(bytes); memcpy(h + off, src, bytes); return off; }
+  size_t zeros(size_t bytes) { const size_t off = reserve(bytes); memset(h + off, 0, bytes); return off; }
+  hipError_t upload(hipStream_t st) { return used ? hipMemcpyAsync(d, h, used, hipMemcpyHostToDevice, st) : hipSuccess; }
+  hipError_t download(hipStream_t st) { return used ? hipMemcpyAsync(h, d, used, hipMemcpyDeviceToHost, st) : hipSuccess; }
+  template <typename T> T* dev(size_t off) { return reinterpret_cast<T*>(d + off); }
+  template <typename T> T* host(size_t off) { return reinterpret_cast<T*>(h + off); }
+  void release() { if (h) (void)hipHostFree(h); if (d) (void)hipFree(d); h = d = nullptr; cap = used = 0; }
 };
 
 struct AsdFrameSlot {
@@ -104,6 +135,7 @@ struct asd_ctx {
 
   // ---- per-call device workspace (see AsdDevBuf)
   AsdDevBuf scratch;
+  AsdXfer up, down;   // per-call upload / result blocks of the tracking entry points (one copy each way)
 
   // ---- local-mapping scratch (state private to mapping.hip)
   void* mapping = nullptr;
@@ -159,6 +191,10 @@ void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);
 void mapping_free(asd_ctx* ctx);
 void bow_free(asd_ctx* ctx);
+// ba.hip: PoseOptimization enqueued behind device-resident matches (fused tracking chains; see the definition)
+int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
+                       const float* d_own, const double* pose7, const double* K, double* d_io);
+inline size_t pose_chain_io_bytes(int n_cur) { return 64 + (size_t)n_cur + 64; }
 // capi.cpp
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 

@@ -935,10 +935,6 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   int rc = extract_check(ctx, image, width, height, stride);
   if (rc != ASD_OK) return rc;
   (void)hipSetDevice(ctx->cfg.device);
-  if (ctx->adopt_pending) {   // an asd_frame_set(desc == NULL) is still copying out of an extraction buffer the worker may reuse
-    ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_adopt));
-    ctx->adopt_pending = false;
-  }
   if (!ctx->ax) {
     // lowest stream priority for ASDNet: the latency-critical tracking kernels on ctx->stream go first; the small
     // front-half kernels get the middle priority so they slot in between the conv workgroups.
@@ -983,6 +979,12 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     ax->th = std::thread(async_worker, ctx);
   }
   AsyncExtract* ax = ctx->ax;
+  if (ctx->adopt_pending) {
+    // an asd_frame_set(desc == NULL) may still be copying out of an extraction buffer: the ASDNet stream -- the only writer of
+    // those buffers -- waits for that copy before anything enqueued from now on runs (no host wait: a stream-side dependency)
+    ASD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_x, ctx->ev_adopt, 0));
+    ctx->adopt_pending = false;
+  }
   {
     std::lock_guard<std::mutex> l(ax->m);
     if (ax->submitted - ax->waited >= (uint64_t)kQueueDepth) {

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 
 #include "ctx.h"
 
@@ -231,6 +232,19 @@ __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a
       if (i0 + r < na) out[(size_t)(i0 + r) * nb + j] = acc[r];
 }
 
+
+// device-to-device copy of descriptor rows as a plain kernel: a hipMemcpyAsync costs the host 15-25 us per call on this
+// stream, a launch ~5 (frame_set's adoption of the extractor's descriptors, asd_bank_put_from_frame)
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+inline hipError_t copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes) {   // bytes % 16 == 0, 16-B aligned
+  const size_t n16 = bytes / 16;
+  if (!n16) return hipSuccess;
+  hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, st, static_cast<const uint4*>(src),
+                     static_cast<uint4*>(dst), n16);
+  return hipGetLastError();
+}
 
 // ---- claim / ratio / rotation-histogram replay on the device ------------------------------------------------------
 // The searches are order dependent: map point q (in input order) takes the best candidate that no EARLIER map point with
@@ -681,49 +695,61 @@ bool replay_on_device(const MatcherState* m, int kind, int n_cur, int nq) {
 
 // k_window_search + k_resolve<KIND> behind one synchronisation: queries are in m->h_queries[0..nq), flags (may be null) are
 // copied through pinned staging, match_cur[n_cur] / *n_matches come back.  kp_last = last frame's device keypoints (KIND 0).
+// what a fused chain adds to a search: tables that travel in the search's upload block, and room for its results in the
+// search's result block
+struct ChainHook {
+  const void* src[3] = {nullptr, nullptr, nullptr};   // host tables (world positions, own positions, hold flags)
+  size_t bytes[3] = {0, 0, 0};
+  size_t result_bytes = 0;                             // room wanted in the result block
+  // enqueue the chain's kernels: match table, the uploaded tables, where the results go (all device pointers)
+  std::function<int(const int* d_match, void* const d_tab[3], void* d_result)> enqueue;
+  const void* h_result = nullptr;                      // out: the chain's results on the host after the call
+};
+
 template <int KIND>
 int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, const float4* kp_last,
                        const uint8_t* obs_pos, const uint8_t* occupied, int check_ori, float nn_ratio, int32_t* match_cur,
-                       int32_t* n_matches) {
+                       int32_t* n_matches, ChainHook* chain = nullptr) {
+  // One upload block (queries, the zeroed candidate counter, flags, the chain's tables), the kernels back to back, one result
+  // block (match table, counters, the chain's results), one synchronisation: a copy costs 15-25 us on this stream whatever
+  // its size (rocprof timeline), five of them per call were a third of the call.
   int rc = ensure_cands(ctx, m, 1);
   if (rc != ASD_OK) return rc;
   hipStream_t st = ctx->stream;
   const int n_cur = F.n;
-  const int need = std::max(n_cur, nq) + 32;
-  if (need > m->res_cap) {
-    if (m->h_res) (void)hipHostFree(m->h_res);
-    m->res_cap = 0;
-    const int cap = std::max(need * 3 / 2, 8192);
-    ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_res, (size_t)cap * sizeof(int) + 16 + 2 * (size_t)cap));
-    m->res_cap = cap;
-  }
-  uint8_t* h_obs = reinterpret_cast<uint8_t*>(m->h_res + m->res_cap + 4);
-  uint8_t* h_occ = h_obs + m->res_cap;
-  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4) + AsdDevBuf::padded((size_t)(n_cur + 16) * 4) + AsdDevBuf::padded(nq) +
-                                          AsdDevBuf::padded(n_cur)));
+  AsdXfer &up = ctx->up, &down = ctx->down;
+  size_t extra = 0;
+  if (chain) for (int i = 0; i < 3; ++i) extra += chain->bytes[i] + 256;
+  ASD_HIP_CHECK(ctx, up.begin(st, (size_t)nq * sizeof(WinQuery) + 256 + (size_t)nq + (size_t)n_cur + 1024 + extra));
+  ASD_HIP_CHECK(ctx, down.begin(st, ((size_t)n_cur + 16) * sizeof(int) + 256 + (chain ? chain->result_bytes : 0)));
+  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4)));
   int* d_pick = ctx->scratch.carve<int>(nq);
-  int* d_out = ctx->scratch.carve<int>((size_t)n_cur + 16);
-  uint8_t* d_obs = ctx->scratch.carve<uint8_t>(nq);
-  uint8_t* d_occ = ctx->scratch.carve<uint8_t>(n_cur);
+  const size_t o_q = up.add(m->h_queries, (size_t)nq * sizeof(WinQuery));
+  const size_t o_total = up.zeros(sizeof(int));
+  const size_t o_obs = obs_pos ? up.add(obs_pos, nq) : 0;
+  const size_t o_occ = KIND == 1 ? up.add(occupied, n_cur) : 0;
+  size_t o_tab[3] = {0, 0, 0};
+  if (chain) for (int i = 0; i < 3; ++i) if (chain->src[i]) o_tab[i] = up.add(chain->src[i], chain->bytes[i]);
+  const size_t o_out = down.reserve(((size_t)n_cur + 16) * sizeof(int));
+  const size_t o_res = chain ? down.reserve(chain->result_bytes) : 0;
+  int* d_out = down.dev<int>(o_out);
+  const int* h_out = down.host<int>(o_out);
   int* d_off = m->d_q_off;
   int* d_cnt = m->d_q_off + nq;
-  int* d_total = m->d_q_off + 2 * nq;
-  if (obs_pos) { memcpy(h_obs, obs_pos, nq); ASD_HIP_CHECK(ctx, hipMemcpyAsync(d_obs, h_obs, nq, hipMemcpyHostToDevice, st)); }
-  if (KIND == 1) { memcpy(h_occ, occupied, n_cur); ASD_HIP_CHECK(ctx, hipMemcpyAsync(d_occ, h_occ, n_cur, hipMemcpyHostToDevice, st)); }
+  int* d_total = up.dev<int>(o_total);
   for (int attempt = 0; attempt < 2; ++attempt) {
-    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_queries, m->h_queries, (size_t)nq * sizeof(WinQuery), hipMemcpyHostToDevice, st));
-    ASD_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(int), st));
+    ASD_HIP_CHECK(ctx, up.upload(st));
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
+    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
                        d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     ResolveArgs a{};
     a.nq = nq; a.n_cur = n_cur;
     a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.meta = m->d_meta;
     a.total = d_total; a.cap = m->cand_cap;
-    a.obs_pos = obs_pos ? d_obs : nullptr;
-    a.occupied = d_occ;
+    a.obs_pos = obs_pos ? up.dev<uint8_t>(o_obs) : nullptr;
+    a.occupied = up.dev<uint8_t>(o_occ);
     a.kp_cur = F.d_kp; a.kp_last = kp_last;
     a.check_ori = check_ori; a.nn_ratio = nn_ratio;
     a.pick = d_pick; a.match_cur = d_out; a.n_matches = d_out + n_cur;
@@ -740,32 +766,38 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     };
     // register-resident candidates per thread: 8, or 16 for long frame-to-frame lists (KIND 1 with 16 spills under the cap)
     constexpr int kBig = KIND == 0 ? 16 : 8;
-    const bool small = m->last_total[KIND] <= 8 * kResolveThreads;   // (24 slots = 60 registers with the queries packed two per register)
+    const bool small = m->last_total[KIND] <= 8 * kResolveThreads;
     if (nq <= 4 * kResolveThreads) { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, kBig>)); }
     else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
-    ASD_HIP_CHECK(ctx, hipGetLastError());
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
-    ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_res, d_out, ((size_t)n_cur + 16) * sizeof(int), hipMemcpyDeviceToHost, st));
+    if (chain) {
+      void* d_tab[3] = {chain->src[0] ? up.dev<void>(o_tab[0]) : nullptr, chain->src[1] ? up.dev<void>(o_tab[1]) : nullptr,
+                        chain->src[2] ? up.dev<void>(o_tab[2]) : nullptr};
+      if ((rc = chain->enqueue(d_out, d_tab, down.dev<void>(o_res))) != ASD_OK) return rc;
+      chain->h_result = down.host<void>(o_res);
+    }
+    ASD_HIP_CHECK(ctx, down.download(st));
     ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const int total = m->h_res[n_cur + 1];
+    const int total = h_out[n_cur + 1];
     m->last_total[KIND] = total;
     if (total > m->cand_cap) {  // the candidate buffers overflowed (k_resolve did not run): grow and search again
       if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
+      *up.host<int>(o_total) = 0;
       continue;
     }
     break;
   }
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
-  memcpy(match_cur, m->h_res, (size_t)n_cur * sizeof(int));
-  *n_matches = m->h_res[n_cur];
+  memcpy(match_cur, h_out, (size_t)n_cur * sizeof(int));
+  *n_matches = h_out[n_cur];
   static const bool timing = getenv("ASD_TIMING") != nullptr;
   if (timing) {
     static double acc[2]; static long calls[2]; static long rounds[2]; static double st_us[2][8];
-    acc[KIND] += ctx->ms_match; rounds[KIND] += m->h_res[n_cur + 2];
-    for (int i = 0; i < 8; ++i) st_us[KIND][i] += 0.01 * m->h_res[n_cur + 3 + i];
+    acc[KIND] += ctx->ms_match; rounds[KIND] += h_out[n_cur + 2];
+    for (int i = 0; i < 8; ++i) st_us[KIND][i] += 0.01 * h_out[n_cur + 3 + i];
     if (++calls[KIND] % 200 == 0)
       fprintf(stderr, "[search+resolve kind %d] device %.3f ms, %.1f iterations, %d candidates; k_resolve: staging %.1f us, iterations %.1f us (the first %.1f; bids %.1f barrier %.1f owners %.1f closing %.1f), outputs %.1f us\n", KIND,
-              acc[KIND] / calls[KIND], (double)rounds[KIND] / calls[KIND], m->h_res[n_cur + 1], st_us[KIND][0] / calls[KIND], st_us[KIND][1] / calls[KIND],
+              acc[KIND] / calls[KIND], (double)rounds[KIND] / calls[KIND], h_out[n_cur + 1], st_us[KIND][0] / calls[KIND], st_us[KIND][1] / calls[KIND],
               st_us[KIND][3] / calls[KIND], st_us[KIND][4] / calls[KIND], st_us[KIND][5] / calls[KIND], st_us[KIND][6] / calls[KIND],
               st_us[KIND][7] / calls[KIND], st_us[KIND][2] / calls[KIND]);
   }
@@ -790,9 +822,7 @@ AsdFrameSlot* slot_of(asd_ctx* ctx, int s) {
 void matcher_free(asd_ctx* ctx) {
   for (auto& f : ctx->frames) {
     if (f.d_desc) (void)hipFree(f.d_desc);
-    if (f.d_kp) (void)hipFree(f.d_kp);
-    if (f.d_cell_start) (void)hipFree(f.d_cell_start);
-    if (f.d_cell_items) (void)hipFree(f.d_cell_items);
+    if (f.d_kp) (void)hipFree(f.d_kp);   // one block: keypoints, cell offsets, cell items
     if (f.h_stage) (void)hipHostFree(f.h_stage);
     if (f.ev_staged) (void)hipEventDestroy(f.ev_staged);
     f.ev_staged = nullptr;
@@ -822,9 +852,12 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   const size_t cap = ctx->cfg.max_patches;
   if (!F->d_desc) {
     ASD_HIP_CHECK(ctx, hipMalloc(&F->d_desc, cap * 128 * sizeof(float)));
-    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_kp, cap * sizeof(float4)));
-    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_cell_start, (GC * GR + 1) * sizeof(int)));
-    ASD_HIP_CHECK(ctx, hipMalloc(&F->d_cell_items, cap * sizeof(int)));
+    // keypoints, cell offsets and cell items in ONE device block laid out like the pinned staging buffer: one copy per frame
+    char* blk = nullptr;
+    ASD_HIP_CHECK(ctx, hipMalloc(&blk, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int)));
+    F->d_kp = reinterpret_cast<float4*>(blk);
+    F->d_cell_start = reinterpret_cast<int32_t*>(blk + cap * sizeof(float4));
+    F->d_cell_items = F->d_cell_start + (GC * GR + 1);
     ASD_HIP_CHECK(ctx, hipHostMalloc(&F->h_stage, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int)));
     ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&F->ev_staged, hipEventDisableTiming));
   } else {
@@ -834,7 +867,7 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   hipStream_t st = ctx->stream;
   if (n > 0) {
     if (desc) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, desc, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, st));
-    else ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, ctx->d_desc_last, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else ASD_HIP_CHECK(ctx, copy_rows(st, F->d_desc, ctx->d_desc_last, (size_t)n * 128 * sizeof(float)));
   }
   F->n = n;
   F->min_x = min_x; F->max_x = max_x; F->min_y = min_y; F->max_y = max_y;
@@ -867,10 +900,8 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   }
   memcpy(hs, F->cell_start.data(), (GC * GR + 1) * sizeof(int));
   if (!F->cell_items.empty()) memcpy(hi, F->cell_items.data(), F->cell_items.size() * sizeof(int));
-  if (n > 0) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_kp, hk, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_cell_start, hs, (GC * GR + 1) * sizeof(int), hipMemcpyHostToDevice, st));
-  if (!F->cell_items.empty())
-    ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_cell_items, hi, F->cell_items.size() * sizeof(int), hipMemcpyHostToDevice, st));
+  // one copy for the three arrays (the block up to the last cell item in use; unused keypoint rows travel along: 16 B each)
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_kp, hk, cap * sizeof(float4) + (GC * GR + 1 + F->cell_items.size()) * sizeof(int), hipMemcpyHostToDevice, st));
   // desc == NULL (the per-frame path): no synchronisation -- every consumer of the slot is enqueued on this stream behind the
   // copies; ev_staged guards the slot's pinned staging buffer, ev_adopt the extraction buffer the descriptors are copied
   // out of (asd_extract_submit waits for it before the worker may reuse that buffer on its own streams).
@@ -1007,7 +1038,9 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
 // mp_desc: host table indexed like the last frame's keypoints, or NULL with mp_rows = bank rows
 static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
                             const float* mp_desc, const int32_t* mp_rows, const float* Tcw, const float* K, float th,
-                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches, const uint8_t* obs_pos) {
+                            int32_t check_orientation, int32_t* match_cur, int32_t* n_matches, const uint8_t* obs_pos,
+                            ChainHook* chain = nullptr, bool* chained = nullptr) {
+  if (chained) *chained = false;
   AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
   if (!C || !L || !has_mp || !Xw || (!mp_desc && !mp_rows) || !Tcw || !K || !match_cur || !n_matches) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
@@ -1042,8 +1075,11 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
     Q = WinQuery{u, v, th * ctx->scale[oct], oct - 1, oct + 1, mp_desc ? i : mp_rows[i]};
   }
   if (replay_on_device(m, 0, C->n, L->n))   // search + claims + rotation histogram on the device, one synchronisation, 4 B per keypoint back
+  {
+    if (chained) *chained = chain != nullptr;
     return search_and_resolve<0>(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, L->d_kp, obs_pos, nullptr, check_orientation, 0.f,
-                                 match_cur, n_matches);
+                                 match_cur, n_matches, chain);
+  }
   SearchResult R;
   const auto tm1 = std::chrono::steady_clock::now();
   if ((rc = window_search(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, &R, 0)) != ASD_OK) return rc;
@@ -1113,7 +1149,8 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
 static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
                              const int32_t* level, const float* view_cos, const float* desc, const int32_t* rows,
                              const uint8_t* occupied, float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches,
-                             const uint8_t* obs_pos) {
+                             const uint8_t* obs_pos, ChainHook* chain = nullptr, bool* chained = nullptr) {
+  if (chained) *chained = false;
   AsdFrameSlot* F = slot_of(ctx, slot_cur);
   if (!F || n_mp < 0 || !match_cur || !n_matches || (n_mp > 0 && (!in_view || !proj || !level || !view_cos || (!desc && !rows))) ||
       (F->n > 0 && !occupied))
@@ -1138,9 +1175,11 @@ static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_m
     Q = WinQuery{proj[2 * q], proj[2 * q + 1], r * ctx->scale[lvl], lvl - 1, lvl, desc ? q : rows[q]};
   }
   if (desc && (rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
-  if (replay_on_device(m, 1, F->n, n_mp))
+  if (replay_on_device(m, 1, F->n, n_mp)) {
+    if (chained) *chained = chain != nullptr;
     return search_and_resolve<1>(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, nullptr, obs_pos, occupied, 0, nn_ratio, match_cur,
-                                 n_matches);
+                                 n_matches, chain);
+  }
   SearchResult R;
   if ((rc = window_search(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, &R, 1)) != ASD_OK) return rc;
   int nmatches = 0;
@@ -1199,6 +1238,123 @@ int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, 
                                   float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive) {
   if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
   return match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, occupied, th, nn_ratio, match_cur, n_matches, mp_obs_positive);
+}
+
+// ---- fused tracking chains -------------------------------------------------------------------------------------------
+// The numeric bodies of Tracking::TrackWithMotionModel (Tracking.cc:664-723: SearchByProjection(cur, last) then
+// Optimizer::PoseOptimization) and Tracking::TrackLocalMap (:725-736 with SearchLocalPoints' matcher call, :803-851) as ONE
+// submission each: search, claim replay, edge assembly and the pose solver are enqueued back to back on the context's stream
+// and the host synchronises once, instead of search -> host -> solver with two round trips.  Same kernels, same edge order
+// (keypoint order, Optimizer.cc:281) as the separate calls, so the results are the same bits (tests/test_track_chain.py).
+namespace {
+// after the chain: outlier flags per KEYPOINT from the per-edge bytes, or the whole PoseOptimization through the separate
+// entry point when the matches were replayed on the host (ASD_MATCH_REPLAY=host, very large inputs)
+int finish_pose_chain(asd_ctx* ctx, const AsdFrameSlot& C, const std::function<const float*(int)>& point_of, bool chained, const double* h_io,
+                      const double* Kd, double* pose7, uint8_t* outlier, int32_t* n_inliers) {
+  const int n_cur = C.n;
+  std::vector<int> kp_of_edge;
+  for (int j = 0; j < n_cur; ++j) { outlier[j] = 0; if (point_of(j)) kp_of_edge.push_back(j); }
+  const int ne = (int)kp_of_edge.size();
+  *n_inliers = 0;
+  if (ne < 3) return ASD_OK;   // Optimizer.cc:323-324
+  if (chained) {
+    memcpy(pose7, h_io, 56);
+    const uint8_t* flags = reinterpret_cast<const uint8_t*>(h_io + 8);
+    for (int e = 0; e < ne; ++e) outlier[kp_of_edge[e]] = flags[e];
+    *n_inliers = ne - (int)(h_io[7] + 0.5);
+    return ASD_OK;
+  }
+  std::vector<double> Xd((size_t)3 * ne), obs((size_t)2 * ne), info(ne);
+  std::vector<uint8_t> out(ne);
+  for (int e = 0; e < ne; ++e) {
+    const int jk = kp_of_edge[e];
+    const float* X = point_of(jk);
+    for (int k = 0; k < 3; ++k) Xd[3 * e + k] = (double)X[k];
+    obs[2 * e] = (double)C.kps[jk].x; obs[2 * e + 1] = (double)C.kps[jk].y;
+    info[e] = (double)ctx->inv_sigma2[C.kps[jk].octave];
+  }
+  const int rc = asd_pose_optimize(ctx, pose7, ne, Xd.data(), obs.data(), info.data(), Kd, out.data(), n_inliers);
+  if (rc != ASD_OK) return rc;
+  for (int e = 0; e < ne; ++e) outlier[kp_of_edge[e]] = out[e];
+  return ASD_OK;
+}
+
+int track_motion_model_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw, const float* mp_desc,
+                            const int32_t* mp_rows, const float* Tcw, const float* K, float th, int32_t check_orientation,
+                            const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier,
+                            int32_t* n_inliers) {
+  AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
+  if (!C || !L || !pose7 || !outlier || !n_inliers || !K) return ASD_ERR_INVALID;
+  const double Kd[4] = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  ChainHook chain;
+  chain.src[0] = Xw; chain.bytes[0] = (size_t)L->n * 12;
+  chain.result_bytes = pose_chain_io_bytes(C->n);
+  chain.enqueue = [&](const int* d_match, void* const d_tab[3], void* d_result) {
+    return pose_chain_enqueue(ctx, C->n, d_match, C->d_kp, static_cast<const float*>(d_tab[0]), nullptr, nullptr, pose7, Kd, static_cast<double*>(d_result));
+  };
+  bool chained = false;
+  int rc = match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, mp_rows, Tcw, K, th, check_orientation, match_cur, n_matches,
+                                    mp_obs_positive, &chain, &chained);
+  if (rc != ASD_OK) return rc;
+  return finish_pose_chain(ctx, *C, [&](int j) -> const float* { return match_cur[j] >= 0 ? Xw + 3 * (size_t)match_cur[j] : nullptr; }, chained,
+                           static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
+}
+
+int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj, const int32_t* level,
+                         const float* view_cos, const float* desc, const int32_t* rows, const float* mp_Xw, const uint8_t* occupied,
+                         const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive, const float* K, double* pose7,
+                         int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  AsdFrameSlot* F = slot_of(ctx, slot_cur);
+  if (!F || !pose7 || !outlier || !n_inliers || !K || (n_mp > 0 && !mp_Xw) || (F->n > 0 && (!occupied || !cur_Xw))) return ASD_ERR_INVALID;
+  const double Kd[4] = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  ChainHook chain;
+  chain.src[0] = mp_Xw; chain.bytes[0] = (size_t)n_mp * 12;
+  chain.src[1] = cur_Xw; chain.bytes[1] = (size_t)F->n * 12;
+  chain.src[2] = occupied; chain.bytes[2] = (size_t)F->n;
+  chain.result_bytes = pose_chain_io_bytes(F->n);
+  chain.enqueue = [&](const int* d_match, void* const d_tab[3], void* d_result) {
+    return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
+                              static_cast<const float*>(d_tab[1]), pose7, Kd, static_cast<double*>(d_result));
+  };
+  bool chained = false;
+  int rc = match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, rows, occupied, th, nn_ratio, match_cur, n_matches,
+                                     mp_obs_positive, &chain, &chained);
+  if (rc != ASD_OK) return rc;
+  return finish_pose_chain(ctx, *F, [&](int j) -> const float* {
+    return occupied[j] ? cur_Xw + 3 * (size_t)j : (match_cur[j] >= 0 ? mp_Xw + 3 * (size_t)match_cur[j] : nullptr); }, chained,
+    static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
+}
+}  // namespace
+
+int asd_track_motion_model(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw, const float* mp_desc,
+                           const float* Tcw, const float* K, float th, int32_t check_orientation, const uint8_t* mp_obs_positive, double* pose7,
+                           int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  if (!mp_desc) return ASD_ERR_INVALID;
+  return track_motion_model_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, nullptr, Tcw, K, th, check_orientation, mp_obs_positive, pose7,
+                                 match_cur, n_matches, outlier, n_inliers);
+}
+int asd_track_motion_model_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw, const int32_t* mp_rows,
+                                const float* Tcw, const float* K, float th, int32_t check_orientation, const uint8_t* mp_obs_positive,
+                                double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  if (!mp_rows) return ASD_ERR_INVALID;
+  return track_motion_model_impl(ctx, slot_cur, slot_last, has_mp, Xw, nullptr, mp_rows, Tcw, K, th, check_orientation, mp_obs_positive, pose7,
+                                 match_cur, n_matches, outlier, n_inliers);
+}
+int asd_track_local_map(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj, const int32_t* level,
+                        const float* view_cos, const float* desc, const float* mp_Xw, const uint8_t* occupied, const float* cur_Xw, float th,
+                        float nn_ratio, const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur, int32_t* n_matches,
+                        uint8_t* outlier, int32_t* n_inliers) {
+  if (n_mp > 0 && !desc) return ASD_ERR_INVALID;
+  return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, nullptr, mp_Xw, occupied, cur_Xw, th, nn_ratio,
+                              mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
+}
+int asd_track_local_map_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj, const int32_t* level,
+                             const float* view_cos, const int32_t* rows, const float* mp_Xw, const uint8_t* occupied, const float* cur_Xw,
+                             float th, float nn_ratio, const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur,
+                             int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
+  return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, mp_Xw, occupied, cur_Xw, th, nn_ratio,
+                              mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
 }
 
 // ORBmatcher::Fuse, search half (ORBmatcher.cc:825-936): the Replace / AddObservation side effects
@@ -1590,7 +1746,7 @@ int asd_bank_put_from_frame(asd_ctx* ctx, int32_t slot, int32_t first_row, int32
   MatcherState* m = mstate(ctx);
   int rc = ensure_bank(ctx, m, first_row + n);
   if (rc != ASD_OK || n == 0) return rc;
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->d_bank + (size_t)first_row * 128, F->d_desc, (size_t)n * 512, hipMemcpyDeviceToDevice, ctx->stream));
+  ASD_HIP_CHECK(ctx, copy_rows(ctx->stream, m->d_bank + (size_t)first_row * 128, F->d_desc, (size_t)n * 512));
   return ASD_OK;
 }
 

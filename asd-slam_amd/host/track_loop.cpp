@@ -34,6 +34,7 @@ struct asd_track_handle {
   double K64[4], pose0[7], inv_sigma2[8];
   asd_ba_problem ba;  // pristine problem (host arrays owned by the caller), copied per LocalBA call
   int kf_interval, lookahead;
+  bool fused = true;  // asd_track_motion_model / asd_track_local_map (one submission per stage) instead of matcher + solver calls
   // state
   int slot = 0;
   std::deque<int> pending;  // frame indices of outstanding submissions, oldest first
@@ -45,6 +46,7 @@ struct asd_track_handle {
   std::vector<float> desc_sync;
   std::vector<float> uv, Xw, Xw2, nrm, dist, maxd, mind, proj, vc;
   std::vector<uint8_t> has, in_view, occ, outl;
+  std::vector<float> cur_Xw;
   std::vector<int32_t> rows, m1, m2, level;
   std::vector<double> Xd, obs, info;
   std::vector<double> ba_poses, ba_points, ba_chi2;
@@ -76,6 +78,8 @@ asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* c
   h->desc_sync.resize((size_t)(1 << 13) * 128);
   return h;
 }
+
+void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on != 0; }
 
 void asd_track_destroy(asd_track_handle* h) {
   if (!h) return;
@@ -172,13 +176,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     for (int i = 0; i < 2 * nl; ++i) h->rows[i] = i;
     h->m1.assign(n, -1);
     int32_t n1 = 0;
-    if ((rc = asd_match_project_frame_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1,
-                                           h->m1.data(), &n1, nullptr)) != ASD_OK)
-      return rc;
-    st->m1 = n1; st->has_m1 = 1;
-    seg(2);
     auto dev = [&](int i, const char* stage) { float ms = 0.f; if (asd_last_stage_ms(ctx, stage, &ms) == ASD_OK) h->kern_ms[i] += ms; };
-    dev(0, "match");
     auto pose_opt = [&](const std::vector<int>& sel, auto point_of, int32_t* ninl) -> int {
       const int m = (int)sel.size();
       h->Xd.resize((size_t)3 * m); h->obs.resize((size_t)2 * m); h->info.resize(m); h->outl.resize(m);
@@ -194,13 +192,34 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       return asd_pose_optimize(ctx, pose, m, h->Xd.data(), h->obs.data(), h->info.data(), h->K64, h->outl.data(), ninl);
     };
     std::vector<int> sel;
-    for (int j = 0; j < n; ++j) if (h->m1[j] >= 0) sel.push_back(j);
-    if (sel.size() >= 3) {
+    if (h->fused) {
+      // Tracking::TrackWithMotionModel's numeric body in one submission (Tracking.cc:664-723)
+      double pose[7];
+      memcpy(pose, h->pose0, sizeof pose);
       int32_t ninl = 0;
-      if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, &ninl)) != ASD_OK) return rc;
+      h->outl.resize(n);
+      if ((rc = asd_track_motion_model_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1, nullptr,
+                                            pose, h->m1.data(), &n1, h->outl.data(), &ninl)) != ASD_OK)
+        return rc;
+      st->m1 = n1; st->has_m1 = 1;
+      seg(2);
+      dev(0, "match");
+      seg(3);
+    } else {
+      if ((rc = asd_match_project_frame_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1,
+                                             h->m1.data(), &n1, nullptr)) != ASD_OK)
+        return rc;
+      st->m1 = n1; st->has_m1 = 1;
+      seg(2);
+      dev(0, "match");
+      for (int j = 0; j < n; ++j) if (h->m1[j] >= 0) sel.push_back(j);
+      if (sel.size() >= 3) {
+        int32_t ninl = 0;
+        if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, &ninl)) != ASD_OK) return rc;
+      }
+      dev(1, "ba");
+      seg(3);
     }
-    dev(1, "ba");
-    seg(3);
     // local map: the last frame's points plus a jittered copy
     const int n2p = 2 * nl;
     h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
@@ -225,22 +244,44 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     for (int j = 0; j < n; ++j) h->occ[j] = h->m1[j] >= 0;
     h->m2.assign(n, -1);
     int32_t n2 = 0;
-    if ((rc = asd_match_project_points_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
-                                            h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2, nullptr)) != ASD_OK)
-      return rc;
-    st->m2 = n2; st->has_m2 = 1;
-    dev(2, "match");
-    seg(5);
-    sel.clear();
-    for (int j = 0; j < n; ++j) if (h->m1[j] >= 0 || h->m2[j] >= 0) sel.push_back(j);
-    if (sel.size() >= 3) {
+    if (h->fused) {
+      // Tracking::TrackLocalMap's numeric body (SearchLocalPoints' matcher call + PoseOptimization, Tracking.cc:725-736, 803-851)
+      h->cur_Xw.assign((size_t)3 * n, 0.f);
+      int nedge = 0;
+      for (int j = 0; j < n; ++j)
+        if (h->m1[j] >= 0) { for (int k = 0; k < 3; ++k) h->cur_Xw[3 * j + k] = h->Xw[3 * h->m1[j] + k]; }
+      double pose[7];
+      memcpy(pose, h->pose0, sizeof pose);
       int32_t ninl = 0;
-      if ((rc = pose_opt(sel, [&](int j) { return h->m1[j] >= 0 ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * std::max(h->m2[j], 0)]; }, &ninl)) != ASD_OK)
+      h->outl.resize(n);
+      if ((rc = asd_track_local_map_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
+                                         h->Xw2.data(), h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->K32, pose, h->m2.data(), &n2,
+                                         h->outl.data(), &ninl)) != ASD_OK)
         return rc;
-      st->inliers = ninl; st->has_inliers = 1;
+      st->m2 = n2; st->has_m2 = 1;
+      dev(2, "match");
+      seg(5);
+      for (int j = 0; j < n; ++j) nedge += h->m1[j] >= 0 || h->m2[j] >= 0;
+      if (nedge >= 3) { st->inliers = ninl; st->has_inliers = 1; }
+      seg(6);
+    } else {
+      if ((rc = asd_match_project_points_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
+                                              h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2, nullptr)) != ASD_OK)
+        return rc;
+      st->m2 = n2; st->has_m2 = 1;
+      dev(2, "match");
+      seg(5);
+      sel.clear();
+      for (int j = 0; j < n; ++j) if (h->m1[j] >= 0 || h->m2[j] >= 0) sel.push_back(j);
+      if (sel.size() >= 3) {
+        int32_t ninl = 0;
+        if ((rc = pose_opt(sel, [&](int j) { return h->m1[j] >= 0 ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * std::max(h->m2[j], 0)]; }, &ninl)) != ASD_OK)
+          return rc;
+        st->inliers = ninl; st->has_inliers = 1;
+      }
+      dev(3, "ba");
+      seg(6);
     }
-    dev(3, "ba");
-    seg(6);
   }
   if (do_ba) {
     const asd_ba_problem& B = h->ba;

@@ -232,10 +232,14 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
         # map point descriptors: the HIP backend keeps them in the device-resident bank (rows 0..n-1 = the last
         # frame's descriptors, rows n..2n-1 = the same again for the jittered copy), the CPU backend gets the table
         be.set_map_descriptors(lframe, ld)
-        m1, n1 = be.match_frame(cur, lframe, len(kps), has, Xw, ld, wl.T, wl.K32, 15.0)
+        fused = getattr(be, "fused", False)   # search + claim replay + PoseOptimization as one submission (asd_track_*)
+        if fused:
+            m1, n1 = be.track_motion_model(cur, lframe, len(kps), has, Xw, wl.T, wl.K32, 15.0, wl.pose0)[:2]
+        else:
+            m1, n1 = be.match_frame(cur, lframe, len(kps), has, Xw, ld, wl.T, wl.K32, 15.0)
         j = np.nonzero(m1 >= 0)[0]
         stats["m1"] = int(n1)
-        if len(j) >= 3:
+        if len(j) >= 3 and not fused:
             obs = np.stack([kps["x"][j], kps["y"][j]], 1).astype(np.float64)
             be.pose_opt(wl.pose0, Xw[m1[j]].astype(np.float64), obs, wl.inv_sigma2[kps["octave"][j]], wl.K64)
         # local map: the last frame's points plus a second, jittered copy (~2x keypoints, like a local map)
@@ -248,14 +252,20 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
         mind = maxd / wl.scale32[7]
         fr = be.frustum(cur, Xw2, n.astype(np.float32), mind, maxd, wl.T, wl.K32)
         occ = (m1 >= 0).astype(np.uint8)
-        m2, n2 = be.match_points(cur, len(kps), fr, d2, occ, 1.0, 0.8)
-        stats["m2"] = int(n2)
-        jj = np.nonzero((m1 >= 0) | (m2 >= 0))[0]
-        if len(jj) >= 3:
-            X = np.where((m1[jj] >= 0)[:, None], Xw[np.maximum(m1[jj], 0)], Xw2[np.maximum(m2[jj], 0)])
-            obs = np.stack([kps["x"][jj], kps["y"][jj]], 1).astype(np.float64)
-            _, _, ninl = be.pose_opt(wl.pose0, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
-            stats["inliers"] = int(ninl)
+        if fused:
+            m2, n2, _, _, ninl = be.track_local_map(cur, len(kps), fr, Xw2, occ, Xw[np.maximum(m1, 0)], 1.0, 0.8, wl.K32, wl.pose0)
+            stats["m2"] = int(n2)
+            if ((m1 >= 0) | (m2 >= 0)).sum() >= 3:
+                stats["inliers"] = int(ninl)
+        else:
+            m2, n2 = be.match_points(cur, len(kps), fr, d2, occ, 1.0, 0.8)
+            stats["m2"] = int(n2)
+            jj = np.nonzero((m1 >= 0) | (m2 >= 0))[0]
+            if len(jj) >= 3:
+                X = np.where((m1[jj] >= 0)[:, None], Xw[np.maximum(m1[jj], 0)], Xw2[np.maximum(m2[jj], 0)])
+                obs = np.stack([kps["x"][jj], kps["y"][jj]], 1).astype(np.float64)
+                _, _, ninl = be.pose_opt(wl.pose0, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
+                stats["inliers"] = int(ninl)
     if do_ba:
         r = be.local_ba(wl.ba)
         stats["ba_chi2"] = float(r["chi2_second"])
@@ -304,6 +314,7 @@ class NativeHost:
                                                       LOOKAHEAD if pipeline else 0))
         if not self.h:
             raise RuntimeError("asd_track_create failed")
+        self.lib.asd_track_set_fused(self.h, int(getattr(be, "fused", True)))
         self.be = be
 
     def run(self, t0, n, prefetch_beyond):
@@ -344,6 +355,7 @@ class HipBackend:
         self.slot = 0
         self.pending = []          # handles of submitted, not yet waited extractions (in order)
         self.pipeline = pipeline
+        self.fused = True          # asd_track_motion_model / asd_track_local_map instead of matcher + solver calls
 
     def image(self, t):
         return self.d_frames[t % len(self.d_frames)]
@@ -397,6 +409,12 @@ class HipBackend:
 
     def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
         return self.hip.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], occ, th, ratio)
+
+    def track_motion_model(self, cur, last, n_cur, has, Xw, T, K, th, pose0):
+        return self.hip.track_motion_model(cur, last, n_cur, has, Xw, self.rows[:len(has)], T, K, th, pose0, True)
+
+    def track_local_map(self, cur, n_cur, fr, mp_Xw, occ, cur_Xw, th, ratio, K, pose0):
+        return self.hip.track_local_map(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], mp_Xw, occ, cur_Xw, th, ratio, K, pose0)
 
     def local_ba(self, prob):
         return self.hip.local_ba(prob)
@@ -700,6 +718,7 @@ def main():
     ap.add_argument("--workload", choices=["kitti-mono", "euroc-stereo"], default="kitti-mono",
                     help="kitti-mono = the headline configuration (BASELINE configs[2]); euroc-stereo = configs[3], a secondary line")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
+    ap.add_argument("--no-fuse", action="store_true", help="matcher and PoseOptimization as separate calls (two host round trips per stage)")
     ap.add_argument("--host", choices=["cxx", "python"], default="cxx",
                     help="who drives the per-frame step: C++ host code over the C ABI (default, as in the reference) or the Python loop")
     args = ap.parse_args()
@@ -727,6 +746,7 @@ def main():
         return run_euroc_stereo(args, pkg, dist, rank, world, device)
     wl = Workload(pkg.synth, seed_offset=rank)
     be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
+    be.fused = not args.no_fuse
     be.native = None
     if args.host == "cxx":
         try:

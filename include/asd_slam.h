@@ -229,6 +229,40 @@ int asd_match_project_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, 
                                   const int32_t* rows, const uint8_t* occupied, float th, float nn_ratio,
                                   int32_t* match_cur, int32_t* n_matches, const uint8_t* mp_obs_positive);
 
+/* Fused tracking chains: the numeric bodies of Tracking::TrackWithMotionModel (Tracking.cc:664-723) and Tracking::TrackLocalMap
+ * (:725-736 with the matcher call of SearchLocalPoints, :803-851) as ONE submission each -- search, claim replay, edge assembly
+ * and Optimizer::PoseOptimization enqueued back to back on the device, one synchronisation at the end (the separate calls
+ * cost two host round trips).  Results are bit-identical to calling the matcher and asd_pose_optimize one after the other.
+ *
+ * asd_track_motion_model = asd_match_project_frame (same arguments) followed by PoseOptimization over the matches: keypoint j
+ * with match_cur[j] = i >= 0 contributes the edge (Xw[i], keypoint j, invSigma2 of its octave: Optimizer.cc:272-310), edges in
+ * keypoint order.  pose7 in = SE3Quat of the predicted Tcw (Tracking.cc:672), out = the optimised pose; outlier[n_cur] =
+ * mvbOutlier (0 where the keypoint has no match); *n_inliers = nInitialCorrespondences - nBad.  The caller keeps the
+ * control flow: the nmatches < 20 retry with 2*th (:681-685) is a second call, the outlier discard (:695-714) a loop over
+ * `outlier`.  Fewer than 3 matches: pose7 untouched, *n_inliers = 0 (Optimizer.cc:323-324). */
+int asd_track_motion_model(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
+                           const float* mp_desc, const float* Tcw, const float* K, float th, int32_t check_orientation,
+                           const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur, int32_t* n_matches,
+                           uint8_t* outlier, int32_t* n_inliers);
+int asd_track_motion_model_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
+                                const int32_t* mp_rows, const float* Tcw, const float* K, float th, int32_t check_orientation,
+                                const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur, int32_t* n_matches,
+                                uint8_t* outlier, int32_t* n_inliers);
+/* asd_track_local_map = asd_match_project_points (same arguments) followed by PoseOptimization over ALL map points of the
+ * frame: keypoint j contributes an edge if occupied[j] != 0 (it held a map point on entry: world position cur_Xw[j][3]) or
+ * match_cur[j] = m >= 0 (world position mp_Xw[m][3]).  mp_Xw[n_mp][3] / cur_Xw[n_cur][3] are f32 world positions
+ * (MapPoint::GetWorldPos); the other outputs as above. */
+int asd_track_local_map(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
+                        const int32_t* level, const float* view_cos, const float* desc, const float* mp_Xw,
+                        const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio,
+                        const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur,
+                        int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
+int asd_track_local_map_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
+                             const int32_t* level, const float* view_cos, const int32_t* rows, const float* mp_Xw,
+                             const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio,
+                             const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur,
+                             int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
+
 /* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
  * n map points: Xw[n][3], normal[n][3] (GetNormal), min_dist[n] / max_dist[n] = the map
  * point's raw mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors of

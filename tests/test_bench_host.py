@@ -20,12 +20,15 @@ def _bench():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline", [True, False])
-def test_cxx_host_equals_python_host(pkg, pipeline):
+@pytest.mark.parametrize("pipeline,fused", [(True, True), (False, True), (True, False)])
+def test_cxx_host_equals_python_host(pkg, pipeline, fused):
+    """fused: the stages run as asd_track_motion_model / asd_track_local_map (one submission each, bench default) or as
+    matcher + PoseOptimization calls (--no-fuse)"""
     bench = _bench()
     wl = bench.Workload(pkg.synth)
     n = bench.KF_INTERVAL + 3          # crosses one LocalBA
     py = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
+    py.fused = fused
     try:
         last, ref = None, []
         for t in range(n):
@@ -34,6 +37,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline):
     finally:
         py.close()
     cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
+    cx.fused = fused
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         got = [cx.native.run(t, 1, True) for t in range(n)]
@@ -44,6 +48,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline):
     assert any("ba_chi2" in s for s in got) and got[-1]["m1"] > 500 and got[-1]["inliers"] > 500
     # one call over the whole range gives the same final state as frame-by-frame calls
     cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
+    cx.fused = fused
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         whole = cx.native.run(0, n, True)

@@ -1,0 +1,140 @@
+"""Fused tracking chains (asd_track_motion_model, asd_track_local_map): the numeric bodies of Tracking::TrackWithMotionModel
+(Tracking.cc:664-723) and Tracking::TrackLocalMap (:725-736, :803-851) as one submission each.  They must return exactly what
+the separate matcher + PoseOptimization calls return (same kernels, same edge order), and the oracle's matcher + the
+reference-g2o-pinned oracle optimiser within the optimiser's tolerance."""
+import numpy as np
+import pytest
+
+from tests.test_matcher import BOUNDS, SCALES, _m1_case, backproject, make_frame, perturbed_descriptors, pose_T
+
+POSE_TOL = 1e-8
+
+
+def _pose7(T):
+    """Converter::toSE3Quat of a row-major Tcw (f32): unit quaternion + translation as f64"""
+    R = T[:3, :3].astype(np.float64)
+    t = T[:3, 3].astype(np.float64)
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    q = np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+    return np.concatenate([q / np.linalg.norm(q), t])
+
+
+def _separate_m1(hip, n_cur, kc, has, Xw, mp_desc, T, K, th, ori, pose0, obs=None):
+    m, nm = hip.match_project_frame(0, 1, n_cur, has, Xw, mp_desc, T, K, th, ori, obs_positive=obs)
+    j = np.nonzero(m >= 0)[0]
+    inv_sigma2 = hip.scale_tables()["inv_sigma2"].astype(np.float64)      # mvInvLevelSigma2 is a float table in the reference
+    outl = np.zeros(n_cur, np.uint8)
+    pose, ninl = pose0.copy(), 0
+    if len(j) >= 3:
+        obsv = np.stack([kc["x"][j], kc["y"][j]], 1).astype(np.float64)
+        pose, o, ninl = hip.pose_optimize(pose0, Xw[m[j]].astype(np.float64), obsv, inv_sigma2[kc["octave"][j]], K.astype(np.float64))
+        outl[j] = o
+    return m, nm, pose, outl, ninl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,th,ori", [(2000, 15.0, True), (600, 30.0, False), (40, 15.0, True)])
+def test_track_motion_model_equals_separate_calls(hip, oracle, synth, n, th, ori):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 400 + n)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    Tg = pose_T(rv=(0.012, -0.018, 0.006), t=(0.12, -0.04, 0.33))        # the motion-model guess the solver starts from
+    pose0 = _pose7(Tg)
+    exp = _separate_m1(hip, n, kc, has, Xw, mp_desc, T, K, th, ori, pose0)
+    got = hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, th, pose0, ori)
+    np.testing.assert_array_equal(got[0], exp[0])
+    assert got[1] == exp[1] and got[4] == exp[4]
+    np.testing.assert_array_equal(got[2], exp[2])                       # same kernels, same edge order: the same bits
+    np.testing.assert_array_equal(got[3], exp[3])
+    # through the descriptor bank
+    hip.bank_put(100, mp_desc)
+    gb = hip.track_motion_model(0, 1, n, has, Xw, np.arange(100, 100 + n, dtype=np.int32), T, K, th, pose0, ori)
+    for a, b in zip(gb, got):
+        np.testing.assert_array_equal(a, b)
+    # the oracle: matcher bit-exact, optimiser (pinned to the reference's g2o) within its tolerance
+    om, onm = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw, mp_desc, T, K, th, ori)
+    np.testing.assert_array_equal(got[0], om)
+    j = np.nonzero(om >= 0)[0]
+    if len(j) >= 3:
+        inv_sigma2 = hip.scale_tables()["inv_sigma2"].astype(np.float64)
+        op, oo, oi = oracle.pose_optimize(pose0, Xw[om[j]].astype(np.float64), np.stack([kc["x"][j], kc["y"][j]], 1).astype(np.float64),
+                                          inv_sigma2[kc["octave"][j]], K.astype(np.float64))
+        assert np.abs(got[2] - op).max() <= POSE_TOL and got[4] == oi
+        np.testing.assert_array_equal(got[3][j], oo)
+    if n >= 600:
+        assert got[4] > 0.4 * has.sum()
+
+
+@pytest.mark.gpu
+def test_track_motion_model_few_matches_and_host_replay(pkg, synth, monkeypatch):
+    """< 3 correspondences leave the pose alone (Optimizer.cc:323-324); a context with the host replay runs the same chain
+    through the separate entry points and returns the same results"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, 700, 431)
+    pose0 = _pose7(pose_T())
+    monkeypatch.setenv("ASD_MATCH_REPLAY", "host")
+    H = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376)
+    monkeypatch.delenv("ASD_MATCH_REPLAY")
+    D = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376)
+    try:
+        res = []
+        for dev in (H, D):
+            dev.frame_set(0, kc, dc, BOUNDS)
+            dev.frame_set(1, kl, dl, BOUNDS)
+            res.append(dev.track_motion_model(0, 1, 700, has, Xw, mp_desc, T, K, 15.0, pose0, True))
+            two = has.copy(); two[2:] = 0
+            m, nm, pose, outl, ninl = dev.track_motion_model(0, 1, 700, two, Xw, mp_desc, T, K, 15.0, pose0, True)
+            assert nm <= 2 and ninl == 0 and not outl.any()
+            np.testing.assert_array_equal(pose, pose0)
+        for a, b in zip(*res):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        H.close()
+        D.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mp,th", [(4000, 1.0), (1500, 5.0)])
+def test_track_local_map_equals_separate_calls(hip, oracle, synth, n_mp, th):
+    kc, dc = make_frame(2000, 190)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(191 + n_mp)
+    src = rng.integers(0, 2000, n_mp)
+    uv = np.stack([kc["x"][src], kc["y"][src]], 1) + rng.uniform(-1.5, 1.5, (n_mp, 2)).astype(np.float32)
+    depth = rng.uniform(3, 60, n_mp)
+    mp_Xw = backproject(T, K, uv, depth)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    normal = mp_Xw.astype(np.float64) - Ow
+    dist = np.linalg.norm(normal, axis=1)
+    normal = (normal / dist[:, None]).astype(np.float32)
+    maxd = (dist * SCALES[kc["octave"][src]]).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    in_view, proj, level, vc = hip.frustum(0, mp_Xw, normal, mind, maxd, T, K)
+    desc = perturbed_descriptors(dc[src], 0.05, 192)
+    occupied = (rng.uniform(size=2000) < 0.3).astype(np.uint8)          # keypoints holding a map point from the first stage
+    cur_Xw = backproject(T, K, np.stack([kc["x"], kc["y"]], 1) + rng.uniform(-0.7, 0.7, (2000, 2)).astype(np.float32),
+                         rng.uniform(4, 50, 2000))
+    pose0 = _pose7(pose_T(rv=(0.011, -0.021, 0.004), t=(0.09, -0.06, 0.31)))
+    # separate calls
+    m, nm = hip.match_project_points(0, 2000, in_view, proj, level, vc, desc, occupied, th, 0.8)
+    sel = np.nonzero((occupied > 0) | (m >= 0))[0]
+    X = np.where((occupied[sel] > 0)[:, None], cur_Xw[sel], mp_Xw[np.maximum(m[sel], 0)]).astype(np.float64)
+    inv_sigma2 = hip.scale_tables()["inv_sigma2"].astype(np.float64)
+    pe, oe, ie = hip.pose_optimize(pose0, X, np.stack([kc["x"][sel], kc["y"][sel]], 1).astype(np.float64), inv_sigma2[kc["octave"][sel]],
+                                   K.astype(np.float64))
+    outl = np.zeros(2000, np.uint8); outl[sel] = oe
+    got = hip.track_local_map(0, 2000, in_view, proj, level, vc, desc, mp_Xw, occupied, cur_Xw, th, 0.8, K, pose0)
+    np.testing.assert_array_equal(got[0], m)
+    assert got[1] == nm and got[4] == ie
+    np.testing.assert_array_equal(got[2], pe)
+    np.testing.assert_array_equal(got[3], outl)
+    assert ie > 0.5 * len(sel)
+    hip.bank_put(9000, desc)
+    gb = hip.track_local_map(0, 2000, in_view, proj, level, vc, np.arange(9000, 9000 + n_mp, dtype=np.int32), mp_Xw, occupied, cur_Xw, th, 0.8,
+                             K, pose0)
+    for a, b in zip(gb, got):
+        np.testing.assert_array_equal(a, b)
+    # oracle matcher on the same inputs
+    om, onm = oracle.match_project_points(oracle.frame(kc, dc, BOUNDS), in_view, proj, level, vc, desc, occupied, th, 0.8)
+    np.testing.assert_array_equal(got[0], om)
