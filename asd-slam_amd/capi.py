@@ -221,9 +221,14 @@ class AsdHip:
         return ms.value, calls.value, patches.value
 
     def asdnet_split_mask(self):
-        """Bit l = conv(l+2) runs on the split-operand (3 x bf16, six products) kernel; 0 = every layer on the f32 MFMA kernels."""
+        """Bit l = conv(l+2) runs on the split-operand kernel; 0 = every layer on the f32 MFMA kernels."""
         self.lib.asd_asdnet_split_mask.restype = C.c_int32
         return int(self.lib.asd_asdnet_split_mask(self.ctx))
+
+    def asdnet_pieces(self):
+        """2 = operands as two fp16 terms, three products (default); 3 = three bf16 terms, six products (ASD_ASDNET_MATH=bf16x3)."""
+        self.lib.asd_asdnet_pieces.restype = C.c_int32
+        return int(self.lib.asd_asdnet_pieces(self.ctx))
 
     def level_size(self, level):
         w, h = C.c_int32(), C.c_int32()
@@ -319,6 +324,29 @@ class AsdHip:
                      C.c_float(th), C.c_float(nn_ratio), _p(None if obs_positive is None else _c(obs_positive, np.uint8)), _p(K), _p(pose),
                      _p(match), C.byref(n), _p(outl), C.byref(ninl)))
         return match, n.value, pose, outl[:n_cur], ninl.value
+
+    def track_local_points(self, slot_cur, n_cur, Xw, normal, min_dist, max_dist, desc_or_rows, Tcw, K, occupied, cur_Xw, th, nn_ratio, pose7,
+                           cos_limit=0.5, obs_positive=None):
+        """frustum test + windows + search + claims + PoseOptimization in one submission"""
+        Xw, normal, min_dist, max_dist = (_c(a, np.float32) for a in (Xw, normal, min_dist, max_dist))
+        Tcw, K, occupied, cur_Xw = _c(Tcw, np.float32), _c(K, np.float32), _c(occupied, np.uint8), _c(cur_Xw, np.float32)
+        d = np.asarray(desc_or_rows)
+        bank = d.dtype.kind in "iu"
+        d = _c(d, np.int32 if bank else np.float32)
+        match, outl = np.empty(n_cur, np.int32), np.empty(max(n_cur, 1), np.uint8)
+        pose = _c(pose7, np.float64).copy()
+        n, ninl = C.c_int32(), C.c_int32()
+        fn = self.lib.asd_track_local_points_bank if bank else self.lib.asd_track_local_points
+        self._chk(fn(self.ctx, slot_cur, len(min_dist), _p(Xw), _p(normal), _p(min_dist), _p(max_dist), _p(d), _p(Tcw), _p(K), C.c_float(cos_limit),
+                     _p(occupied), _p(cur_Xw), C.c_float(th), C.c_float(nn_ratio), _p(None if obs_positive is None else _c(obs_positive, np.uint8)),
+                     _p(pose), _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        return match, n.value, pose, outl[:n_cur], ninl.value
+
+    def debug_level_sweep(self, lo, hi):
+        n = C.c_int64()
+        self.lib.asd_debug_level_sweep.restype = C.c_int32
+        bad = self.lib.asd_debug_level_sweep(self.ctx, C.c_float(lo), C.c_float(hi), C.byref(n))
+        return bad, n.value
 
     def match_project_keyframe(self, slot_cur, n_cur, valid, Xw, min_dist, max_dist, desc, kf_angle, occupied, Tcw, K, th, orb_dist,
                                check_ori=True):

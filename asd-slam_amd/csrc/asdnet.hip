@@ -484,12 +484,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP = 1>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP = 1, int NP = 3>
 struct X3Cfg {
   static constexpr int HO = HIN / S;
   static constexpr int INROWS = (ROWS - 1) * S + 3;
   static constexpr int INCOLS = (HO - 1) * S + 3;
-  static constexpr int PIXB = CIN * 6 + 16;  // bytes per staged pixel: an odd multiple of 16 B -> b128 reads of 16 consecutive pixels cover all banks
+  static constexpr int PIXB = CIN * 2 * NP + 16;  // bytes per staged pixel (NP 16-bit pieces per element): an odd multiple of 16 B -> b128 reads of 16 consecutive pixels cover all banks
+  static constexpr int GRPB = 16 * NP;           // bytes of one 8-cin group of a pixel: its NP pieces, 16 B each
   static constexpr int NW = WM * WN;
   static constexpr int NTH = 64 * NW;
   static constexpr int M_PATCH = ROWS * HO;
@@ -499,7 +500,7 @@ struct X3Cfg {
   static constexpr int KCH = ASD_X3_S16 ? 32 : 16;  // cin per k-chunk = K of the MFMA shape
   static constexpr int NC16 = CIN / KCH;            // chunks per tap
   static constexpr int NCHUNK = 9 * NC16;
-  static constexpr int CHUNKB = KCH * 6 * COUT;     // bytes of weight image per chunk: [piece 3][k-group KCH/8][cout][8 bf16]
+  static constexpr int CHUNKB = KCH * 2 * NP * COUT;  // bytes of weight image per chunk: [piece NP][k-group KCH/8][cout][8 x 16 bit]
   static constexpr int ACT_BYTES = INROWS * INCOLS * PIXB;
   static constexpr int LDS_BYTES = PP * ACT_BYTES;
   static_assert((PIXB / 16) % 2 == 1, "pixel stride must be an odd multiple of 16 B");
@@ -528,12 +529,36 @@ __device__ inline void split8(const f32x4& v0, const f32x4& v1, u32x4& ph, u32x4
   }
 }
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false>
+
+// activations are multiplied by this before the fp16 split: |x| up to 4094 stays finite (a BN-normalised ReLU output is O(1));
+// beyond that the high piece is inf, the low piece NaN and the descriptor comes out NaN rather than silently wrong
+constexpr float kActScale = 16.f;
+
+// The two-piece form (NP = 2, ASD_ASDNET_MATH=f16x2): x * 2^k = h + l with h = fp16(x 2^k) (round to nearest) and
+// l = fp16(x 2^k - h): 22 significant bits instead of 24, three products (l h, h l, h h) instead of six.  The power-of-two
+// pre-scale keeps h inside fp16's range and l out of its subnormals for everything but values that are negligible anyway.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ inline void split8_f16(const f32x4& v0, const f32x4& v1, float scale, u32x4& ph, u32x4& pl) {
+  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  f16x8 h, l;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float xs = x[j] * scale;
+    h[j] = (_Float16)xs;
+    l[j] = (_Float16)(xs - (float)h[j]);
+  }
+  ph = __builtin_bit_cast(u32x4, h);
+  pl = __builtin_bit_cast(u32x4, l);
+}
+
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
 __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
-                                                         unsigned long long* __restrict__ stamps) {
-  using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
+                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale) {
+  // NP = 3: bf16 pieces, six products (in_scale = out_scale = 1); NP = 2: fp16 pieces of x * in_scale, three products, the
+  // accumulators are multiplied by out_scale = 1 / (in_scale * the layer's weight scale) in the epilogue (powers of two: exact)
+  using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   constexpr int NTH = C::NTH, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_b[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -551,18 +576,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
   // ---- B operand stream: chunk c = tap * NC16 + c16, this lane's 8 k values of (piece, k-group kg, cout)
   const uint8_t* wl = wimg + ((size_t)kg * COUT + wn * NT * 32 + lr) * 16;
   constexpr int NB = NT * SUB;  // B sub-tiles of this wave
-  auto load_b = [&](int c, u32x4 (&b)[NB][3]) {
+  auto load_b = [&](int c, u32x4 (&b)[NB][NP]) {
     const uint8_t* wc = wl + (size_t)((ASD_X3_ABL & 1) ? (c & 1) : c) * C::CHUNKB;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[nb][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * KG * COUT * 16 + nb * TW * 16);
+      for (int p = 0; p < NP; ++p) b[nb][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * KG * COUT * 16 + nb * TW * 16);
   };
   // B operands run RB - 1 chunks ahead through a register ring of RB slots; the chunk loop is unrolled RB times so that the
   // slot of every chunk is a compile-time constant (no register copies)
   constexpr int RB = 3;
   static_assert(C::NCHUNK % RB == 0, "chunk count");
-  u32x4 br[RB][NB][3];
+  u32x4 br[RB][NB][NP];
 #pragma unroll
   for (int d = 0; d < RB - 1; ++d) load_b(d, br[d]);
 
@@ -643,12 +668,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
           }
         }
         u32x4 ph, pm, pl;
-        if constexpr ((ASD_X3_ABL & 64) != 0) { ph = __builtin_bit_cast(u32x4, ra); pm = __builtin_bit_cast(u32x4, rb); pl = ph; }
-        else split8(ra, rb, ph, pm, pl);
-        uint8_t* dst = smem_b + pix * C::PIXB + q * 48;
-        *reinterpret_cast<u32x4*>(dst) = ph;
-        *reinterpret_cast<u32x4*>(dst + 16) = pm;
-        *reinterpret_cast<u32x4*>(dst + 32) = pl;
+        uint8_t* dst = smem_b + pix * C::PIXB + q * C::GRPB;
+        if constexpr (NP == 2) {
+          split8_f16(ra, rb, in_scale, ph, pl);
+          *reinterpret_cast<u32x4*>(dst) = ph;
+          *reinterpret_cast<u32x4*>(dst + 16) = pl;
+        } else {
+          if constexpr ((ASD_X3_ABL & 64) != 0) { ph = __builtin_bit_cast(u32x4, ra); pm = __builtin_bit_cast(u32x4, rb); pl = ph; }
+          else split8(ra, rb, ph, pm, pl);
+          *reinterpret_cast<u32x4*>(dst) = ph;
+          *reinterpret_cast<u32x4*>(dst + 16) = pm;
+          *reinterpret_cast<u32x4*>(dst + 32) = pl;
+        }
       }
     }
   } else
@@ -681,11 +712,17 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
         const int pixg = pix0 + (rb + b) * PSTEP;
         if (rb + b < NROUND && pixg < PP * NPIXB) {
           u32x4 ph, pm, pl;
-          split8(v0[b], v1[b], ph, pm, pl);
-          uint8_t* dst = smem_b + (pixg / NPIXB) * C::ACT_BYTES + (pixg % NPIXB) * C::PIXB + c8 * 48;
-          *reinterpret_cast<u32x4*>(dst) = ph;
-          *reinterpret_cast<u32x4*>(dst + 16) = pm;
-          *reinterpret_cast<u32x4*>(dst + 32) = pl;
+          uint8_t* dst = smem_b + (pixg / NPIXB) * C::ACT_BYTES + (pixg % NPIXB) * C::PIXB + c8 * C::GRPB;
+          if constexpr (NP == 2) {
+            split8_f16(v0[b], v1[b], in_scale, ph, pl);
+            *reinterpret_cast<u32x4*>(dst) = ph;
+            *reinterpret_cast<u32x4*>(dst + 16) = pl;
+          } else {
+            split8(v0[b], v1[b], ph, pm, pl);
+            *reinterpret_cast<u32x4*>(dst) = ph;
+            *reinterpret_cast<u32x4*>(dst + 16) = pm;
+            *reinterpret_cast<u32x4*>(dst + 32) = pl;
+          }
         }
       }
     }
@@ -704,19 +741,22 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
     const int m = wm * MT * 32 + ma * TW + lr;
     const int pp = PP > 1 ? m / C::M_PATCH : 0, mm = m - pp * C::M_PATCH;
     const int rr = mm / C::HO, ox = mm % C::HO;
-    abase[ma] = pp * C::ACT_BYTES + ((rr * S) * C::INCOLS + ox * S) * C::PIXB + kg * 48;
+    abase[ma] = pp * C::ACT_BYTES + ((rr * S) * C::INCOLS + ox * S) * C::PIXB + kg * C::GRPB;
   }
   auto chunk_off = [&](int c) {
     const int tap = c / C::NC16, c16 = c % C::NC16;
-    return ((tap / 3) * C::INCOLS + (tap % 3)) * C::PIXB + c16 * (KG * 48);
+    return ((tap / 3) * C::INCOLS + (tap % 3)) * C::PIXB + c16 * (KG * C::GRPB);
   };
-  auto load_a = [&](int off, u32x4 (&a)[3]) {
+  auto load_a = [&](int off, u32x4 (&a)[NP]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const u32x4*>(smem_b + off + p * 16);
+    for (int p = 0; p < NP; ++p) a[p] = *reinterpret_cast<const u32x4*>(smem_b + off + p * 16);
   };
   auto bf = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+  auto hf = [](const u32x4& v) { return __builtin_bit_cast(f16x8, v); };
   auto mma = [&](const u32x4& x, const u32x4& y, accv& c) {
     if constexpr ((ASD_X3_ABL & 8) != 0) { asm volatile("" ::"v"(x), "v"(y)); }  // tuning: operands fetched, no MFMA
+    else if constexpr (NP == 2 && S16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(x), hf(y), c, 0, 0, 0);
+    else if constexpr (NP == 2) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf(x), hf(y), c, 0, 0, 0);
     else if constexpr (S16) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(x), bf(y), c, 0, 0, 0);
     else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf(x), bf(y), c, 0, 0, 0);
   };
@@ -725,7 +765,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
   // NA sub-tiles, a multiple of the ring size, so every sub-tile's slot is a compile-time constant
   constexpr int PD = ASD_X3_PD, RS = PD + 1;
   static_assert((RB * NA) % RS == 0, "ring slots must be static");
-  u32x4 ar[RS][3];
+  u32x4 ar[RS][NP];
 #pragma unroll
   for (int q = 0; q < PD; ++q) load_a(abase[q % NA] + chunk_off(q / NA), ar[q]);
   // diagnostic only (stamps == nullptr in every product launch): shader clock and 100 MHz wall clock around the MFMA loop
@@ -740,28 +780,33 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
       const int c = c0 + u;
       // past the end: a redundant re-read of the last chunk instead of a branch
       load_b(c + RB - 1 < C::NCHUNK ? c + RB - 1 : C::NCHUNK - 1, br[(u + RB - 1) % RB]);
-      __builtin_amdgcn_sched_group_barrier(0x020, 3 * NB, 0);
-      const u32x4 (&bc)[NB][3] = br[u];
+      __builtin_amdgcn_sched_group_barrier(0x020, NP * NB, 0);
+      const u32x4 (&bc)[NB][NP] = br[u];
 #pragma unroll
       for (int ma = 0; ma < NA; ++ma) {
         const int q = u * NA + ma;            // sub-tile index within the iteration
         const int qn = q + PD;                // the sub-tile fetched now (past the end: re-reads the last chunk, unused)
         load_a(abase[qn % NA] + offs[qn / NA], ar[qn % RS]);
-        const u32x4 (&ac)[3] = ar[q % RS];
+        const u32x4 (&ac)[NP] = ar[q % RS];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          // smallest products first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-          mma(ac[2], bc[nb][0], acc[ma][nb]);
-          mma(ac[0], bc[nb][2], acc[ma][nb]);
-          mma(ac[1], bc[nb][1], acc[ma][nb]);
-          mma(ac[1], bc[nb][0], acc[ma][nb]);
-          mma(ac[0], bc[nb][1], acc[ma][nb]);
-          mma(ac[0], bc[nb][0], acc[ma][nb]);
+          if constexpr (NP == 2) {   // smallest products first: (l,h) (h,l) (h,h)
+            mma(ac[1], bc[nb][0], acc[ma][nb]);
+            mma(ac[0], bc[nb][1], acc[ma][nb]);
+            mma(ac[0], bc[nb][0], acc[ma][nb]);
+          } else {                   // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+            mma(ac[2], bc[nb][0], acc[ma][nb]);
+            mma(ac[0], bc[nb][2], acc[ma][nb]);
+            mma(ac[1], bc[nb][1], acc[ma][nb]);
+            mma(ac[1], bc[nb][0], acc[ma][nb]);
+            mma(ac[0], bc[nb][1], acc[ma][nb]);
+            mma(ac[0], bc[nb][0], acc[ma][nb]);
+          }
         }
         // issue order within the sub-tile: one operand read behind every 2 * NB MFMAs
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB, 0);
+        for (int p = 0; p < NP; ++p) {   // NP (NP + 1) / 2 products per pair of sub-tiles, NP operand reads: spread evenly
+          __builtin_amdgcn_sched_group_barrier(0x008, (NP * (NP + 1) / 2) * NB / NP, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
       }
@@ -786,8 +831,9 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict
       for (int r = 0; r < AR; ++r) {
         const int m = m0 + (S16 ? 4 * kg + r : (r & 3) + 8 * (r >> 2) + 4 * h);
         const size_t o = (size_t)pp * C::HO * C::HO * COUT + (size_t)(m - pp * C::M_PATCH) * COUT + co;
-        const float v = acc[ma][nb][r] + bv;
-        if (!(ASD_X3_ABL & 4) || v == 12345.f) op[o] = v > 0.f ? v : 0.f;
+        const float v = (NP == 2 ? acc[ma][nb][r] * out_scale : acc[ma][nb][r]) + bv;
+        // ReLU; the fp16 form lets a NaN through (an activation beyond fp16's range must reach the descriptor, not become 0)
+        if (!(ASD_X3_ABL & 4) || v == 12345.f) op[o] = NP == 2 ? (v < 0.f ? 0.f : v) : (v > 0.f ? v : 0.f);
       }
     }
   }
@@ -1016,11 +1062,13 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
   return hipGetLastError();
 }
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
 hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
-                          const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr) {
-  using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP>;
-  auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1>;
+                          const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr,
+                          float in_scale = 1.f, float out_scale = 1.f) {
+  using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
+  auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP>;
+  // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds <= 160 * 1024, "band does not fit LDS");
   static bool attr_set = false;
@@ -1030,7 +1078,8 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
     attr_set = true;
   }
   if (grid_out) *grid_out = ((n + PP - 1) / PP) * (C::HO / ROWS);
-  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps);
+  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,
+                     in_scale, out_scale);
   return hipGetLastError();
 }
 
@@ -1049,10 +1098,29 @@ inline void split3_host(float x, uint16_t& h, uint16_t& m, uint16_t& l) {
   h = (uint16_t)(hu >> 16); m = (uint16_t)(mu >> 16); l = (uint16_t)(r2u >> 16);
 }
 
-// split B-operand image of a 3x3 layer: [tap][cin/KCH][piece][k-group][cout][8 bf16] with cin = KCH*c + 8*group + j
-// (KCH = 16 for the 32x32x16 MFMA shape, 32 for 16x16x32), BN scale folded in f32 first (the same folded value the f32 image holds)
-void build_wx3(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<uint16_t>& img) {
-  img.assign((size_t)9 * L.cin * L.cout * 3, 0);
+// two-term fp16 split of one (pre-scaled) f32, round to nearest (host twin of split8_f16)
+inline void split2_host(float xs, uint16_t& h, uint16_t& l) {
+  const _Float16 hh = (_Float16)xs;
+  const _Float16 ll = (_Float16)(xs - (float)hh);
+  memcpy(&h, &hh, 2);
+  memcpy(&l, &ll, 2);
+}
+
+// power of two that brings the largest folded weight of a layer into [2^13, 2^14): fp16's range with a factor 4 to spare
+inline float weight_scale_f16(const float* w, size_t count, const std::vector<float>& inv, size_t per_cout) {
+  float mx = 0.f;
+  for (size_t i = 0; i < count; ++i) mx = std::max(mx, std::fabs(w[i] * inv[i / per_cout]));
+  if (!(mx > 0.f) || !std::isfinite(mx)) return 1.f;
+  int e;
+  (void)std::frexp(mx, &e);   // mx = f 2^e, f in [0.5, 1)
+  return std::ldexp(1.f, 14 - e);
+}
+
+// split B-operand image of a 3x3 layer: [tap][cin/KCH][piece][k-group][cout][8 x 16 bit] with cin = KCH*c + 8*group + j
+// (KCH = 16 for the 32x32x16 MFMA shape, 32 for 16x16x32), BN scale folded in f32 first (the same folded value the f32 image holds).
+// np = 3: exact bf16 pieces; np = 2: fp16 pieces of the folded weight times wscale.
+void build_wx3(const LayerSpec& L, const float* w, const std::vector<float>& inv, std::vector<uint16_t>& img, int np = 3, float wscale = 1.f) {
+  img.assign((size_t)9 * L.cin * L.cout * np, 0);
   constexpr int kch = ASD_X3_S16 ? 32 : 16, kg = kch / 8;
   const int nc16 = L.cin / kch;
   for (int tap = 0; tap < 9; ++tap)
@@ -1060,10 +1128,11 @@ void build_wx3(const LayerSpec& L, const float* w, const std::vector<float>& inv
       for (int co = 0; co < L.cout; ++co) {
         const float v = w[((size_t)co * L.cin + ci) * 9 + tap] * inv[co];
         uint16_t p[3];
-        split3_host(v, p[0], p[1], p[2]);
+        if (np == 3) split3_host(v, p[0], p[1], p[2]);
+        else split2_host(v * wscale, p[0], p[1]);
         const int c16 = ci / kch, hh = (ci % kch) / 8, j = ci % 8;
-        for (int q = 0; q < 3; ++q)
-          img[(((((size_t)tap * nc16 + c16) * 3 + q) * kg + hh) * L.cout + co) * 8 + j] = p[q];
+        for (int q = 0; q < np; ++q)
+          img[(((((size_t)tap * nc16 + c16) * np + q) * kg + hh) * L.cout + co) * 8 + j] = p[q];
       }
 }
 
@@ -1102,6 +1171,7 @@ void asdnet_free(asd_ctx* ctx) {
     if (ctx->d_bias[i]) (void)hipFree(ctx->d_bias[i]);
     if (ctx->d_wimg[i]) (void)hipFree(ctx->d_wimg[i]);
     if (ctx->d_wx3[i]) (void)hipFree(ctx->d_wx3[i]);
+    if (ctx->d_wx2[i]) (void)hipFree(ctx->d_wx2[i]);
   }
 }
 
@@ -1158,6 +1228,12 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
       build_wx3(L, conv_w[l], inv, x3);
       if (!ctx->d_wx3[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wx3[l], x3.size() * sizeof(uint16_t)));
       ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wx3[l], x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      // the two-piece fp16 image (ASD_ASDNET_MATH=f16x2) and the power of two its weights were scaled by
+      const float ws = weight_scale_f16(conv_w[l], (size_t)L.cout * L.cin * 9, inv, (size_t)L.cin * 9);
+      ctx->wx2_scale[l] = ws;
+      build_wx3(L, conv_w[l], inv, x3, 2, ws);
+      if (!ctx->d_wx2[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wx2[l], x3.size() * sizeof(uint16_t)));
+      ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wx2[l], x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
   }
   ctx->weights_loaded = true;
@@ -1180,22 +1256,29 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
 #define PROF_MARK(i) do { if (prof) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->prof_ev[pset][i], st)); } while (0)
   PROF_MARK(0);
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
-  if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (launch_conv_x3<L2S_CFG, true>(st, d_patches, ctx->d_wx3[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
+  // ASD_ASDNET_MATH=f16x2: two fp16 pieces per operand, three products (kActScale and the per-layer weight scale are undone in the epilogue)
+  const bool p2 = ctx->net_pieces == 2;
+#define X3_LAUNCH(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                       \
+  (p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,               \
+                                     1.f / (kActScale * ctx->wx2_scale[l]))                                                                \
+      : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p))
+  if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L2S_CFG, true, 1, d_patches, a1, ctx->d_w1, ctx->d_bias[0])));
   else ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);
-  if (ctx->net_split & 2) ASD_HIP_CHECK(ctx, (launch_conv_x3<L3S_CFG>(st, a1, ctx->d_wx3[2], ctx->d_bias[2], a0, n)));
+  if (ctx->net_split & 2) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L3S_CFG, false, 2, a1, a0, nullptr, nullptr)));
   else
   ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
   PROF_MARK(3);
-  if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (launch_conv_x3<L4S_CFG>(st, a0, ctx->d_wx3[3], ctx->d_bias[3], a1, n)));
+  if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L4S_CFG, false, 3, a0, a1, nullptr, nullptr)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
   PROF_MARK(4);
-  if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (launch_conv_x3<L5S_CFG>(st, a1, ctx->d_wx3[4], ctx->d_bias[4], a0, n)));
+  if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L5S_CFG, false, 4, a1, a0, nullptr, nullptr)));
   else
   ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
   PROF_MARK(5);
-  if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (launch_conv_x3<L6S_CFG>(st, a0, ctx->d_wx3[5], ctx->d_bias[5], a1, n)));
+  if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L6S_CFG, false, 5, a0, a1, nullptr, nullptr)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
+#undef X3_LAUNCH
   PROF_MARK(6);
   if (ctx->net_split & 32)
     hipLaunchKernelGGL(k_fc_x3, dim3((npad + FCS_MP - 1) / FCS_MP, FC_SK), dim3(256), 0, st, a1, static_cast<const uint8_t*>(ctx->d_wx3[6]), ctx->d_part, n, npad);

@@ -33,6 +33,22 @@ void build_tables(asd_ctx* c) {
     c->inv_scale[i] = 1.0f / c->scale[i];
     c->inv_sigma2[i] = 1.0f / c->sigma2[i];
   }
+  {  // level_thr (see ctx.h): bisection is valid because ceil(logf(r) / ls) does not decrease with r (asd_debug_level_sweep checks it)
+    const float ls = std::log(scaleFactor);  // Frame.cc:74: float log of the float scale factor
+    auto level_of = [&](float r) { return (int)std::ceil(std::log(r) / ls); };
+    c->level_thr[0] = 0.f;
+    for (int k = 1; k < ASD_MAX_LEVELS; ++k) {
+      uint32_t lo, hi;  // bit patterns of positive floats order like the values
+      const float flo = 0.25f, fhi = 1.0e30f;
+      memcpy(&lo, &flo, 4); memcpy(&hi, &fhi, 4);
+      while (lo < hi) {  // smallest pattern with level_of >= k
+        const uint32_t mid = lo + (hi - lo) / 2;
+        float fm; memcpy(&fm, &mid, 4);
+        if (level_of(fm) >= k) hi = mid; else lo = mid + 1;
+      }
+      memcpy(&c->level_thr[k], &lo, 4);
+    }
+  }
   const int nfeatures = c->cfg.n_features;
   float factor = (float)(1.0f / (double)scaleFactor);
   float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
@@ -95,13 +111,16 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
   }
   build_tables(c);
-  // ASDNet arithmetic: split-bf16 kernels by default; ASD_ASDNET_MATH=f32 keeps every layer on the f32 MFMA kernels,
+  // ASDNet arithmetic: split-operand kernels by default (two fp16 terms; ASD_ASDNET_MATH=bf16x3 for three bf16 terms);
+  // ASD_ASDNET_MATH=f32 keeps every layer on the f32 MFMA kernels,
   // ASD_ASDNET_SPLIT_LAYERS=<mask> picks layers (bit 0 = conv2 ... bit 4 = conv6, bit 5 = fc)
   c->net_split = 0x3f;
   if (const char* e = getenv("ASD_MATCH_REPLAY")) c->match_replay_host = !strcmp(e, "host");   // matcher.hip, k_resolve
   if (const char* e = getenv("ASD_ASDNET_MATH")) {
     if (!strcmp(e, "f32")) c->net_split = 0;
-    else if (strcmp(e, "split")) fprintf(stderr, "libasdhip: ASD_ASDNET_MATH=%s not understood (f32 | split); using split\n", e);
+    else if (!strcmp(e, "f16x2")) c->net_pieces = 2;
+    else if (!strcmp(e, "bf16x3")) c->net_pieces = 3;
+    else if (strcmp(e, "split")) fprintf(stderr, "libasdhip: ASD_ASDNET_MATH=%s not understood (f32 | split | f16x2 | bf16x3); using f16x2\n", e);
   }
   if (const char* e = getenv("ASD_ASDNET_SPLIT_LAYERS")) c->net_split = (int)strtol(e, nullptr, 0) & 0x3f;
   // tracking kernels (small, latency critical) outrank the pipelined extractor's stream
@@ -226,6 +245,7 @@ int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms) {
 }
 
 int32_t asd_asdnet_split_mask(const asd_ctx* ctx) { return ctx ? (ctx->net_split & 0x3f) : 0; }
+int32_t asd_asdnet_pieces(const asd_ctx* ctx) { return ctx ? ctx->net_pieces : 0; }
 
 int asd_profile_enable(asd_ctx* ctx, int32_t on) {
   if (!ctx) return ASD_ERR_INVALID;
@@ -251,6 +271,30 @@ int asd_profile_get(asd_ctx* ctx, int32_t layer, double* total_ms, int32_t* call
 }
 
 void* asd_ctx_stream(asd_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// MapPoint::PredictScale's level by the comparison rule the device uses (ctx.h, level_thr)
+static inline int level_by_thresholds(const asd_ctx* ctx, float ratio) {
+  int s = 0;
+  for (int k = 1; k < ctx->cfg.n_levels; ++k) s += ratio >= ctx->level_thr[k];
+  return s;
+}
+int32_t asd_debug_level_sweep(const asd_ctx* ctx, float lo, float hi, int64_t* n_checked) {
+  // every float in [lo, hi]: the threshold rule against ceil(logf(r) / logf(scaleFactor)) clamped to the level range
+  if (!ctx || !(lo > 0.f) || !(hi >= lo) || !n_checked) return -1;
+  const float ls = std::log(ctx->cfg.scale_factor);
+  uint32_t a, b;
+  memcpy(&a, &lo, 4); memcpy(&b, &hi, 4);
+  int32_t bad = 0;
+  for (uint32_t u = a;; ++u) {
+    float r; memcpy(&r, &u, 4);
+    int s = (int)std::ceil(std::log(r) / ls);
+    if (s < 0) s = 0; else if (s >= ctx->cfg.n_levels) s = ctx->cfg.n_levels - 1;
+    bad += s != level_by_thresholds(ctx, r);
+    if (u == b) break;
+  }
+  *n_checked = (int64_t)b - (int64_t)a + 1;
+  return bad;
+}
 
 int asd_device_alloc(asd_ctx* ctx, uint64_t bytes, void** dptr) {
   if (!ctx || !dptr) return ASD_ERR_INVALID;

@@ -102,6 +102,10 @@ struct asd_ctx {
   // ---- extractor tables (ORBextractor.cc:459-512)
   float scale[ASD_MAX_LEVELS], inv_scale[ASD_MAX_LEVELS], sigma2[ASD_MAX_LEVELS], inv_sigma2[ASD_MAX_LEVELS];
   int features_per_level[ASD_MAX_LEVELS];
+  // MapPoint::PredictScale without a logarithm: level_thr[k] (k = 1 .. n_levels-1) is the smallest float ratio r with
+  // ceil(logf(r) / logf(scaleFactor)) >= k, found by bisection over float bit patterns with the host's own logf at
+  // asd_ctx_create, so the device predicts the level by comparisons and gets libm's answer bit for bit
+  float level_thr[ASD_MAX_LEVELS];
   int umax[16];
 
   // ---- ASDNet
@@ -111,6 +115,9 @@ struct asd_ctx {
   float* d_wimg[7] = {};        // MFMA B-operand images, layers 2..7 (index 1..6)
   void* d_wx3[7] = {};          // the same weights split into three bf16 terms (asdnet.hip, split-operand kernels)
   bool match_replay_host = false;  // ASD_MATCH_REPLAY=host (read at asd_ctx_create): matcher claim replay on the host
+  void* d_wx2[7] = {};          // layers 1..5 split into two fp16 terms of (weight * wx2_scale[l]) (ASD_ASDNET_MATH=f16x2)
+  float wx2_scale[7] = {1, 1, 1, 1, 1, 1, 1};
+  int net_pieces = 2;           // 3 = bf16x3 (six products, exact operands), 2 = fp16x2 (three products, 22-bit operands)
   int net_split = 1;            // ASD_ASDNET_MATH: 1 = split-bf16 kernels where a layer has one, 0 = f32 MFMA everywhere
   float* d_act[2] = {};         // ping-pong NHWC activations
   float* d_part = nullptr;      // split-K partials of the last layer

@@ -484,6 +484,54 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     for (int i = 0; i < 4; ++i) a.n_matches[7 + i] = ph[i]; }
 }
 
+// Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) + the search window of
+// ORBmatcher::SearchByProjection(F, vpMapPoints, th) (:60-70), one thread per map point, straight into the query table of
+// k_window_search.  The arithmetic is asd_frustum's, operation for operation (f32 with the two double accumulations of the
+// reference; -ffp-contract=off; IEEE division and square root), and the level comes from comparisons with thresholds that the
+// host derived from its own logf (ctx.h, level_thr), so the queries are the ones the host would have written.
+struct FrustumArgs {
+  int n, n_levels, bfactor;
+  const float* Xw; const float* normal; const float* min_dist; const float* max_dist;
+  const int* rows;          // bank row per map point, or null: descriptor row = map point index
+  float T[16], Ow[3];
+  float fx, fy, cx, cy, min_x, max_x, min_y, max_y, cos_limit, th;
+  float level_thr[ASD_MAX_LEVELS], scale[ASD_MAX_LEVELS];
+  WinQuery* queries;
+};
+__global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= a.n) return;
+  WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
+  const float* P = a.Xw + 3 * (size_t)q;
+  float Pc[3];
+  for (int r = 0; r < 3; ++r) {
+    const float t0 = a.T[r * 4 + 0] * P[0] + a.T[r * 4 + 1] * P[1] + a.T[r * 4 + 2] * P[2];
+    Pc[r] = (float)((double)t0 + (double)a.T[r * 4 + 3]);
+  }
+  bool ok = !(Pc[2] < 0.0f);
+  const float invz = 1.0f / Pc[2];
+  const float u = a.fx * Pc[0] * invz + a.cx, v = a.fy * Pc[1] * invz + a.cy;
+  if (u < a.min_x || u > a.max_x || v < a.min_y || v > a.max_y) ok = false;
+  const float maxD = 1.2f * a.max_dist[q], minD = 0.8f * a.min_dist[q];
+  const float PO[3] = {P[0] - a.Ow[0], P[1] - a.Ow[1], P[2] - a.Ow[2]};
+  const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
+  const float dist = (float)sqrt(nn);
+  if (dist < minD || dist > maxD) ok = false;
+  const float* Pn = a.normal + 3 * (size_t)q;
+  const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+  const float vc = (float)(dot / dist);
+  if (vc < a.cos_limit) ok = false;
+  if (ok) {
+    const float ratio = a.max_dist[q] / dist;
+    int lvl = 0;
+    for (int k = 1; k < a.n_levels; ++k) lvl += ratio >= a.level_thr[k];
+    float r = vc > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
+    if (a.bfactor) r *= a.th;
+    Q = WinQuery{u, v, r * a.scale[lvl], lvl - 1, lvl, a.rows ? a.rows[q] : q};
+  }
+  a.queries[q] = Q;
+}
+
 // ---- host helpers -------------------------------------------------------------------------
 inline void three_maxima(const int* cnt, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1584-1625
   int max1 = 0, max2 = 0, max3 = 0;
@@ -697,13 +745,17 @@ bool replay_on_device(const MatcherState* m, int kind, int n_cur, int nq) {
 // copied through pinned staging, match_cur[n_cur] / *n_matches come back.  kp_last = last frame's device keypoints (KIND 0).
 // what a fused chain adds to a search: tables that travel in the search's upload block, and room for its results in the
 // search's result block
+constexpr int kChainTabs = 8;
 struct ChainHook {
-  const void* src[3] = {nullptr, nullptr, nullptr};   // host tables (world positions, own positions, hold flags)
-  size_t bytes[3] = {0, 0, 0};
-  size_t result_bytes = 0;                             // room wanted in the result block
+  const void* src[kChainTabs] = {};   // host tables that travel in the upload block (world positions, flags, ...)
+  size_t bytes[kChainTabs] = {};
+  size_t result_bytes = 0;            // room wanted in the result block
+  // optional: the queries are made on the device from the uploaded tables (frustum test + window of every map point)
+  // instead of being copied from m->h_queries; called after the upload, before the search
+  std::function<int(WinQuery* d_queries, void* const* d_tab)> prepare;
   // enqueue the chain's kernels: match table, the uploaded tables, where the results go (all device pointers)
-  std::function<int(const int* d_match, void* const d_tab[3], void* d_result)> enqueue;
-  const void* h_result = nullptr;                      // out: the chain's results on the host after the call
+  std::function<int(const int* d_match, void* const* d_tab, void* d_result)> enqueue;
+  const void* h_result = nullptr;     // out: the chain's results on the host after the call
 };
 
 template <int KIND>
@@ -719,17 +771,18 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
   const int n_cur = F.n;
   AsdXfer &up = ctx->up, &down = ctx->down;
   size_t extra = 0;
-  if (chain) for (int i = 0; i < 3; ++i) extra += chain->bytes[i] + 256;
+  if (chain) for (int i = 0; i < kChainTabs; ++i) extra += chain->bytes[i] + 256;
   ASD_HIP_CHECK(ctx, up.begin(st, (size_t)nq * sizeof(WinQuery) + 256 + (size_t)nq + (size_t)n_cur + 1024 + extra));
   ASD_HIP_CHECK(ctx, down.begin(st, ((size_t)n_cur + 16) * sizeof(int) + 256 + (chain ? chain->result_bytes : 0)));
   ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4)));
   int* d_pick = ctx->scratch.carve<int>(nq);
-  const size_t o_q = up.add(m->h_queries, (size_t)nq * sizeof(WinQuery));
+  const bool dev_queries = chain && chain->prepare;
+  const size_t o_q = dev_queries ? up.reserve((size_t)nq * sizeof(WinQuery)) : up.add(m->h_queries, (size_t)nq * sizeof(WinQuery));
   const size_t o_total = up.zeros(sizeof(int));
   const size_t o_obs = obs_pos ? up.add(obs_pos, nq) : 0;
   const size_t o_occ = KIND == 1 ? up.add(occupied, n_cur) : 0;
-  size_t o_tab[3] = {0, 0, 0};
-  if (chain) for (int i = 0; i < 3; ++i) if (chain->src[i]) o_tab[i] = up.add(chain->src[i], chain->bytes[i]);
+  size_t o_tab[kChainTabs] = {};
+  if (chain) for (int i = 0; i < kChainTabs; ++i) if (chain->src[i]) o_tab[i] = up.add(chain->src[i], chain->bytes[i]);
   const size_t o_out = down.reserve(((size_t)n_cur + 16) * sizeof(int));
   const size_t o_res = chain ? down.reserve(chain->result_bytes) : 0;
   int* d_out = down.dev<int>(o_out);
@@ -739,6 +792,9 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
   int* d_total = up.dev<int>(o_total);
   for (int attempt = 0; attempt < 2; ++attempt) {
     ASD_HIP_CHECK(ctx, up.upload(st));
+    void* d_tab[kChainTabs];
+    for (int i = 0; i < kChainTabs; ++i) d_tab[i] = (chain && chain->src[i]) ? up.dev<void>(o_tab[i]) : nullptr;
+    if (dev_queries && (rc = chain->prepare(up.dev<WinQuery>(o_q), d_tab)) != ASD_OK) return rc;
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
     hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
@@ -771,8 +827,6 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
     if (chain) {
-      void* d_tab[3] = {chain->src[0] ? up.dev<void>(o_tab[0]) : nullptr, chain->src[1] ? up.dev<void>(o_tab[1]) : nullptr,
-                        chain->src[2] ? up.dev<void>(o_tab[2]) : nullptr};
       if ((rc = chain->enqueue(d_out, d_tab, down.dev<void>(o_res))) != ASD_OK) return rc;
       chain->h_result = down.host<void>(o_res);
     }
@@ -1289,7 +1343,7 @@ int track_motion_model_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
   ChainHook chain;
   chain.src[0] = Xw; chain.bytes[0] = (size_t)L->n * 12;
   chain.result_bytes = pose_chain_io_bytes(C->n);
-  chain.enqueue = [&](const int* d_match, void* const d_tab[3], void* d_result) {
+  chain.enqueue = [&](const int* d_match, void* const* d_tab, void* d_result) {
     return pose_chain_enqueue(ctx, C->n, d_match, C->d_kp, static_cast<const float*>(d_tab[0]), nullptr, nullptr, pose7, Kd, static_cast<double*>(d_result));
   };
   bool chained = false;
@@ -1312,7 +1366,7 @@ int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uin
   chain.src[1] = cur_Xw; chain.bytes[1] = (size_t)F->n * 12;
   chain.src[2] = occupied; chain.bytes[2] = (size_t)F->n;
   chain.result_bytes = pose_chain_io_bytes(F->n);
-  chain.enqueue = [&](const int* d_match, void* const d_tab[3], void* d_result) {
+  chain.enqueue = [&](const int* d_match, void* const* d_tab, void* d_result) {
     return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
                               static_cast<const float*>(d_tab[1]), pose7, Kd, static_cast<double*>(d_result));
   };
@@ -1322,6 +1376,80 @@ int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uin
   if (rc != ASD_OK) return rc;
   return finish_pose_chain(ctx, *F, [&](int j) -> const float* {
     return occupied[j] ? cur_Xw + 3 * (size_t)j : (match_cur[j] >= 0 ? mp_Xw + 3 * (size_t)match_cur[j] : nullptr); }, chained,
+    static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
+}
+
+// Tracking::SearchLocalPoints (Tracking.cc:803-851: isInFrustum for every local map point, then SearchByProjection) +
+// Optimizer::PoseOptimization = Tracking::TrackLocalMap's numeric body (:725-736) with the frustum test and the search windows
+// made on the device too: the host uploads the map points (position, normal, distance bounds) and gets matches and pose back.
+int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal, const float* min_dist,
+                            const float* max_dist, const float* desc, const int32_t* rows, const float* Tcw, const float* K, float cos_limit,
+                            const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive,
+                            double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  AsdFrameSlot* F = slot_of(ctx, slot_cur);
+  if (!F || n_mp < 0 || !Tcw || !K || !pose7 || !match_cur || !n_matches || !outlier || !n_inliers ||
+      (n_mp > 0 && (!Xw || !normal || !min_dist || !max_dist || (!desc && !rows))) || (F->n > 0 && (!occupied || !cur_Xw)))
+    return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  if (n_mp == 0 || F->n == 0 || !replay_on_device(m, 1, F->n, n_mp)) {
+    // host frustum + the chain on its outputs (also the fallback for very large maps)
+    std::vector<uint8_t> in_view(std::max(n_mp, 1));
+    std::vector<float> proj((size_t)2 * std::max(n_mp, 1)), vc(std::max(n_mp, 1));
+    std::vector<int32_t> level(std::max(n_mp, 1));
+    int rc = asd_frustum(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, Tcw, K, cos_limit, in_view.data(), proj.data(), level.data(), vc.data());
+    if (rc != ASD_OK) return rc;
+    return track_local_map_impl(ctx, slot_cur, n_mp, in_view.data(), proj.data(), level.data(), vc.data(), desc, rows, Xw, occupied, cur_Xw, th,
+                                nn_ratio, mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
+  }
+  std::fill(match_cur, match_cur + F->n, -1);
+  *n_matches = 0;
+  int rc = ensure_queries(ctx, m, n_mp);
+  if (rc != ASD_OK) return rc;
+  if (!desc)
+    for (int q = 0; q < n_mp; ++q)
+      if (rows[q] < 0 || rows[q] >= m->bank_cap) { ctx->set_error("bank row %d out of range", rows[q]); return ASD_ERR_INVALID; }
+  if (desc && (rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
+  const double Kd[4] = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  FrustumArgs fa{};
+  fa.n = n_mp; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = th != 1.0;
+  memcpy(fa.T, Tcw, sizeof fa.T);
+  for (int i = 0; i < 3; ++i) {  // mOw = -mRcw.t()*mtcw (Frame.cc:157): transposed gemm accumulates in double
+    double sum = 0;
+    for (int k = 0; k < 3; ++k) sum += (double)Tcw[k * 4 + i] * (double)Tcw[k * 4 + 3];
+    fa.Ow[i] = (float)(-1.0 * sum);
+  }
+  fa.fx = K[0]; fa.fy = K[1]; fa.cx = K[2]; fa.cy = K[3];
+  fa.min_x = F->min_x; fa.max_x = F->max_x; fa.min_y = F->min_y; fa.max_y = F->max_y;
+  fa.cos_limit = cos_limit; fa.th = th;
+  for (int l = 0; l < ASD_MAX_LEVELS; ++l) { fa.level_thr[l] = ctx->level_thr[l]; fa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f; }
+  ChainHook chain;
+  chain.src[0] = Xw; chain.bytes[0] = (size_t)n_mp * 12;
+  chain.src[1] = cur_Xw; chain.bytes[1] = (size_t)F->n * 12;
+  chain.src[2] = occupied; chain.bytes[2] = (size_t)F->n;
+  chain.src[3] = normal; chain.bytes[3] = (size_t)n_mp * 12;
+  chain.src[4] = min_dist; chain.bytes[4] = (size_t)n_mp * 4;
+  chain.src[5] = max_dist; chain.bytes[5] = (size_t)n_mp * 4;
+  if (!desc) { chain.src[6] = rows; chain.bytes[6] = (size_t)n_mp * 4; }
+  chain.result_bytes = pose_chain_io_bytes(F->n);
+  chain.prepare = [&](WinQuery* d_queries, void* const* d_tab) -> int {
+    fa.Xw = static_cast<const float*>(d_tab[0]); fa.normal = static_cast<const float*>(d_tab[3]);
+    fa.min_dist = static_cast<const float*>(d_tab[4]); fa.max_dist = static_cast<const float*>(d_tab[5]);
+    fa.rows = desc ? nullptr : static_cast<const int*>(d_tab[6]);
+    fa.queries = d_queries;
+    hipLaunchKernelGGL(k_frustum_queries, dim3((n_mp + 255) / 256), dim3(256), 0, ctx->stream, fa);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    return ASD_OK;
+  };
+  chain.enqueue = [&](const int* d_match, void* const* d_tab, void* d_result) {
+    return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
+                              static_cast<const float*>(d_tab[1]), pose7, Kd, static_cast<double*>(d_result));
+  };
+  rc = search_and_resolve<1>(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, nullptr, mp_obs_positive, occupied, 0, nn_ratio, match_cur, n_matches,
+                             &chain);
+  if (rc != ASD_OK) return rc;
+  return finish_pose_chain(ctx, *F, [&](int j) -> const float* {
+    return occupied[j] ? cur_Xw + 3 * (size_t)j : (match_cur[j] >= 0 ? Xw + 3 * (size_t)match_cur[j] : nullptr); }, true,
     static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
 }
 }  // namespace
@@ -1355,6 +1483,22 @@ int asd_track_local_map_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
   if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
   return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, mp_Xw, occupied, cur_Xw, th, nn_ratio,
                               mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
+}
+int asd_track_local_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal, const float* min_dist,
+                           const float* max_dist, const float* desc, const float* Tcw, const float* K, float viewing_cos_limit,
+                           const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive, double* pose7,
+                           int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  if (n_mp > 0 && !desc) return ASD_ERR_INVALID;
+  return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, desc, nullptr, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
+                                 nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers);
+}
+int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal, const float* min_dist,
+                                const float* max_dist, const int32_t* rows, const float* Tcw, const float* K, float viewing_cos_limit,
+                                const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive,
+                                double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
+  return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, nullptr, rows, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
+                                 nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers);
 }
 
 // ORBmatcher::Fuse, search half (ORBmatcher.cc:825-936): the Replace / AddObservation side effects

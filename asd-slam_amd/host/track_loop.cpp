@@ -236,16 +236,18 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     }
     h->in_view.resize(n2p); h->proj.resize((size_t)2 * n2p); h->level.resize(n2p); h->vc.resize(n2p);
     seg(7);
-    if ((rc = asd_frustum(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->T, h->K32, 0.5f, h->in_view.data(),
-                          h->proj.data(), h->level.data(), h->vc.data())) != ASD_OK)
-      return rc;
+    if (!h->fused) {   // fused: isInFrustum / PredictScale / search windows are made on the device inside asd_track_local_points
+      if ((rc = asd_frustum(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->T, h->K32, 0.5f, h->in_view.data(),
+                            h->proj.data(), h->level.data(), h->vc.data())) != ASD_OK)
+        return rc;
+    }
     seg(4);
     h->occ.resize(n);
     for (int j = 0; j < n; ++j) h->occ[j] = h->m1[j] >= 0;
     h->m2.assign(n, -1);
     int32_t n2 = 0;
     if (h->fused) {
-      // Tracking::TrackLocalMap's numeric body (SearchLocalPoints' matcher call + PoseOptimization, Tracking.cc:725-736, 803-851)
+      // Tracking::TrackLocalMap's numeric body (SearchLocalPoints: frustum loop + matcher, then PoseOptimization; Tracking.cc:725-736, 803-851)
       h->cur_Xw.assign((size_t)3 * n, 0.f);
       int nedge = 0;
       for (int j = 0; j < n; ++j)
@@ -254,9 +256,9 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       memcpy(pose, h->pose0, sizeof pose);
       int32_t ninl = 0;
       h->outl.resize(n);
-      if ((rc = asd_track_local_map_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
-                                         h->Xw2.data(), h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->K32, pose, h->m2.data(), &n2,
-                                         h->outl.data(), &ninl)) != ASD_OK)
+      if ((rc = asd_track_local_points_bank(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->rows.data(), h->T,
+                                            h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, pose, h->m2.data(), &n2,
+                                            h->outl.data(), &ninl)) != ASD_OK)
         return rc;
       st->m2 = n2; st->has_m2 = 1;
       dev(2, "match");

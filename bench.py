@@ -35,7 +35,7 @@ N_FRAMES = 30          # distinct synthetic frames kept resident in HBM, cycled
 BOUNDS = (0.0, 1241.0, 0.0, 376.0)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters (dense f32 matrix)
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # dense bf16: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (the guide's "~2.5 PF dense")
-SPLIT_PRODUCTS = 6              # bf16 MFMAs per f32 multiply-add in the split-operand kernels (asdnet.hip, K1s)
+SPLIT_PRODUCTS = {2: 3, 3: 6}   # 16-bit MFMA products per f32 multiply-add in the split-operand kernels (asdnet.hip, K1s), by piece count
 L2_MACS = 9_437_184            # conv2 (32->32 @32x32) MACs per patch, SURVEY 8(a) E6
 
 
@@ -250,10 +250,11 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
         lv = np.concatenate([lk["octave"], lk["octave"]])
         maxd = dist * wl.scale32[lv]            # f32 * f32, mirrored term by term in host/track_loop.cpp
         mind = maxd / wl.scale32[7]
-        fr = be.frustum(cur, Xw2, n.astype(np.float32), mind, maxd, wl.T, wl.K32)
         occ = (m1 >= 0).astype(np.uint8)
-        if fused:
-            m2, n2, _, _, ninl = be.track_local_map(cur, len(kps), fr, Xw2, occ, Xw[np.maximum(m1, 0)], 1.0, 0.8, wl.K32, wl.pose0)
+        fr = None if fused else be.frustum(cur, Xw2, n.astype(np.float32), mind, maxd, wl.T, wl.K32)
+        if fused:   # frustum test, level prediction and search windows on the device too (asd_track_local_points)
+            m2, n2, _, _, ninl = be.track_local_points(cur, len(kps), Xw2, n.astype(np.float32), mind, maxd, occ, Xw[np.maximum(m1, 0)],
+                                                       1.0, 0.8, wl.T, wl.K32, wl.pose0)
             stats["m2"] = int(n2)
             if ((m1 >= 0) | (m2 >= 0)).sum() >= 3:
                 stats["inliers"] = int(ninl)
@@ -413,8 +414,8 @@ class HipBackend:
     def track_motion_model(self, cur, last, n_cur, has, Xw, T, K, th, pose0):
         return self.hip.track_motion_model(cur, last, n_cur, has, Xw, self.rows[:len(has)], T, K, th, pose0, True)
 
-    def track_local_map(self, cur, n_cur, fr, mp_Xw, occ, cur_Xw, th, ratio, K, pose0):
-        return self.hip.track_local_map(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], mp_Xw, occ, cur_Xw, th, ratio, K, pose0)
+    def track_local_points(self, cur, n_cur, Xw, normal, mind, maxd, occ, cur_Xw, th, ratio, T, K, pose0):
+        return self.hip.track_local_points(cur, n_cur, Xw, normal, mind, maxd, self.rows[:len(Xw)], T, K, occ, cur_Xw, th, ratio, pose0)
 
     def local_ba(self, prob):
         return self.hip.local_ba(prob)
@@ -786,12 +787,15 @@ def main():
         if ("k_conv_x3" in tj.get("kernel", "")) == split:   # PMC figure of the kernel family that actually ran
             traffic = tj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/traffic_conv2.json (separate rocprofv3 --pmc passes via tools/collect_traffic.py; not measured in this run)"
+    pieces = be.hip.asdnet_pieces()
     if split:
-        # f32 work on the bf16 pipe: the ceiling for ALGORITHMIC f32 FLOP is the dense bf16 peak / 6 products
-        peak = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
-        roof_kernel = "k_conv_x3<32,32,32,1,8,4,1,1,true> (ASDNet input_norm+conv1+conv2; f32 operands split into 3 bf16 terms, 6 bf16 MFMA products per multiply-add, f32 accumulate)"
-        roof_extra = {"peak_basis": f"dense bf16 MFMA {PEAK_BF16_MFMA_TFLOPS} TFLOP/s / {SPLIT_PRODUCTS} products",
-                      "executed_bf16_tflops": SPLIT_PRODUCTS * achieved, "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+        # f32 work on the 16-bit matrix pipe: the ceiling for ALGORITHMIC f32 FLOP is the dense f16/bf16 peak / products per multiply-add
+        nprod = SPLIT_PRODUCTS[pieces]
+        form = "2 fp16 terms, 3 f16 MFMA products" if pieces == 2 else "3 bf16 terms, 6 bf16 MFMA products"
+        peak = PEAK_BF16_MFMA_TFLOPS / nprod
+        roof_kernel = f"k_conv_x3<32,32,32,1,8,4,1,1,true,{pieces}> (ASDNet input_norm+conv1+conv2; f32 operands split into {form} per multiply-add, f32 accumulate)"
+        roof_extra = {"peak_basis": f"dense f16/bf16 MFMA {PEAK_BF16_MFMA_TFLOPS} TFLOP/s / {nprod} products",
+                      "executed_16bit_tflops": nprod * achieved, "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
     else:
         peak = PEAK_F32_MFMA_TFLOPS
         roof_kernel = "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)"
@@ -810,8 +814,11 @@ def main():
                                    "isInFrustum+SearchByProjection(map)+PoseOptimization per frame, LocalBA "
                                    "(24+12 KF, 6000 MP, ~29k edges) every 15 frames",
                        "keypoints": int(stats.get("n_kp", 0)), "kf_interval": KF_INTERVAL,
-                       "asdnet_math": ("f32 results on the bf16 matrix pipe: every f32 operand = exact sum of 3 bf16 terms, 6 cross products, f32 accumulate "
-                                       "(error at the level of the f32 MFMA chain; ASD_ASDNET_MATH=f32 selects the f32 MFMA kernels)") if split
+                       "asdnet_math": (("f32 results on the f16 matrix pipe: every f32 operand = h + l in two fp16 terms (22 bits), products lh, hl, hh, f32 accumulate "
+                                        if pieces == 2 else
+                                        "f32 results on the bf16 matrix pipe: every f32 operand = exact sum of 3 bf16 terms, 6 cross products, f32 accumulate ") +
+                                       "(error against a float64 forward at the level of the f32 MFMA chain, tests/test_asdnet.py; "
+                                       "ASD_ASDNET_MATH=f16x2|bf16x3|f32 selects the kernels)") if split
                                       else "f32 MFMA (v_mfma_f32_32x32x2_f32)",
                        "parallelism": f"replicas x{world} (independent sequences, no collective)",
                        "host": "C++ host loop over the C ABI (asd-slam_amd/host/track_loop.cpp)" if args.host == "cxx" else "Python loop (ctypes)",

@@ -263,6 +263,22 @@ int asd_track_local_map_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const
                              const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur,
                              int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
 
+/* The same with Tracking::SearchLocalPoints' frustum loop (Tracking.cc:817-835) on the device as well: the map points are given
+ * as for asd_frustum (position, normal, raw mfMinDistance / mfMaxDistance) together with the frame pose Tcw they are projected
+ * with; isInFrustum, PredictScale (the level by comparison with thresholds derived from the host's logf: same value as libm's)
+ * and the search windows are computed on the device, then asd_track_local_map's chain runs.  Xw doubles as the position
+ * table of the new matches' edges. */
+int asd_track_local_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal,
+                           const float* min_dist, const float* max_dist, const float* desc, const float* Tcw, const float* K,
+                           float viewing_cos_limit, const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio,
+                           const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur, int32_t* n_matches,
+                           uint8_t* outlier, int32_t* n_inliers);
+int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal,
+                                const float* min_dist, const float* max_dist, const int32_t* rows, const float* Tcw,
+                                const float* K, float viewing_cos_limit, const uint8_t* occupied, const float* cur_Xw, float th,
+                                float nn_ratio, const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur,
+                                int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
+
 /* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
  * n map points: Xw[n][3], normal[n][3] (GetNormal), min_dist[n] / max_dist[n] = the map
  * point's raw mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors of
@@ -466,6 +482,13 @@ int asd_profile_get(asd_ctx* ctx, int32_t layer, double* total_ms, int32_t* call
  * see asdnet.hip); the others use v_mfma_f32_32x32x2_f32.  Chosen at asd_ctx_create: environment ASD_ASDNET_MATH=f32 clears
  * every bit, ASD_ASDNET_SPLIT_LAYERS=<mask> sets them individually; default all conv layers split. */
 int32_t asd_asdnet_split_mask(const asd_ctx* ctx);
+/* How the split-operand 3x3 conv kernels carry an f32 operand (chosen at asd_ctx_create by ASD_ASDNET_MATH):
+ *   2  ("f16x2", the default; "split" is an alias)  x 2^k = h + l with two fp16 terms (22 significant bits), the three products
+ *      l h, h l, h h accumulated in f32 on the f16 matrix pipe; against a float64 forward the descriptors are as close as those
+ *      of the f32 MFMA chain (tests/test_asdnet.py).  Activations must stay below 4094 in magnitude (BatchNorm keeps them O(1));
+ *      beyond that the descriptor comes out NaN, never silently wrong.
+ *   3  ("bf16x3")  exact sum of three bf16 terms, six products; no range restriction; 1.35x the ASDNet time of the default. */
+int32_t asd_asdnet_pieces(const asd_ctx* ctx);
 /* Raw handles for harnesses that keep inputs resident (bench.py): the ctx stream
  * (hipStream_t) and device scratch. */
 void* asd_ctx_stream(asd_ctx* ctx);
@@ -474,6 +497,10 @@ int asd_device_free(asd_ctx* ctx, void* dptr);
 int asd_memcpy_h2d(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int asd_memcpy_d2h(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int asd_sync(asd_ctx* ctx);
+/* Test aid: MapPoint::PredictScale (MapPoint.cc:438-453) is evaluated on the device by comparing the distance ratio with
+ * per-level thresholds derived from the host's logf at asd_ctx_create; this sweeps EVERY float in [lo, hi] and returns the
+ * number of ratios for which the comparison rule and ceil(logf(r) / logf(scaleFactor)) (clamped) disagree (expected 0). */
+int32_t asd_debug_level_sweep(const asd_ctx* ctx, float lo, float hi, int64_t* n_checked);
 /* Runs `reps` back-to-back repetitions of the ASDNet forward on resident buffers and
  * returns the average per-repetition device time (hipEvents on the ctx stream). */
 int asd_describe_timed(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc,

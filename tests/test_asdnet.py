@@ -33,10 +33,13 @@ def test_hip_matches_golden(hip, asdnet_golden):
 
 
 @pytest.mark.gpu
-def test_other_mfma_shape_build_matches_golden(pkg, synth, asdnet_golden, monkeypatch):
-    """build matrix: libasdhip_s32.so = the same sources with the split-operand kernels on v_mfma_f32_32x32x16_bf16
-    (ASD_X3_S16=0; the default is 16x16x32).  Same golden descriptors, same tolerance, and within 2e-6 of the default build."""
+@pytest.mark.parametrize("math", ["f16x2", "bf16x3"])
+def test_other_mfma_shape_build_matches_golden(pkg, synth, asdnet_golden, monkeypatch, math):
+    """build matrix: libasdhip_s32.so = the same sources with the split-operand kernels on the 32x32x16 MFMA shape
+    (ASD_X3_S16=0; the default is 16x16x32), in both operand forms.  Same golden descriptors, same tolerance, and within 2e-6
+    of the default build."""
     import os
+    monkeypatch.setenv("ASD_ASDNET_MATH", math)
     alt = os.path.join(os.path.dirname(pkg.lib_path()), "libasdhip_s32.so")
     assert os.path.exists(alt), "libasdhip_s32.so not built: run __graft_entry__.build()"
     monkeypatch.setenv("ASDHIP_LIB", alt)
@@ -48,7 +51,7 @@ def test_other_mfma_shape_build_matches_golden(pkg, synth, asdnet_golden, monkey
         layers = synth.asdnet_weights(int(g["weight_seed"]))
         other.load_weights(layers)
         base.load_weights(layers)
-        assert other.asdnet_split_mask() == 63
+        assert other.asdnet_split_mask() == 63 and other.asdnet_pieces() == (2 if math == "f16x2" else 3)
         a, b = other.describe(g["patches"]), base.describe(g["patches"])
         np.testing.assert_allclose(a, g["desc"], atol=DESC_ATOL, rtol=0)
         np.testing.assert_allclose(a, b, atol=2e-6, rtol=0)
@@ -127,12 +130,11 @@ def _f64_truth(synth, patches):
     return (x / torch.sqrt((x * x).sum(1, keepdim=True) + 1e-10)).numpy()
 
 
-@pytest.fixture(scope="module")
-def hip_f32(pkg):
-    """A second context with every ASDNet layer on the f32 MFMA kernels (ASD_ASDNET_MATH=f32 is read at context creation)."""
+def _ctx_with_math(pkg, mode):
+    """a context created under ASD_ASDNET_MATH=<mode> (the variable is read at context creation)"""
     import os
     old = os.environ.get("ASD_ASDNET_MATH")
-    os.environ["ASD_ASDNET_MATH"] = "f32"
+    os.environ["ASD_ASDNET_MATH"] = mode
     try:
         ctx = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096)
     finally:
@@ -141,6 +143,21 @@ def hip_f32(pkg):
         else:
             os.environ["ASD_ASDNET_MATH"] = old
     ctx.load_weights(pkg.synth.asdnet_weights(0))
+    return ctx
+
+
+@pytest.fixture(scope="module")
+def hip_f32(pkg):
+    """A second context with every ASDNet layer on the f32 MFMA kernels."""
+    ctx = _ctx_with_math(pkg, "f32")
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def hip_bf16x3(pkg):
+    """A context with conv2..conv6 on the three-piece bf16 form of the split-operand kernels (six products instead of three)."""
+    ctx = _ctx_with_math(pkg, "bf16x3")
     yield ctx
     ctx.close()
 
@@ -171,3 +188,59 @@ def test_split_operand_kernels_are_f32_accurate(hip, hip_f32, synth, asdnet_gold
     assert e_f32.max() < 2e-6 and e_split.max() < 2e-6
     assert np.sqrt((e_split ** 2).mean()) <= 1.5 * np.sqrt((e_f32 ** 2).mean()) + 1e-9
     assert np.abs(d_split - d_f32).max() < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", ["f16x2", "bf16x3"])
+def test_operand_forms_accuracy(hip, hip_f32, hip_bf16x3, synth, asdnet_golden, oracle, math):
+    """The two operand forms of the split kernels.  f16x2 (default): two fp16 pieces (22 significant bits), three MFMA products
+    per pair; bf16x3: three bf16 pieces (exact), six products.  Both are held to the same bar: inside the parity tolerance of the
+    oracle and the golden descriptors, and against a float64 forward an error of the f32 MFMA chain's size."""
+    ctx = hip if math == "f16x2" else hip_bf16x3
+    assert ctx.asdnet_pieces() == (2 if math == "f16x2" else 3)
+    patches = np.concatenate([asdnet_golden["patches"], synth.random_patches(192, seed=11)])
+    truth = _f64_truth(synth, patches)
+    d = ctx.describe(patches).astype(np.float64)
+    d_f32 = hip_f32.describe(patches).astype(np.float64)
+    e, e_f32 = np.abs(d - truth), np.abs(d_f32 - truth)
+    rms, rms32 = np.sqrt((e ** 2).mean()), np.sqrt((e_f32 ** 2).mean())
+    print("%s max %.3e rms %.3e | f32 max %.3e rms %.3e" % (math, e.max(), rms, e_f32.max(), rms32))
+    assert np.isfinite(d).all()
+    assert e.max() < 2e-6
+    assert rms <= 1.5 * rms32 + 1e-9
+    np.testing.assert_allclose(d[:len(asdnet_golden["patches"])], asdnet_golden["desc"], atol=DESC_ATOL, rtol=0)
+    for n in (1, 33):   # ragged counts
+        p = synth.random_patches(n, seed=300 + n)
+        np.testing.assert_allclose(ctx.describe(p), oracle.asdnet_forward(synth.asdnet_weights(0), p), atol=DESC_ATOL, rtol=0)
+
+
+@pytest.mark.gpu
+def test_f16x2_range_is_loud(pkg, synth):
+    """f16x2 carries activations * 16 in fp16: an activation beyond 4094 cannot be represented.  The kernels do not clamp: the
+    descriptor of such a patch is NaN (visible), and bf16x3 / f32 handle the same weights."""
+    import os
+    layers = [list(l) for l in synth.asdnet_weights(0)]
+    w0, m0, v0 = layers[0]
+    layers[0] = (np.asarray(w0) * np.float32(1e4), m0, v0)   # conv1 outputs ~1e4 x a normalised activation (BN variance left as is)
+    patches = synth.random_patches(8, seed=5)
+    ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    try:
+        ctx.load_weights(layers)
+        assert ctx.asdnet_pieces() == 2
+        assert np.isnan(ctx.describe(patches)).any()
+    finally:
+        ctx.close()
+    old = os.environ.get("ASD_ASDNET_MATH")
+    os.environ["ASD_ASDNET_MATH"] = "bf16x3"
+    try:
+        ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    finally:
+        if old is None:
+            del os.environ["ASD_ASDNET_MATH"]
+        else:
+            os.environ["ASD_ASDNET_MATH"] = old
+    try:
+        ctx.load_weights(layers)
+        assert np.isfinite(ctx.describe(patches)).all()
+    finally:
+        ctx.close()

@@ -138,3 +138,62 @@ def test_track_local_map_equals_separate_calls(hip, oracle, synth, n_mp, th):
     # oracle matcher on the same inputs
     om, onm = oracle.match_project_points(oracle.frame(kc, dc, BOUNDS), in_view, proj, level, vc, desc, occupied, th, 0.8)
     np.testing.assert_array_equal(got[0], om)
+
+
+@pytest.mark.gpu
+def test_predict_scale_thresholds_equal_logf(pkg):
+    """MapPoint::PredictScale (MapPoint.cc:438-453) on the device is a comparison of the distance ratio with thresholds found
+    with the host's logf at asd_ctx_create: EVERY float ratio in [0.2, 40] (all levels of a 1.2 pyramid and far beyond both
+    clamps) gives the level ceil(logf(r) / logf(scaleFactor)) gives -- also for other pyramids."""
+    for scale, levels in ((1.2, 8), (1.5, 5), (1.1, 12)):
+        h = pkg.AsdHip(n_features=500, scale_factor=scale, n_levels=levels, max_width=640, max_height=240, max_patches=1000)
+        try:
+            bad, n = h.debug_level_sweep(0.2, 40.0)
+            assert bad == 0 and n > 60_000_000
+        finally:
+            h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mp,th", [(4000, 1.0), (900, 3.0)])
+def test_track_local_points_equals_frustum_plus_chain(hip, oracle, synth, n_mp, th):
+    """asd_track_local_points (frustum test, level prediction and search windows on the device) against asd_frustum on the
+    host followed by asd_track_local_map: identical matches, pose bits and outlier flags -- i.e. the device wrote exactly the
+    queries the host would have written, for points in front of / behind the camera, outside the image, too near / far, with
+    a wrong viewing angle, and at every pyramid level"""
+    kc, dc = make_frame(2000, 290)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(291 + n_mp)
+    src = rng.integers(0, 2000, n_mp)
+    uv = np.stack([kc["x"][src], kc["y"][src]], 1) + rng.uniform(-1.5, 1.5, (n_mp, 2)).astype(np.float32)
+    uv[: n_mp // 12] += 2500                                   # outside the image
+    depth = rng.uniform(3, 60, n_mp)
+    depth[n_mp // 12: n_mp // 8] *= -1                         # behind the camera
+    Xw = backproject(T, K, uv, depth)
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    normal = Xw.astype(np.float64) - Ow
+    dist = np.linalg.norm(normal, axis=1)
+    normal = normal / dist[:, None] + rng.normal(0, 0.45, normal.shape)      # some beyond the 60 degree viewing cone
+    normal = (normal / np.linalg.norm(normal, axis=1, keepdims=True)).astype(np.float32)
+    maxd = (dist * SCALES[kc["octave"][src]] * rng.uniform(0.7, 1.4, n_mp)).astype(np.float32)   # all levels, some out of range
+    mind = (maxd / np.float32(SCALES[7]) * rng.uniform(0.8, 1.3, n_mp)).astype(np.float32)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    desc = perturbed_descriptors(dc[src], 0.05, 292)
+    occupied = (rng.uniform(size=2000) < 0.3).astype(np.uint8)
+    cur_Xw = backproject(T, K, np.stack([kc["x"], kc["y"]], 1) + rng.uniform(-0.7, 0.7, (2000, 2)).astype(np.float32), rng.uniform(4, 50, 2000))
+    pose0 = _pose7(pose_T(rv=(0.011, -0.021, 0.004), t=(0.09, -0.06, 0.31)))
+    in_view, proj, level, vc = hip.frustum(0, Xw, normal, mind, maxd, T, K)
+    oin, oproj, olevel, ovc = oracle.frustum(oracle.frame(kc, dc, BOUNDS), Xw, normal, mind, maxd, T, K)
+    np.testing.assert_array_equal(in_view, oin)
+    np.testing.assert_array_equal(level, olevel)
+    assert 0.2 * n_mp < in_view.sum() < 0.9 * n_mp and len(set(level[in_view > 0])) >= 6
+    exp = hip.track_local_map(0, 2000, in_view, proj, level, vc, desc, Xw, occupied, cur_Xw, th, 0.8, K, pose0)
+    got = hip.track_local_points(0, 2000, Xw, normal, mind, maxd, desc, T, K, occupied, cur_Xw, th, 0.8, pose0)
+    for a, b in zip(got, exp):
+        np.testing.assert_array_equal(a, b)
+    hip.bank_put(12000, desc)
+    gb = hip.track_local_points(0, 2000, Xw, normal, mind, maxd, np.arange(12000, 12000 + n_mp, dtype=np.int32), T, K, occupied, cur_Xw, th, 0.8, pose0)
+    for a, b in zip(gb, exp):
+        np.testing.assert_array_equal(a, b)
+    assert got[1] > 0 and got[4] > 100
