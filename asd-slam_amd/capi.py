@@ -535,7 +535,7 @@ class AsdHip:
                                              _p(outlier), C.byref(ninl)))
         return pose, outlier, ninl.value
 
-    def local_ba(self, prob, its_first=5, its_second=10):
+    def _ba_pack(self, prob, its_first, its_second):
         poses = _c(prob["poses"], np.float64).copy()
         points = _c(prob["points"], np.float64).copy()
         fixed = _c(prob["fixed"], np.uint8)
@@ -549,10 +549,37 @@ class AsdHip:
                            e_point.ctypes.data, e_pose.ctypes.data, e_obs.ctypes.data, e_info.ctypes.data,
                            (C.c_double * 4)(*[float(k) for k in prob["K"]]), its_first, its_second)
         r = asd_ba_result(chi2.ctypes.data, dpos.ctypes.data, out1.ctypes.data, 0.0, 0.0, 0, 0)
-        self._chk(self.lib.asd_local_ba(self.ctx, C.byref(p), C.byref(r)))
+        keep = (poses, points, fixed, e_point, e_pose, e_obs, e_info, chi2, dpos, out1)   # the structs hold raw addresses
+        return p, r, keep
+
+    @staticmethod
+    def _ba_unpack(r, keep):
+        poses, points, _f, _ep, _es, _eo, _ei, chi2, dpos, out1 = keep
         return dict(poses=poses, points=points, edge_chi2=chi2, edge_depth_pos=dpos, edge_outlier1=out1,
                     chi2_first=r.chi2_first, chi2_second=r.chi2_second, iters_first=r.iters_first,
                     iters_second=r.iters_second)
+
+    def local_ba(self, prob, its_first=5, its_second=10):
+        p, r, keep = self._ba_pack(prob, its_first, its_second)
+        self._chk(self.lib.asd_local_ba(self.ctx, C.byref(p), C.byref(r)))
+        return self._ba_unpack(r, keep)
+
+    def local_ba_submit(self, prob, its_first=5, its_second=10):
+        """LocalBundleAdjustment on the library's local-mapping lane (LocalMapping.cc:92 runs beside Tracking): returns at
+        once; local_ba_wait() returns the result dict.  One run at a time."""
+        p, r, keep = self._ba_pack(prob, its_first, its_second)
+        self._chk(self.lib.asd_local_ba_submit(self.ctx, C.byref(p), C.byref(r)))
+        self._ba_job = (p, r, keep)   # the library owns these until wait
+
+    def local_ba_wait(self):
+        rc = self.lib.asd_local_ba_wait(self.ctx)
+        job, self._ba_job = getattr(self, "_ba_job", None), None
+        self._chk(rc)
+        p, r, keep = job
+        return self._ba_unpack(r, keep)
+
+    def local_ba_poll(self):
+        return int(self.lib.asd_local_ba_poll(self.ctx))
 
     def tcw_to_pose7(self, T):
         T = _c(T, np.float32)

@@ -954,8 +954,18 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     AsyncExtract* ax = new AsyncExtract();
     hipStream_t sx = nullptr;
     auto build = [&]() -> int {
+      int reserve = 0;
+      if (const char* e = getenv("ASD_EXTRACT_RESERVE_CUS")) reserve = atoi(e);
+      if (reserve > 0 && reserve < ctx->num_cu) {   // measurement knob, see the note above
+        uint32_t mask[16] = {};
+        const int words = (ctx->num_cu + 31) / 32;
+        for (int cu = 0; cu < ctx->num_cu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
+        ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&sx, words, mask));
+        ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ax->stream_f, words, mask));
+      } else {
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_mid));
+      }
       ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners));
       for (int i = 0; i < kSlots; ++i) {
         int r;

@@ -35,6 +35,14 @@ struct asd_track_handle {
   asd_ba_problem ba;  // pristine problem (host arrays owned by the caller), copied per LocalBA call
   int kf_interval, lookahead;
   bool fused = true;  // asd_track_motion_model / asd_track_local_map (one submission per stage) instead of matcher + solver calls
+  // LocalBA on the library's local-mapping lane (asd_local_ba_submit / _wait), the way the reference runs it on its LocalMapping
+  // thread beside Tracking (LocalMapping.cc:92): submitted at the keyframe, collected before the next submission and at the end
+  // of every asd_track_run, so a run contains all of the LocalBA work it started.
+  bool async_ba = true;
+  bool ba_out = false;      // a submission is outstanding
+  long ba_step = -1;        // the step that submitted it
+  asd_ba_problem ba_p;
+  asd_ba_result ba_r;
   // state
   int slot = 0;
   std::deque<int> pending;  // frame indices of outstanding submissions, oldest first
@@ -80,6 +88,19 @@ asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* c
 }
 
 void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on != 0; }
+void asd_track_set_async_ba(asd_track_handle* h, int32_t on) { if (h) h->async_ba = on != 0; }
+
+// collect the outstanding LocalBA; its chi2 goes into *st only when the step that submitted it is the one st describes
+static int collect_ba(asd_track_handle* h, asd_track_stats* st, long st_step) {
+  if (!h->ba_out) return ASD_OK;
+  const auto b0 = std::chrono::steady_clock::now();
+  const int rc = asd_local_ba_wait(h->ctx);
+  h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
+  h->ba_out = false;
+  if (rc != ASD_OK) return rc;
+  if (st && st_step == h->ba_step) { st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1; }
+  return ASD_OK;
+}
 
 void asd_track_destroy(asd_track_handle* h) {
   if (!h) return;
@@ -88,6 +109,7 @@ void asd_track_destroy(asd_track_handle* h) {
     (void)asd_extract_wait_view(h->ctx, &k, &d, &n);
     h->pending.pop_front();
   }
+  (void)collect_ba(h, nullptr, -1);
   if (getenv("ASD_TIMING") && h->steps)
   {
     fprintf(stderr, "[track_loop] steps %ld  extract wait %.3f ms/step  local BA %.3f ms/step\n", h->steps, h->wait_ms / h->steps,
@@ -286,19 +308,25 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     }
   }
   if (do_ba) {
+    if ((rc = collect_ba(h, nullptr, -1)) != ASD_OK) return rc;   // the previous keyframe's run (its buffers are reused below)
     const asd_ba_problem& B = h->ba;
     h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
     h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);
     h->ba_chi2.assign(B.n_edges, 0.0); h->ba_dpos.assign(B.n_edges, 0); h->ba_out1.assign(B.n_edges, 0);
-    asd_ba_problem p = B;
-    p.poses = h->ba_poses.data(); p.points = h->ba_points.data();
-    asd_ba_result r;
-    memset(&r, 0, sizeof r);
-    r.edge_chi2 = h->ba_chi2.data(); r.edge_depth_pos = h->ba_dpos.data(); r.edge_outlier1 = h->ba_out1.data();
+    h->ba_p = B;
+    h->ba_p.poses = h->ba_poses.data(); h->ba_p.points = h->ba_points.data();
+    memset(&h->ba_r, 0, sizeof h->ba_r);
+    h->ba_r.edge_chi2 = h->ba_chi2.data(); h->ba_r.edge_depth_pos = h->ba_dpos.data(); h->ba_r.edge_outlier1 = h->ba_out1.data();
     const auto b0 = std::chrono::steady_clock::now();
-    if ((rc = asd_local_ba(ctx, &p, &r)) != ASD_OK) return rc;
+    if (h->async_ba) {
+      if ((rc = asd_local_ba_submit(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
+      h->ba_out = true;
+      h->ba_step = h->steps;
+    } else {
+      if ((rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
+      st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
+    }
     h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
-    st->ba_chi2 = r.chi2_second; st->has_ba = 1;
   }
   seg(7);
   h->last_kps.assign(kps, kps + n);
@@ -320,7 +348,7 @@ int asd_track_run(asd_track_handle* h, int32_t t0, int32_t n, int32_t prefetch_b
     const int rc = track_step(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats);
     if (rc != ASD_OK) return rc;
   }
-  return ASD_OK;
+  return collect_ba(h, stats, h->steps - 1);   // the run ends with its LocalBA finished (and reported if the last step started it)
 }
 
 }  // extern "C"

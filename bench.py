@@ -268,8 +268,15 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
                 _, _, ninl = be.pose_opt(wl.pose0, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
                 stats["inliers"] = int(ninl)
     if do_ba:
-        r = be.local_ba(wl.ba)
-        stats["ba_chi2"] = float(r["chi2_second"])
+        if getattr(be, "async_ba", False):
+            # LocalBA on the library's local-mapping lane (the reference runs it on the LocalMapping thread beside Tracking,
+            # LocalMapping.cc:92): submitted here, collected before the next submission and at the end of the run
+            be.local_ba_collect()
+            be.local_ba_submit(wl.ba)
+            stats["ba_submitted"] = True
+        else:
+            r = be.local_ba(wl.ba)
+            stats["ba_chi2"] = float(r["chi2_second"])
     return (kps, desc, cur), stats
 
 
@@ -316,6 +323,7 @@ class NativeHost:
         if not self.h:
             raise RuntimeError("asd_track_create failed")
         self.lib.asd_track_set_fused(self.h, int(getattr(be, "fused", True)))
+        self.lib.asd_track_set_async_ba(self.h, int(getattr(be, "async_ba", True)))
         self.be = be
 
     def run(self, t0, n, prefetch_beyond):
@@ -357,6 +365,8 @@ class HipBackend:
         self.pending = []          # handles of submitted, not yet waited extractions (in order)
         self.pipeline = pipeline
         self.fused = True          # asd_track_motion_model / asd_track_local_map instead of matcher + solver calls
+        self.async_ba = True       # LocalBA on the local-mapping lane (asd_local_ba_submit / _wait) instead of in line
+        self.ba_out = False
 
     def image(self, t):
         return self.d_frames[t % len(self.d_frames)]
@@ -420,10 +430,21 @@ class HipBackend:
     def local_ba(self, prob):
         return self.hip.local_ba(prob)
 
+    def local_ba_submit(self, prob):
+        self.hip.local_ba_submit(prob)
+        self.ba_out = True
+
+    def local_ba_collect(self):
+        if not self.ba_out:
+            return None
+        self.ba_out = False
+        return self.hip.local_ba_wait()
+
     def close(self):
         if getattr(self, "native", None) is not None:
-            self.native.close()      # drains its own read-ahead queue
+            self.native.close()      # drains its own read-ahead queue and LocalBA lane
         self.drain()
+        self.local_ba_collect()
         self.hip.close()
 
 
@@ -492,6 +513,11 @@ def run_steps_python(be, wl, t0, n, last, prefetch_beyond=False):
         t = t0 + i
         nxt = [be.image(t + k) for k in range(1, LOOKAHEAD + 1) if (i + k < n or prefetch_beyond)]
         last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1), next_handles=nxt)
+    if getattr(be, "async_ba", False):   # the run ends with its LocalBA finished (and reported if the last step started it)
+        r = be.local_ba_collect()
+        if stats.pop("ba_submitted", False) and r is not None:
+            stats["ba_chi2"] = float(r["chi2_second"])
+    stats.pop("ba_submitted", None)
     return last, stats
 
 
@@ -719,6 +745,7 @@ def main():
     ap.add_argument("--workload", choices=["kitti-mono", "euroc-stereo"], default="kitti-mono",
                     help="kitti-mono = the headline configuration (BASELINE configs[2]); euroc-stereo = configs[3], a secondary line")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
+    ap.add_argument("--sync-ba", action="store_true", help="LocalBA in line with tracking (asd_local_ba) instead of on the local-mapping lane (asd_local_ba_submit / _wait)")
     ap.add_argument("--no-fuse", action="store_true", help="matcher and PoseOptimization as separate calls (two host round trips per stage)")
     ap.add_argument("--host", choices=["cxx", "python"], default="cxx",
                     help="who drives the per-frame step: C++ host code over the C ABI (default, as in the reference) or the Python loop")
@@ -748,6 +775,7 @@ def main():
     wl = Workload(pkg.synth, seed_offset=rank)
     be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
     be.fused = not args.no_fuse
+    be.async_ba = not args.sync_ba
     be.native = None
     if args.host == "cxx":
         try:
@@ -822,6 +850,9 @@ def main():
                                       else "f32 MFMA (v_mfma_f32_32x32x2_f32)",
                        "parallelism": f"replicas x{world} (independent sequences, no collective)",
                        "host": "C++ host loop over the C ABI (asd-slam_amd/host/track_loop.cpp)" if args.host == "cxx" else "Python loop (ctypes)",
+                       "local_ba": ("in line with tracking (asd_local_ba)" if args.sync_ba else
+                                    "on the library's local-mapping lane (asd_local_ba_submit at the keyframe, own thread + stream, the reference's "
+                                    "LocalMapping thread, LocalMapping.cc:92); every run is collected inside the timed region"),
                        "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t)" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": roof_kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

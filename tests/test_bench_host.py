@@ -20,15 +20,16 @@ def _bench():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline,fused", [(True, True), (False, True), (True, False)])
-def test_cxx_host_equals_python_host(pkg, pipeline, fused):
+@pytest.mark.parametrize("pipeline,fused,async_ba", [(True, True, True), (False, True, True), (True, False, True), (True, True, False)])
+def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba):
     """fused: the stages run as asd_track_motion_model / asd_track_local_map (one submission each, bench default) or as
-    matcher + PoseOptimization calls (--no-fuse)"""
+    matcher + PoseOptimization calls (--no-fuse); async_ba: LocalBA on the local-mapping lane (default) or in line (--sync-ba)"""
     bench = _bench()
     wl = bench.Workload(pkg.synth)
     n = bench.KF_INTERVAL + 3          # crosses one LocalBA
     py = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
     py.fused = fused
+    py.async_ba = async_ba
     try:
         last, ref = None, []
         for t in range(n):
@@ -38,6 +39,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused):
         py.close()
     cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
     cx.fused = fused
+    cx.async_ba = async_ba
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         got = [cx.native.run(t, 1, True) for t in range(n)]
@@ -49,6 +51,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused):
     # one call over the whole range gives the same final state as frame-by-frame calls
     cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
     cx.fused = fused
+    cx.async_ba = async_ba
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         whole = cx.native.run(0, n, True)

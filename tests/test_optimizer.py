@@ -219,6 +219,44 @@ def test_hip_local_ba_edge_cases(hip, oracle, synth):
 
 
 @pytest.mark.gpu
+def test_local_ba_lane_equals_inline_and_runs_beside_tracking(hip, synth):
+    """asd_local_ba_submit / _wait: LocalBundleAdjustment on the library's local-mapping lane (the reference calls it from the
+    LocalMapping thread while Tracking goes on, LocalMapping.cc:92).  Same kernels in the same order on another stream:
+    bit-identical to asd_local_ba -- also with PoseOptimization calls of the tracking side running meanwhile -- and the
+    one-run-at-a-time rules of the header are enforced."""
+    prob = synth.ba_problem()
+    inline = hip.local_ba(prob)
+    assert hip.local_ba_poll() == 0
+    with pytest.raises(Exception):
+        hip.local_ba_wait()                     # nothing submitted
+    pr = synth.pose_problem(n=2000, seed=0, outlier_frac=0.1)
+    ref_pose = hip.pose_optimize(pr["pose"], pr["Xw"], pr["obs"], pr["info"], pr["K"])
+    hip.local_ba_submit(prob)
+    assert hip.local_ba_poll() in (1, 2)
+    with pytest.raises(Exception):
+        hip.local_ba_submit(prob)               # one run at a time
+    with pytest.raises(Exception):
+        hip.local_ba(prob)                      # the solver's buffers are in use
+    during = [hip.pose_optimize(pr["pose"], pr["Xw"], pr["obs"], pr["info"], pr["K"]) for _ in range(8)]   # tracking side, meanwhile
+    got = hip.local_ba_wait()
+    assert hip.local_ba_poll() == 0
+    for k in ("poses", "points", "edge_chi2", "edge_depth_pos", "edge_outlier1"):
+        np.testing.assert_array_equal(got[k], inline[k])
+    assert (got["iters_first"], got["iters_second"], got["chi2_second"]) == (inline["iters_first"], inline["iters_second"], inline["chi2_second"])
+    for d in during:
+        np.testing.assert_array_equal(d[0], ref_pose[0])
+        np.testing.assert_array_equal(d[1], ref_pose[1])
+    # an invalid problem is refused at submit, and the lane stays usable
+    bad = dict(prob)
+    bad["e_pose"] = prob["e_pose"].copy(); bad["e_pose"][0] = 99
+    with pytest.raises(Exception):
+        hip.local_ba_submit(bad)
+    hip.local_ba_submit(prob)
+    again = hip.local_ba_wait()
+    np.testing.assert_array_equal(again["poses"], inline["poses"])
+
+
+@pytest.mark.gpu
 def test_hip_pose_conversions(hip, oracle, synth):
     rng = np.random.default_rng(5)
     for _ in range(20):

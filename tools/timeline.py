@@ -34,3 +34,30 @@ for a, b in zip(frames[-20:-1], frames[-19:]):
     per.append((tr[b]["s"] - tr[a]["s"]) / 1e3)
     busy.append(sum(r["e"] - r["s"] for r in tr[a:b]) / 1e3)
 print(f"last {len(per)} frames: period {sum(per) / len(per):.1f} us, kernels on the tracking stream {sum(busy) / len(busy):.1f} us, gaps {sum(per) / len(per) - sum(busy) / len(busy):.1f} us")
+
+# frames that ran beside a LocalBA (any k_ba_* kernel of another queue inside the frame's span) against those that did not
+ba = sorted((r["s"], r["e"]) for r in rows if r["n"].startswith("k_ba_"))
+if ba:
+    import bisect
+    bs = [b[0] for b in ba]
+    with_ba, without = [], []
+    for a, b in zip(frames[2:-1], frames[3:]):
+        t_a, t_b = tr[a]["s"], tr[b]["s"]
+        k = bisect.bisect_left(bs, t_a)
+        n_ba = 0
+        while k < len(ba) and ba[k][0] < t_b:
+            n_ba += 1
+            k += 1
+        (with_ba if n_ba else without).append(((t_b - t_a) / 1e3, n_ba, sum(r["e"] - r["s"] for r in tr[a:b]) / 1e3, (a, b)))
+    if with_ba and without:
+        med = lambda v: sorted(v)[len(v) // 2]
+        print(f"frames beside LocalBA kernels: {len(with_ba)}, median period {med([p for p, _, _, _ in with_ba]):.1f} us "
+              f"(tracking kernels {med([k for _, _, k, _ in with_ba]):.1f} us, {sum(n for _, n, _, _ in with_ba) / len(with_ba):.0f} BA kernels inside); "
+              f"other frames: {len(without)}, median period {med([p for p, _, _, _ in without]):.1f} us "
+              f"(tracking kernels {med([k for _, _, k, _ in without]):.1f} us)")
+        names = sorted({r["n"] for r in tr})
+        for nm in names:
+            a = [r["e"] - r["s"] for _, _, _, (x, y) in with_ba for r in tr[x:y] if r["n"] == nm]
+            b = [r["e"] - r["s"] for _, _, _, (x, y) in without for r in tr[x:y] if r["n"] == nm]
+            if a and b:
+                print(f"   {nm:36s} beside BA {sum(a) / len(a) / 1e3:7.1f} us x{len(a) / len(with_ba):.1f}   alone {sum(b) / len(b) / 1e3:7.1f} us x{len(b) / len(without):.1f}")
