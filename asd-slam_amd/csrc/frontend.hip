@@ -936,15 +936,16 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   if (rc != ASD_OK) return rc;
   (void)hipSetDevice(ctx->cfg.device);
   if (!ctx->ax) {
-    // lowest stream priority for ASDNet: the latency-critical tracking kernels on ctx->stream go first; the small
-    // front-half kernels get the middle priority so they slot in between the conv workgroups.
-    // (Keeping 4 / 8 / 16 / 32 CUs out of these streams with hipExtStreamCreateWithCUMask, so that the tracking kernels
-    //  always find a free one, was measured three times.  With the split-operand ASDNet: PoseOptimization of the
-    //  local-map stage drops from 0.31 to 0.18 ms device time -- its workgroup no longer waits for a CU -- but a masked
-    //  stream runs ASDNet 9 % slower whatever the mask (0.80 -> 0.88 ms), which puts the extractor back on the critical
-    //  path: 720-750 frames/s either way.  Round 2, ASDNet at 0.80 ms with 0.5 ms of slack: reserving 8 / 16 / 32 CUs gives
-    //  711 / 722 / 750 frames/s against 757 without a mask -- the masked ASDNet takes 0.87-0.88 ms and the tracking kernels
-    //  do not get faster by more than that costs.)
+    // Without a CU mask: lowest stream priority for ASDNet (the latency-critical tracking kernels on ctx->stream go first), the
+    // small front-half kernels get the middle priority so they slot in between the conv workgroups.  Default:
+    // 16 CUs are kept out of both streams (hipExtStreamCreateWithCUMask; ASD_EXTRACT_RESERVE_CUS=<n> changes the number, 0 = no
+    // mask and stream priorities instead): the tracking stream's single-workgroup kernels want 70-100 KB of LDS on one CU, and with
+    // ASDNet workgroups (50-70 KB each, two or three per CU) refilling every CU as soon as one drains they wait tens of
+    // microseconds for a CU with enough free LDS.  History of this measurement: with the six-product ASDNet (0.80 ms) on the
+    // critical path, a masked stream ran ASDNet 9 % slower whatever the mask and frames/s did not move (round 1: 720-750 either
+    // way; round 2: 711 / 722 / 750 with 8 / 16 / 32 CUs reserved against 757 without).  With the three-product ASDNet (0.62 ms, the
+    // extractor has slack) and LocalBA on its own lane the tracking chain is the critical path, and the reservation pays:
+    // 958-960 frames/s without, 991 / 1000-1015 / 1013 with 8 / 16 / 32 CUs reserved (ASDNet 0.61 -> 0.65-0.67 ms).
     // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
     // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
     // will ever take (asd_extract_wait would block forever).
@@ -954,9 +955,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     AsyncExtract* ax = new AsyncExtract();
     hipStream_t sx = nullptr;
     auto build = [&]() -> int {
-      int reserve = 0;
+      int reserve = 16;
       if (const char* e = getenv("ASD_EXTRACT_RESERVE_CUS")) reserve = atoi(e);
-      if (reserve > 0 && reserve < ctx->num_cu) {   // measurement knob, see the note above
+      if (reserve > 0 && reserve < ctx->num_cu / 2) {
         uint32_t mask[16] = {};
         const int words = (ctx->num_cu + 31) / 32;
         for (int cu = 0; cu < ctx->num_cu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);

@@ -42,10 +42,12 @@ def main():
         busy = sum(a for a, _ in m) / max(len(m), 1)
         flop = [f for p, f in FLOP.items() if k.startswith(p)]
         split = "k_conv_x3" in k or "k_fc_x3" in k
-        # f32 MFMA 32x32x2: 4096 FLOP, 64 cycles; bf16 MFMA 32x32x16: 32768 FLOP, 32 cycles, six per f32-equivalent chunk
-        n_mfma = (6 * n * flop[0] / 32768 if split else n * flop[0] / 4096) if flop else 0
+        # f32 MFMA 32x32x2: 4096 FLOP, 64 cycles; 16-bit MFMA 32x32x16 (or two 16x16x32): 32768 FLOP, 32 cycles; per f32-equivalent
+        # chunk the split kernels issue six products (three bf16 pieces) or three (two fp16 pieces: last template argument 2)
+        products = 3 if re.search(r",\s*2>$", k.strip()) else 6
+        n_mfma = (products * n * flop[0] / 32768 if split else n * flop[0] / 4096) if flop else 0
         out[k] = {"avg_us": dur / 1e3, "effective_clock_GHz": ga / 8 / dur, "SQ_VALU_MFMA_BUSY_CYCLES": busy,
-                  "expected_busy_cycles": (32 if split else 64) * n_mfma, "mfma_busy_fraction": busy / (ga / 8 * 1024),
+                  "products_per_multiply_add": products if split else 1, "expected_busy_cycles": (32 if split else 64) * n_mfma, "mfma_busy_fraction": busy / (ga / 8 * 1024),
                   "tflops": (n * flop[0] / (dur * 1e-9) / 1e12) if flop else None}
     print(json.dumps({"n_patches": n, "kernels": out,
                       "source": "rocprofv3 --pmc GRBM_GUI_ACTIVE / --pmc SQ_VALU_MFMA_BUSY_CYCLES (separate passes), tools/time_asdnet.py"}, indent=1))
