@@ -295,8 +295,9 @@ class AsdHip:
         return out, n.value
 
     # ---- fused tracking chains (search + claim replay + PoseOptimization, one synchronisation)
-    def track_motion_model(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_desc_or_rows, Tcw, K, th, pose7, check_ori=True, obs_positive=None):
-        """mp_desc_or_rows: float [n][128] descriptors or int32 bank rows.  -> (match_cur, n_matches, pose7, outlier, n_inliers)"""
+    def track_motion_model(self, slot_cur, slot_last, n_cur, has_mp, Xw, mp_desc_or_rows, Tcw, K, th, pose7, check_ori=True, obs_positive=None, split=False):
+        """mp_desc_or_rows: float [n][128] descriptors or int32 bank rows.  -> (match_cur, n_matches, pose7, outlier, n_inliers);
+        split=True: asd_track_async + the call (returns None once the work is enqueued), track_finish() returns the tuple"""
         has_mp, Xw, Tcw, K = _c(has_mp, np.uint8), _c(Xw, np.float32), _c(Tcw, np.float32), _c(K, np.float32)
         d = np.asarray(mp_desc_or_rows)
         bank = d.dtype.kind in "iu"
@@ -305,12 +306,17 @@ class AsdHip:
         pose = _c(pose7, np.float64).copy()
         n, ninl = C.c_int32(), C.c_int32()
         fn = self.lib.asd_track_motion_model_bank if bank else self.lib.asd_track_motion_model
+        if split:
+            self._chk(self.lib.asd_track_async(self.ctx))
         self._chk(fn(self.ctx, slot_cur, slot_last, _p(has_mp), _p(Xw), _p(d), _p(Tcw), _p(K), C.c_float(th), int(check_ori),
                      _p(None if obs_positive is None else _c(obs_positive, np.uint8)), _p(pose), _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        if split:
+            self._track_job = (match, n, pose, outl, ninl, n_cur)   # the library writes these at track_finish
+            return None
         return match, n.value, pose, outl[:n_cur], ninl.value
 
     def track_local_map(self, slot_cur, n_cur, in_view, proj, level, view_cos, desc_or_rows, mp_Xw, occupied, cur_Xw, th, nn_ratio, K, pose7,
-                        obs_positive=None):
+                        obs_positive=None, split=False):
         in_view, proj, level = _c(in_view, np.uint8), _c(proj, np.float32), _c(level, np.int32)
         view_cos, mp_Xw, occupied, cur_Xw, K = _c(view_cos, np.float32), _c(mp_Xw, np.float32), _c(occupied, np.uint8), _c(cur_Xw, np.float32), _c(K, np.float32)
         d = np.asarray(desc_or_rows)
@@ -320,13 +326,18 @@ class AsdHip:
         pose = _c(pose7, np.float64).copy()
         n, ninl = C.c_int32(), C.c_int32()
         fn = self.lib.asd_track_local_map_bank if bank else self.lib.asd_track_local_map
+        if split:
+            self._chk(self.lib.asd_track_async(self.ctx))
         self._chk(fn(self.ctx, slot_cur, len(in_view), _p(in_view), _p(proj), _p(level), _p(view_cos), _p(d), _p(mp_Xw), _p(occupied), _p(cur_Xw),
                      C.c_float(th), C.c_float(nn_ratio), _p(None if obs_positive is None else _c(obs_positive, np.uint8)), _p(K), _p(pose),
                      _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        if split:
+            self._track_job = (match, n, pose, outl, ninl, n_cur)   # the library writes these at track_finish
+            return None
         return match, n.value, pose, outl[:n_cur], ninl.value
 
     def track_local_points(self, slot_cur, n_cur, Xw, normal, min_dist, max_dist, desc_or_rows, Tcw, K, occupied, cur_Xw, th, nn_ratio, pose7,
-                           cos_limit=0.5, obs_positive=None):
+                           cos_limit=0.5, obs_positive=None, split=False):
         """frustum test + windows + search + claims + PoseOptimization in one submission"""
         Xw, normal, min_dist, max_dist = (_c(a, np.float32) for a in (Xw, normal, min_dist, max_dist))
         Tcw, K, occupied, cur_Xw = _c(Tcw, np.float32), _c(K, np.float32), _c(occupied, np.uint8), _c(cur_Xw, np.float32)
@@ -337,9 +348,22 @@ class AsdHip:
         pose = _c(pose7, np.float64).copy()
         n, ninl = C.c_int32(), C.c_int32()
         fn = self.lib.asd_track_local_points_bank if bank else self.lib.asd_track_local_points
+        if split:
+            self._chk(self.lib.asd_track_async(self.ctx))
         self._chk(fn(self.ctx, slot_cur, len(min_dist), _p(Xw), _p(normal), _p(min_dist), _p(max_dist), _p(d), _p(Tcw), _p(K), C.c_float(cos_limit),
                      _p(occupied), _p(cur_Xw), C.c_float(th), C.c_float(nn_ratio), _p(None if obs_positive is None else _c(obs_positive, np.uint8)),
                      _p(pose), _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        if split:
+            self._track_job = (match, n, pose, outl, ninl, n_cur)   # the library writes these at track_finish
+            return None
+        return match, n.value, pose, outl[:n_cur], ninl.value
+
+    def track_finish(self):
+        """completes the asd_track_* call started with split=True -> (match_cur, n_matches, pose7, outlier, n_inliers)"""
+        rc = self.lib.asd_track_finish(self.ctx)
+        job, self._track_job = getattr(self, "_track_job", None), None
+        self._chk(rc)
+        match, n, pose, outl, ninl, n_cur = job
         return match, n.value, pose, outl[:n_cur], ninl.value
 
     def debug_level_sweep(self, lo, hi):

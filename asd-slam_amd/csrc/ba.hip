@@ -1294,6 +1294,7 @@ extern "C" {
 
 int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, const double* obs,
                       const double* inv_sigma2, const double* K, uint8_t* outlier, int32_t* n_inliers) {
+  if (ctx && asd_track_busy(ctx, "asd_pose_optimize")) return ASD_ERR_INVALID;
   if (!ctx || !pose7 || n < 0 || !K || !n_inliers || (n > 0 && (!Xw || !obs || !inv_sigma2 || !outlier))) return ASD_ERR_INVALID;
   for (int i = 0; i < n; ++i) outlier[i] = 0;
   if (n < 3) { *n_inliers = 0; return ASD_OK; }  // Optimizer.cc:323-324

@@ -381,3 +381,10 @@ int asd_pose7_to_tcw(const double* p, float* T) {
 }
 
 }  // extern "C"
+
+bool asd_track_busy(asd_ctx* ctx, const char* who) {
+  if (!ctx->track_has_pending) return false;
+  ctx->set_error("%s: an asd_track_* call started with asd_track_async is outstanding -- asd_track_finish first (meanwhile only asd_extract_submit/"
+                 "wait*, asd_frame_set on another slot, asd_bank_put* and asd_local_ba_submit/wait/poll may be called)", who);
+  return true;
+}

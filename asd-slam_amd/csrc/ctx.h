@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -143,6 +144,9 @@ struct asd_ctx {
   // ---- per-call device workspace (see AsdDevBuf)
   AsdDevBuf scratch;
   AsdXfer up, down;   // per-call upload / result blocks of the tracking entry points (one copy each way)
+  // asd_track_async / asd_track_finish: the completion of an asd_track_* call that returned after enqueueing its work
+  bool track_async_armed = false, track_has_pending = false;
+  std::function<int()> track_pending;
 
   // ---- local-mapping scratch (state private to mapping.hip)
   void* mapping = nullptr;
@@ -193,6 +197,9 @@ void frontend_async_shutdown(asd_ctx* ctx);
 // true while submissions of asd_extract_submit have not been waited for: the worker thread owns the shared pyramid / score /
 // blur buffers and the ASDNet activations then, and the synchronous entry points that use them must refuse to run
 bool asd_extractor_busy(asd_ctx* ctx, const char* who);
+// true (+ error message) while an asd_track_* call armed with asd_track_async has not been finished: its upload / result blocks,
+// the matcher's candidate buffers and the pose solver's staging are in use
+bool asd_track_busy(asd_ctx* ctx, const char* who);
 // matcher.hip / ba.hip
 void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);

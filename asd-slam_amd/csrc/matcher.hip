@@ -20,7 +20,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <array>
 #include <functional>
+#include <memory>
 
 #include "ctx.h"
 
@@ -674,6 +676,7 @@ struct SearchResult { const int* off; const int* cnt; const int* idx; const floa
 // queries are already in m->h_queries[0..nq); d_q = query descriptor table on the device
 // kind: 0 frame-to-frame, 1 local map, 2 fuse, 3 other -- only sizes the speculative read-back
 int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, SearchResult* res, int kind = 3) {
+  if (asd_track_busy(ctx, "matcher call")) return ASD_ERR_INVALID;
   static const bool timing = getenv("ASD_TIMING") != nullptr;   // per-kind host-side split, printed every 200 searches
   static double tacc[4][3]; static long tcalls[4];
   const auto tw0 = std::chrono::steady_clock::now();
@@ -761,39 +764,51 @@ struct ChainHook {
 template <int KIND>
 int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, const float* d_q, const float4* kp_last,
                        const uint8_t* obs_pos, const uint8_t* occupied, int check_ori, float nn_ratio, int32_t* match_cur,
-                       int32_t* n_matches, ChainHook* chain = nullptr) {
+                       int32_t* n_matches, ChainHook* chain = nullptr, std::function<int()>* defer = nullptr) {
   // One upload block (queries, the zeroed candidate counter, flags, the chain's tables), the kernels back to back, one result
   // block (match table, counters, the chain's results), one synchronisation: a copy costs 15-25 us on this stream whatever
   // its size (rocprof timeline), five of them per call were a third of the call.
+  // Split in two: `attempt` enqueues everything (inputs are consumed: they live in the pinned upload block from then on),
+  // `complete` synchronises, handles a candidate-buffer overflow (grow, enqueue again) and unpacks.  With `defer` the caller gets
+  // `complete` back instead of having it run (asd_track_async / asd_track_finish); `chain` must then outlive it.
+  if (asd_track_busy(ctx, "matcher call")) return ASD_ERR_INVALID;
   int rc = ensure_cands(ctx, m, 1);
   if (rc != ASD_OK) return rc;
   hipStream_t st = ctx->stream;
   const int n_cur = F.n;
-  AsdXfer &up = ctx->up, &down = ctx->down;
-  size_t extra = 0;
-  if (chain) for (int i = 0; i < kChainTabs; ++i) extra += chain->bytes[i] + 256;
-  ASD_HIP_CHECK(ctx, up.begin(st, (size_t)nq * sizeof(WinQuery) + 256 + (size_t)nq + (size_t)n_cur + 1024 + extra));
-  ASD_HIP_CHECK(ctx, down.begin(st, ((size_t)n_cur + 16) * sizeof(int) + 256 + (chain ? chain->result_bytes : 0)));
-  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4)));
+  const AsdFrameSlot* Fp = &F;
+  {
+    AsdXfer &up = ctx->up, &down = ctx->down;
+    size_t extra = 0;
+    if (chain) for (int i = 0; i < kChainTabs; ++i) extra += chain->bytes[i] + 256;
+    ASD_HIP_CHECK(ctx, up.begin(st, (size_t)nq * sizeof(WinQuery) + 256 + (size_t)nq + (size_t)n_cur + 1024 + extra));
+    ASD_HIP_CHECK(ctx, down.begin(st, ((size_t)n_cur + 16) * sizeof(int) + 256 + (chain ? chain->result_bytes : 0)));
+    ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4)));
+  }
   int* d_pick = ctx->scratch.carve<int>(nq);
   const bool dev_queries = chain && chain->prepare;
-  const size_t o_q = dev_queries ? up.reserve((size_t)nq * sizeof(WinQuery)) : up.add(m->h_queries, (size_t)nq * sizeof(WinQuery));
-  const size_t o_total = up.zeros(sizeof(int));
-  const size_t o_obs = obs_pos ? up.add(obs_pos, nq) : 0;
-  const size_t o_occ = KIND == 1 ? up.add(occupied, n_cur) : 0;
-  size_t o_tab[kChainTabs] = {};
-  if (chain) for (int i = 0; i < kChainTabs; ++i) if (chain->src[i]) o_tab[i] = up.add(chain->src[i], chain->bytes[i]);
-  const size_t o_out = down.reserve(((size_t)n_cur + 16) * sizeof(int));
-  const size_t o_res = chain ? down.reserve(chain->result_bytes) : 0;
-  int* d_out = down.dev<int>(o_out);
-  const int* h_out = down.host<int>(o_out);
-  int* d_off = m->d_q_off;
-  int* d_cnt = m->d_q_off + nq;
-  int* d_total = up.dev<int>(o_total);
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  const size_t o_q = dev_queries ? ctx->up.reserve((size_t)nq * sizeof(WinQuery)) : ctx->up.add(m->h_queries, (size_t)nq * sizeof(WinQuery));
+  const size_t o_total = ctx->up.zeros(sizeof(int));
+  const bool has_obs = obs_pos != nullptr;
+  const size_t o_obs = has_obs ? ctx->up.add(obs_pos, nq) : 0;
+  const size_t o_occ = KIND == 1 ? ctx->up.add(occupied, n_cur) : 0;
+  std::array<size_t, kChainTabs> o_tab{};
+  std::array<bool, kChainTabs> has_tab{};
+  if (chain) for (int i = 0; i < kChainTabs; ++i) if (chain->src[i]) { o_tab[i] = ctx->up.add(chain->src[i], chain->bytes[i]); has_tab[i] = true; }
+  const size_t o_out = ctx->down.reserve(((size_t)n_cur + 16) * sizeof(int));
+  const size_t o_res = chain ? ctx->down.reserve(chain->result_bytes) : 0;
+
+  auto attempt = [=]() -> int {
+    AsdXfer &up = ctx->up, &down = ctx->down;
+    const AsdFrameSlot& F = *Fp;
+    int* d_out = down.dev<int>(o_out);
+    int* d_off = m->d_q_off;
+    int* d_cnt = m->d_q_off + nq;
+    int* d_total = up.dev<int>(o_total);
+    int rc;
     ASD_HIP_CHECK(ctx, up.upload(st));
     void* d_tab[kChainTabs];
-    for (int i = 0; i < kChainTabs; ++i) d_tab[i] = (chain && chain->src[i]) ? up.dev<void>(o_tab[i]) : nullptr;
+    for (int i = 0; i < kChainTabs; ++i) d_tab[i] = has_tab[i] ? up.dev<void>(o_tab[i]) : nullptr;
     if (dev_queries && (rc = chain->prepare(up.dev<WinQuery>(o_q), d_tab)) != ASD_OK) return rc;
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
@@ -804,7 +819,7 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     a.nq = nq; a.n_cur = n_cur;
     a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.meta = m->d_meta;
     a.total = d_total; a.cap = m->cand_cap;
-    a.obs_pos = obs_pos ? up.dev<uint8_t>(o_obs) : nullptr;
+    a.obs_pos = has_obs ? up.dev<uint8_t>(o_obs) : nullptr;
     a.occupied = up.dev<uint8_t>(o_occ);
     a.kp_cur = F.d_kp; a.kp_last = kp_last;
     a.check_ori = check_ori; a.nn_ratio = nn_ratio;
@@ -831,31 +846,44 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       chain->h_result = down.host<void>(o_res);
     }
     ASD_HIP_CHECK(ctx, down.download(st));
-    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const int total = h_out[n_cur + 1];
-    m->last_total[KIND] = total;
-    if (total > m->cand_cap) {  // the candidate buffers overflowed (k_resolve did not run): grow and search again
-      if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
-      *up.host<int>(o_total) = 0;
-      continue;
+    return ASD_OK;
+  };
+
+  auto complete = [=]() -> int {
+    const int* h_out = ctx->down.host<int>(o_out);
+    int rc;
+    for (int round = 0;; ++round) {
+      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      const int total = h_out[n_cur + 1];
+      m->last_total[KIND] = total;
+      if (total > m->cand_cap && round == 0) {  // the candidate buffers overflowed (k_resolve did not run): grow and search again
+        if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
+        *ctx->up.host<int>(o_total) = 0;
+        if ((rc = attempt()) != ASD_OK) return rc;
+        continue;
+      }
+      break;
     }
-    break;
-  }
-  ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
-  memcpy(match_cur, h_out, (size_t)n_cur * sizeof(int));
-  *n_matches = h_out[n_cur];
-  static const bool timing = getenv("ASD_TIMING") != nullptr;
-  if (timing) {
-    static double acc[2]; static long calls[2]; static long rounds[2]; static double st_us[2][8];
-    acc[KIND] += ctx->ms_match; rounds[KIND] += h_out[n_cur + 2];
-    for (int i = 0; i < 8; ++i) st_us[KIND][i] += 0.01 * h_out[n_cur + 3 + i];
-    if (++calls[KIND] % 200 == 0)
-      fprintf(stderr, "[search+resolve kind %d] device %.3f ms, %.1f iterations, %d candidates; k_resolve: staging %.1f us, iterations %.1f us (the first %.1f; bids %.1f barrier %.1f owners %.1f closing %.1f), outputs %.1f us\n", KIND,
-              acc[KIND] / calls[KIND], (double)rounds[KIND] / calls[KIND], h_out[n_cur + 1], st_us[KIND][0] / calls[KIND], st_us[KIND][1] / calls[KIND],
-              st_us[KIND][3] / calls[KIND], st_us[KIND][4] / calls[KIND], st_us[KIND][5] / calls[KIND], st_us[KIND][6] / calls[KIND],
-              st_us[KIND][7] / calls[KIND], st_us[KIND][2] / calls[KIND]);
-  }
-  return ASD_OK;
+    ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+    memcpy(match_cur, h_out, (size_t)n_cur * sizeof(int));
+    *n_matches = h_out[n_cur];
+    static const bool timing = getenv("ASD_TIMING") != nullptr;
+    if (timing) {
+      static double acc[2]; static long calls[2]; static long rounds[2]; static double st_us[2][8];
+      acc[KIND] += ctx->ms_match; rounds[KIND] += h_out[n_cur + 2];
+      for (int i = 0; i < 8; ++i) st_us[KIND][i] += 0.01 * h_out[n_cur + 3 + i];
+      if (++calls[KIND] % 200 == 0)
+        fprintf(stderr, "[search+resolve kind %d] device %.3f ms, %.1f iterations, %d candidates; k_resolve: staging %.1f us, iterations %.1f us (the first %.1f; bids %.1f barrier %.1f owners %.1f closing %.1f), outputs %.1f us\n", KIND,
+                acc[KIND] / calls[KIND], (double)rounds[KIND] / calls[KIND], h_out[n_cur + 1], st_us[KIND][0] / calls[KIND], st_us[KIND][1] / calls[KIND],
+                st_us[KIND][3] / calls[KIND], st_us[KIND][4] / calls[KIND], st_us[KIND][5] / calls[KIND], st_us[KIND][6] / calls[KIND],
+                st_us[KIND][7] / calls[KIND], st_us[KIND][2] / calls[KIND]);
+    }
+    return ASD_OK;
+  };
+
+  if ((rc = attempt()) != ASD_OK) return rc;
+  if (defer) { *defer = complete; return ASD_OK; }
+  return complete();
 }
 
 // query descriptors: host table -> pinned staging -> device (one async copy)
@@ -999,6 +1027,7 @@ int asd_frame_features_in_area(asd_ctx* ctx, int32_t slot, float x, float y, flo
 int asd_dist_matrix(asd_ctx* ctx, const float* a, int32_t na, const float* b, int32_t nb, float* out) {
   if (!ctx || na < 0 || nb < 0 || ((na > 0 && nb > 0) && (!a || !b || !out))) return ASD_ERR_INVALID;
   if (na == 0 || nb == 0) return ASD_OK;
+  if (asd_track_busy(ctx, "asd_dist_matrix")) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   float *da = nullptr, *db = nullptr, *dout = nullptr;
   hipStream_t st = ctx->stream;
@@ -1093,7 +1122,7 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
 static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw,
                             const float* mp_desc, const int32_t* mp_rows, const float* Tcw, const float* K, float th,
                             int32_t check_orientation, int32_t* match_cur, int32_t* n_matches, const uint8_t* obs_pos,
-                            ChainHook* chain = nullptr, bool* chained = nullptr) {
+                            ChainHook* chain = nullptr, bool* chained = nullptr, std::function<int()>* defer = nullptr) {
   if (chained) *chained = false;
   AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
   if (!C || !L || !has_mp || !Xw || (!mp_desc && !mp_rows) || !Tcw || !K || !match_cur || !n_matches) return ASD_ERR_INVALID;
@@ -1132,7 +1161,7 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
   {
     if (chained) *chained = chain != nullptr;
     return search_and_resolve<0>(ctx, m, *C, L->n, mp_desc ? m->d_qdesc : m->d_bank, L->d_kp, obs_pos, nullptr, check_orientation, 0.f,
-                                 match_cur, n_matches, chain);
+                                 match_cur, n_matches, chain, defer);
   }
   SearchResult R;
   const auto tm1 = std::chrono::steady_clock::now();
@@ -1203,7 +1232,7 @@ static int match_project_frame_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot
 static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj,
                              const int32_t* level, const float* view_cos, const float* desc, const int32_t* rows,
                              const uint8_t* occupied, float th, float nn_ratio, int32_t* match_cur, int32_t* n_matches,
-                             const uint8_t* obs_pos, ChainHook* chain = nullptr, bool* chained = nullptr) {
+                             const uint8_t* obs_pos, ChainHook* chain = nullptr, bool* chained = nullptr, std::function<int()>* defer = nullptr) {
   if (chained) *chained = false;
   AsdFrameSlot* F = slot_of(ctx, slot_cur);
   if (!F || n_mp < 0 || !match_cur || !n_matches || (n_mp > 0 && (!in_view || !proj || !level || !view_cos || (!desc && !rows))) ||
@@ -1232,7 +1261,7 @@ static int match_project_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_m
   if (replay_on_device(m, 1, F->n, n_mp)) {
     if (chained) *chained = chain != nullptr;
     return search_and_resolve<1>(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, nullptr, obs_pos, occupied, 0, nn_ratio, match_cur,
-                                 n_matches, chain);
+                                 n_matches, chain, defer);
   }
   SearchResult R;
   if ((rc = window_search(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, &R, 1)) != ASD_OK) return rc;
@@ -1333,50 +1362,75 @@ int finish_pose_chain(asd_ctx* ctx, const AsdFrameSlot& C, const std::function<c
   return ASD_OK;
 }
 
+// The three chains share one shape: build the hook (everything its callbacks need captured BY VALUE: they may run again from
+// the completion when the candidate buffers overflowed), enqueue, then either run the completion or hand it to the caller
+// (`defer`, asd_track_async).  The completion reads the caller's OUTPUT arrays and, of the inputs, only copies made here.
 int track_motion_model_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw, const float* mp_desc,
                             const int32_t* mp_rows, const float* Tcw, const float* K, float th, int32_t check_orientation,
                             const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier,
-                            int32_t* n_inliers) {
+                            int32_t* n_inliers, std::function<int()>* defer) {
   AsdFrameSlot *C = slot_of(ctx, slot_cur), *L = slot_of(ctx, slot_last);
   if (!C || !L || !pose7 || !outlier || !n_inliers || !K) return ASD_ERR_INVALID;
-  const double Kd[4] = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
-  ChainHook chain;
-  chain.src[0] = Xw; chain.bytes[0] = (size_t)L->n * 12;
-  chain.result_bytes = pose_chain_io_bytes(C->n);
-  chain.enqueue = [&](const int* d_match, void* const* d_tab, void* d_result) {
-    return pose_chain_enqueue(ctx, C->n, d_match, C->d_kp, static_cast<const float*>(d_tab[0]), nullptr, nullptr, pose7, Kd, static_cast<double*>(d_result));
+  const std::array<double, 4> Kd = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  std::array<double, 7> p0;
+  memcpy(p0.data(), pose7, sizeof(double) * 7);
+  auto chain = std::make_shared<ChainHook>();
+  chain->src[0] = Xw; chain->bytes[0] = (size_t)L->n * 12;
+  chain->result_bytes = pose_chain_io_bytes(C->n);
+  chain->enqueue = [ctx, C, Kd, p0](const int* d_match, void* const* d_tab, void* d_result) {
+    return pose_chain_enqueue(ctx, C->n, d_match, C->d_kp, static_cast<const float*>(d_tab[0]), nullptr, nullptr, p0.data(), Kd.data(), static_cast<double*>(d_result));
   };
   bool chained = false;
+  std::function<int()> search_done;
   int rc = match_project_frame_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, mp_rows, Tcw, K, th, check_orientation, match_cur, n_matches,
-                                    mp_obs_positive, &chain, &chained);
+                                    mp_obs_positive, chain.get(), &chained, defer ? &search_done : nullptr);
   if (rc != ASD_OK) return rc;
-  return finish_pose_chain(ctx, *C, [&](int j) -> const float* { return match_cur[j] >= 0 ? Xw + 3 * (size_t)match_cur[j] : nullptr; }, chained,
-                           static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
+  auto fin = [=]() -> int {
+    if (search_done) { const int r = search_done(); if (r != ASD_OK) return r; }
+    return finish_pose_chain(ctx, *C, [=](int j) -> const float* { return match_cur[j] >= 0 ? Xw + 3 * (size_t)match_cur[j] : nullptr; }, chained,
+                             static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+  };
+  if (defer && search_done) { *defer = fin; return ASD_OK; }   // (a search that finished on the host is complete already)
+  return fin();
 }
 
 int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj, const int32_t* level,
                          const float* view_cos, const float* desc, const int32_t* rows, const float* mp_Xw, const uint8_t* occupied,
                          const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive, const float* K, double* pose7,
-                         int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+                         int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers, std::function<int()>* defer) {
   AsdFrameSlot* F = slot_of(ctx, slot_cur);
   if (!F || !pose7 || !outlier || !n_inliers || !K || (n_mp > 0 && !mp_Xw) || (F->n > 0 && (!occupied || !cur_Xw))) return ASD_ERR_INVALID;
-  const double Kd[4] = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
-  ChainHook chain;
-  chain.src[0] = mp_Xw; chain.bytes[0] = (size_t)n_mp * 12;
-  chain.src[1] = cur_Xw; chain.bytes[1] = (size_t)F->n * 12;
-  chain.src[2] = occupied; chain.bytes[2] = (size_t)F->n;
-  chain.result_bytes = pose_chain_io_bytes(F->n);
-  chain.enqueue = [&](const int* d_match, void* const* d_tab, void* d_result) {
+  const std::array<double, 4> Kd = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  std::array<double, 7> p0;
+  memcpy(p0.data(), pose7, sizeof(double) * 7);
+  auto chain = std::make_shared<ChainHook>();
+  chain->src[0] = mp_Xw; chain->bytes[0] = (size_t)n_mp * 12;
+  chain->src[1] = cur_Xw; chain->bytes[1] = (size_t)F->n * 12;
+  chain->src[2] = occupied; chain->bytes[2] = (size_t)F->n;
+  chain->result_bytes = pose_chain_io_bytes(F->n);
+  chain->enqueue = [ctx, F, Kd, p0](const int* d_match, void* const* d_tab, void* d_result) {
     return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
-                              static_cast<const float*>(d_tab[1]), pose7, Kd, static_cast<double*>(d_result));
+                              static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(), static_cast<double*>(d_result));
   };
   bool chained = false;
+  std::function<int()> search_done;
   int rc = match_project_points_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, rows, occupied, th, nn_ratio, match_cur, n_matches,
-                                     mp_obs_positive, &chain, &chained);
+                                     mp_obs_positive, chain.get(), &chained, defer ? &search_done : nullptr);
   if (rc != ASD_OK) return rc;
+  if (defer && search_done) {
+    auto occ = std::make_shared<std::vector<uint8_t>>(occupied, occupied + F->n);   // the completion must not read the caller's inputs
+    *defer = [=]() -> int {
+      const int r = search_done();
+      if (r != ASD_OK) return r;
+      const uint8_t* oc = occ->data();
+      return finish_pose_chain(ctx, *F, [=](int j) -> const float* { return (oc[j] || match_cur[j] >= 0) ? reinterpret_cast<const float*>(oc) : nullptr; },
+                               true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+    };
+    return ASD_OK;
+  }
   return finish_pose_chain(ctx, *F, [&](int j) -> const float* {
     return occupied[j] ? cur_Xw + 3 * (size_t)j : (match_cur[j] >= 0 ? mp_Xw + 3 * (size_t)match_cur[j] : nullptr); }, chained,
-    static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
+    static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
 }
 
 // Tracking::SearchLocalPoints (Tracking.cc:803-851: isInFrustum for every local map point, then SearchByProjection) +
@@ -1385,7 +1439,8 @@ int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uin
 int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal, const float* min_dist,
                             const float* max_dist, const float* desc, const int32_t* rows, const float* Tcw, const float* K, float cos_limit,
                             const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive,
-                            double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+                            double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers,
+                            std::function<int()>* defer) {
   AsdFrameSlot* F = slot_of(ctx, slot_cur);
   if (!F || n_mp < 0 || !Tcw || !K || !pose7 || !match_cur || !n_matches || !outlier || !n_inliers ||
       (n_mp > 0 && (!Xw || !normal || !min_dist || !max_dist || (!desc && !rows))) || (F->n > 0 && (!occupied || !cur_Xw)))
@@ -1400,7 +1455,7 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
     int rc = asd_frustum(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, Tcw, K, cos_limit, in_view.data(), proj.data(), level.data(), vc.data());
     if (rc != ASD_OK) return rc;
     return track_local_map_impl(ctx, slot_cur, n_mp, in_view.data(), proj.data(), level.data(), vc.data(), desc, rows, Xw, occupied, cur_Xw, th,
-                                nn_ratio, mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
+                                nn_ratio, mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers, defer);
   }
   std::fill(match_cur, match_cur + F->n, -1);
   *n_matches = 0;
@@ -1410,7 +1465,9 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
     for (int q = 0; q < n_mp; ++q)
       if (rows[q] < 0 || rows[q] >= m->bank_cap) { ctx->set_error("bank row %d out of range", rows[q]); return ASD_ERR_INVALID; }
   if (desc && (rc = upload_qdesc(ctx, m, desc, n_mp)) != ASD_OK) return rc;
-  const double Kd[4] = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  const std::array<double, 4> Kd = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  std::array<double, 7> p0;
+  memcpy(p0.data(), pose7, sizeof(double) * 7);
   FrustumArgs fa{};
   fa.n = n_mp; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = th != 1.0;
   memcpy(fa.T, Tcw, sizeof fa.T);
@@ -1423,82 +1480,133 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
   fa.min_x = F->min_x; fa.max_x = F->max_x; fa.min_y = F->min_y; fa.max_y = F->max_y;
   fa.cos_limit = cos_limit; fa.th = th;
   for (int l = 0; l < ASD_MAX_LEVELS; ++l) { fa.level_thr[l] = ctx->level_thr[l]; fa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f; }
-  ChainHook chain;
-  chain.src[0] = Xw; chain.bytes[0] = (size_t)n_mp * 12;
-  chain.src[1] = cur_Xw; chain.bytes[1] = (size_t)F->n * 12;
-  chain.src[2] = occupied; chain.bytes[2] = (size_t)F->n;
-  chain.src[3] = normal; chain.bytes[3] = (size_t)n_mp * 12;
-  chain.src[4] = min_dist; chain.bytes[4] = (size_t)n_mp * 4;
-  chain.src[5] = max_dist; chain.bytes[5] = (size_t)n_mp * 4;
-  if (!desc) { chain.src[6] = rows; chain.bytes[6] = (size_t)n_mp * 4; }
-  chain.result_bytes = pose_chain_io_bytes(F->n);
-  chain.prepare = [&](WinQuery* d_queries, void* const* d_tab) -> int {
-    fa.Xw = static_cast<const float*>(d_tab[0]); fa.normal = static_cast<const float*>(d_tab[3]);
-    fa.min_dist = static_cast<const float*>(d_tab[4]); fa.max_dist = static_cast<const float*>(d_tab[5]);
-    fa.rows = desc ? nullptr : static_cast<const int*>(d_tab[6]);
-    fa.queries = d_queries;
-    hipLaunchKernelGGL(k_frustum_queries, dim3((n_mp + 255) / 256), dim3(256), 0, ctx->stream, fa);
+  auto chain = std::make_shared<ChainHook>();
+  chain->src[0] = Xw; chain->bytes[0] = (size_t)n_mp * 12;
+  chain->src[1] = cur_Xw; chain->bytes[1] = (size_t)F->n * 12;
+  chain->src[2] = occupied; chain->bytes[2] = (size_t)F->n;
+  chain->src[3] = normal; chain->bytes[3] = (size_t)n_mp * 12;
+  chain->src[4] = min_dist; chain->bytes[4] = (size_t)n_mp * 4;
+  chain->src[5] = max_dist; chain->bytes[5] = (size_t)n_mp * 4;
+  const bool by_rows = desc == nullptr;
+  if (by_rows) { chain->src[6] = rows; chain->bytes[6] = (size_t)n_mp * 4; }
+  chain->result_bytes = pose_chain_io_bytes(F->n);
+  chain->prepare = [ctx, fa, by_rows, n_mp](WinQuery* d_queries, void* const* d_tab) -> int {
+    FrustumArgs a = fa;
+    a.Xw = static_cast<const float*>(d_tab[0]); a.normal = static_cast<const float*>(d_tab[3]);
+    a.min_dist = static_cast<const float*>(d_tab[4]); a.max_dist = static_cast<const float*>(d_tab[5]);
+    a.rows = by_rows ? static_cast<const int*>(d_tab[6]) : nullptr;
+    a.queries = d_queries;
+    hipLaunchKernelGGL(k_frustum_queries, dim3((n_mp + 255) / 256), dim3(256), 0, ctx->stream, a);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
-  chain.enqueue = [&](const int* d_match, void* const* d_tab, void* d_result) {
+  chain->enqueue = [ctx, F, Kd, p0](const int* d_match, void* const* d_tab, void* d_result) {
     return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
-                              static_cast<const float*>(d_tab[1]), pose7, Kd, static_cast<double*>(d_result));
+                              static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(), static_cast<double*>(d_result));
   };
+  std::function<int()> search_done;
   rc = search_and_resolve<1>(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, nullptr, mp_obs_positive, occupied, 0, nn_ratio, match_cur, n_matches,
-                             &chain);
+                             chain.get(), defer ? &search_done : nullptr);
   if (rc != ASD_OK) return rc;
-  return finish_pose_chain(ctx, *F, [&](int j) -> const float* {
-    return occupied[j] ? cur_Xw + 3 * (size_t)j : (match_cur[j] >= 0 ? Xw + 3 * (size_t)match_cur[j] : nullptr); }, true,
-    static_cast<const double*>(chain.h_result), Kd, pose7, outlier, n_inliers);
+  auto occ = std::make_shared<std::vector<uint8_t>>(occupied, occupied + F->n);   // the completion must not read the caller's inputs
+  auto fin = [=]() -> int {
+    if (search_done) { const int r = search_done(); if (r != ASD_OK) return r; }
+    const uint8_t* oc = occ->data();
+    // chained: finish_pose_chain only asks which keypoints carry an edge (the positions went to the device in the upload block)
+    return finish_pose_chain(ctx, *F, [=](int j) -> const float* { return (oc[j] || match_cur[j] >= 0) ? reinterpret_cast<const float*>(oc) : nullptr; },
+                             true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+  };
+  if (defer && search_done) { *defer = fin; return ASD_OK; }
+  return fin();
 }
+
+// asd_track_async / asd_track_finish: run an asd_track_* entry point split in two
+extern "C++" {
+template <typename Impl>
+int run_track(asd_ctx* ctx, Impl&& impl) {
+  if (!ctx) return ASD_ERR_INVALID;
+  if (asd_track_busy(ctx, "asd_track_*")) return ASD_ERR_INVALID;
+  const bool async = ctx->track_async_armed;
+  ctx->track_async_armed = false;
+  std::function<int()> fin;
+  const int rc = impl(async ? &fin : nullptr);
+  if (!async || rc != ASD_OK) return rc;
+  ctx->track_pending = fin ? std::move(fin) : std::function<int()>([] { return (int)ASD_OK; });   // finished on the host already
+  ctx->track_has_pending = true;
+  return ASD_OK;
+}
+}  // extern "C++"
 }  // namespace
 
 int asd_track_motion_model(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw, const float* mp_desc,
                            const float* Tcw, const float* K, float th, int32_t check_orientation, const uint8_t* mp_obs_positive, double* pose7,
                            int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
   if (!mp_desc) return ASD_ERR_INVALID;
-  return track_motion_model_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, nullptr, Tcw, K, th, check_orientation, mp_obs_positive, pose7,
-                                 match_cur, n_matches, outlier, n_inliers);
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_motion_model_impl(ctx, slot_cur, slot_last, has_mp, Xw, mp_desc, nullptr, Tcw, K, th, check_orientation, mp_obs_positive, pose7,
+                                   match_cur, n_matches, outlier, n_inliers, defer); });
 }
 int asd_track_motion_model_bank(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, const uint8_t* has_mp, const float* Xw, const int32_t* mp_rows,
                                 const float* Tcw, const float* K, float th, int32_t check_orientation, const uint8_t* mp_obs_positive,
                                 double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
   if (!mp_rows) return ASD_ERR_INVALID;
-  return track_motion_model_impl(ctx, slot_cur, slot_last, has_mp, Xw, nullptr, mp_rows, Tcw, K, th, check_orientation, mp_obs_positive, pose7,
-                                 match_cur, n_matches, outlier, n_inliers);
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_motion_model_impl(ctx, slot_cur, slot_last, has_mp, Xw, nullptr, mp_rows, Tcw, K, th, check_orientation, mp_obs_positive, pose7,
+                                   match_cur, n_matches, outlier, n_inliers, defer); });
 }
 int asd_track_local_map(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj, const int32_t* level,
                         const float* view_cos, const float* desc, const float* mp_Xw, const uint8_t* occupied, const float* cur_Xw, float th,
                         float nn_ratio, const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur, int32_t* n_matches,
                         uint8_t* outlier, int32_t* n_inliers) {
   if (n_mp > 0 && !desc) return ASD_ERR_INVALID;
-  return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, nullptr, mp_Xw, occupied, cur_Xw, th, nn_ratio,
-                              mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, desc, nullptr, mp_Xw, occupied, cur_Xw, th, nn_ratio,
+                                mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers, defer); });
 }
 int asd_track_local_map_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uint8_t* in_view, const float* proj, const int32_t* level,
                              const float* view_cos, const int32_t* rows, const float* mp_Xw, const uint8_t* occupied, const float* cur_Xw,
                              float th, float nn_ratio, const uint8_t* mp_obs_positive, const float* K, double* pose7, int32_t* match_cur,
                              int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
   if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
-  return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, mp_Xw, occupied, cur_Xw, th, nn_ratio,
-                              mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers);
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_local_map_impl(ctx, slot_cur, n_mp, in_view, proj, level, view_cos, nullptr, rows, mp_Xw, occupied, cur_Xw, th, nn_ratio,
+                                mp_obs_positive, K, pose7, match_cur, n_matches, outlier, n_inliers, defer); });
 }
 int asd_track_local_points(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal, const float* min_dist,
                            const float* max_dist, const float* desc, const float* Tcw, const float* K, float viewing_cos_limit,
                            const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive, double* pose7,
                            int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
   if (n_mp > 0 && !desc) return ASD_ERR_INVALID;
-  return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, desc, nullptr, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
-                                 nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers);
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, desc, nullptr, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
+                                   nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers, defer); });
 }
 int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const float* Xw, const float* normal, const float* min_dist,
                                 const float* max_dist, const int32_t* rows, const float* Tcw, const float* K, float viewing_cos_limit,
                                 const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive,
                                 double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
   if (n_mp > 0 && !rows) return ASD_ERR_INVALID;
-  return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, nullptr, rows, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
-                                 nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers);
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, nullptr, rows, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
+                                   nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers, defer); });
+
+}
+
+int asd_track_async(asd_ctx* ctx) {
+  if (!ctx) return ASD_ERR_INVALID;
+  if (asd_track_busy(ctx, "asd_track_async")) return ASD_ERR_INVALID;
+  ctx->track_async_armed = true;
+  return ASD_OK;
+}
+
+int asd_track_finish(asd_ctx* ctx) {
+  if (!ctx) return ASD_ERR_INVALID;
+  if (!ctx->track_has_pending) { ctx->set_error("asd_track_finish: no asd_track_* call is outstanding (asd_track_async arms the next one)"); return ASD_ERR_INVALID; }
+  (void)hipSetDevice(ctx->cfg.device);
+  std::function<int()> fin = std::move(ctx->track_pending);
+  ctx->track_pending = nullptr;
+  ctx->track_has_pending = false;
+  return fin();
 }
 
 // ORBmatcher::Fuse, search half (ORBmatcher.cc:825-936): the Replace / AddObservation side effects

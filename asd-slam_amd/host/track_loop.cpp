@@ -39,6 +39,18 @@ struct asd_track_handle {
   // thread beside Tracking (LocalMapping.cc:92): submitted at the keyframe, collected before the next submission and at the end
   // of every asd_track_run, so a run contains all of the LocalBA work it started.
   bool async_ba = true;
+  // split-phase stages (asd_track_async / asd_track_finish): while a stage's kernels run, the host does the work that does not
+  // depend on its result -- the local-map tables under the motion-model stage, and under the local-map stage the NEXT frame's
+  // construction (wait for its extraction, AssignFeaturesToGrid + descriptor adoption, read-ahead submission, descriptor-bank
+  // rows, projected points), which the reference's Frame constructor does before tracking that frame
+  bool split = true;
+  int stop_after = -1;      // no read-ahead beyond this frame (-1 = unbounded)
+  int prep_t = -1;          // the frame prepare_frame() has made ready (its grid sits in slot `slot`), -1 = none
+  const asd_keypoint* prep_kps = nullptr;
+  int32_t prep_n = 0;
+  int32_t c2_n2 = 0, c2_ninl = 0;   // outputs of an outstanding local-map stage (stable addresses)
+  double c2_pose[7];
+  std::vector<uint8_t> outl2;
   bool ba_out = false;      // a submission is outstanding
   long ba_step = -1;        // the step that submitted it
   asd_ba_problem ba_p;
@@ -89,6 +101,7 @@ asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* c
 
 void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on != 0; }
 void asd_track_set_async_ba(asd_track_handle* h, int32_t on) { if (h) h->async_ba = on != 0; }
+void asd_track_set_split(asd_track_handle* h, int32_t on) { if (h) h->split = on != 0; }
 
 // collect the outstanding LocalBA; its chi2 goes into *st only when the step that submitted it is the one st describes
 static int collect_ba(asd_track_handle* h, asd_track_stats* st, long st_step) {
@@ -120,6 +133,181 @@ void asd_track_destroy(asd_track_handle* h) {
             h->kern_ms[2] / h->steps, h->kern_ms[3] / h->steps);
   }
   delete h;
+}
+
+// ---- split-phase form of the fused step --------------------------------------------------------------------------------
+// Frame construction for frame t: take its extraction (read-ahead result or a synchronous one), AssignFeaturesToGrid + adopt the
+// descriptors, keep the read-ahead queue full, and -- when there is a previous frame -- the inputs of the motion-model stage
+// (projected points of the previous frame, its descriptors as bank rows).  Everything here is enqueued on the context's stream
+// behind whatever stage is still in flight and reads none of its results.
+static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& next) {
+  asd_ctx* ctx = h->ctx;
+  const int nf = (int)h->d_frames.size();
+  int rc;
+  auto tp = std::chrono::steady_clock::now();
+  auto seg = [&](int i) {
+    const auto now = std::chrono::steady_clock::now();
+    h->seg_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  };
+  const asd_keypoint* kps = nullptr;
+  int32_t n = 0;
+  if (!h->pending.empty() && h->pending.front() == t) {
+    const float* d = nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
+    if ((rc = asd_extract_wait_view(ctx, &kps, &d, &n)) != ASD_OK) return rc;
+    h->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    h->pending.pop_front();
+  } else {
+    while (!h->pending.empty()) {
+      const asd_keypoint* k; const float* d; int32_t nn;
+      if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
+      h->pending.pop_front();
+    }
+    if ((rc = asd_extract_device(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
+    kps = h->kps.data();
+  }
+  h->slot ^= 1;
+  seg(7);
+  if ((rc = asd_frame_set(ctx, h->slot, kps, nullptr, n, 0.f, (float)h->W, 0.f, (float)h->H)) != ASD_OK) return rc;
+  seg(0);
+  if (h->lookahead > 0) {
+    bool same = h->pending.size() <= next.size();
+    for (size_t i = 0; same && i < h->pending.size(); ++i) same = h->pending[i] == next[i];
+    if (!same) {
+      while (!h->pending.empty()) {
+        const asd_keypoint* k; const float* d; int32_t nn;
+        if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
+        h->pending.pop_front();
+      }
+    }
+    for (size_t i = h->pending.size(); i < next.size(); ++i) {
+      if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
+      h->pending.push_back(next[i]);
+    }
+  }
+  seg(1);
+  if (h->have_last) {
+    const std::vector<asd_keypoint>& lk = h->last_kps;
+    const int nl = (int)lk.size();
+    const float fx = h->K32[0], fy = h->K32[1], cx = h->K32[2], cy = h->K32[3];
+    const float z = 1.003f, c3 = (float)(3 * 1.003), c02 = (float)(0.2 * 1.003), depth = 20.0f;
+    h->Xw.resize((size_t)3 * nl);
+    for (int i = 0; i < nl; ++i) {
+      const float u = (lk[i].x - 620.5f) * z + 620.5f - c3;
+      const float v = (lk[i].y - 188.0f) * z + 188.0f - c02;
+      h->Xw[3 * i + 0] = (u - cx) / fx * depth;
+      h->Xw[3 * i + 1] = (v - cy) / fy * depth;
+      h->Xw[3 * i + 2] = depth;
+    }
+    h->has.assign(nl, 1);
+    seg(7);
+    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
+    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, nl, nl)) != ASD_OK) return rc;
+    h->rows.resize((size_t)2 * nl);
+    for (int i = 0; i < 2 * nl; ++i) h->rows[i] = i;
+    seg(2);
+  }
+  h->prep_t = t; h->prep_kps = kps; h->prep_n = n;
+  return ASD_OK;
+}
+
+static int submit_ba(asd_track_handle* h, asd_track_stats* st);
+
+static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::vector<int>& next, asd_track_stats* st) {
+  asd_ctx* ctx = h->ctx;
+  int rc;
+  auto tp = std::chrono::steady_clock::now();
+  auto seg = [&](int i) {
+    const auto now = std::chrono::steady_clock::now();
+    h->seg_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  };
+  if (h->prep_t != t && (rc = prepare_frame(h, t, next)) != ASD_OK) return rc;
+  tp = std::chrono::steady_clock::now();
+  const asd_keypoint* kps = h->prep_kps;
+  const int32_t n = h->prep_n;
+  const int cur = h->slot;
+  h->prep_t = -1;
+  memset(st, 0, sizeof *st);
+  st->n_kp = n;
+  const bool had_last = h->have_last;
+  int n2p = 0;
+  if (had_last) {
+    const std::vector<asd_keypoint>& lk = h->last_kps;
+    const int nl = (int)lk.size();
+    // ---- Tracking::TrackWithMotionModel's numeric body, enqueued (Tracking.cc:664-723)
+    h->m1.assign(n, -1);
+    int32_t n1 = 0, ninl1 = 0;
+    double pose[7];
+    memcpy(pose, h->pose0, sizeof pose);
+    h->outl.resize(n);
+    if ((rc = asd_track_async(ctx)) != ASD_OK) return rc;
+    if ((rc = asd_track_motion_model_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1, nullptr,
+                                          pose, h->m1.data(), &n1, h->outl.data(), &ninl1)) != ASD_OK)
+      return rc;
+    seg(2);
+    // ---- under it: the local map's tables (the last frame's points plus a jittered copy; nothing here needs the stage's result)
+    n2p = 2 * nl;
+    h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
+    for (int i = 0; i < nl; ++i)
+      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
+    for (int i = 0; i < n2p; ++i) {
+      const float* P = &h->Xw2[3 * i];
+      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
+      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
+      h->dist[i] = nn;
+      const int lv = lk[i % nl].octave;
+      h->maxd[i] = nn * h->scale32[lv];
+      h->mind[i] = h->maxd[i] / h->scale32[7];
+    }
+    seg(7);
+    if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
+    st->m1 = n1; st->has_m1 = 1;
+    seg(3);
+    // ---- Tracking::TrackLocalMap's numeric body, enqueued (Tracking.cc:725-736, 803-851)
+    h->occ.resize(n);
+    h->cur_Xw.assign((size_t)3 * n, 0.f);
+    for (int j = 0; j < n; ++j) {
+      h->occ[j] = h->m1[j] >= 0;
+      if (h->m1[j] >= 0) for (int k = 0; k < 3; ++k) h->cur_Xw[3 * j + k] = h->Xw[3 * h->m1[j] + k];
+    }
+    h->m2.assign(n, -1);
+    h->outl2.resize(n);
+    memcpy(h->c2_pose, h->pose0, sizeof h->c2_pose);
+    h->c2_n2 = 0; h->c2_ninl = 0;
+    seg(7);
+    if ((rc = asd_track_async(ctx)) != ASD_OK) return rc;
+    if ((rc = asd_track_local_points_bank(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->rows.data(), h->T,
+                                          h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose, h->m2.data(), &h->c2_n2,
+                                          h->outl2.data(), &h->c2_ninl)) != ASD_OK)
+      return rc;
+    seg(5);
+  }
+  // ---- under the local-map stage: this frame becomes the last frame, LocalBA goes to its lane, the next frame is constructed
+  h->last_kps.assign(kps, kps + n);
+  h->last_slot = cur;
+  h->have_last = true;
+  if (do_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;
+  seg(7);
+  if (!next.empty() && next[0] == t + 1) {
+    std::vector<int> after(next.begin() + 1, next.end());
+    after.push_back(next.back() + 1);   // the queue of frame t+1: t+2 .. t+1+lookahead (asd_track_run trims it at the end of a run)
+    if ((int)after.size() > h->lookahead) after.resize(h->lookahead);
+    if (h->stop_after >= 0) while (!after.empty() && after.back() > h->stop_after) after.pop_back();
+    if ((rc = prepare_frame(h, t + 1, after)) != ASD_OK) return rc;
+    tp = std::chrono::steady_clock::now();
+  }
+  if (had_last) {
+    if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
+    st->m2 = h->c2_n2; st->has_m2 = 1;
+    int nedge = 0;
+    for (int j = 0; j < n; ++j) nedge += h->m1[j] >= 0 || h->m2[j] >= 0;
+    if (nedge >= 3) { st->inliers = h->c2_ninl; st->has_inliers = 1; }
+    seg(6);
+  }
+  ++h->steps;
+  return ASD_OK;
 }
 
 static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<int>& next, asd_track_stats* st) {
@@ -307,32 +495,39 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       seg(6);
     }
   }
-  if (do_ba) {
-    if ((rc = collect_ba(h, nullptr, -1)) != ASD_OK) return rc;   // the previous keyframe's run (its buffers are reused below)
-    const asd_ba_problem& B = h->ba;
-    h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
-    h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);
-    h->ba_chi2.assign(B.n_edges, 0.0); h->ba_dpos.assign(B.n_edges, 0); h->ba_out1.assign(B.n_edges, 0);
-    h->ba_p = B;
-    h->ba_p.poses = h->ba_poses.data(); h->ba_p.points = h->ba_points.data();
-    memset(&h->ba_r, 0, sizeof h->ba_r);
-    h->ba_r.edge_chi2 = h->ba_chi2.data(); h->ba_r.edge_depth_pos = h->ba_dpos.data(); h->ba_r.edge_outlier1 = h->ba_out1.data();
-    const auto b0 = std::chrono::steady_clock::now();
-    if (h->async_ba) {
-      if ((rc = asd_local_ba_submit(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
-      h->ba_out = true;
-      h->ba_step = h->steps;
-    } else {
-      if ((rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
-      st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
-    }
-    h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
-  }
+  if (do_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;
   seg(7);
   h->last_kps.assign(kps, kps + n);
   h->last_slot = cur;
   h->have_last = true;
   ++h->steps;
+  return ASD_OK;
+}
+
+
+// LocalBA at a keyframe: on the lane (collected later) or in line
+static int submit_ba(asd_track_handle* h, asd_track_stats* st) {
+  asd_ctx* ctx = h->ctx;
+  int rc;
+  if ((rc = collect_ba(h, nullptr, -1)) != ASD_OK) return rc;   // the previous keyframe's run (its buffers are reused below)
+  const asd_ba_problem& B = h->ba;
+  h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
+  h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);
+  h->ba_chi2.assign(B.n_edges, 0.0); h->ba_dpos.assign(B.n_edges, 0); h->ba_out1.assign(B.n_edges, 0);
+  h->ba_p = B;
+  h->ba_p.poses = h->ba_poses.data(); h->ba_p.points = h->ba_points.data();
+  memset(&h->ba_r, 0, sizeof h->ba_r);
+  h->ba_r.edge_chi2 = h->ba_chi2.data(); h->ba_r.edge_depth_pos = h->ba_dpos.data(); h->ba_r.edge_outlier1 = h->ba_out1.data();
+  const auto b0 = std::chrono::steady_clock::now();
+  if (h->async_ba) {
+    if ((rc = asd_local_ba_submit(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
+    h->ba_out = true;
+    h->ba_step = h->steps;
+  } else {
+    if ((rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
+    st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
+  }
+  h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();
   return ASD_OK;
 }
 
@@ -345,7 +540,11 @@ int asd_track_run(asd_track_handle* h, int32_t t0, int32_t n, int32_t prefetch_b
     next.clear();
     for (int k = 1; k <= h->lookahead; ++k)
       if (i + k < n || prefetch_beyond) next.push_back(t + k);
-    const int rc = track_step(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats);
+    h->stop_after = prefetch_beyond ? -1 : t0 + n - 1;   // the last frame a read-ahead submission may be made for
+    const bool split = h->fused && h->split;
+    if (!split && h->prep_t >= 0) { h->prep_t = -1; }    // (a frame prepared by the split step is simply prepared again)
+    const int rc = split ? track_step_split(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats)
+                         : track_step(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats);
     if (rc != ASD_OK) return rc;
   }
   return collect_ba(h, stats, h->steps - 1);   // the run ends with its LocalBA finished (and reported if the last step started it)

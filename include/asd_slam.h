@@ -279,6 +279,19 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
                                 float nn_ratio, const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur,
                                 int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
 
+/* Split-phase execution of the asd_track_* calls.  asd_track_async(ctx) arms the NEXT asd_track_motion_model[_bank] /
+ * asd_track_local_map[_bank] / asd_track_local_points[_bank] call on this context: it returns as soon as its work is enqueued
+ * -- every INPUT array has been consumed by then and may be reused, the OUTPUT arrays (pose7, match_cur, n_matches,
+ * outlier, n_inliers) must stay valid -- and asd_track_finish(ctx) waits for the device, fills the outputs and returns the
+ * status the synchronous call would have returned (same results bit for bit: same kernels, same order).  The host work of
+ * the next frame that does not depend on this result -- Frame construction in the reference: asd_extract_wait[_view],
+ * asd_frame_set on ANOTHER slot, asd_extract_submit, asd_bank_put*, and asd_local_ba_submit / _wait / _poll -- may run in
+ * between (it is enqueued behind the chain on the context's stream); any other call that uses the matcher or the pose solver
+ * returns ASD_ERR_INVALID until asd_track_finish.  An armed call that fails returns its error and leaves nothing outstanding;
+ * asd_track_finish with nothing outstanding is ASD_ERR_INVALID. */
+int asd_track_async(asd_ctx* ctx);
+int asd_track_finish(asd_ctx* ctx);
+
 /* Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) for
  * n map points: Xw[n][3], normal[n][3] (GetNormal), min_dist[n] / max_dist[n] = the map
  * point's raw mfMinDistance / mfMaxDistance (the 0.8 / 1.2 invariance factors of

@@ -20,10 +20,12 @@ def _bench():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline,fused,async_ba", [(True, True, True), (False, True, True), (True, False, True), (True, True, False)])
-def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba):
+@pytest.mark.parametrize("pipeline,fused,async_ba,split", [(True, True, True, True), (False, True, True, True), (True, False, True, True), (True, True, False, True),
+                                                             (True, True, True, False)])
+def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split):
     """fused: the stages run as asd_track_motion_model / asd_track_local_map (one submission each, bench default) or as
-    matcher + PoseOptimization calls (--no-fuse); async_ba: LocalBA on the local-mapping lane (default) or in line (--sync-ba)"""
+    matcher + PoseOptimization calls (--no-fuse); async_ba: LocalBA on the local-mapping lane (default) or in line (--sync-ba); split: the C++ host's split-phase
+    stages (asd_track_async / asd_track_finish, default) or each stage run to completion (--no-split)"""
     bench = _bench()
     wl = bench.Workload(pkg.synth)
     n = bench.KF_INTERVAL + 3          # crosses one LocalBA
@@ -40,6 +42,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba):
     cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
     cx.fused = fused
     cx.async_ba = async_ba
+    cx.split = split
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         got = [cx.native.run(t, 1, True) for t in range(n)]
@@ -52,6 +55,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba):
     cx = bench.HipBackend(pkg, wl, 0, pipeline=pipeline)
     cx.fused = fused
     cx.async_ba = async_ba
+    cx.split = split
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         whole = cx.native.run(0, n, True)

@@ -51,6 +51,15 @@ def test_track_motion_model_equals_separate_calls(hip, oracle, synth, n, th, ori
     gb = hip.track_motion_model(0, 1, n, has, Xw, np.arange(100, 100 + n, dtype=np.int32), T, K, th, pose0, ori)
     for a, b in zip(gb, got):
         np.testing.assert_array_equal(a, b)
+    # split in two (asd_track_async / asd_track_finish): inputs may be clobbered once the call has returned, the next frame's
+    # frame_set on another slot may run in between
+    has2, Xw2, rows2, T2, K2, p2 = has.copy(), Xw.copy(), np.arange(100, 100 + n, dtype=np.int32), T.copy(), K.copy(), pose0.copy()
+    assert hip.track_motion_model(0, 1, n, has2, Xw2, rows2, T2, K2, th, p2, ori, split=True) is None
+    has2[:] = 0; Xw2[:] = 7; rows2[:] = 0; T2[:] = 0; K2[:] = 1; p2[:] = 9
+    hip.frame_set(2, kl, dl, BOUNDS)
+    gs = hip.track_finish()
+    for a, b in zip(gs, got):
+        np.testing.assert_array_equal(a, b)
     # the oracle: matcher bit-exact, optimiser (pinned to the reference's g2o) within its tolerance
     om, onm = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw, mp_desc, T, K, th, ori)
     np.testing.assert_array_equal(got[0], om)
@@ -197,3 +206,51 @@ def test_track_local_points_equals_frustum_plus_chain(hip, oracle, synth, n_mp, 
     for a, b in zip(gb, exp):
         np.testing.assert_array_equal(a, b)
     assert got[1] > 0 and got[4] > 100
+    # split in two: every input is consumed when the call returns
+    cp = [a.copy() for a in (Xw, normal, mind, maxd, occupied, cur_Xw, pose0)]
+    assert hip.track_local_points(0, 2000, cp[0], cp[1], cp[2], cp[3], desc, T, K, cp[4], cp[5], th, 0.8, cp[6], split=True) is None
+    for a in cp:
+        a[:] = 3
+    k2, d2 = make_frame(500, 77)
+    hip.frame_set(1, k2, d2, BOUNDS)                 # the next frame's grid, behind the chain on the same stream
+    gs = hip.track_finish()
+    for a, b in zip(gs, exp):
+        np.testing.assert_array_equal(a, b)
+    # same through asd_track_local_map
+    assert hip.track_local_map(0, 2000, in_view, proj, level, vc, desc, Xw, occupied, cur_Xw, th, 0.8, K, pose0, split=True) is None
+    gs = hip.track_finish()
+    for a, b in zip(gs, exp):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_split_phase_rules(hip, synth):
+    """asd_track_async arms exactly the next asd_track_* call; while that call is outstanding the matcher and the pose solver are
+    refused (their buffers are in use), asd_track_finish without an outstanding call is an error, and a failing armed call leaves
+    nothing outstanding."""
+    n = 300
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 911)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    pose0 = _pose7(pose_T())
+    with pytest.raises(Exception):
+        hip.track_finish()
+    ref = hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, 15.0, pose0)
+    assert hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, 15.0, pose0, split=True) is None
+    with pytest.raises(Exception):
+        hip.match_project_frame(0, 1, n, has, Xw, mp_desc, T, K, 15.0, True)
+    with pytest.raises(Exception):
+        hip.pose_optimize(pose0, Xw[:50].astype(np.float64), np.zeros((50, 2)), np.ones(50), K.astype(np.float64))
+    with pytest.raises(Exception):
+        hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, 15.0, pose0)
+    got = hip.track_finish()
+    for a, b in zip(got, ref):
+        np.testing.assert_array_equal(a, b)
+    # an armed call that is refused (bad slot) leaves nothing outstanding and does not stay armed
+    with pytest.raises(Exception):
+        hip.track_motion_model(0, 99, n, has, Xw, mp_desc, T, K, 15.0, pose0, split=True)
+    with pytest.raises(Exception):
+        hip.track_finish()
+    again = hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, 15.0, pose0)
+    for a, b in zip(again, ref):
+        np.testing.assert_array_equal(a, b)
