@@ -156,6 +156,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   ctx->scratch.release();
   ctx->up.release();
   ctx->down.release();
+  if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
   if (ctx->ev_adopt) (void)hipEventDestroy(ctx->ev_adopt);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -146,6 +146,7 @@ struct asd_ctx {
   AsdXfer up, down;   // per-call upload / result blocks of the tracking entry points (one copy each way)
   // asd_track_async / asd_track_finish: the completion of an asd_track_* call that returned after enqueueing its work
   bool track_async_armed = false, track_has_pending = false;
+  hipEvent_t ev_chain = nullptr;   // end of the last search (+ chain) enqueued by search_and_resolve
   std::function<int()> track_pending;
 
   // ---- local-mapping scratch (state private to mapping.hip)

@@ -843,62 +843,32 @@ struct AsyncExtract {
 static void async_worker(asd_ctx* ctx) {
   AsyncExtract* ax = ctx->ax;
   (void)hipSetDevice(ctx->cfg.device);
-  AsyncJob* inflight = nullptr;  // back half enqueued, results not yet handed over
-  auto finish = [&](AsyncJob* a) {
-    ExtractSlot& S = ax->slots[a->slot];
-    const int rc = extract_finish(ctx, S, a->job.n, a->kps.data(), nullptr);
-    std::lock_guard<std::mutex> l(ax->m);
-    if (rc != ASD_OK) a->job.rc = rc;
-    a->state = AsyncJob::DONE;
-  };
+  // The worker only ENQUEUES: front half of the next queued frame (two host syncs + the host quadtree), then its back half
+  // (ASDNet + read-back) behind the previous frame's on the ASDNet stream -- and on to the next job.  It never waits for a back
+  // half: the thread that calls asd_extract_wait synchronises on the frame's end event itself (wait_oldest).  Waiting here put
+  // the hand-over (event wait, wake-up, angle copy) between one frame's ASDNet and the NEXT BUT ONE frame's front half, which
+  // then started ~0.4 ms into the next ASDNet and no longer fitted under it (rocprofv3: the ASDNet queue idled 0.3 ms per frame).
   for (;;) {
     AsyncJob* next = nullptr;
     {
       std::unique_lock<std::mutex> l(ax->m);
-      for (;;) {
-        if (ax->stop) break;
-        if (ax->started < ax->submitted) { next = &ax->jobs[ax->started % kSlots]; ++ax->started; next->state = AsyncJob::FRONT; break; }
-        if (inflight) {
-          // nothing queued: hand the in-flight frame over as soon as its back half is done, but keep an eye on the queue
-          if (hipEventQuery(ax->slots[inflight->slot].ev_end) == hipSuccess) break;
-          ax->cv.wait_for(l, std::chrono::microseconds(40));
-        } else {
-          ax->cv.wait(l);
-        }
-      }
-      if (ax->stop) {
-        l.unlock();
-        if (inflight) finish(inflight);
-        ax->cv.notify_all();
-        return;
-      }
-    }
-    if (!next) {  // in-flight frame finished, queue empty
-      finish(inflight);
-      inflight = nullptr;
-      ax->cv.notify_all();
-      continue;
+      ax->cv.wait(l, [&] { return ax->stop || ax->started < ax->submitted; });
+      if (ax->stop) return;
+      next = &ax->jobs[ax->started % kSlots];
+      ++ax->started;
+      next->state = AsyncJob::FRONT;
     }
     ExtractSlot& S = ax->slots[next->slot];
     int32_t n = 0;
     int rc = extract_front(ctx, next->job, S, ax->stream_f, ax->ev_corners, next->kps.data(), &n);
     next->job.n = n;
-    // queue this frame's ASDNet behind the previous one (same stream: its activation buffers are free by then) BEFORE
-    // waiting for the previous frame, so the matrix cores go from one forward pass straight into the next
     if (rc == ASD_OK && n > 0) rc = extract_back_enqueue(ctx, S, n, ctx->stream_x);
-    if (inflight) {  // the previous frame's ASDNet ran underneath this front half
-      finish(inflight);
-      inflight = nullptr;
-      ax->cv.notify_all();
-    }
-    if (rc != ASD_OK || n == 0) {
-      { std::lock_guard<std::mutex> l(ax->m); next->job.rc = rc; next->state = AsyncJob::DONE; }
-      ax->cv.notify_all();
-    } else {
+    {
       std::lock_guard<std::mutex> l(ax->m);
-      next->state = AsyncJob::BACK;
-      inflight = next;
+      next->job.rc = rc;
+      next->state = (rc != ASD_OK || n == 0) ? AsyncJob::DONE : AsyncJob::BACK;   // BACK: enqueued, the waiter synchronises
     }
+    ax->cv.notify_all();
   }
 }
 
@@ -962,7 +932,13 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
         const int words = (ctx->num_cu + 31) / 32;
         for (int cu = 0; cu < ctx->num_cu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
         ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&sx, words, mask));
-        ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ax->stream_f, words, mask));
+        // only the ASDNet stream is masked: two CU-masked streams are served by ONE hardware queue whatever their masks
+        // (rocprofv3: same Queue_Id; the next frame's front half ran only after the previous frame's ASDNet had drained, which
+        // costs the extractor the overlap of its two halves).  The front half's stream gets the HIGHEST priority instead: its
+        // fifteen kernels are a few microseconds of small workgroups each, but beside ASDNet at equal priority every one of them
+        // waited 20-60 us for its turn (rocprofv3: k_resize 4 -> 20-66 us, k_fast_score 11 -> 54), the front half stretched
+        // from 0.35 to 0.75 ms and the ASDNet queue idled 0.4 ms per frame waiting for it: 932-954 -> 1017-1023 frames/s
+        ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_greatest));
       } else {
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_mid));
@@ -1013,19 +989,33 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   return ASD_OK;
 }
 
-// oldest outstanding submission: blocks until it is DONE, returns its job (nullptr + error code on failure)
+// oldest outstanding submission: blocks until its back half has been enqueued, synchronises on its end event in THIS thread and
+// hands the job over (nullptr + error code on failure)
 static AsyncJob* wait_oldest(asd_ctx* ctx, int* rc) {
   AsyncExtract* ax = ctx->ax;
-  std::unique_lock<std::mutex> l(ax->m);
-  if (ax->waited == ax->submitted) { ctx->set_error("asd_extract_wait: nothing was submitted"); *rc = ASD_ERR_INVALID; return nullptr; }
-  AsyncJob& a = ax->jobs[ax->waited % kSlots];
-  ax->cv.wait(l, [&] { return a.state == AsyncJob::DONE; });
-  ++ax->waited;
-  if (a.job.rc != ASD_OK) { *rc = a.job.rc; return nullptr; }
-  ctx->last_n = a.job.n;
-  ctx->d_desc_last = ax->slots[a.slot].d_desc;
+  AsyncJob* a;
+  {
+    std::unique_lock<std::mutex> l(ax->m);
+    if (ax->waited == ax->submitted) { ctx->set_error("asd_extract_wait: nothing was submitted"); *rc = ASD_ERR_INVALID; return nullptr; }
+    a = &ax->jobs[ax->waited % kSlots];
+    ax->cv.wait(l, [&] { return a->state == AsyncJob::BACK || a->state == AsyncJob::DONE; });
+  }
+  if (a->state == AsyncJob::BACK) {   // only this thread moves a job from BACK to DONE
+    (void)hipSetDevice(ctx->cfg.device);
+    const int frc = extract_finish(ctx, ax->slots[a->slot], a->job.n, a->kps.data(), nullptr);
+    std::lock_guard<std::mutex> l(ax->m);
+    if (frc != ASD_OK) a->job.rc = frc;
+    a->state = AsyncJob::DONE;
+  }
+  {
+    std::lock_guard<std::mutex> l(ax->m);
+    ++ax->waited;
+  }
+  if (a->job.rc != ASD_OK) { *rc = a->job.rc; return nullptr; }
+  ctx->last_n = a->job.n;
+  ctx->d_desc_last = ax->slots[a->slot].d_desc;
   *rc = ASD_OK;
-  return &a;
+  return a;
 }
 
 int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_out) {

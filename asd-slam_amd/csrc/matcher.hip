@@ -846,6 +846,10 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       chain->h_result = down.host<void>(o_res);
     }
     ASD_HIP_CHECK(ctx, down.download(st));
+    // the completion waits for THIS point of the stream, not for the stream: a split-phase caller enqueues the next frame's grid
+    // and descriptor copies behind the chain, and they are not part of its result
+    if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st));
     return ASD_OK;
   };
 
@@ -853,7 +857,7 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     const int* h_out = ctx->down.host<int>(o_out);
     int rc;
     for (int round = 0;; ++round) {
-      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_chain));
       const int total = h_out[n_cur + 1];
       m->last_total[KIND] = total;
       if (total > m->cand_cap && round == 0) {  // the candidate buffers overflowed (k_resolve did not run): grow and search again

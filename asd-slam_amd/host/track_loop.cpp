@@ -81,7 +81,7 @@ asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* c
                                    const float* T, const double* pose0, const double* inv_sigma2, const float* scale32,
                                    const asd_ba_problem* ba, int32_t kf_interval, int32_t lookahead) {
   if (!ctx || n_frames < 1 || !d_frames || !K32 || !T || !pose0 || !inv_sigma2 || !scale32 || !ba || kf_interval < 1 || lookahead < 0 ||
-      lookahead >= ASD_EXTRACT_QUEUE)
+      lookahead > ASD_EXTRACT_QUEUE)   // a step waits for its own frame before it submits: never more than `lookahead` outstanding
     return nullptr;
   asd_track_handle* h = new asd_track_handle();
   h->ctx = ctx;

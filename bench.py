@@ -872,7 +872,7 @@ def main():
                        "local_ba": ("in line with tracking (asd_local_ba)" if args.sync_ba else
                                     "on the library's local-mapping lane (asd_local_ba_submit at the keyframe, own thread + stream, the reference's "
                                     "LocalMapping thread, LocalMapping.cc:92); every run is collected inside the timed region"),
-                       "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t)" if not args.no_pipeline else "none (sequential)"},
+                       "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t, one finished frame in hand)" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": roof_kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source,
