@@ -146,7 +146,7 @@ template <bool WRITE>
 __global__ __launch_bounds__(64) void k_cell_nms(const CellDev* __restrict__ cells, PyrDev P,
                                                  const uint8_t* __restrict__ score, int ini_th,
                                                  int* __restrict__ cell_count, const int* __restrict__ cell_off,
-                                                 uint32_t* __restrict__ out) {
+                                                 uint32_t* __restrict__ out, int out_cap) {
   const CellDev c = cells[blockIdx.x];
   const LevelDev& L = P.lv[c.level];
   const uint8_t* S = score + L.off;
@@ -188,7 +188,9 @@ __global__ __launch_bounds__(64) void k_cell_nms(const CellDev* __restrict__ cel
       const unsigned long long m = __ballot(w);
       if (w) {
         const int pos = base + __popcll(m & ((1ull << lane) - 1));
-        out[pos] = (uint32_t)(x - kMinBorder) | ((uint32_t)(y - kMinBorder) << 12) | ((uint32_t)s << 24);
+        // `out` is pinned host memory (the host reads the list right after this kernel): never past its end; the host sees
+        // total > capacity in level_start and reports the overflow
+        if (pos < out_cap) out[pos] = (uint32_t)(x - kMinBorder) | ((uint32_t)(y - kMinBorder) << 12) | ((uint32_t)s << 24);
       }
       base += __popcll(m);
     }
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(64) void k_cell_nms(const CellDev* __restrict__ cel
 // exclusive scan of the per-cell counts (all levels) + per-level start offsets.  One workgroup.
 __global__ __launch_bounds__(1024) void k_cell_scan(const int* __restrict__ cell_count, int ncells,
                                                     const int* __restrict__ level_cell_start, int nlevels,
-                                                    int* __restrict__ cell_off, int* __restrict__ level_start) {
+                                                    int* __restrict__ cell_off, int* __restrict__ level_start,
+                                                    int* __restrict__ level_start_host) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -225,11 +228,14 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const int* __restrict__ cell
   }
   if (t <= nlevels) {
     // level_start[l] = offset of the level's first cell; level_start[nlevels] = total
-    if (t == nlevels) level_start[t] = carry_s;
+    int v;
+    if (t == nlevels) v = carry_s;
     else {
       const int c = level_cell_start[t];
-      level_start[t] = c < ncells ? cell_off[c] : carry_s;
+      v = c < ncells ? cell_off[c] : carry_s;
     }
+    level_start[t] = v;
+    level_start_host[t] = v;   // pinned: the host needs the counts together with the corner list, one synchronisation
   }
 }
 
@@ -409,7 +415,6 @@ struct FrontendState {
   CellDev* d_cells = nullptr;
   int cells_cap = 0;
   int *d_cell_count = nullptr, *d_cell_off = nullptr, *d_level_cell_start = nullptr, *d_level_start = nullptr;
-  uint32_t* d_corners = nullptr;
   size_t corners_cap = 0;
   uint32_t* h_corners = nullptr;  // pinned
   int* h_level_start = nullptr;   // pinned
@@ -461,7 +466,6 @@ int frontend_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_level_start, (ASD_MAX_LEVELS + 1) * sizeof(int)));
   // 3x3 strict NMS keeps at most one pixel per 2x2 block
   fe->corners_cap = bytes / 4 + 1024;
-  ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_corners, fe->corners_cap * sizeof(uint32_t)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_corners, fe->corners_cap * sizeof(uint32_t)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_level_start, (ASD_MAX_LEVELS + 1) * sizeof(int)));
   const size_t np = ctx->cfg.max_patches;
@@ -477,7 +481,7 @@ void frontend_free(asd_ctx* ctx) {
   FrontendState* fe = ctx->fe;
   if (!fe) return;
   void* dev[] = {fe->d_pyr, fe->d_blur, fe->d_score, fe->d_xofs, fe->d_ialpha, fe->d_yofs, fe->d_ibeta, fe->d_cells,
-                 fe->d_cell_count, fe->d_cell_off, fe->d_level_cell_start, fe->d_level_start, fe->d_corners,
+                 fe->d_cell_count, fe->d_cell_off, fe->d_level_cell_start, fe->d_level_start,
                  fe->d_kps, fe->d_angles};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {fe->h_corners, fe->h_level_start, fe->h_kps, fe->h_angles, fe->h_desc};
@@ -678,25 +682,24 @@ static int extract_front(asd_ctx* ctx, const ExtractJob& J, ExtractSlot& S, hipS
   // E2 FAST score, per-cell NMS, compaction
   const int ncells = (int)fe->h_cells.size();
   hipLaunchKernelGGL(k_fast_score, dim3(P.total_tiles), dim3(256), 0, st, P, fe->d_pyr, fe->d_score, ctx->cfg.min_th_fast);
+  // the corner list and the per-level counts are written straight into pinned host memory by the kernels that produce them:
+  // one synchronisation instead of counts D2H -> sync -> list D2H -> sync (the second round trip took 0.23 ms beside ASDNet)
   hipLaunchKernelGGL(k_cell_nms<false>, dim3(ncells), dim3(64), 0, st, fe->d_cells, P, fe->d_score, ctx->cfg.ini_th_fast,
-                     fe->d_cell_count, fe->d_cell_off, fe->d_corners);
+                     fe->d_cell_count, fe->d_cell_off, fe->h_corners, 0);
   hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, st, fe->d_cell_count, ncells, fe->d_level_cell_start, nl,
-                     fe->d_cell_off, fe->d_level_start);
+                     fe->d_cell_off, fe->d_level_start, fe->h_level_start);
   hipLaunchKernelGGL(k_cell_nms<true>, dim3(ncells), dim3(64), 0, st, fe->d_cells, P, fe->d_score, ctx->cfg.ini_th_fast,
-                     fe->d_cell_count, fe->d_cell_off, fe->d_corners);
+                     fe->d_cell_count, fe->d_cell_off, fe->h_corners, (int)fe->corners_cap);
   ASD_HIP_CHECK(ctx, hipGetLastError());
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_level_start, fe->d_level_start, (nl + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  const int total = fe->h_level_start[nl];
-  const auto t_counts = now();
-  if ((size_t)total > fe->corners_cap) { ctx->set_error("corner buffer overflow"); return ASD_ERR_CAPACITY; }
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(fe->h_corners, fe->d_corners, (size_t)total * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipEventRecord(ev_corners, st));
   // E5a blur runs on the GPU while the host does the quadtree
   hipLaunchKernelGGL(k_blur7, dim3(P.total_tiles), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   // E3 quadtree per level on the host (DistributeOctTree): wait for the corner list only
   ASD_HIP_CHECK(ctx, hipEventSynchronize(ev_corners));
+  const auto t_counts = now();
+  const int total = fe->h_level_start[nl];
+  if ((size_t)total > fe->corners_cap) { ctx->set_error("corner buffer overflow"); return ASD_ERR_CAPACITY; }
   const auto t_corners = now();
   // unpack + quadtree per level in parallel (levels are independent), then assemble in level order
   const std::function<void(int)> level_job = [&](int l) {
@@ -848,8 +851,12 @@ static void async_worker(asd_ctx* ctx) {
   // half: the thread that calls asd_extract_wait synchronises on the frame's end event itself (wait_oldest).  Waiting here put
   // the hand-over (event wait, wake-up, angle copy) between one frame's ASDNet and the NEXT BUT ONE frame's front half, which
   // then started ~0.4 ms into the next ASDNet and no longer fitted under it (rocprofv3: the ASDNet queue idled 0.3 ms per frame).
+  static const bool timing = getenv("ASD_TIMING") != nullptr;
+  double t_idle = 0, t_front = 0, t_back = 0;
+  long jobs = 0;
   for (;;) {
     AsyncJob* next = nullptr;
+    const auto w0 = std::chrono::steady_clock::now();
     {
       std::unique_lock<std::mutex> l(ax->m);
       ax->cv.wait(l, [&] { return ax->stop || ax->started < ax->submitted; });
@@ -858,11 +865,19 @@ static void async_worker(asd_ctx* ctx) {
       ++ax->started;
       next->state = AsyncJob::FRONT;
     }
+    const auto w1 = std::chrono::steady_clock::now();
     ExtractSlot& S = ax->slots[next->slot];
     int32_t n = 0;
     int rc = extract_front(ctx, next->job, S, ax->stream_f, ax->ev_corners, next->kps.data(), &n);
+    const auto w2 = std::chrono::steady_clock::now();
     next->job.n = n;
     if (rc == ASD_OK && n > 0) rc = extract_back_enqueue(ctx, S, n, ctx->stream_x);
+    if (timing) {
+      const auto w3 = std::chrono::steady_clock::now();
+      auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+      t_idle += us(w0, w1); t_front += us(w1, w2); t_back += us(w2, w3);
+      if (++jobs % 200 == 0) fprintf(stderr, "[extract worker] per frame: waiting for a job %.0f us, front half %.0f us, back half enqueue %.0f us\n", t_idle / jobs, t_front / jobs, t_back / jobs);
+    }
     {
       std::lock_guard<std::mutex> l(ax->m);
       next->job.rc = rc;
