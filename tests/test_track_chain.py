@@ -75,6 +75,34 @@ def test_track_motion_model_equals_separate_calls(hip, oracle, synth, n, th, ori
 
 
 @pytest.mark.gpu
+def test_track_motion_model_projection_on_device_edge_cases(hip, synth):
+    """asd_track_motion_model makes the projection loop (ORBmatcher.cc:1343-1368) on the device (k_project_queries); the separate
+    asd_match_project_frame call makes it on the host.  Points behind the camera, at depth zero, outside the image on every side,
+    exactly on the image border, without a map point, and non-finite positions must fall the same way in both."""
+    n = 1200
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 4242)
+    rng = np.random.default_rng(7)
+    Xw = Xw.copy(); has = has.copy()
+    Xw[0:60, 2] *= -1                                  # behind the camera
+    Xw[60:70, 2] = -T[2, 3] / max(abs(T[2, 2]), 1e-3)  # depth ~ 0
+    Xw[70:130, 0] += rng.choice([-400.0, 400.0], 60).astype(np.float32)   # far outside left / right
+    Xw[130:190, 1] += rng.choice([-150.0, 150.0], 60).astype(np.float32)  # above / below
+    Xw[190:196] = np.float32(np.inf); Xw[196:200] = np.float32(np.nan)
+    has[200:260] = 0
+    # a point that projects exactly onto the right image border (u == max_x is inside: the test is u > max_x)
+    Xw[260] = backproject(T, K, np.array([[BOUNDS[1], 100.0]], np.float32), np.array([12.0]))[0]
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    pose0 = _pose7(pose_T(rv=(0.01, -0.015, 0.004), t=(0.1, -0.03, 0.3)))
+    for th in (15.0, 30.0):
+        exp = _separate_m1(hip, n, kc, has, Xw, mp_desc, T, K, th, True, pose0)
+        got = hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, th, pose0, True)
+        for a, b in zip(got, exp):
+            np.testing.assert_array_equal(a, b)
+    assert got[1] > 300
+
+
+@pytest.mark.gpu
 def test_track_motion_model_few_matches_and_host_replay(pkg, synth, monkeypatch):
     """< 3 correspondences leave the pose alone (Optimizer.cc:323-324); a context with the host replay runs the same chain
     through the separate entry points and returns the same results"""
