@@ -189,6 +189,14 @@ __device__ inline bool chol6_solve(const double* H, double lambda, const double*
 struct PoseOptArgs {
   int n;
   const int* n_dev;     // fused chains: the edge count produced on the device by k_pose_edges (n then = capacity)
+  // fused chains, LDS form: the kernel itself compacts the matched keypoints (keypoint order = the edge order of Optimizer.cc:281)
+  // straight into its LDS edge store -- no k_pose_edges launch, no [n][6] records in HBM.  g_src != null selects this.
+  const int* g_src;       // [g_ncur] row of g_tab, or -1
+  const uint8_t* g_hold;  // [g_ncur] or null: the keypoint carries its own point (g_own)
+  const float* g_tab;     // [.][3]
+  const float* g_own;     // [g_ncur][3] or null
+  const float4* g_kp;     // (x, y, octave bits, angle)
+  int g_ncur;
   const double* edges;  // [n][6] as uploaded: Xw, obs, inv_sigma2
   double fx, fy, cx, cy;
   double* soa_g;        // [8][n] global scratch (used when the problem does not fit LDS)
@@ -370,13 +378,33 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
 template <int MODE>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   PoseOptArgs a = a_in;
-  if (a.n_dev) {   // the matches were made on the device (asd_track_*): the edge count is only known there
-    a.n = *a.n_dev;
-    if (a.n < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
-      if (threadIdx.x < 7) a.io[threadIdx.x] = a.pose0[threadIdx.x];
-      if (threadIdx.x == 7) a.io[7] = 0.0;
-      return;
+  constexpr int kGatherChunks = 9;   // 150 KB / 35 B per edge: at most 4388 keypoints reach the LDS form
+  __shared__ int g_cnt[kGatherChunks * kPoseWaves + 1];
+  const bool gather = MODE == 2 && a.g_src != nullptr;
+  if (gather) {   // count the matched keypoints per (chunk, wave), scan: edge count and every wave's first edge
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunks = (a.g_ncur + kPoseThreads - 1) / kPoseThreads;
+    for (int c = 0; c < nchunks; ++c) {
+      const int j = c * kPoseThreads + threadIdx.x;
+      const bool has = j < a.g_ncur && ((a.g_hold && a.g_hold[j]) || a.g_src[j] >= 0);
+      const unsigned long long m = __ballot(has);
+      if (lane == 0) g_cnt[c * kPoseWaves + wave] = __popcll(m);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+      for (int i = 0; i < nchunks * kPoseWaves; ++i) { const int v = g_cnt[i]; g_cnt[i] = sum; sum += v; }
+      g_cnt[kGatherChunks * kPoseWaves] = sum;
+    }
+    __syncthreads();
+    a.n = g_cnt[kGatherChunks * kPoseWaves];
+  } else if (a.n_dev) {   // the matches were made on the device (asd_track_*): the edge count is only known there
+    a.n = *a.n_dev;
+  }
+  if ((gather || a.n_dev) && a.n < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
+    if (threadIdx.x < 7) a.io[threadIdx.x] = a.pose0[threadIdx.x];
+    if (threadIdx.x == 7) a.io[7] = 0.0;
+    return;
   }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
   // the read-ahead extractor: ask the SIMD arbiters to issue its waves first
@@ -396,6 +424,29 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     outl = lvl + a.n;
     E.isg_tab = S.isg_tab;
     float* uvf = reinterpret_cast<float*>(E.uv);
+    if (gather) {
+      const int lane = t & 63, wave = t >> 6;
+      const int nchunks = (a.g_ncur + kPoseThreads - 1) / kPoseThreads;
+      for (int c = 0; c < nchunks; ++c) {
+        const int j = c * kPoseThreads + t;
+        int row = -1;
+        bool mine = false;
+        if (j < a.g_ncur) {
+          if (a.g_hold && a.g_hold[j]) mine = true;
+          else row = a.g_src[j];
+        }
+        const bool has = mine || row >= 0;
+        const unsigned long long m = __ballot(has);
+        if (has) {
+          const int e = g_cnt[c * kPoseWaves + wave] + __popcll(m & ((1ull << lane) - 1));
+          const float* X = mine ? a.g_own + 3 * (size_t)j : a.g_tab + 3 * (size_t)row;
+          const float4 k = a.g_kp[j];
+          E.xyz[e] = (double)X[0]; E.xyz[(size_t)a.n + e] = (double)X[1]; E.xyz[(size_t)2 * a.n + e] = (double)X[2];
+          uvf[2 * e] = k.x; uvf[2 * e + 1] = k.y;           // kpUn.pt is f32 in the reference: nothing is rounded
+          E.isgi[e] = (uint8_t)__float_as_int(k.z);          // octave -> index into the information-value table
+        }
+      }
+    } else {
     for (int i = t; i < 6 * a.n; i += kPoseThreads) {
       const int k = i % 6, e = i / 6;
       const double v = a.edges[i];
@@ -403,6 +454,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       else if (k < 5) uvf[2 * e + (k - 3)] = (float)v;  // exact: checked on the host
     }
     for (int i = t; i < a.n; i += kPoseThreads) E.isgi[i] = a.isgi[i];
+    }
     if (t < 16) S.isg_tab[t] = a.isg_tab[t];
   } else {
     if constexpr (MODE == 1) {
@@ -1262,21 +1314,26 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   if ((rc = s->po_Xw.ensure(ctx, idx_off + ((size_t)n_cur + 63) / 64 * 64 + 64)) || (rc = s->po_err.ensure(ctx, (size_t)n_cur * 64)) ||
       (rc = s->po_level.ensure(ctx, (size_t)2 * n_cur)) || (rc = s->pc_n.ensure(ctx, 16)))
     return rc;
-  PoseEdgesArgs e{};
-  e.n_cur = n_cur; e.src = d_src; e.hold = d_hold; e.tab = d_tab; e.own = d_own; e.kp = d_kp;
-  for (int l = 0; l < ASD_MAX_LEVELS; ++l) e.inv_sigma2[l] = l < ctx->cfg.n_levels ? ctx->inv_sigma2[l] : 0.f;
-  e.edges = s->po_Xw.as<double>(); e.isgi = s->po_Xw.as<uint8_t>() + idx_off; e.n_out = s->pc_n.as<int>();
-  hipLaunchKernelGGL(k_pose_edges, dim3(1), dim3(1024), 0, st, e);
-  ASD_HIP_CHECK(ctx, hipGetLastError());
+  const size_t lds_compact = (size_t)n_cur * 35 + 16;
+  const int mode = (ctx->cfg.n_levels <= 16 && lds_compact <= 150 * 1024) ? 2 : 0;
   PoseOptArgs a{};
-  a.n = n_cur; a.n_dev = s->pc_n.as<int>();
-  a.edges = s->po_Xw.as<double>(); a.isgi = s->po_Xw.as<uint8_t>() + idx_off;
+  a.n = n_cur;
+  if (mode == 2) {   // the solver gathers its edges itself (LDS form)
+    a.g_src = d_src; a.g_hold = d_hold; a.g_tab = d_tab; a.g_own = d_own; a.g_kp = d_kp; a.g_ncur = n_cur;
+  } else {           // larger than LDS: edge records through HBM
+    PoseEdgesArgs e{};
+    e.n_cur = n_cur; e.src = d_src; e.hold = d_hold; e.tab = d_tab; e.own = d_own; e.kp = d_kp;
+    for (int l = 0; l < ASD_MAX_LEVELS; ++l) e.inv_sigma2[l] = l < ctx->cfg.n_levels ? ctx->inv_sigma2[l] : 0.f;
+    e.edges = s->po_Xw.as<double>(); e.isgi = s->po_Xw.as<uint8_t>() + idx_off; e.n_out = s->pc_n.as<int>();
+    hipLaunchKernelGGL(k_pose_edges, dim3(1), dim3(1024), 0, st, e);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    a.n_dev = s->pc_n.as<int>();
+    a.edges = s->po_Xw.as<double>(); a.isgi = s->po_Xw.as<uint8_t>() + idx_off;
+  }
   for (int k = 0; k < 16; ++k) a.isg_tab[k] = k < ctx->cfg.n_levels ? (double)ctx->inv_sigma2[k] : 0.0;   // invSigma2 is a float in the reference (Optimizer.cc:300)
   memcpy(a.pose0, pose7, 56);
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
   a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;
-  const size_t lds_compact = (size_t)n_cur * 35 + 16;
-  const int mode = (ctx->cfg.n_levels <= 16 && lds_compact <= 150 * 1024) ? 2 : 0;
   a.use_lds = mode;
   a.debug = 0;
   static bool attr_set = false;
