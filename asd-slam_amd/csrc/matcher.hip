@@ -277,6 +277,8 @@ struct ResolveArgs {
   int* pick;                  // [nq] scratch: the keypoint q writes (-1 none)
   int* match_cur;             // out [n_cur]
   int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations
+  int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches: the kernel stores its outputs there as
+                              // well, so the host needs no copy command behind the chain (the device copy feeds the pose solver)
 };
 constexpr int kResolveThreads = 512, kResolveMaxQPT = 8;   // up to 4096 queries
 // SLOTS = candidates a thread keeps in registers (template parameter: 8, 16 or 24, i.e. up to 12288 candidates register resident;
@@ -293,6 +295,8 @@ constexpr int kResolveThreads = 512, kResolveMaxQPT = 8;   // up to 4096 queries
 // order sets the level and later ones, not being `<`, leave it).  Everything the iterations touch is in registers or LDS.
 template <int KIND, int QPT, int kResolveSlots>
 __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {   // <= 128 VGPRs: 8 waves beside one ASDNet workgroup
+#define OUT(i, v) do { const int v_ = (v); a.match_cur[i] = v_; if (a.mirror) a.mirror[i] = v_; } while (0)
+#define CNT(i, v) do { const int v_ = (v); a.n_matches[i] = v_; if (a.mirror) a.mirror[a.n_cur + (i)] = v_; } while (0)
   extern __shared__ unsigned long long lds_q[];
   unsigned long long* key1 = lds_q;                                   // [nq]
   unsigned long long* key2 = lds_q + a.nq;                            // [nq] (KIND 1)
@@ -304,12 +308,12 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
   const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
   const int total = *a.total;
   if (total > a.cap) {   // truncated lists: the host grows the buffers and searches again
-    if (t == 0) { a.n_matches[0] = 0; a.n_matches[1] = total; a.n_matches[2] = 0; }
+    if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
     return;
   }
   if (total == 0) {      // nothing in any window
-    for (int j = t; j < a.n_cur; j += kResolveThreads) a.match_cur[j] = -1;
-    if (t == 0) { a.n_matches[0] = 0; a.n_matches[1] = 0; a.n_matches[2] = 0; }
+    for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, -1);
+    if (t == 0) { CNT(0, 0); CNT(1, 0); CNT(2, 0); }
     return;
   }
   constexpr unsigned long long kNone = ~0ull;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     if (pick[k] >= 0) { atomicMax(&last[pick[k]], t + k * kResolveThreads); ++mine; }
   if (mine) atomicAdd(&n_written, mine);
   __syncthreads();
-  for (int j = t; j < a.n_cur; j += kResolveThreads) a.match_cur[j] = last[j];
+  for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, last[j]);
   if (KIND == 0 && a.check_ori) {
     int bin[QPT];
 #pragma unroll
@@ -476,15 +480,17 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     int removed = 0;
 #pragma unroll
     for (int k = 0; k < QPT; ++k)   // every write in a discarded bin clears the keypoint and is subtracted (:1437-1450)
-      if (bin[k] >= 0 && bin[k] != keep[0] && bin[k] != keep[1] && bin[k] != keep[2]) { a.match_cur[pick[k]] = -1; ++removed; }
+      if (bin[k] >= 0 && bin[k] != keep[0] && bin[k] != keep[1] && bin[k] != keep[2]) { OUT(pick[k], -1); ++removed; }
     if (removed) atomicAdd(&n_removed, removed);
   }
   __syncthreads();
-  if (t == 0) { a.n_matches[0] = (KIND == 1 ? 2 : 1) * n_written - n_removed; a.n_matches[1] = *a.total; a.n_matches[2] = it + 1;
+  if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, *a.total); CNT(2, it + 1);
     // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs -- in units of 10 ns
-    a.n_matches[3] = (int)(ts1 - ts0); a.n_matches[4] = (int)(ts2 - ts1); a.n_matches[5] = (int)(__builtin_amdgcn_s_memrealtime() - ts2); a.n_matches[6] = (int)(ts_it0 - ts1);
-    for (int i = 0; i < 4; ++i) a.n_matches[7 + i] = ph[i]; }
+    CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
+    for (int i = 0; i < 4; ++i) CNT(7 + i, ph[i]); }
 }
+#undef OUT
+#undef CNT
 
 // Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) + the search window of
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) (:60-70), one thread per map point, straight into the query table of
@@ -860,6 +866,8 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     a.kp_cur = F.d_kp; a.kp_last = kp_last;
     a.check_ori = check_ori; a.nn_ratio = nn_ratio;
     a.pick = d_pick; a.match_cur = d_out; a.n_matches = d_out + n_cur;
+    static const bool zero_copy = getenv("ASD_RESULT_COPY") == nullptr;   // results stored by the kernels straight into the pinned block
+    a.mirror = zero_copy ? down.host<int>(o_out) : nullptr;
     const size_t lds = resolve_lds_bytes(KIND, n_cur, nq);
     auto launch = [&](auto kern) -> hipError_t {
       static bool attr_set = false;   // per instantiation: more than 64 KB of dynamic LDS has to be asked for once
@@ -878,10 +886,10 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
     if (chain) {
-      if ((rc = chain->enqueue(d_out, d_tab, down.dev<void>(o_res))) != ASD_OK) return rc;
+      if ((rc = chain->enqueue(d_out, d_tab, zero_copy ? down.host<void>(o_res) : down.dev<void>(o_res))) != ASD_OK) return rc;
       chain->h_result = down.host<void>(o_res);
     }
-    ASD_HIP_CHECK(ctx, down.download(st));
+    if (!zero_copy) ASD_HIP_CHECK(ctx, down.download(st));
     // the completion waits for THIS point of the stream, not for the stream: a split-phase caller enqueues the next frame's grid
     // and descriptor copies behind the chain, and they are not part of its result
     if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
