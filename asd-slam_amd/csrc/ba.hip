@@ -151,32 +151,49 @@ __device__ inline void block_reduce(double (&v)[N], double* red, double* out /*[
   __syncthreads();
 }
 
+// every loop fully unrolled: with run-time indices A[] and inv[] live in scratch memory (336 B per lane, ~1450 cycles per solve on
+// the single lane that runs it); unrolled they are registers
 __device__ inline bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
   double A[36], inv[6];
+#pragma unroll
   for (int i = 0; i < 36; ++i) A[i] = H[i];
+#pragma unroll
   for (int j = 0; j < 6; ++j) A[j * 7] += lambda;
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double d = A[j * 6 + j];
+#pragma unroll
     for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
-    if (!(d > 0)) return false;
+    if (!(d > 0)) ok = false;
     inv[j] = asd_rsqrt(d);
     A[j * 6 + j] = d * inv[j];
+#pragma unroll
     for (int i = j + 1; i < 6; ++i) {
       double s = A[i * 6 + j];
+#pragma unroll
       for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
       A[i * 6 + j] = s * inv[j];
     }
   }
+  if (!ok) return false;
+  double y[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
     double s = b[i];
-    for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * x[k];
-    x[i] = s * inv[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * y[k];
+    y[i] = s * inv[i];
   }
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
-    double s = x[i];
-    for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * x[k];
-    x[i] = s * inv[i];
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * y[k];
+    y[i] = s * inv[i];
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = y[i];
   return true;
 }
 
@@ -310,7 +327,7 @@ __device__ inline void pose_pass(const PoseOptArgs& a, const EdgeStore<MODE>& E,
   double acc[29];
 #pragma unroll
   for (int k = 0; k < 29; ++k) acc[k] = 0.0;
-  const int n = a.n;
+  const int n = E.n;   // (the edge count of the fused chains is made on the device: a.n is then only a capacity)
   const long long c0 = a.debug ? clock64() : 0;
   // Branch-free body (inactive or out-of-range lanes run with weight 0 and keep their stored error), unrolled by
   // two so the scheduler can interleave two independent edges: with one wave per SIMD nothing else hides the
@@ -377,7 +394,10 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
 // compiler falls back to FLAT loads, whose latency dominated the edge loop.
 template <int MODE>
 __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
-  PoseOptArgs a = a_in;
+  // no private copy of the argument block: a copy that is indexed at run time (pose0[t], isg_tab[t]) lives in scratch memory, and
+  // every a.fx / a.n of the passes then is a scratch load
+  const PoseOptArgs& a = a_in;
+  int ne = a.n;   // edge count (fused chains: made on the device below, a.n is then only the capacity)
   constexpr int kGatherChunks = 9;   // 150 KB / 35 B per edge: at most 4388 keypoints reach the LDS form
   __shared__ int g_cnt[kGatherChunks * kPoseWaves + 1];
   const bool gather = MODE == 2 && a.g_src != nullptr;
@@ -397,11 +417,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       g_cnt[kGatherChunks * kPoseWaves] = sum;
     }
     __syncthreads();
-    a.n = g_cnt[kGatherChunks * kPoseWaves];
+    ne = g_cnt[kGatherChunks * kPoseWaves];
   } else if (a.n_dev) {   // the matches were made on the device (asd_track_*): the edge count is only known there
-    a.n = *a.n_dev;
+    ne = *a.n_dev;
   }
-  if ((gather || a.n_dev) && a.n < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
+  if ((gather || a.n_dev) && ne < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
     if (threadIdx.x < 7) a.io[threadIdx.x] = a.pose0[threadIdx.x];
     if (threadIdx.x == 7) a.io[7] = 0.0;
     return;
@@ -413,15 +433,15 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) double dyn[];
   const int t = threadIdx.x;
   EdgeStore<MODE> E{};
-  E.n = a.n;
+  E.n = ne;
   uint8_t *lvl, *outl;
   // a.edges = the [n][6] records as uploaded (coalesced read, transposed write); a.isgi = information-value index per edge
   if constexpr (MODE == 2) {
     E.xyz = dyn;
-    E.uv = reinterpret_cast<float2*>(dyn + (size_t)3 * a.n);
-    E.isgi = reinterpret_cast<uint8_t*>(E.uv + a.n);
-    lvl = E.isgi + a.n;
-    outl = lvl + a.n;
+    E.uv = reinterpret_cast<float2*>(dyn + (size_t)3 * ne);
+    E.isgi = reinterpret_cast<uint8_t*>(E.uv + ne);
+    lvl = E.isgi + ne;
+    outl = lvl + ne;
     E.isg_tab = S.isg_tab;
     float* uvf = reinterpret_cast<float*>(E.uv);
     if (gather) {
@@ -441,34 +461,34 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
           const int e = g_cnt[c * kPoseWaves + wave] + __popcll(m & ((1ull << lane) - 1));
           const float* X = mine ? a.g_own + 3 * (size_t)j : a.g_tab + 3 * (size_t)row;
           const float4 k = a.g_kp[j];
-          E.xyz[e] = (double)X[0]; E.xyz[(size_t)a.n + e] = (double)X[1]; E.xyz[(size_t)2 * a.n + e] = (double)X[2];
+          E.xyz[e] = (double)X[0]; E.xyz[(size_t)ne + e] = (double)X[1]; E.xyz[(size_t)2 * ne + e] = (double)X[2];
           uvf[2 * e] = k.x; uvf[2 * e + 1] = k.y;           // kpUn.pt is f32 in the reference: nothing is rounded
           E.isgi[e] = (uint8_t)__float_as_int(k.z);          // octave -> index into the information-value table
         }
       }
     } else {
-    for (int i = t; i < 6 * a.n; i += kPoseThreads) {
+    for (int i = t; i < 6 * ne; i += kPoseThreads) {
       const int k = i % 6, e = i / 6;
       const double v = a.edges[i];
-      if (k < 3) E.xyz[(size_t)k * a.n + e] = v;
+      if (k < 3) E.xyz[(size_t)k * ne + e] = v;
       else if (k < 5) uvf[2 * e + (k - 3)] = (float)v;  // exact: checked on the host
     }
-    for (int i = t; i < a.n; i += kPoseThreads) E.isgi[i] = a.isgi[i];
+    for (int i = t; i < ne; i += kPoseThreads) E.isgi[i] = a.isgi[i];
     }
     if (t < 16) S.isg_tab[t] = a.isg_tab[t];
   } else {
     if constexpr (MODE == 1) {
       E.soa = dyn;
-      lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)6 * a.n);
-      outl = lvl + a.n;
+      lvl = reinterpret_cast<uint8_t*>(dyn + (size_t)6 * ne);
+      outl = lvl + ne;
     } else {
       E.soa = a.soa_g;
       lvl = a.flags_g;
-      outl = a.flags_g + a.n;
+      outl = a.flags_g + ne;
     }
-    for (int i = t; i < 6 * a.n; i += kPoseThreads) E.soa[(size_t)(i % 6) * a.n + i / 6] = a.edges[i];
+    for (int i = t; i < 6 * ne; i += kPoseThreads) E.soa[(size_t)(i % 6) * ne + i / 6] = a.edges[i];
   }
-  for (int i = t; i < a.n; i += kPoseThreads) { lvl[i] = 0; outl[i] = 0; }
+  for (int i = t; i < ne; i += kPoseThreads) { lvl[i] = 0; outl[i] = 0; }
   if (t == 0) {
     Pose7 T0{a.pose0[0], a.pose0[1], a.pose0[2], a.pose0[3], a.pose0[4], a.pose0[5], a.pose0[6]};
     quat_normalize(T0.qx, T0.qy, T0.qz, T0.qw);
@@ -565,7 +585,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       const Pose7 T = S.T, Te = S.Teval;
       double Re[9];
       quat_to_rot(Te, Re);
-      const int n = a.n;
+      const int n = ne;
       for (int i = t; i < n; i += kPoseThreads) {
         double X, Y, Z, ou, ov, isg, e0, e1;
         E.load(i, X, Y, Z, ou, ov, isg);
@@ -592,7 +612,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       printf("[pose_opt] round %d: %d passes, nBad %d; cycles/pass: edges %lld (slowest wave %lld) reduce %lld solve+oplus %lld (solve %lld) accept %lld\n", round, S.npass,
              nBad, S.cyc[0] / S.npass, S.dbg[0] / S.npass, S.cyc[1] / S.npass, S.cyc[2] / S.npass, S.dbg[1] / S.npass, S.cyc[3] / S.npass);
     if (round == 2) robust = false;  // e->setRobustKernel(0)
-    if (a.n < 10) break;             // optimizer.edges().size() < 10
+    if (ne < 10) break;             // optimizer.edges().size() < 10
   }
   if (t == 0) {
     a.io[0] = S.T.qx; a.io[1] = S.T.qy; a.io[2] = S.T.qz; a.io[3] = S.T.qw;
@@ -601,10 +621,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   }
   // outlier flags to the (pinned host) io block, eight per 8-byte store
   unsigned long long* og8 = reinterpret_cast<unsigned long long*>(a.io + 8);
-  for (int i = t; i < (a.n + 7) / 8; i += kPoseThreads) {
+  for (int i = t; i < (ne + 7) / 8; i += kPoseThreads) {
     unsigned long long w = 0;
     for (int k = 0; k < 8; ++k)
-      if (8 * i + k < a.n) w |= (unsigned long long)outl[8 * i + k] << (8 * k);
+      if (8 * i + k < ne) w |= (unsigned long long)outl[8 * i + k] << (8 * k);
     og8[i] = w;
   }
 }
