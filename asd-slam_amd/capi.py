@@ -212,6 +212,14 @@ class AsdHip:
         self._chk(self.lib.asd_extract_wait(self.ctx, _p(self._kps_buf), _p(self._desc_buf), C.byref(n)))
         return self._kps_buf[:n.value], self._desc_buf[:n.value]
 
+    def extract_last_view(self):
+        self.lib.asd_extract_last_view.restype = C.c_uint64
+        return int(self.lib.asd_extract_last_view(self.ctx))
+
+    def extract_view_valid(self, view_id):
+        self.lib.asd_extract_view_valid.restype = C.c_int32
+        return bool(self.lib.asd_extract_view_valid(self.ctx, C.c_uint64(view_id)))
+
     def profile_enable(self, on=True):
         self._chk(self.lib.asd_profile_enable(self.ctx, int(on)))
 

@@ -841,6 +841,7 @@ struct AsyncExtract {
   ExtractSlot slots[kSlots];
   AsyncJob jobs[kSlots];     // ring: job of submission s lives in jobs[s % kSlots]
   uint64_t submitted = 0, started = 0, waited = 0;  // counters: submitted >= started >= waited
+  uint64_t last_view = ~0ull;                       // submission index of the most recently waited job
 };
 
 static void async_worker(asd_ctx* ctx) {
@@ -1029,6 +1030,7 @@ static AsyncJob* wait_oldest(asd_ctx* ctx, int* rc) {
   if (a->job.rc != ASD_OK) { *rc = a->job.rc; return nullptr; }
   ctx->last_n = a->job.n;
   ctx->d_desc_last = ax->slots[a->slot].d_desc;
+  ax->last_view = ax->waited - 1;   // submission index of the job just handed over (asd_extract_last_view)
   *rc = ASD_OK;
   return a;
 }
@@ -1054,6 +1056,21 @@ int asd_extract_wait_view(asd_ctx* ctx, const asd_keypoint** kps, const float** 
   *desc = ctx->ax->slots[a->slot].h_desc;
   *n_out = a->job.n;
   return ASD_OK;
+}
+
+uint64_t asd_extract_last_view(const asd_ctx* ctx) {
+  if (!ctx || !ctx->ax) return ~0ull;
+  std::lock_guard<std::mutex> l(ctx->ax->m);
+  return ctx->ax->last_view;
+}
+
+int32_t asd_extract_view_valid(asd_ctx* ctx, uint64_t view_id) {
+  if (!ctx || !ctx->ax) return 0;
+  AsyncExtract* ax = ctx->ax;
+  std::lock_guard<std::mutex> l(ax->m);
+  // submission view_id lives in ring entry view_id % kSlots; submission view_id + kSlots takes that entry (keypoints) and its slot
+  // (descriptors, angles)
+  return view_id < ax->waited && ax->submitted <= view_id + (uint64_t)kSlots ? 1 : 0;
 }
 
 int asd_get_level_size(const asd_ctx* ctx, int32_t level, int32_t* width, int32_t* height) {

@@ -133,6 +133,13 @@ int asd_extract_wait(asd_ctx* ctx, asd_keypoint* kps, float* desc, int32_t* n_ou
  * wrap them as the Frame's mvKeys / mDescriptors (cv::Mat header over foreign data) for the frame's lifetime in
  * the tracker, which is two frames. */
 int asd_extract_wait_view(asd_ctx* ctx, const asd_keypoint** kps, const float** desc, int32_t* n_out);
+/* The lifetime of a view, checkable: asd_extract_last_view returns the id of the view handed out by the most recent
+ * asd_extract_wait / asd_extract_wait_view (ids count submissions from 0), and asd_extract_view_valid(ctx, id) is 1 as long
+ * as no later submission has been given that view's buffers -- exactly: while fewer than ASD_EXTRACT_QUEUE + 2 submissions
+ * have been made after the one the view belongs to -- and 0 afterwards (or for an id that was never handed out).  A caller
+ * that keeps a view across frames (mCurrentFrame / mLastFrame) can assert this where it dereferences it. */
+uint64_t asd_extract_last_view(const asd_ctx* ctx);
+int32_t asd_extract_view_valid(asd_ctx* ctx, uint64_t view_id);
 
 /* Intermediate products of the last asd_extract, for tests and for callers that read
  * ORBextractor::mvImagePyramid (ORBextractor.h:87).  Level images are returned WITHOUT

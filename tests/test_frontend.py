@@ -307,6 +307,43 @@ def test_pipelined_extract_equals_sync(hip, synth):
 
 
 @pytest.mark.gpu
+def test_view_lifetime_is_checkable(pkg, synth):
+    """asd_extract_last_view / asd_extract_view_valid: a view stays valid -- and its contents intact -- until the submission that
+    takes its buffers (ASD_EXTRACT_QUEUE + 2 = 5 submissions after its own) has been made, and the library says so."""
+    ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    try:
+        ctx.load_weights(synth.asdnet_weights(0))
+        imgs = [np.ascontiguousarray(synth.scene_frame(t)[:240, :640]) for t in range(3)]
+        ref = [ctx.extract(im) for im in imgs]
+        dev = []
+        for im in imgs:
+            p = ctx.device_alloc(im.nbytes)
+            ctx.h2d(p, im)
+            dev.append(p)
+        imgs = dev
+        assert not ctx.extract_view_valid(0)                  # nothing handed out yet
+        ctx.extract_submit(imgs[0], 640, 240, 640)            # submission 0
+        k0, d0 = ctx.extract_wait(view=True)
+        v0 = ctx.extract_last_view()
+        assert v0 == 0 and ctx.extract_view_valid(v0)
+        for s in range(1, 5):                                 # submissions 1..4: the view of 0 survives all of them
+            ctx.extract_submit(imgs[s % 3], 640, 240, 640)
+            ctx.extract_wait(view=True)
+            assert ctx.extract_last_view() == s
+            assert ctx.extract_view_valid(v0), f"after submission {s}"
+            np.testing.assert_array_equal(k0, ref[0][0])
+            np.testing.assert_array_equal(d0, ref[0][1])
+        ctx.extract_submit(imgs[1], 640, 240, 640)            # submission 5 takes the buffers of submission 0
+        assert not ctx.extract_view_valid(v0)
+        assert ctx.extract_view_valid(1) and ctx.extract_view_valid(4)
+        assert not ctx.extract_view_valid(5)                  # not waited yet: never handed out
+        ctx.extract_wait(view=True)
+        assert ctx.extract_view_valid(5)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_pipelined_extract_device_descriptors_adoptable(hip, oracle, synth):
     """asd_frame_set(desc=NULL) after asd_extract_wait adopts THAT frame's device descriptors even though the next
     frames' ASDNet passes are already running: checked through a matcher that reads the slot's descriptors"""
