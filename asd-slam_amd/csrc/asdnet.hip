@@ -552,7 +552,7 @@ __device__ inline void split8_f16(const f32x4& v0, const f32x4& v1, float scale,
 }
 
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
-__global__ __launch_bounds__(64 * WM * WN) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
+__global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
                                                          unsigned long long* __restrict__ stamps, float in_scale, float out_scale) {
@@ -1368,11 +1368,17 @@ extern "C" int asd_debug_x3_clock(asd_ctx* ctx, int layer, int n, int reps, doub
   for (int r = 0; r < reps; ++r) {
     unsigned long long* sp = r + 1 == reps ? stamps : nullptr;
     hipError_t e = hipErrorInvalidValue;
-    if (layer == 2) e = launch_conv_x3<L2S_CFG, true>(st, ctx->d_patches, ctx->d_wx3[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0], sp, &grid);
-    else if (layer == 3) e = launch_conv_x3<L3S_CFG>(st, a1, ctx->d_wx3[2], ctx->d_bias[2], a0, n, nullptr, nullptr, sp, &grid);
-    else if (layer == 4) e = launch_conv_x3<L4S_CFG>(st, a0, ctx->d_wx3[3], ctx->d_bias[3], a1, n, nullptr, nullptr, sp, &grid);
-    else if (layer == 5) e = launch_conv_x3<L5S_CFG>(st, a1, ctx->d_wx3[4], ctx->d_bias[4], a0, n, nullptr, nullptr, sp, &grid);
-    else if (layer == 6) e = launch_conv_x3<L6S_CFG>(st, a0, ctx->d_wx3[5], ctx->d_bias[5], a1, n, nullptr, nullptr, sp, &grid);
+    const bool p2 = ctx->net_pieces == 2;
+#define X3_CLK(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                          \
+  (p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, sp, &grid, kActScale,                       \
+                                     1.f / (kActScale * ctx->wx2_scale[l]))                                                                \
+      : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p, sp, &grid))
+    if (layer == 2) e = X3_CLK(L2S_CFG, true, 1, ctx->d_patches, a1, ctx->d_w1, ctx->d_bias[0]);
+    else if (layer == 3) e = X3_CLK(L3S_CFG, false, 2, a1, a0, nullptr, nullptr);
+    else if (layer == 4) e = X3_CLK(L4S_CFG, false, 3, a0, a1, nullptr, nullptr);
+    else if (layer == 5) e = X3_CLK(L5S_CFG, false, 4, a1, a0, nullptr, nullptr);
+    else if (layer == 6) e = X3_CLK(L6S_CFG, false, 5, a0, a1, nullptr, nullptr);
+#undef X3_CLK
     ASD_HIP_CHECK(ctx, e);
   }
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
