@@ -1,3 +1,8 @@
+"""The extractor's two queues in a rocprofv3 kernel trace (bench.py or tools/extract_throughput.py): period of the ASDNet queue, its
+kernel time, the idle time between one forward's k_l2norm and the next forward's first conv, a listing of both queues over two
+frames, and the distance from a frame's last front-half kernel (k_angle_patch) to its first ASDNet kernel.
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -o t -- python3 bench.py --steps 150 --warmup 30 --cpu-frames 0
+  python3 tools/extractor_timeline.py gpurun_out/trace"""
 import csv,re,statistics as st,sys,glob
 f=glob.glob(sys.argv[1]+"/**/*kernel_trace.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
