@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/asd_slam.h"
@@ -306,6 +307,100 @@ struct Optimizer {
     if (pbStopFlag && *pbStopFlag) return 0;  // :595-597
     return asd_local_ba(c.get(), problem, result);
   }
+};
+
+// ---- Tracking (Tracking.cc): the two per-frame stages as one submission each ------------------------------------------------
+// The reference runs matcher.SearchByProjection and Optimizer::PoseOptimization back to back in TrackWithMotionModel (:664-723)
+// and in TrackLocalMap (:725-736 with SearchLocalPoints :803-851); asd_track_motion_model / asd_track_local_points do the pair
+// behind one synchronisation and return the same bits as the two calls (tests/test_track_chain.py).
+struct Tracking {
+  // bool Tracking::TrackWithMotionModel(): Cur.mTcw holds the motion-model prediction on entry (mVelocity * mLastFrame.mTcw, :677).
+  // `points` = LastFrame's map points indexed like LastFrame.mvKeysUn (null where there is none).  Writes Cur.mvpMapPoints,
+  // Cur.mvbOutlier and Cur.mTcw, discards outliers like :704-719 and returns nmatchesMap >= 10 (:723); *nmatches_out gets the
+  // matcher's count of the accepted search.
+  static bool TrackWithMotionModel(Context& c, FrameView& Cur, const FrameView& Last, const std::vector<const MapPointView*>& points,
+                                   const Camera& K, bool checkOrientation = true, int* nmatches_out = nullptr, int* ninliers_out = nullptr) {
+    const int nl = Last.N(), nc = Cur.N();
+    std::vector<uint8_t> has(nl, 0), obs(nl, 1);
+    std::vector<float> Xw((size_t)nl * 3, 0.f), desc((size_t)nl * ASD_DESC_DIM, 0.f);
+    for (int i = 0; i < nl; ++i)
+      if (points[i]) {
+        has[i] = 1;
+        obs[i] = points[i]->nObs > 0;
+        for (int k = 0; k < 3; ++k) Xw[3 * i + k] = points[i]->Xw[k];
+        for (int k = 0; k < ASD_DESC_DIM; ++k) desc[(size_t)i * ASD_DESC_DIM + k] = points[i]->descriptor[k];
+      }
+    const float Kv[4] = {K.fx, K.fy, K.cx, K.cy};
+    std::vector<int32_t> match(nc, -1);
+    std::vector<uint8_t> outl(std::max(nc, 1), 0);
+    double pose[7], pose_in[7];
+    asd_tcw_to_pose7(Cur.mTcw, pose_in);
+    int32_t n = 0, ninl = 0;
+    float th = 15.f;                                                   // :673-675 (monocular)
+    for (int attempt = 0; attempt < 2; ++attempt, th *= 2) {           // :679-687: a second search with 2*th when fewer than 20 matches
+      for (int k = 0; k < 7; ++k) pose[k] = pose_in[k];
+      if (asd_track_motion_model(c.get(), Cur.slot, Last.slot, has.data(), Xw.data(), desc.data(), Cur.mTcw, Kv, th, checkOrientation, obs.data(),
+                                 pose, match.data(), &n, outl.data(), &ninl) != ASD_OK)
+        return false;
+      if (n >= 20) break;
+    }
+    if (nmatches_out) *nmatches_out = n;
+    if (ninliers_out) *ninliers_out = ninl;
+    Cur.mvpMapPoints.assign(nc, -1);
+    Cur.mvbOutlier.assign(nc, 0);
+    if (n < 20) return false;                                          // :689-690
+    asd_pose7_to_tcw(pose, Cur.mTcw);
+    int nmatchesMap = 0;
+    for (int j = 0; j < nc; ++j) {
+      if (match[j] < 0) continue;
+      if (outl[j]) continue;                                           // :708-716: the map point is dropped from the frame
+      Cur.mvpMapPoints[j] = Last.mvpMapPoints[match[j]];
+      if (points[match[j]]->nObs > 0) ++nmatchesMap;                   // :717-718
+    }
+    return nmatchesMap >= 10;
+  }
+
+  // Tracking::SearchLocalPoints + Optimizer::PoseOptimization (TrackLocalMap's numeric body): `local` = mvpLocalMapPoints not
+  // already in the frame, `ids` their map-point ids, `cur_points` the points the frame already holds (indexed like mvKeysUn,
+  // null where none).  Returns the inlier count; writes Cur.mvpMapPoints (new matches), mvbOutlier and mTcw.
+  static int TrackLocalMap(Context& c, FrameView& Cur, const std::vector<MapPointView>& local, const std::vector<int32_t>& ids,
+                           const std::vector<const MapPointView*>& cur_points, const Camera& K, float th = 1.f, float nnratio = 0.8f) {
+    const int n = (int)local.size(), nc = Cur.N();
+    std::vector<float> Xw((size_t)n * 3), nrm((size_t)n * 3), mind(n), maxd(n), desc((size_t)n * ASD_DESC_DIM), curX((size_t)nc * 3, 0.f);
+    std::vector<uint8_t> obs(n, 1), occupied(nc, 0), outl(std::max(nc, 1), 0);
+    for (int m = 0; m < n; ++m) {
+      for (int k = 0; k < 3; ++k) { Xw[3 * m + k] = local[m].Xw[k]; nrm[3 * m + k] = local[m].normal[k]; }
+      mind[m] = local[m].mfMinDistance; maxd[m] = local[m].mfMaxDistance;
+      obs[m] = local[m].nObs > 0;
+      for (int k = 0; k < ASD_DESC_DIM; ++k) desc[(size_t)m * ASD_DESC_DIM + k] = local[m].descriptor[k];
+    }
+    for (int j = 0; j < nc; ++j)
+      if (cur_points[j]) { occupied[j] = 1; for (int k = 0; k < 3; ++k) curX[3 * j + k] = cur_points[j]->Xw[k]; }
+    const float Kv[4] = {K.fx, K.fy, K.cx, K.cy};
+    std::vector<int32_t> match(nc, -1);
+    double pose[7];
+    asd_tcw_to_pose7(Cur.mTcw, pose);
+    int32_t nm = 0, ninl = 0;
+    if (asd_track_local_points(c.get(), Cur.slot, n, Xw.data(), nrm.data(), mind.data(), maxd.data(), desc.data(), Cur.mTcw, Kv, 0.5f,
+                               occupied.data(), curX.data(), th, nnratio, obs.data(), pose, match.data(), &nm, outl.data(), &ninl) != ASD_OK)
+      return 0;
+    asd_pose7_to_tcw(pose, Cur.mTcw);
+    Cur.mvpMapPoints.resize(nc, -1);
+    Cur.mvbOutlier.assign(nc, 0);
+    for (int j = 0; j < nc; ++j) {
+      if (match[j] >= 0) Cur.mvpMapPoints[j] = ids[match[j]];
+      Cur.mvbOutlier[j] = outl[j];
+    }
+    return ninl;
+  }
+};
+
+// LocalMapping::Run's call of Optimizer::LocalBundleAdjustment (LocalMapping.cc:92) on the library's local-mapping lane: Submit
+// returns at once (problem / result stay owned by the library), Tracking goes on, Wait returns the run's status.
+struct LocalMapping {
+  static int LocalBundleAdjustmentSubmit(Context& c, asd_ba_problem* problem, asd_ba_result* result) { return asd_local_ba_submit(c.get(), problem, result); }
+  static int LocalBundleAdjustmentWait(Context& c) { return asd_local_ba_wait(c.get()); }
+  static bool Busy(Context& c) { return asd_local_ba_poll(c.get()) == 1; }
 };
 
 // MapPoint::ComputeDistinctiveDescriptors for a batch of map points (MapPoint.cc:271-338): observations[s] = the

@@ -60,6 +60,54 @@ int main(int argc, char** argv) {
     std::vector<const asd::MapPointView*> cur_pts(F[1].N(), nullptr);
     for (int j = 0; j < F[1].N(); ++j) if (F[1].mvpMapPoints[j] >= 0) cur_pts[j] = &mps[F[1].mvpMapPoints[j]];
     const int ninl = asd::Optimizer::PoseOptimization(ctx, &F[1], cur_pts, K, extractor.GetInverseScaleSigmaSquares());  // :693
+    // the same stage as ONE submission (asd::Tracking::TrackWithMotionModel = asd_track_motion_model): same matches, same pose bits
+    int chain_ok = 0;
+    {
+      asd::FrameView G = F[1];
+      G.mvpMapPoints.clear(); G.mvbOutlier.clear();
+      for (int k = 0; k < 16; ++k) G.mTcw[k] = (k % 5 == 0) ? 1.f : 0.f;      // the pose the separate calls started from
+      int nm2 = 0, ninl2 = 0;
+      const bool ok = asd::Tracking::TrackWithMotionModel(ctx, G, F[0], pmp, K, true, &nm2, &ninl2);
+      bool same = ok && nm2 == nmatches && ninl2 == ninl;
+      for (int k = 0; k < 16 && same; ++k) same = G.mTcw[k] == F[1].mTcw[k];
+      for (int j = 0; j < G.N() && same; ++j)   // the frame keeps its inlier matches (Tracking.cc:704-719)
+        same = G.mvpMapPoints[j] == (F[1].mvbOutlier[j] ? -1 : F[1].mvpMapPoints[j]);
+      chain_ok = same;
+      // ... and TrackLocalMap's body on the points the frame did not take, with LocalBundleAdjustment running on its lane meanwhile
+      std::vector<asd::MapPointView> local;
+      std::vector<int32_t> ids;
+      std::vector<uint8_t> taken(mps.size(), 0);
+      std::vector<const asd::MapPointView*> curp(G.N(), nullptr);
+      for (int j = 0; j < G.N(); ++j) if (G.mvpMapPoints[j] >= 0) { taken[G.mvpMapPoints[j]] = 1; curp[j] = &mps[G.mvpMapPoints[j]]; }
+      for (size_t i = 0; i < mps.size(); ++i) if (!taken[i]) { local.push_back(mps[i]); ids.push_back((int32_t)i); }
+      // a small bundle: two keyframes (the first fixed) observing the frame's inlier points
+      std::vector<double> poses = {0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0}, pts, eobs, einfo;
+      std::vector<uint8_t> fixed = {1, 0};
+      std::vector<int32_t> ept, eps;
+      asd_tcw_to_pose7(G.mTcw, &poses[7]);
+      for (int j = 0; j < G.N() && pts.size() < 3 * 400; ++j)
+        if (curp[j]) {
+          const int m = G.mvpMapPoints[j], pid = (int)pts.size() / 3;
+          int j0 = -1;
+          for (int q = 0; q < F[0].N(); ++q) if (F[0].mvpMapPoints[q] == m) { j0 = q; break; }
+          if (j0 < 0) continue;
+          for (int k = 0; k < 3; ++k) pts.push_back(mps[m].Xw[k]);
+          ept.push_back(pid); eps.push_back(0); eobs.push_back(F[0].mvKeysUn[j0].x); eobs.push_back(F[0].mvKeysUn[j0].y); einfo.push_back(1.0);
+          ept.push_back(pid); eps.push_back(1); eobs.push_back(G.mvKeysUn[j].x); eobs.push_back(G.mvKeysUn[j].y); einfo.push_back(1.0);
+        }
+      asd_ba_problem pr{};
+      pr.n_poses = 2; pr.n_points = (int32_t)pts.size() / 3; pr.n_edges = (int32_t)ept.size();
+      pr.poses = poses.data(); pr.fixed = fixed.data(); pr.points = pts.data(); pr.e_point = ept.data(); pr.e_pose = eps.data();
+      pr.e_obs = eobs.data(); pr.e_info = einfo.data(); pr.K[0] = K.fx; pr.K[1] = K.fy; pr.K[2] = K.cx; pr.K[3] = K.cy; pr.its_first = 5; pr.its_second = 10;
+      std::vector<double> chi2(ept.size()); std::vector<uint8_t> dpos(ept.size()), out1(ept.size());
+      asd_ba_result rs{};
+      rs.edge_chi2 = chi2.data(); rs.edge_depth_pos = dpos.data(); rs.edge_outlier1 = out1.data();
+      const bool ba_sub = pr.n_points >= 10 && asd::LocalMapping::LocalBundleAdjustmentSubmit(ctx, &pr, &rs) == ASD_OK;
+      const int ninl3 = asd::Tracking::TrackLocalMap(ctx, G, local, ids, curp, K);
+      const bool ba_ok = ba_sub && asd::LocalMapping::LocalBundleAdjustmentWait(ctx) == ASD_OK && rs.iters_second > 0;
+      printf("chain: same=%d local-map inliers=%d lane BA ok=%d (%d points, chi2 %.3f)\n", (int)same, ninl3, (int)ba_ok, pr.n_points, rs.chi2_second);
+      chain_ok = chain_ok && ninl3 > 50 && ba_ok;
+    }
     // what LocalMapping::SearchInNeighbors does with the same points once frame 1 became a keyframe (LocalMapping.cc:557-636)
     asd::ORBmatcher fuser(ctx);
     std::vector<int32_t> bestIdx;
@@ -93,7 +141,7 @@ int main(int argc, char** argv) {
     }
     printf("kp0=%d kp1=%d matches=%d inliers=%d fused=%d bow=%d t=(%.4f %.4f %.4f)\n", F[0].N(), F[1].N(), nmatches, ninl, nfused, nbow,
            F[1].mTcw[3], F[1].mTcw[7], F[1].mTcw[11]);
-    return (nmatches > 100 && ninl > 50 && nfused > 0 && nbow > 0) ? 0 : 1;
+    return (nmatches > 100 && ninl > 50 && nfused > 0 && nbow > 0 && chain_ok) ? 0 : 1;
   } catch (const std::exception& e) {
     fprintf(stderr, "error: %s\n", e.what());
     return 3;
