@@ -924,14 +924,16 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   if (!ctx->ax) {
     // Without a CU mask: lowest stream priority for ASDNet (the latency-critical tracking kernels on ctx->stream go first), the
     // small front-half kernels get the middle priority so they slot in between the conv workgroups.  Default:
-    // 16 CUs are kept out of both streams (hipExtStreamCreateWithCUMask; ASD_EXTRACT_RESERVE_CUS=<n> changes the number, 0 = no
+    // 32 CUs (the last 32 mask bits: one XCD's worth) are kept out of the ASDNet stream (hipExtStreamCreateWithCUMask; ASD_EXTRACT_RESERVE_CUS=<n> changes the number, 0 = no
     // mask and stream priorities instead): the tracking stream's single-workgroup kernels want 70-100 KB of LDS on one CU, and with
     // ASDNet workgroups (50-70 KB each, two or three per CU) refilling every CU as soon as one drains they wait tens of
     // microseconds for a CU with enough free LDS.  History of this measurement: with the six-product ASDNet (0.80 ms) on the
     // critical path, a masked stream ran ASDNet 9 % slower whatever the mask and frames/s did not move (round 1: 720-750 either
     // way; round 2: 711 / 722 / 750 with 8 / 16 / 32 CUs reserved against 757 without).  With the three-product ASDNet (0.62 ms, the
     // extractor has slack) and LocalBA on its own lane the tracking chain is the critical path, and the reservation pays:
-    // 958-960 frames/s without, 991 / 1000-1015 / 1013 with 8 / 16 / 32 CUs reserved (ASDNet 0.61 -> 0.65-0.67 ms).
+    // 958-960 frames/s without, 991 / 1000-1015 / 1013 with 8 / 16 / 32 CUs reserved (ASDNet 0.61 -> 0.65-0.67 ms).  Re-measured at the
+    // end of round 2 (everything else in place): 993 / 1135-1151 / 1147 / 1161-1177 / 1159 frames/s with 8 / 16 / 24 / 32 / 48, ASDNet
+    // 0.61 / 0.62-0.63 / 0.62 / 0.63 / 0.70 ms: 32 it is.
     // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
     // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
     // will ever take (asd_extract_wait would block forever).
@@ -941,7 +943,7 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     AsyncExtract* ax = new AsyncExtract();
     hipStream_t sx = nullptr;
     auto build = [&]() -> int {
-      int reserve = 16;
+      int reserve = 32;
       if (const char* e = getenv("ASD_EXTRACT_RESERVE_CUS")) reserve = atoi(e);
       if (reserve > 0 && reserve < ctx->num_cu / 2) {
         uint32_t mask[16] = {};
