@@ -45,15 +45,22 @@ struct GridDev {
 // (segments may land in any order, each query's own list is in reference order), pass 2 writes
 // (candidate index, distance).  Arithmetic of the cell range / distance tests is the float
 // arithmetic of Frame.cc:226-265 verbatim.
-__global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
+#ifndef ASD_SEARCH_WAVES
+#define ASD_SEARCH_WAVES 8
+#endif
+constexpr int kSearchWaves = ASD_SEARCH_WAVES;   // queries (waves) per workgroup
+__global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
                                                        const float* __restrict__ qdesc, const float* __restrict__ cdesc,
                                                        int* __restrict__ q_off, int* __restrict__ q_cnt,
                                                        int* __restrict__ total, int cap, int* __restrict__ out_idx,
                                                        float* __restrict__ out_dist, unsigned* __restrict__ out_meta = nullptr) {
   const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= nq) return;
-  const WinQuery Q = queries[q];
+  const int q = blockIdx.x * kSearchWaves + (threadIdx.x >> 6);
+  // the waves of a workgroup reserve their segments with ONE atomicAdd (2000 same-address atomics, one per query, were a
+  // serial chain through one L2 channel): every wave stays alive up to the barriers below, a query beyond nq counts as empty
+  __shared__ int wg_cnt[kSearchWaves], wg_base;
+  const bool live = q < nq;
+  const WinQuery Q = live ? queries[q] : WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
   int cnt = 0, off = 0;
   bool empty = Q.qrow < 0;
   const int nMinCellX = max(0, (int)floorf((Q.x - G.min_x - Q.r) * G.inv_w));
@@ -62,8 +69,9 @@ __global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery
   const int nMaxCellY = min(ASD_GRID_ROWS - 1, (int)ceilf((Q.y - G.min_y + Q.r) * G.inv_h));
   if (nMinCellX >= ASD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ASD_GRID_ROWS || nMaxCellY < 0) empty = true;
   const bool check = (Q.min_level > 0) || (Q.max_level >= 0);
-  for (int pass = 0; pass < 2 && !empty; ++pass) {
+  for (int pass = 0; pass < 2; ++pass) {
     int pos = 0;
+    if (!empty)
     for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
       const int b = G.cell_start[ix * ASD_GRID_ROWS + nMinCellY], e = G.cell_start[ix * ASD_GRID_ROWS + nMaxCellY + 1];
       for (int base = b; base < e; base += 64) {
@@ -108,13 +116,20 @@ __global__ __launch_bounds__(256) void k_window_search(GridDev G, const WinQuery
     }
     if (pass == 0) {
       cnt = pos;
-      if (cnt == 0) break;
-      int o = 0;
-      if (lane == 0) o = atomicAdd(total, cnt);
-      off = __shfl(o, 0);
+      if (lane == 0) wg_cnt[threadIdx.x >> 6] = cnt;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < kSearchWaves; ++w) sum += wg_cnt[w];
+        wg_base = sum ? atomicAdd(total, sum) : 0;
+      }
+      __syncthreads();
+      off = wg_base;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wg_cnt[w];
+      if (cnt == 0) empty = true;
     }
   }
-  if (lane == 0) { q_cnt[q] = cnt; q_off[q] = off; }
+  if (lane == 0 && live) { q_cnt[q] = cnt; q_off[q] = cnt ? off : 0; }
 }
 
 // Node-restricted search (BoW-guided matchers): query q is matched against the explicit candidate list
@@ -737,7 +752,7 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
     ASD_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(int), st));
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
+    hipLaunchKernelGGL(k_window_search, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
                        d_total, m->cand_cap, m->d_idx, m->d_dist);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
@@ -854,7 +869,7 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     if (dev_queries && (rc = chain->prepare(up.dev<WinQuery>(o_q), d_tab)) != ASD_OK) return rc;
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
+    hipLaunchKernelGGL(k_window_search, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
                        d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     ResolveArgs a{};
