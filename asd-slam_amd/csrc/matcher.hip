@@ -49,16 +49,19 @@ struct GridDev {
 #define ASD_SEARCH_WAVES 8
 #endif
 constexpr int kSearchWaves = ASD_SEARCH_WAVES;   // queries (waves) per workgroup
+constexpr int kSearchCols = 16;                  // fast path: windows of up to this many grid columns ...
+constexpr int kSearchList = 128;                 // ... and up to this many candidates per query
 __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
                                                        const float* __restrict__ qdesc, const float* __restrict__ cdesc,
                                                        int* __restrict__ q_off, int* __restrict__ q_cnt,
                                                        int* __restrict__ total, int cap, int* __restrict__ out_idx,
                                                        float* __restrict__ out_dist, unsigned* __restrict__ out_meta = nullptr) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * kSearchWaves + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * kSearchWaves + wave;
   // the waves of a workgroup reserve their segments with ONE atomicAdd (2000 same-address atomics, one per query, were a
   // serial chain through one L2 channel): every wave stays alive up to the barriers below, a query beyond nq counts as empty
   __shared__ int wg_cnt[kSearchWaves], wg_base;
+  __shared__ int cand_l[kSearchWaves][kSearchList];
   const bool live = q < nq;
   const WinQuery Q = live ? queries[q] : WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
   int cnt = 0, off = 0;
@@ -69,9 +72,37 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
   const int nMaxCellY = min(ASD_GRID_ROWS - 1, (int)ceilf((Q.y - G.min_y + Q.r) * G.inv_h));
   if (nMinCellX >= ASD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ASD_GRID_ROWS || nMaxCellY < 0) empty = true;
   const bool check = (Q.min_level > 0) || (Q.max_level >= 0);
-  for (int pass = 0; pass < 2; ++pass) {
+  auto accept = [&](const float4& kp) {
+    const int oct = __float_as_int(kp.z);
+    bool ok = true;
+    if (check) {
+      if (oct < Q.min_level) ok = false;
+      if (Q.max_level >= 0 && oct > Q.max_level) ok = false;
+    }
+    const float dx = kp.x - Q.x, dy = kp.y - Q.y;
+    if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) ok = false;
+    return ok;
+  };
+  auto score = [&](int idx, int p) {   // exact summation order of DescriptorDistance (sequential f32), candidate p of the list
+    const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)Q.qrow * 128);
+    const float4* bb = reinterpret_cast<const float4*>(cdesc + (size_t)idx * 128);
+    float sqd = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float4 x = a[k], y = bb[k];
+      float d;
+      d = x.x - y.x; sqd = sqd + d * d;
+      d = x.y - y.y; sqd = sqd + d * d;
+      d = x.z - y.z; sqd = sqd + d * d;
+      d = x.w - y.w; sqd = sqd + d * d;
+    }
+    out_idx[off + p] = idx;
+    out_dist[off + p] = sqd;
+    if (out_meta) out_meta[off + p] = ((unsigned)p << 16) | (unsigned)q;   // k_resolve: position in the list | query
+  };
+  // the general walk (any window, any list length): one dependent chain cell range -> items -> keypoints per column and pass
+  auto walk = [&](int pass) {
     int pos = 0;
-    if (!empty)
     for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
       const int b = G.cell_start[ix * ASD_GRID_ROWS + nMinCellY], e = G.cell_start[ix * ASD_GRID_ROWS + nMaxCellY + 1];
       for (int base = b; base < e; base += 64) {
@@ -80,53 +111,77 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
         int idx = 0;
         if (it < e) {
           idx = G.cell_items[it];
-          const float4 kp = G.kp[idx];
-          const int oct = __float_as_int(kp.z);
-          ok = true;
-          if (check) {
-            if (oct < Q.min_level) ok = false;
-            if (Q.max_level >= 0 && oct > Q.max_level) ok = false;
-          }
-          const float dx = kp.x - Q.x, dy = kp.y - Q.y;
-          if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) ok = false;
+          ok = accept(G.kp[idx]);
         }
         const unsigned long long m = __ballot(ok);
         if (pass == 1 && ok) {
-          const int p = off + pos + __popcll(m & ((1ull << lane) - 1));
-          if (p < cap) {
-            const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)Q.qrow * 128);
-            const float4* bb = reinterpret_cast<const float4*>(cdesc + (size_t)idx * 128);
-            float sqd = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < 32; ++k) {
-              const float4 x = a[k], y = bb[k];
-              float d;
-              d = x.x - y.x; sqd = sqd + d * d;
-              d = x.y - y.y; sqd = sqd + d * d;
-              d = x.z - y.z; sqd = sqd + d * d;
-              d = x.w - y.w; sqd = sqd + d * d;
-            }
-            out_idx[p] = idx;
-            out_dist[p] = sqd;
-            if (out_meta) out_meta[p] = ((unsigned)(p - off) << 16) | (unsigned)q;   // k_resolve: position in the list | query
-          }
+          const int p = pos + __popcll(m & ((1ull << lane) - 1));
+          if (off + p < cap) score(idx, p);
         }
         pos += __popcll(m);
       }
     }
-    if (pass == 0) {
-      cnt = pos;
-      if (lane == 0) wg_cnt[threadIdx.x >> 6] = cnt;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int sum = 0;
-        for (int w = 0; w < kSearchWaves; ++w) sum += wg_cnt[w];
-        wg_base = sum ? atomicAdd(total, sum) : 0;
+    return pos;
+  };
+  // Fast path (wave-uniform choice): the window's columns fit kSearchCols register slots and no column holds more than 64 items.
+  // All column ranges are fetched together, then all item lists, then all keypoints -- three round trips instead of three per
+  // column -- and the accepted keypoints are parked in LDS in list order, so that the second pass is one distance per lane
+  // instead of a second walk.  Same visiting order (columns ascending, items in cell order), same arithmetic.
+  const int ncol = nMaxCellX - nMinCellX + 1;
+  bool fast = !empty && ncol <= kSearchCols;
+  int cb[kSearchCols], ce[kSearchCols];
+  if (fast) {
+#pragma unroll
+    for (int c = 0; c < kSearchCols; ++c) {
+      const int ix = min(nMinCellX + c, nMaxCellX);
+      cb[c] = G.cell_start[ix * ASD_GRID_ROWS + nMinCellY];
+      ce[c] = G.cell_start[ix * ASD_GRID_ROWS + nMaxCellY + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < kSearchCols; ++c) {
+      if (c >= ncol) ce[c] = cb[c];                 // unused slot: empty range
+      if (ce[c] - cb[c] > 64) fast = false;
+    }
+  }
+  if (fast) {
+    int idxc[kSearchCols];
+#pragma unroll
+    for (int c = 0; c < kSearchCols; ++c) idxc[c] = cb[c] + lane < ce[c] ? G.cell_items[cb[c] + lane] : -1;
+    float4 kpc[kSearchCols];
+#pragma unroll
+    for (int c = 0; c < kSearchCols; ++c) kpc[c] = idxc[c] >= 0 ? G.kp[idxc[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    int pos = 0;
+#pragma unroll
+    for (int c = 0; c < kSearchCols; ++c) {
+      const bool ok = idxc[c] >= 0 && accept(kpc[c]);
+      const unsigned long long m = __ballot(ok);
+      if (ok) {
+        const int p = pos + __popcll(m & ((1ull << lane) - 1));
+        if (p < kSearchList) cand_l[wave][p] = idxc[c];
       }
-      __syncthreads();
-      off = wg_base;
-      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += wg_cnt[w];
-      if (cnt == 0) empty = true;
+      pos += __popcll(m);
+    }
+    cnt = pos;
+    if (cnt > kSearchList) fast = false;            // (the list did not fit: the second pass walks again)
+  } else if (!empty) {
+    cnt = walk(0);
+  }
+  if (lane == 0) wg_cnt[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int sum = 0;
+    for (int w = 0; w < kSearchWaves; ++w) sum += wg_cnt[w];
+    wg_base = sum ? atomicAdd(total, sum) : 0;
+  }
+  __syncthreads();
+  off = wg_base;
+  for (int w = 0; w < wave; ++w) off += wg_cnt[w];
+  if (cnt > 0) {
+    if (fast) {
+      for (int p = lane; p < cnt; p += 64)
+        if (off + p < cap) score(cand_l[wave][p], p);
+    } else {
+      (void)walk(1);
     }
   }
   if (lane == 0 && live) { q_cnt[q] = cnt; q_off[q] = cnt ? off : 0; }
