@@ -1829,6 +1829,7 @@ extern "C" {
 int asd_local_ba(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
   int rc = local_ba_check(ctx, pr, res);
   if (rc != ASD_OK) return rc;
+  if (asd_track_busy(ctx, "asd_local_ba")) return ASD_ERR_INVALID;   // runs on the context's stream behind the outstanding stage: use the lane
   BaState* s = ba_state(ctx);
   if (lane_outstanding(s)) {
     ctx->set_error("asd_local_ba: a run submitted with asd_local_ba_submit is outstanding (the solver's device buffers are in use); call asd_local_ba_wait first");

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -49,6 +50,9 @@ struct AsdDevBuf {
 // One pinned host block + its device twin.  A hipMemcpyAsync costs ~15-25 us on the tracking stream (host call + the hop to
 // the copy engine), whatever its size, so everything a call uploads -- queries, flags, tables -- is packed into ONE block and
 // travels in one copy; results come back the same way (AsdXfer used in the other direction).
+// device-side copy kernel (matcher.hip): dst / src 16-B aligned, bytes % 16 == 0; src may be pinned host memory
+hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes);
+
 struct AsdXfer {
   char* h = nullptr;
   char* d = nullptr;
@@ -68,7 +72,13 @@ struct AsdXfer {
   size_t reserve(size_t bytes) { const size_t off = used; used += (bytes + 255) / 256 * 256; return off; }
   size_t add(const void* src, size_t bytes) { const size_t off = reserve(bytes); memcpy(h + off, src, bytes); return off; }
   size_t zeros(size_t bytes) { const size_t off = reserve(bytes); memset(h + off, 0, bytes); return off; }
-  hipError_t upload(hipStream_t st) { return used ? hipMemcpyAsync(d, h, used, hipMemcpyHostToDevice, st) : hipSuccess; }
+  // a KERNEL reads the pinned block over PCIe and writes the device twin: an async H2D copy command costs this stream 50-60 us
+  // of latency whatever its size (rocprofv3: the gap in front of every chain's first kernel), a 150 KB kernel copy ~10
+  hipError_t upload(hipStream_t st) {
+    if (!used) return hipSuccess;
+    static const bool by_kernel = getenv("ASD_UPLOAD_COPY") == nullptr;   // ASD_UPLOAD_COPY=1: copy commands instead
+    return by_kernel ? asd_copy_rows(st, d, h, (used + 15) / 16 * 16) : hipMemcpyAsync(d, h, used, hipMemcpyHostToDevice, st);
+  }
   hipError_t download(hipStream_t st) { return used ? hipMemcpyAsync(h, d, used, hipMemcpyDeviceToHost, st) : hipSuccess; }
   template <typename T> T* dev(size_t off) { return reinterpret_cast<T*>(d + off); }
   template <typename T> T* host(size_t off) { return reinterpret_cast<T*>(h + off); }

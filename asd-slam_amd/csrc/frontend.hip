@@ -27,6 +27,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -842,6 +843,7 @@ struct AsyncExtract {
   AsyncJob jobs[kSlots];     // ring: job of submission s lives in jobs[s % kSlots]
   uint64_t submitted = 0, started = 0, waited = 0;  // counters: submitted >= started >= waited
   uint64_t last_view = ~0ull;                       // submission index of the most recently waited job
+  bool x_shared = false;                            // ctx->stream_x is the process-wide CU-masked stream: never destroyed
 };
 
 static void async_worker(asd_ctx* ctx) {
@@ -899,9 +901,11 @@ void frontend_async_shutdown(asd_ctx* ctx) {
   for (auto& S : ax->slots) slot_free(S);
   if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
   if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
+  const bool x_shared = ax->x_shared;
   delete ax;
   ctx->ax = nullptr;
-  if (ctx->stream_x) { (void)hipStreamDestroy(ctx->stream_x); ctx->stream_x = nullptr; }
+  if (ctx->stream_x && !x_shared) (void)hipStreamDestroy(ctx->stream_x);
+  ctx->stream_x = nullptr;
 }
 
 bool asd_extractor_busy(asd_ctx* ctx, const char* who) {
@@ -951,7 +955,23 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
         // the LAST `reserve` mask bits; measured alternatives at 16 CUs: the first 16 bits 961 frames/s, every 16th bit 973-991 (ASDNet
         // 0.94 ms: a mask that takes CUs out of every XCD unbalances it), every 16th with rotating low bits 1013, against 1123-1158
         for (int cu = 0; cu < ctx->num_cu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-        ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&sx, words, mask));
+        // hipStreamDestroy of a CU-masked stream hangs now and then on this ROCm (found with a step trace of asd_ctx_destroy: one
+        // in ~6 teardowns, always inside that call, after the stream had been synchronised).  The masked stream is therefore
+        // created once per (device, mask) and process and never destroyed; contexts of one process share it, which orders their
+        // ASDNet passes among each other -- they would share the matrix cores anyway.
+        {
+          static std::mutex cache_m;
+          static std::map<std::pair<int, int>, hipStream_t> cache;
+          std::lock_guard<std::mutex> l(cache_m);
+          auto it = cache.find({ctx->cfg.device, reserve});
+          if (it == cache.end()) {
+            ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&sx, words, mask));
+            cache[{ctx->cfg.device, reserve}] = sx;
+          } else {
+            sx = it->second;
+          }
+          ax->x_shared = true;
+        }
         // only the ASDNet stream is masked: two CU-masked streams are served by ONE hardware queue whatever their masks
         // (rocprofv3: same Queue_Id; the next frame's front half ran only after the previous frame's ASDNet had drained, which
         // costs the extractor the overlap of its two halves).  The front half's stream gets the HIGHEST priority instead: its
@@ -977,7 +997,7 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
       for (auto& S : ax->slots) slot_free(S);
       if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
       if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
-      if (sx) (void)hipStreamDestroy(sx);
+      if (sx && !ax->x_shared) (void)hipStreamDestroy(sx);
       delete ax;
       return rc;
     }

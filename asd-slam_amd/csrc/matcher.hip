@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a
 __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
-inline hipError_t copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes) {   // bytes % 16 == 0, 16-B aligned
+hipError_t copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes) {   // bytes % 16 == 0, 16-B aligned
   const size_t n16 = bytes / 16;
   if (!n16) return hipSuccess;
   hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, st, static_cast<const uint4*>(src),
@@ -1019,6 +1019,8 @@ AsdFrameSlot* slot_of(asd_ctx* ctx, int s) {
 }
 }  // namespace
 
+hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes) { return copy_rows(st, dst, src, bytes); }
+
 void matcher_free(asd_ctx* ctx) {
   for (auto& f : ctx->frames) {
     if (f.d_desc) (void)hipFree(f.d_desc);
@@ -1054,11 +1056,11 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
     ASD_HIP_CHECK(ctx, hipMalloc(&F->d_desc, cap * 128 * sizeof(float)));
     // keypoints, cell offsets and cell items in ONE device block laid out like the pinned staging buffer: one copy per frame
     char* blk = nullptr;
-    ASD_HIP_CHECK(ctx, hipMalloc(&blk, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int)));
+    ASD_HIP_CHECK(ctx, hipMalloc(&blk, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int) + 16));
     F->d_kp = reinterpret_cast<float4*>(blk);
     F->d_cell_start = reinterpret_cast<int32_t*>(blk + cap * sizeof(float4));
     F->d_cell_items = F->d_cell_start + (GC * GR + 1);
-    ASD_HIP_CHECK(ctx, hipHostMalloc(&F->h_stage, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int)));
+    ASD_HIP_CHECK(ctx, hipHostMalloc(&F->h_stage, cap * (sizeof(float4) + sizeof(int)) + (GC * GR + 1) * sizeof(int) + 16));
     ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&F->ev_staged, hipEventDisableTiming));
   } else {
     // the slot's pinned staging buffer is about to be rewritten: its previous copies (a frame or more ago) must have left it
@@ -1101,7 +1103,12 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   memcpy(hs, F->cell_start.data(), (GC * GR + 1) * sizeof(int));
   if (!F->cell_items.empty()) memcpy(hi, F->cell_items.data(), F->cell_items.size() * sizeof(int));
   // one copy for the three arrays (the block up to the last cell item in use; unused keypoint rows travel along: 16 B each)
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_kp, hk, cap * sizeof(float4) + (GC * GR + 1 + F->cell_items.size()) * sizeof(int), hipMemcpyHostToDevice, st));
+  {
+    static const bool by_kernel = getenv("ASD_UPLOAD_COPY") == nullptr;   // ASD_UPLOAD_COPY=1: copy commands instead
+    const size_t bytes = cap * sizeof(float4) + (GC * GR + 1 + F->cell_items.size()) * sizeof(int);
+    if (by_kernel) ASD_HIP_CHECK(ctx, copy_rows(st, F->d_kp, hk, (bytes + 15) / 16 * 16));
+    else ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_kp, hk, bytes, hipMemcpyHostToDevice, st));
+  }
   // desc == NULL (the per-frame path): no synchronisation -- every consumer of the slot is enqueued on this stream behind the
   // copies; ev_staged guards the slot's pinned staging buffer, ev_adopt the extraction buffer the descriptors are copied
   // out of (asd_extract_submit waits for it before the worker may reuse that buffer on its own streams).

@@ -288,7 +288,7 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
   h->last_kps.assign(kps, kps + n);
   h->last_slot = cur;
   h->have_last = true;
-  if (do_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;
+  if (do_ba && h->async_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;   // (in line: after the stage has finished, below)
   seg(7);
   if (!next.empty() && next[0] == t + 1) {
     std::vector<int> after(next.begin() + 1, next.end());
@@ -306,6 +306,7 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     if (nedge >= 3) { st->inliers = h->c2_ninl; st->has_inliers = 1; }
     seg(6);
   }
+  if (do_ba && !h->async_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;   // asd_local_ba uses the context's stream: no stage outstanding
   ++h->steps;
   return ASD_OK;
 }

@@ -1,5 +1,11 @@
 import importlib.util
 import os
+import faulthandler
+import sys
+
+if os.environ.get("ASD_TEST_WATCHDOG"):   # diagnostics: Python stacks of all threads after N seconds (a call stuck in C code never returns to pytest-timeout)
+    _wd = open(os.environ.get("ASD_TEST_WATCHDOG_FILE", "/tmp/asd_watchdog.txt"), "w")
+    faulthandler.dump_traceback_later(float(os.environ["ASD_TEST_WATCHDOG"]), exit=True, file=_wd)
 import sys
 
 import numpy as np
