@@ -498,7 +498,14 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   __syncthreads();
   bool robust = true;
   int nBad = 0;
+  bool flags_changed = true;   // did the previous round's re-classification change any flag?
   for (int round = 0; round < 4; ++round) {
+    // A round is a deterministic function of (input pose, active set, robust kernel on / off): it restarts from the input pose
+    // (Optimizer.cc:337).  If the previous round's re-classification changed no flag, rounds 1 and 2 (robust kernel still on) would
+    // repeat the previous round operation for operation -- same passes, same pose, same re-classification -- so they are not run:
+    // the state they would leave is the state that is there.  (Typical steady-state frame: the outlier set is final after round 0 or 1.)
+    const bool repeat = round >= 1 && round <= 2 && !flags_changed;
+    if (!repeat) {
     if (t == 0) { S.T = S.T0; S.npass = 0; for (int q = 0; q < 4; ++q) { S.cyc[q] = 0; S.dbg[q] = 0; } }  // every round restarts from the input pose (Optimizer.cc:337)
     __syncthreads();
     pose_pass(a, E, lvl, S, robust);
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     }
     // ---- re-classification (Optimizer.cc:341-368)
     double nb[1] = {0.0};
+    int chg = 0;
     {
       const Pose7 T = S.T, Te = S.Teval;
       double Re[9];
@@ -600,17 +608,20 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
           pass_error(Re, Te.tx, Te.ty, Te.tz, X, Y, Z, ou, ov, a.fx, a.fy, a.cx, a.cy, true, iz, xz, yz, e0, e1);
         }
         const float chi2 = (float)((e0 * e0 + e1 * e1) * isg);
-        if (chi2 > kChi2Mono) { outl[i] = 1; lvl[i] = 1; nb[0] += 1.0; }
-        else { outl[i] = 0; lvl[i] = 0; }
+        const uint8_t bad = chi2 > kChi2Mono ? 1 : 0;
+        chg |= bad != outl[i];
+        outl[i] = bad; lvl[i] = bad;
+        if (bad) nb[0] += 1.0;
       }
     }
-    __syncthreads();
+    flags_changed = __syncthreads_or(chg) != 0;
     block_reduce<1, kPoseWaves>(nb, S.red, S.sums);
     nBad = (int)(S.sums[0] + 0.5);
     __syncthreads();
     if (a.debug && t == 0)
       printf("[pose_opt] round %d: %d passes, nBad %d; cycles/pass: edges %lld (slowest wave %lld) reduce %lld solve+oplus %lld (solve %lld) accept %lld\n", round, S.npass,
              nBad, S.cyc[0] / S.npass, S.dbg[0] / S.npass, S.cyc[1] / S.npass, S.cyc[2] / S.npass, S.dbg[1] / S.npass, S.cyc[3] / S.npass);
+    }   // !repeat
     if (round == 2) robust = false;  // e->setRobustKernel(0)
     if (ne < 10) break;             // optimizer.edges().size() < 10
   }
