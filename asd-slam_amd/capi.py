@@ -597,8 +597,9 @@ class AsdHip:
         return self._ba_unpack(r, keep)
 
     def local_ba_submit(self, prob, its_first=5, its_second=10):
-        """LocalBundleAdjustment on the library's local-mapping lane (LocalMapping.cc:92 runs beside Tracking): returns at
-        once; local_ba_wait() returns the result dict.  One run at a time."""
+        """LocalBundleAdjustment on the library's OPTIONAL lane: returns at once; local_ba_wait() returns the result dict.  One run
+        at a time.  Not the reference's order -- Tracking.cc:797 -> LocalMapping.cc:89 runs it in line (local_ba above); frames tracked
+        while a run is out read the pre-BA map."""
         p, r, keep = self._ba_pack(prob, its_first, its_second)
         self._chk(self.lib.asd_local_ba_submit(self.ctx, C.byref(p), C.byref(r)))
         self._ba_job = (p, r, keep)   # the library owns these until wait

@@ -1274,13 +1274,15 @@ struct BaState {
   int* h_misc = nullptr;        // pinned: status, maxdiag (2 ints), n_bad
   char* h_po = nullptr;         // pinned staging of asd_pose_optimize
   size_t h_po_cap = 0;
-  struct BaLane* lane = nullptr;   // asd_local_ba_submit / _wait: the local-mapping lane (own thread, stream and events)
+  struct BaLane* lane = nullptr;   // asd_local_ba_submit / _wait: the optional LocalBA lane (own thread, stream and events)
 };
 
-// The reference runs LocalBundleAdjustment on its LocalMapping thread, beside Tracking (LocalMapping.cc:57-101 Run() ->
-// Optimizer::LocalBundleAdjustment at :92).  The lane is that thread for the numeric core: one job at a time on a stream of
-// its own, so the ~4 ms of a LocalBA -- fifteen trials of small
-// kernels with a host decision in between -- run under the next frames' tracking instead of in front of them.
+// OPTIONAL lane, not the reference's order.  This fork of ORB-SLAM2 has no mapping thread: Tracking::CreateNewKeyFrame calls
+// LocalMapping::DoMapping() in line (Tracking.cc:797 -> LocalMapping.cc:59-113, Optimizer::LocalBundleAdjustment at :89;
+// LocalMapping::Run at :120 is dead residue, System.cc starts no thread), so LocalBA has finished before the next frame is tracked --
+// that is asd_local_ba.  The lane (asd_local_ba_submit / _wait) runs the same solver as one job at a time on a stream of its
+// own, beside the caller's next frames; those frames then read the map as it was BEFORE this LocalBA, which is a different data
+// dependency from the reference (upstream ORB-SLAM2's threaded arrangement), offered for integrators who want it.
 struct BaLane {
   std::thread th;
   std::mutex m;

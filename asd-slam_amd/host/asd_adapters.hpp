@@ -395,8 +395,10 @@ struct Tracking {
   }
 };
 
-// LocalMapping::Run's call of Optimizer::LocalBundleAdjustment (LocalMapping.cc:92) on the library's local-mapping lane: Submit
-// returns at once (problem / result stay owned by the library), Tracking goes on, Wait returns the run's status.
+// OPTIONAL: Optimizer::LocalBundleAdjustment on the library's lane.  The reference calls it IN LINE (Tracking.cc:797 ->
+// LocalMapping::DoMapping, LocalMapping.cc:89; no mapping thread exists in this fork) -- that is asd::Optimizer::LocalBundleAdjustment /
+// asd_local_ba.  Submit returns at once (problem / result stay owned by the library), Tracking goes on against the PRE-BA map, Wait
+// returns the run's status: upstream ORB-SLAM2's concurrency, a different data dependency from this reference.
 struct LocalMapping {
   static int LocalBundleAdjustmentSubmit(Context& c, asd_ba_problem* problem, asd_ba_result* result) { return asd_local_ba_submit(c.get(), problem, result); }
   static int LocalBundleAdjustmentWait(Context& c) { return asd_local_ba_wait(c.get()); }

@@ -35,10 +35,12 @@ struct asd_track_handle {
   asd_ba_problem ba;  // pristine problem (host arrays owned by the caller), copied per LocalBA call
   int kf_interval, lookahead;
   bool fused = true;  // asd_track_motion_model / asd_track_local_map (one submission per stage) instead of matcher + solver calls
-  // LocalBA on the library's local-mapping lane (asd_local_ba_submit / _wait), the way the reference runs it on its LocalMapping
-  // thread beside Tracking (LocalMapping.cc:92): submitted at the keyframe, collected before the next submission and at the end
-  // of every asd_track_run, so a run contains all of the LocalBA work it started.
-  bool async_ba = true;
+  // LocalBA in the reference's order (default): Tracking::CreateNewKeyFrame calls LocalMapping::DoMapping IN LINE (Tracking.cc:797 ->
+  // LocalMapping.cc:59-113, LocalBundleAdjustment at :89; this fork starts no mapping thread, LocalMapping::Run is dead code), so
+  // frame t+1 is tracked against the map the keyframe's LocalBA has already rewritten: asd_local_ba at the keyframe, before the next
+  // frame's stages.  async_ba = the library's optional lane (asd_local_ba_submit / _wait): the run goes on beside the next frames,
+  // which then read the PRE-BA map -- a different data dependency from the reference, measured only as a variant.
+  bool async_ba = false;
   // split-phase stages (asd_track_async / asd_track_finish): while a stage's kernels run, the host does the work that does not
   // depend on its result -- the local-map tables under the motion-model stage, and under the local-map stage the NEXT frame's
   // construction (wait for its extraction, AssignFeaturesToGrid + descriptor adoption, read-ahead submission, descriptor-bank

@@ -270,8 +270,8 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
                 stats["inliers"] = int(ninl)
     if do_ba:
         if getattr(be, "async_ba", False):
-            # LocalBA on the library's local-mapping lane (the reference runs it on the LocalMapping thread beside Tracking,
-            # LocalMapping.cc:92): submitted here, collected before the next submission and at the end of the run
+            # variant only (--lane-ba): LocalBA on the library's lane, beside the next frames' tracking -- NOT the reference's order
+            # (Tracking.cc:797 -> LocalMapping.cc:89 is an in-line call): submitted here, collected before the next submission
             be.local_ba_collect()
             be.local_ba_submit(wl.ba)
             stats["ba_submitted"] = True
@@ -324,7 +324,7 @@ class NativeHost:
         if not self.h:
             raise RuntimeError("asd_track_create failed")
         self.lib.asd_track_set_fused(self.h, int(getattr(be, "fused", True)))
-        self.lib.asd_track_set_async_ba(self.h, int(getattr(be, "async_ba", True)))
+        self.lib.asd_track_set_async_ba(self.h, int(getattr(be, "async_ba", False)))
         self.lib.asd_track_set_split(self.h, int(getattr(be, "split", True)))
         self.be = be
 
@@ -367,7 +367,7 @@ class HipBackend:
         self.pending = []          # handles of submitted, not yet waited extractions (in order)
         self.pipeline = pipeline
         self.fused = True          # asd_track_motion_model / asd_track_local_map instead of matcher + solver calls
-        self.async_ba = True       # LocalBA on the local-mapping lane (asd_local_ba_submit / _wait) instead of in line
+        self.async_ba = False      # True: LocalBA on the library's lane (asd_local_ba_submit / _wait) instead of in line (the reference's order)
         self.ba_out = False
 
     def image(self, t):
@@ -748,7 +748,11 @@ def main():
                     help="kitti-mono = the headline configuration (BASELINE configs[2]); euroc-stereo = configs[3], a secondary line")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
     ap.add_argument("--no-split", action="store_true", help="C++ host: run each asd_track_* stage to completion before any other host work (no asd_track_async / asd_track_finish)")
-    ap.add_argument("--sync-ba", action="store_true", help="LocalBA in line with tracking (asd_local_ba) instead of on the local-mapping lane (asd_local_ba_submit / _wait)")
+    ap.add_argument("--lane-ba", action="store_true",
+                    help="variant: LocalBA on the library's lane (asd_local_ba_submit / _wait) beside the next frames, which then track against the "
+                         "pre-BA map -- not the reference's order (Tracking.cc:797 -> LocalMapping.cc:89 runs it in line, the default here)")
+    ap.add_argument("--sync-ba", action="store_true", help="(default since round 3, kept for old command lines) LocalBA in line with tracking")
+    ap.add_argument("--no-lane-variant", action="store_true", help="skip the extra untimed-for-the-headline pass that measures the lane variant (N = 1 only)")
     ap.add_argument("--no-fuse", action="store_true", help="matcher and PoseOptimization as separate calls (two host round trips per stage)")
     ap.add_argument("--host", choices=["cxx", "python"], default="cxx",
                     help="who drives the per-frame step: C++ host code over the C ABI (default, as in the reference) or the Python loop")
@@ -778,7 +782,7 @@ def main():
     wl = Workload(pkg.synth, seed_offset=rank)
     be = HipBackend(pkg, wl, device=device, pipeline=not args.no_pipeline)
     be.fused = not args.no_fuse
-    be.async_ba = not args.sync_ba
+    be.async_ba = bool(args.lane_ba)
     be.split = not args.no_split
     be.native = None
     if args.host == "cxx":
@@ -789,7 +793,7 @@ def main():
             args.host = "python"
 
     # one-time initialisation that a short --warmup would otherwise leave inside the timed region: the LocalBA solver's device
-    # buffers, pinned staging and the local-mapping lane (thread + stream) come into being with the first run (21 ms against 4 ms
+    # buffers, pinned staging and (--lane-ba) the lane's thread + stream come into being with the first run (21 ms against 4 ms
     # for every later one), and the first keyframe is frame 14 ...
     if be.async_ba:
         be.hip.local_ba_submit(wl.ba); be.hip.local_ba_wait()
@@ -810,6 +814,28 @@ def main():
     dt = time.perf_counter() - t0
     tmax = dist.max(dt)
     frames_total = dist.sum(float(args.steps))
+
+    # The optional lane (asd_local_ba_submit): the same K frames once more with LocalBA running beside the next frames' tracking.  It
+    # changes the data dependency (frames t+1.. read the pre-BA map), so it is reported as an extra key and never as `value`.
+    lane_variant = None
+    if world == 1 and not args.lane_ba and not args.no_lane_variant:
+        be.hip.profile_enable(False)
+        be.async_ba = True
+        if be.native is not None:
+            be.native.lib.asd_track_set_async_ba(be.native.h, 1)
+        be.hip.local_ba_submit(wl.ba); be.hip.local_ba_wait()      # untimed: the lane's thread + stream come into being here
+        tl = prime + args.warmup + args.steps
+        last, _ = run_steps(be, wl, tl, KF_INTERVAL, last, prefetch_beyond=True)
+        be.hip.sync(); device_sync(device)
+        l0 = time.perf_counter()
+        last, _ = run_steps(be, wl, tl + KF_INTERVAL, args.steps, last, prefetch_beyond=True)
+        be.hip.sync(); device_sync(device)
+        ldt = time.perf_counter() - l0
+        lane_variant = {"value": args.steps / ldt, "unit": "frames/s", "ms_per_step": 1e3 * ldt / args.steps, "steps": args.steps,
+                        "what": "asd_local_ba_submit at the keyframe, own thread + stream, collected before the next submission and at the end "
+                                "of the run; frames t+1.. are tracked against the map as it was BEFORE that LocalBA -- not the reference's "
+                                "order, so poses on a real sequence differ from the reference's; optional entry point, never the headline"}
+        be.async_ba = False
 
     # per-kernel device time of the dominant kernel (ASDNet conv2, f32 MFMA), hipEvents on the ctx stream
     layer_names = ["norm+conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7(fc)", "l2norm"]
@@ -869,9 +895,10 @@ def main():
                        "stages": ("each asd_track_* stage run to completion" if (args.no_split or args.no_fuse or args.host != "cxx") else
                                   "split-phase (asd_track_async / asd_track_finish): the local-map tables are built under the motion-model stage, the next "
                                   "frame is constructed (extraction hand-over, grid, descriptor adoption, read-ahead submission) under the local-map stage"),
-                       "local_ba": ("in line with tracking (asd_local_ba)" if args.sync_ba else
-                                    "on the library's local-mapping lane (asd_local_ba_submit at the keyframe, own thread + stream, the reference's "
-                                    "LocalMapping thread, LocalMapping.cc:92); every run is collected inside the timed region"),
+                       "local_ba": ("on the library's optional lane (asd_local_ba_submit at the keyframe, own thread + stream; later frames read "
+                                    "the pre-BA map: NOT the reference's order); every run is collected inside the timed region" if args.lane_ba else
+                                    "in line (reference order): asd_local_ba at the keyframe, before the next frame is tracked "
+                                    "(Tracking.cc:797 -> LocalMapping::DoMapping, LocalMapping.cc:59-113, BA at :89; the reference has no mapping thread)"),
                        "pipeline": f"ExtractDesc read-ahead of {LOOKAHEAD} frames on separate HIP streams (front half of t+2 under ASDNet of t+1 under tracking of t, one finished frame in hand)" if not args.no_pipeline else "none (sequential)"},
             "roofline": {"bound": "mfma", "kernel": roof_kernel,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
@@ -882,6 +909,8 @@ def main():
             "asdnet_layers": layers,
             "last_step": stats,
         }
+        if lane_variant is not None:
+            out["lane_variant"] = lane_variant
         if args.cpu_frames > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only
             cb = CpuBackend(pkg, wl)
             nf = args.cpu_frames
@@ -898,6 +927,9 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     dist.close()
+    if os.environ.get("ASD_DUMP_MAPS"):   # diagnostics: module load bases, to resolve a native stack printed at exit
+        with open(os.environ["ASD_DUMP_MAPS"], "w") as f:
+            f.write(open("/proc/self/maps").read())
 
 
 if __name__ == "__main__":

@@ -482,11 +482,14 @@ typedef struct asd_ba_result {
  * rounds with the chi2 > 5.991 || depth <= 0 gating in between.  The caller applies the
  * erase policy (Optimizer.cc:652-700) from edge_chi2 / edge_depth_pos. */
 int asd_local_ba(asd_ctx* ctx, asd_ba_problem* problem, asd_ba_result* result);
-/* The same computation on the library's local-mapping lane.  The reference calls LocalBundleAdjustment from its
- * LocalMapping thread while Tracking goes on with the next frames (LocalMapping.cc:57-101, the call at :92); these two
- * entry points give the integrator that concurrency without a second context: _submit hands the problem to a worker
- * thread that runs it on a HIP stream of its own and returns at once; the tracking entry points (asd_extract*, asd_frame_set, asd_match_*, asd_track_*, asd_pose_optimize)
- * may be called meanwhile.  *problem, *result and every array they point to belong to the library until _wait
+/* The same computation on an OPTIONAL lane of the library -- not the reference's order.  In this reference LocalBundleAdjustment
+ * runs in line: Tracking::CreateNewKeyFrame -> LocalMapping::DoMapping (Tracking.cc:797, LocalMapping.cc:59-113, the call at
+ * :89); there is no mapping thread (LocalMapping::Run, :120, is never started), so frame t+1 is tracked against the map that
+ * the keyframe's LocalBA has already rewritten: that is asd_local_ba above.  These entry points offer upstream ORB-SLAM2's
+ * concurrent arrangement to an integrator who wants it: _submit hands the problem to a worker thread that runs it on a HIP
+ * stream of its own and returns at once; the tracking entry points (asd_extract*, asd_frame_set, asd_match_*, asd_track_*,
+ * asd_pose_optimize) may be called meanwhile -- the frames tracked meanwhile read the PRE-BA map, so poses depart from the
+ * reference's.  *problem, *result and every array they point to belong to the library until _wait
  * returns; _wait blocks until the run has finished and returns ITS status (results bit-identical to asd_local_ba:
  * same kernels, same order).  One run at a time: a second _submit before _wait, asd_local_ba while a run is outstanding
  * and _wait with nothing submitted return ASD_ERR_INVALID.  asd_local_ba_poll: 0 = idle, 1 = running, 2 = finished and

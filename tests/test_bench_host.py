@@ -20,11 +20,11 @@ def _bench():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline,fused,async_ba,split", [(True, True, True, True), (False, True, True, True), (True, False, True, True), (True, True, False, True),
-                                                             (True, True, True, False)])
+@pytest.mark.parametrize("pipeline,fused,async_ba,split", [(True, True, False, True), (False, True, False, True), (True, False, False, True), (True, True, True, True),
+                                                             (True, True, False, False)])
 def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split):
     """fused: the stages run as asd_track_motion_model / asd_track_local_map (one submission each, bench default) or as
-    matcher + PoseOptimization calls (--no-fuse); async_ba: LocalBA on the local-mapping lane (default) or in line (--sync-ba); split: the C++ host's split-phase
+    matcher + PoseOptimization calls (--no-fuse); async_ba: LocalBA in line (default, the reference's order) or on the optional lane (--lane-ba); split: the C++ host's split-phase
     stages (asd_track_async / asd_track_finish, default) or each stage run to completion (--no-split)"""
     bench = _bench()
     wl = bench.Workload(pkg.synth)

@@ -220,8 +220,8 @@ def test_hip_local_ba_edge_cases(hip, oracle, synth):
 
 @pytest.mark.gpu
 def test_local_ba_lane_equals_inline_and_runs_beside_tracking(hip, synth):
-    """asd_local_ba_submit / _wait: LocalBundleAdjustment on the library's local-mapping lane (the reference calls it from the
-    LocalMapping thread while Tracking goes on, LocalMapping.cc:92).  Same kernels in the same order on another stream:
+    """asd_local_ba_submit / _wait: LocalBundleAdjustment on the library's optional lane (the reference itself calls it in line,
+    Tracking.cc:797 -> LocalMapping.cc:89).  Same kernels in the same order on another stream:
     bit-identical to asd_local_ba -- also with PoseOptimization calls of the tracking side running meanwhile -- and the
     one-run-at-a-time rules of the header are enforced."""
     prob = synth.ba_problem()
