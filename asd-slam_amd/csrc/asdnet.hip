@@ -1033,11 +1033,13 @@ hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const 
   auto kern = k_conv_mfma<CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING, 0, FUSE1>;
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds <= 160 * 1024, "band + weight ring do not fit LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsdPerDeviceOnce attr_set;   // per instantiation; the attribute belongs to the current device (the caller selected the context's)
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (attr_set.need(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done(dev_);
   }
   hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, wimg, bias, out, w1, b1, n);
   return hipGetLastError();
@@ -1049,11 +1051,13 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
   auto kern = k_conv_mfma_p<CIN, COUT, HIN, S, ROWS, WM, WN, KC>;
   constexpr int lds = (2 * C::ACT_FLOATS + 2 * C::WCHUNK) * 4;
   static_assert(lds <= 160 * 1024, "double-buffered band does not fit LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsdPerDeviceOnce attr_set;   // per instantiation; the attribute belongs to the current device (the caller selected the context's)
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (attr_set.need(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done(dev_);
   }
   const int ntiles = n * (C::HO / ROWS);
   const int per_cu = std::max(1, std::min(4, (160 * 1024) / lds));
@@ -1071,11 +1075,13 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds <= 160 * 1024, "band does not fit LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsdPerDeviceOnce attr_set;   // per instantiation; the attribute belongs to the current device (the caller selected the context's)
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (attr_set.need(dev_)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done(dev_);
   }
   if (grid_out) *grid_out = ((n + PP - 1) / PP) * (C::HO / ROWS);
   hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,

@@ -22,7 +22,11 @@
 //   k_ba_schur      one workgroup per upper 6x6 block: Hpp + lambda I - sum_l (B Dinv) B^T  (dense)
 //   k_ba_chol       blocked Cholesky + triangular solves in one workgroup
 //   k_ba_backsub    landmark-parallel xl = Dinv (bl - B^T xp), point update, gain-ratio partials
-// The Levenberg accept/reject logic (scalars only) runs on the host between launches.
+// The Levenberg accept/reject logic (optimization_algorithm_levenberg.cpp:61-189) runs ON THE DEVICE since round 3: the scalars
+// live in LmState, a one-thread kernel (k_ba_lm_control) behind every trial takes the decision the host used to take after a
+// synchronisation, and every other kernel reads lambda / "is this step needed" from that state -- a step whose answer is no
+// exits at once.  The host enqueues whole iterations ("blocks" = linearise group + trial group + control + restore) ahead and
+// synchronises once per chunk of blocks instead of once per trial.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -697,6 +701,15 @@ __global__ __launch_bounds__(1024) void k_pose_edges(PoseEdgesArgs a) {
 }
 
 // ---------------------------------------------------------------- LocalBA kernels
+// Levenberg state of the running round (device memory; k_ba_lm_control mirrors it into pinned host memory after every trial)
+struct LmState {
+  double lambda, ni, currentChi, iniChi, rho;
+  unsigned long long maxdiag_bits;   // max |diag(H)| over poses and landmarks as the bit pattern of a non-negative double
+  int it, qmax, nBad, done, need_lin, restore, trials, iters_done, chol_ok, iterations, first, pad_;
+};
+struct LmLog { double lambda, cur, temp, scale; };   // one record per trial (ASD_BA_DEBUG, tests)
+constexpr int kLmLogCap = 128;
+
 struct BaDev {
   // problem
   int P, L, E;
@@ -731,11 +744,18 @@ struct BaDev {
   // dense system
   double* A;    // [n][n]
   double* bs;   // [n]
-  int* status;
-  unsigned long long* maxdiag_bits;
-  double* partial;  // per-block partial sums: [0, scale_off) residual cost, [scale_off, ..) gain-ratio terms
-  int scale_off;
+  LmState* lm;        // device
+  LmState* lm_host;   // pinned mirror, written by k_ba_lm_control / k_ba_lm_begin
+  LmLog* lm_log;      // device, [kLmLogCap]
+  double* partial;    // device: per-block partial sums: [0, scale_off) residual cost, [scale_off, ..) gain-ratio terms
+  int scale_off, gE, gL, gP;
 };
+
+// lambda of the trial being computed: computeLambdaInit (block_solver.hpp:564-580, tau = 1e-5) until the first control step has
+// stored it -- a pure function of the state, so the trial kernels need no "initialise lambda" launch in front of them
+__device__ inline double lm_lambda(const LmState* lm) {
+  return lm->first ? 1e-5 * __longlong_as_double((long long)lm->maxdiag_bits) : lm->lambda;
+}
 
 __device__ inline void ba_project_error(const BaDev& d, int e) {
   double Xc[3];
@@ -745,8 +765,9 @@ __device__ inline void ba_project_error(const BaDev& d, int e) {
 }
 
 // computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114): partial[blockIdx] = block sum
-__global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust) {
+__global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust, int always) {
   __shared__ double red[4 * 32], out[1];
+  if (!always && d.lm->done) return;
   const int k = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (k < d.Ea) {
@@ -763,6 +784,7 @@ __global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust) {
 
 // linearizeOplus + constructQuadraticForm per active edge (uses the stored error, like g2o)
 __global__ __launch_bounds__(256) void k_ba_linearize(BaDev d, int robust) {
+  if (d.lm->done || !d.lm->need_lin) return;   // a retry after a rejected trial keeps the system (only lambda changes)
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= d.Ea) return;
   const int e = d.act[k];
@@ -806,6 +828,7 @@ __device__ inline void atomic_max_pos_double(unsigned long long* addr, double v)
 // then the fixed-order block reduction (bit-reproducible).
 __global__ __launch_bounds__(256) void k_ba_reduce_pose(BaDev d) {
   __shared__ double red[4 * 32], out[27];
+  if (d.lm->done || !d.lm->need_lin) return;
   const int h = blockIdx.x;
   const int b = d.ps_start[h], e = d.ps_start[h + 1];
   double acc[27];
@@ -822,11 +845,12 @@ __global__ __launch_bounds__(256) void k_ba_reduce_pose(BaDev d) {
     const double s = out[t];
     d.Hpp[(size_t)h * 27 + t] = s;
     // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
-    if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(d.maxdiag_bits, fabs(s));
+    if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(&d.lm->maxdiag_bits, fabs(s));
   }
 }
 
 __global__ __launch_bounds__(256) void k_ba_reduce_point(BaDev d) {
+  if (d.lm->done || !d.lm->need_lin) return;
   const int h = blockIdx.x * 256 + threadIdx.x;
   if (h >= d.nLa) return;
   double s[9];
@@ -834,11 +858,13 @@ __global__ __launch_bounds__(256) void k_ba_reduce_point(BaDev d) {
   for (int k = d.pt_start[h]; k < d.pt_start[h + 1]; ++k)
     for (int q = 0; q < 9; ++q) s[q] += d.Hl[(size_t)k * 9 + q];
   for (int q = 0; q < 9; ++q) d.Hll[(size_t)h * 9 + q] = s[q];
-  atomic_max_pos_double(d.maxdiag_bits, fmax(fabs(s[0]), fmax(fabs(s[3]), fabs(s[5]))));
+  atomic_max_pos_double(&d.lm->maxdiag_bits, fmax(fabs(s[0]), fmax(fabs(s[3]), fabs(s[5]))));
 }
 
 // per landmark: Dinv = (Hll + lambda I)^-1, db = Dinv bl, and for its free-pose edges Y = B Dinv, c = B db
-__global__ __launch_bounds__(256) void k_ba_point_dinv(BaDev d, double lambda) {
+__global__ __launch_bounds__(256) void k_ba_point_dinv(BaDev d) {
+  if (d.lm->done) return;
+  const double lambda = lm_lambda(d.lm);
   const int h = blockIdx.x * 256 + threadIdx.x;
   if (h >= d.nLa) return;
   const double* H = d.Hll + (size_t)h * 9;
@@ -858,6 +884,7 @@ __global__ __launch_bounds__(256) void k_ba_point_dinv(BaDev d, double lambda) {
 // Y_k = B_k Dinv_l and c_k = B_k (Dinv_l bl) for every active edge to a free pose: one lane per edge (the per-landmark
 // loop this replaces ran on 24 workgroups only and read its edges with an 18-double stride between lanes)
 __global__ __launch_bounds__(256) void k_ba_edge_y(BaDev d) {
+  if (d.lm->done) return;
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= d.Ea) return;
   const int e = d.act[k];
@@ -883,8 +910,10 @@ struct SchurBlocks {
   const int* pair_start;               // [nblk+1]
   const int2* pairs;
 };
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb, double lambda) {
+__global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb) {
   __shared__ double red[4 * 64], out[42];
+  if (d.lm->done) return;
+  const double lambda = lm_lambda(d.lm);
   const int blk = blockIdx.x, bi = sb.blk_i[blk], bj = sb.blk_j[blk];
   const int n = 6 * d.nPf;
   double acc[42];
@@ -933,9 +962,10 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb, doubl
 // replaced by one reciprocal per pivot and the triangular block index comes from a table, not from sqrt().
 constexpr int kCholThreads = 1024;
 __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __restrict__ A, const double* __restrict__ bs,
-                                                              double* __restrict__ x, int n, int* status) {
+                                                              double* __restrict__ x, int n, LmState* lm) {
   // all LDS in the dynamic region (a static in front of it would shift its base off 16-B alignment)
   extern __shared__ __attribute__((aligned(16))) double L[];
+  if (lm->done) return;
   const int t = threadIdx.x, nt = blockDim.x, nb = n / 6;
   const int nblk = nb * (nb + 1) / 2;
   double* xs = L + (size_t)nblk * 36;   // [192] right-hand side / solution
@@ -1067,15 +1097,177 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
   }
 #undef LB
   for (int i = t; i < n; i += nt) x[i] = xs[i];
-  if (t == 0) *status = ok;
+  if (t == 0) lm->chol_ok = ok;
+}
+
+// The same solve by block elimination with EXPLICIT inverses of the 6x6 pivot blocks (default up to 31 pose blocks):
+//   for j: W = A_jj^-1 ; T_I = A_Ij W (I > j) ; A_IK -= T_I A_Kj^T (I >= K > j) ; b_I -= T_I b_j        (block LDL^T, L_Ij = T_I)
+//   then y_j = W_j b_j and x_j = y_j - sum_{I > j} T_Ij^T x_I.
+// Why: the Cholesky above spends 24 x ~3.7k cycles in the single-lane factorisation of the diagonal block -- six pivots, each a
+// chain of ~14 dependent fp64 instructions (pivot update, 1/sqrt with two Newton steps, column scaling) at ~44 cycles a link --
+// plus a 21-link forward substitution per panel row.  The inverse of a symmetric 6x6 from two 3x3 cofactor inverses (P, then the
+// Schur complement S = R - Q P^-1 Q^T) has two reciprocals on its critical path instead of six inverse square roots (~36 links),
+// every wave computes it redundantly from LDS (nothing to broadcast, no barrier in front of the panel), and the panel / trailing
+// update / both substitutions become 6-term dot products with no triangular dependency inside a block.
+// Positive definiteness (linear_solver_dense.h:96 fails on a non-positive LDLT pivot) is checked on the leading minors of P and S.
+__device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double (&o)[6]) {
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  const double m2 = a * d - b * b;
+  const double id = nr_rcp(det);
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id; o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = m2 * id;
+  return a > 0 && m2 > 0 && det > 0;
+}
+// A: symmetric 6x6, lower triangle valid, row-major [6][6]; W: full inverse [6][6]
+__device__ inline bool inv6_sym(const double* A, double (&W)[36]) {
+  double Pi[6], Si[6];
+  bool ok = inv3_sym(A[0], A[6], A[12], A[7], A[13], A[14], Pi);
+  const double PiF[9] = {Pi[0], Pi[1], Pi[2], Pi[1], Pi[3], Pi[4], Pi[2], Pi[4], Pi[5]};
+  double Q[9], U[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Q[r * 3 + c] = A[(3 + r) * 6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) U[r * 3 + c] = Q[r * 3] * PiF[c] + Q[r * 3 + 1] * PiF[3 + c] + Q[r * 3 + 2] * PiF[6 + c];
+  double S[6];   // (0,0) (1,0) (2,0) (1,1) (2,1) (2,2) of R - U Q^T
+  {
+    int q = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = c; r < 3; ++r) S[q++] = A[(3 + r) * 6 + 3 + c] - (U[r * 3] * Q[c * 3] + U[r * 3 + 1] * Q[c * 3 + 1] + U[r * 3 + 2] * Q[c * 3 + 2]);
+  }
+  ok = inv3_sym(S[0], S[1], S[2], S[3], S[4], S[5], Si) && ok;
+  const double SiF[9] = {Si[0], Si[1], Si[2], Si[1], Si[3], Si[4], Si[2], Si[4], Si[5]};
+  double W21[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) W21[r * 3 + c] = -(SiF[r * 3] * U[c] + SiF[r * 3 + 1] * U[3 + c] + SiF[r * 3 + 2] * U[6 + c]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      W[r * 6 + c] = PiF[r * 3 + c] - (U[r] * W21[c] + U[3 + r] * W21[3 + c] + U[6 + r] * W21[6 + c]);
+      W[(3 + r) * 6 + c] = W21[r * 3 + c];
+      W[c * 6 + 3 + r] = W21[r * 3 + c];
+      W[(3 + r) * 6 + 3 + c] = SiF[r * 3 + c];
+    }
+  return ok;
+}
+
+constexpr int kSolveThreads = 1024, kSolveMaxBlocks = 31;
+__global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __restrict__ A, const double* __restrict__ bs,
+                                                                double* __restrict__ x, int n, LmState* lm) {
+  extern __shared__ __attribute__((aligned(16))) double L[];
+  if (lm->done) return;
+  const int t = threadIdx.x, nt = blockDim.x, nb = n / 6, wave = t >> 6, lane = t & 63;
+  const int nblk = nb * (nb + 1) / 2;
+  double* Tp = L + (size_t)nblk * 36;                 // [nb - 1][36] panel T_I of the current step
+  double* xs = Tp + (size_t)(kSolveMaxBlocks - 1) * 36;   // [192] right-hand side / solution
+  double* Ww = xs + 192;                              // [16 waves][36] every wave's copy of the pivot block's inverse
+  int& ok = *reinterpret_cast<int*>(Ww + (kSolveThreads / 64) * 36);
+  short2* tri = reinterpret_cast<short2*>(Ww + (kSolveThreads / 64) * 36 + 2);  // [nblk] packed lower-triangle index -> (I, J)
+#define LB(I, J) (L + ((size_t)((I) * ((I) + 1) / 2 + (J))) * 36)
+  for (int I = t; I < nb; I += nt)
+    for (int J = 0; J <= I; ++J) tri[I * (I + 1) / 2 + J] = make_short2((short)I, (short)J);
+  if (t == 0) ok = 1;
+  __syncthreads();
+  for (int idx = t; idx < nblk * 36; idx += nt) {
+    const int blk = idx / 36, e = idx % 36;
+    const short2 ij = tri[blk];
+    L[idx] = A[(size_t)(6 * ij.x + e / 6) * n + 6 * ij.y + e % 6];
+  }
+  for (int i = t; i < n; i += nt) xs[i] = bs[i];
+  __syncthreads();
+  double* myW = Ww + wave * 36;
+  for (int jb = 0; jb < nb; ++jb) {
+    // every wave inverts the pivot block for itself (same bits in every wave) and keeps it in its own LDS rows
+    double W[36];
+    const bool good = inv6_sym(LB(jb, jb), W);
+    if (lane < 36) {
+      double v = 0.0;
+#pragma unroll
+      for (int q = 0; q < 36; ++q) v = lane == q ? W[q] : v;   // static register indices
+      myW[lane] = v;
+    }
+    if (t == 0 && !good) ok = 0;
+    const int m = nb - jb - 1;
+    // panel: T_I = A_Ij W
+    for (int idx = t; idx < m * 36; idx += nt) {
+      const int I = jb + 1 + idx / 36, e = idx % 36, r = e / 6, c = e % 6;
+      const double* a = LB(I, jb) + r * 6;
+      double s2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s2 += a[k] * myW[k * 6 + c];
+      Tp[idx] = s2;
+    }
+    __syncthreads();
+    // trailing update A_IK -= T_I A_Kj^T (I >= K > j) and the right-hand side rows below
+    const int mblk = m * (m + 1) / 2;
+    for (int idx = t; idx < mblk * 36 + m * 6; idx += nt) {
+      if (idx < mblk * 36) {
+        const int bq = idx / 36, e = idx % 36;
+        const short2 ik = tri[bq];
+        const int r = e / 6, c = e % 6;
+        const double* ti = Tp + ik.x * 36 + r * 6;
+        const double* ak = LB(jb + 1 + ik.y, jb) + c * 6;
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s2 += ti[k] * ak[k];
+        LB(jb + 1 + ik.x, jb + 1 + ik.y)[e] -= s2;
+      } else {
+        const int row = idx - mblk * 36;
+        const double* ti = Tp + (row / 6) * 36 + (row % 6) * 6;
+        double s2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s2 += ti[c] * xs[6 * jb + c];
+        xs[6 * (jb + 1) + row] -= s2;
+      }
+    }
+    __syncthreads();
+    // T_I takes A_Ij's place (backward substitution), W the pivot block's
+    for (int idx = t; idx < m * 36; idx += nt) LB(jb + 1 + idx / 36, jb)[idx % 36] = Tp[idx];
+    if (t < 36) LB(jb, jb)[t] = myW[t];
+    __syncthreads();
+  }
+  // y_j = W_j z_j, then x_j = y_j - sum_{I > j} T_Ij^T x_I right-looking from the last block
+  double yv = 0.0;
+  if (t < n) {
+    const int j = t / 6, r = t % 6;
+    const double* w = LB(j, j) + r * 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) yv += w[k] * xs[6 * j + k];
+  }
+  __syncthreads();
+  if (t < n) xs[t] = yv;
+  __syncthreads();
+  for (int jb = nb - 1; jb >= 1; --jb) {
+    if (t < jb * 6) {
+      const int K = t / 6, c = t % 6;
+      const double* a = LB(jb, K);
+      double s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s2 += a[r * 6 + c] * xs[6 * jb + r];
+      xs[t] -= s2;
+    }
+    __syncthreads();
+  }
+#undef LB
+  for (int i = t; i < n; i += nt) x[i] = xs[i];
+  if (t == 0) lm->chol_ok = ok;
 }
 
 // dense SPD solve A x = bs (n = 6 nPf) in one workgroup: right-looking Cholesky on 6-wide panels,
 // then forward / backward substitution by panels.  status = 0 if a pivot is not positive.
 __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const double* __restrict__ bs,
-                                                  double* __restrict__ x, int n, int* status) {
+                                                  double* __restrict__ x, int n, LmState* lm) {
   __shared__ double Ljj[36];
   __shared__ int ok;
+  if (lm->done) return;
   const int t = threadIdx.x, nt = blockDim.x;
   if (t == 0) ok = 1;
   __syncthreads();
@@ -1162,12 +1354,14 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
     }
     __syncthreads();
   }
-  if (t == 0) *status = ok;
+  if (t == 0) lm->chol_ok = ok;
 }
 
 // xl = Dinv (bl - B^T xp); backup + update of the point; gain-ratio partial sum_j x_j (lambda x_j + b_j)
-__global__ __launch_bounds__(256) void k_ba_backsub(BaDev d, double lambda) {
+__global__ __launch_bounds__(256) void k_ba_backsub(BaDev d) {
   __shared__ double red[4 * 32], out[1];
+  if (d.lm->done) return;
+  const double lambda = lm_lambda(d.lm);
   const int h = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (h < d.nLa) {
@@ -1197,8 +1391,10 @@ __global__ __launch_bounds__(256) void k_ba_backsub(BaDev d, double lambda) {
 }
 
 // pose update (oplus) with backup; pose part of the gain-ratio denominator into partial[offset + block]
-__global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, double lambda, int partial_off) {
+__global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, int partial_off) {
   __shared__ double red[4 * 32], out[1];
+  if (d.lm->done) return;
+  const double lambda = lm_lambda(d.lm);
   const int h = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (h < d.nPf) {
@@ -1215,14 +1411,98 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, double lambda, 
   if (threadIdx.x == 0) d.partial[partial_off + blockIdx.x] = out[0];
 }
 
+// _optimizer->pop() after a rejected trial: k_ba_lm_control says whether the trial just evaluated was one
 __global__ __launch_bounds__(256) void k_ba_restore(BaDev d) {
+  if (!d.lm->restore) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < d.nPf) { const int p = d.pose_of_h[i]; d.pose[p] = d.pose_bak[p]; }
   if (i < d.nLa) { const int l = d.pt_of_h[i]; for (int r = 0; r < 3; ++r) d.pts[3 * l + r] = d.pts_bak[3 * l + r]; }
 }
 
+// ---- Levenberg control on the device (optimization_algorithm_levenberg.cpp:61-189) ----------------------------------------
+// One thread; the sums run over the per-workgroup partials in index order, the order the host loop used.
+// x^3 as pow(x, 3) returns it: the product is formed with its rounding errors carried along (two fma residuals) and rounded once
+__device__ inline double cube_rn(double x) {
+  const double p = x * x, e = fma(x, x, -p);
+  const double q = p * x, f = fma(p, x, -q);
+  return q + (f + e * x);
+}
+// the per-workgroup partial sums come into LDS with one coalesced read; thread 0 then adds them in index order
+constexpr int kLmThreads = 256, kLmMaxPartials = 2048;
+__device__ inline int lm_stage_partials(const BaDev& d, double* sh) {
+  const int np = min(d.scale_off + d.gL + d.gP, kLmMaxPartials);
+  for (int i = threadIdx.x; i < np; i += kLmThreads) sh[i] = d.partial[i];
+  __syncthreads();
+  return np;
+}
+// start of a round: computeActiveErrors + activeRobustChi2 have just run (k_ba_error, always)
+__global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin(BaDev d, int iterations) {
+  __shared__ double sh[kLmMaxPartials];
+  lm_stage_partials(d, sh);
+  if (threadIdx.x != 0) return;
+  LmState S;
+  double sum = 0;
+  for (int i = 0; i < d.gE; ++i) sum += sh[i];
+  S.lambda = -1; S.ni = 2; S.currentChi = sum; S.iniChi = sum; S.rho = 0;
+  S.maxdiag_bits = 0;
+  S.it = 0; S.qmax = 0; S.nBad = 0; S.done = iterations <= 0 ? 1 : 0; S.need_lin = 1; S.restore = 0; S.trials = 0; S.iters_done = 0;
+  S.chol_ok = 1; S.iterations = iterations; S.first = 1; S.pad_ = 0;
+  *d.lm = S;
+  *d.lm_host = S;
+}
+// behind every trial (solve, update, computeActiveErrors): accept or reject, next lambda, end of iteration / of the round
+__global__ __launch_bounds__(kLmThreads) void k_ba_lm_control(BaDev d) {
+  __shared__ double sh[kLmMaxPartials];
+  if (d.lm->done) return;
+  lm_stage_partials(d, sh);
+  if (threadIdx.x != 0) return;
+  LmState S = *d.lm;
+  if (S.first) {   // computeLambdaInit after the first buildSystem (:86-91)
+    S.lambda = 1e-5 * __longlong_as_double((long long)S.maxdiag_bits);
+    S.ni = 2; S.nBad = 0; S.first = 0;
+  }
+  S.need_lin = 0; S.restore = 0;
+  double tempChi = 0, scale = 0;
+  for (int i = 0; i < d.gE; ++i) tempChi += sh[i];
+  if (d.nPf > 0) for (int i = 0; i < d.gP; ++i) scale += sh[d.scale_off + d.gL + i];   // poses first, then landmarks
+  for (int i = 0; i < d.gL; ++i) scale += sh[d.scale_off + i];
+  const bool ok2 = d.nPf == 0 || S.chol_ok == 1;
+  if (S.trials < kLmLogCap) d.lm_log[S.trials] = LmLog{S.lambda, S.currentChi, tempChi, scale};
+  if (!ok2) tempChi = 1.7976931348623157e308;
+  double rho = S.currentChi - tempChi;
+  scale += 1e-3;
+  rho /= scale;
+  if (rho > 0 && isfinite(tempChi)) {
+    double alpha = 1. - cube_rn(2 * rho - 1);
+    alpha = fmin(alpha, 2. / 3.);
+    S.lambda *= fmax(1. / 3., alpha);
+    S.ni = 2;
+    S.currentChi = tempChi;
+  } else {
+    S.lambda *= S.ni;
+    S.ni *= 2;
+    S.restore = 1;   // _optimizer->pop(): k_ba_restore, the next launch
+  }
+  S.rho = rho;
+  S.qmax++;
+  S.trials++;
+  if (!(rho < 0 && S.qmax < 10)) {   // the do-while of :98-146 ends: the iteration is over
+    S.iters_done++;
+    int stop = (S.qmax == 10 || rho == 0) ? 1 : 0;
+    if (!stop) {
+      if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) S.nBad++; else S.nBad = 0;
+      if (S.nBad >= 3) stop = 1;
+    }
+    S.it++;
+    if (stop || S.it >= S.iterations) S.done = 1;
+    else { S.need_lin = 1; S.iniChi = S.currentChi; S.qmax = 0; S.rho = 0; }
+  }
+  *d.lm = S;
+  *d.lm_host = S;
+}
+
 // activeRobustChi2() over the stored errors (no recomputation)
-__global__ __launch_bounds__(256) void k_ba_chi2_stored(BaDev d, int robust) {
+__global__ __launch_bounds__(256) void k_ba_chi2_stored(BaDev d, int robust, double* __restrict__ sums /* pinned host */) {
   __shared__ double red[4 * 32], out[1];
   const int k = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
@@ -1234,7 +1514,7 @@ __global__ __launch_bounds__(256) void k_ba_chi2_stored(BaDev d, int robust) {
     part[0] = r0;
   }
   block_reduce<1>(part, red, out);
-  if (threadIdx.x == 0) d.partial[blockIdx.x] = out[0];
+  if (threadIdx.x == 0) sums[blockIdx.x] = out[0];
 }
 
 // final per-edge outputs: chi2 from the stored error, isDepthPositive from the current estimate
@@ -1271,7 +1551,9 @@ struct BaState {
   DevBuf pc_n;   // fused chains: edge count made on the device
   double* h_partial = nullptr;  // pinned
   size_t h_partial_cap = 0;
-  int* h_misc = nullptr;        // pinned: status, maxdiag (2 ints), n_bad
+  LmState* h_lm = nullptr;      // pinned mirror of the device's Levenberg state
+  DevBuf lm;                    // device: LmState + the per-trial log
+  int lm_blocks[2] = {0, 0};    // trials the previous LocalBA's rounds took: length of the first chunk of blocks enqueued ahead
   char* h_po = nullptr;         // pinned staging of asd_pose_optimize
   size_t h_po_cap = 0;
   struct BaLane* lane = nullptr;   // asd_local_ba_submit / _wait: the optional LocalBA lane (own thread, stream and events)
@@ -1321,12 +1603,12 @@ void ba_free(asd_ctx* ctx) {
   }
   DevBuf* all[] = {&s->pose, &s->pose_bak, &s->pts, &s->pts_bak, &s->e_pt, &s->e_ps, &s->obs, &s->info, &s->err, &s->act,
                    &s->pose_h, &s->pt_h, &s->pose_of_h, &s->pt_of_h, &s->pt_start, &s->ps_start, &s->ps_edges, &s->Bk,
-                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc,
+                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm,
                    &s->partial, &s->blk_i, &s->blk_j, &s->pair_start, &s->pairs, &s->chi2, &s->dpos, &s->po_Xw,
                    &s->po_obs, &s->po_info, &s->po_err, &s->po_level, &s->po_outlier, &s->po_pose, &s->pc_n};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (s->h_partial) (void)hipHostFree(s->h_partial);
-  if (s->h_misc) (void)hipHostFree(s->h_misc);
+  if (s->h_lm) (void)hipHostFree(s->h_lm);
   if (s->h_po) (void)hipHostFree(s->h_po);
   delete s;
   ctx->ba = nullptr;
@@ -1369,10 +1651,10 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;
   a.use_lds = mode;
   a.debug = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsdPerDeviceOnce attr_set;
+  if (attr_set.need(ctx->cfg.device)) {
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+    attr_set.done(ctx->cfg.device);
   }
   if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
   else hipLaunchKernelGGL(k_pose_opt<0>, dim3(1), dim3(kPoseThreads), 0, st, a);
@@ -1448,11 +1730,11 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   else if (!no_lds && lds_full <= 150 * 1024) mode = 1;
   a.use_lds = mode;
   a.debug = getenv("ASD_POSE_DEBUG") ? 1 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static AsdPerDeviceOnce attr_set;
+  if (attr_set.need(ctx->cfg.device)) {
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+    attr_set.done(ctx->cfg.device);
   }
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
   if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
@@ -1522,7 +1804,9 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     ASD_HIP_CHECK(ctx, hipHostMalloc(&s->h_partial, npartial * 2 * 8));
     s->h_partial_cap = npartial * 2;
   }
-  if (!s->h_misc) ASD_HIP_CHECK(ctx, hipHostMalloc(&s->h_misc, 64));
+  if (!s->h_lm) ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_lm), sizeof(LmState)));
+  ENS(lm, sizeof(LmState) + 64 + sizeof(LmLog) * kLmLogCap);
+  if (npartial > (size_t)kLmMaxPartials) { ctx->set_error("asd_local_ba: %d edges exceed the control kernel's %d partial sums", E, kLmMaxPartials); return ASD_ERR_CAPACITY; }
 
   // upload the problem: poses normalised like SE3Quat's constructor does
   std::vector<Pose7> hp(P);
@@ -1555,9 +1839,12 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   d.db = s->db.as<double>(); d.x = s->x.as<double>(); d.A = s->A.as<double>(); d.bs = s->bs.as<double>();
   // status and the per-workgroup partial sums are read by the host after every trial: the kernels store them straight into
   // pinned host memory (a few hundred doubles), which removes two copy commands per trial from the lane's queue
-  d.status = s->h_misc;
-  d.maxdiag_bits = reinterpret_cast<unsigned long long*>(s->misc.as<char>() + 8);
-  d.partial = s->h_partial;
+  // the Levenberg scalars and the per-workgroup partial sums they are made of stay on the device (k_ba_lm_control); the host sees
+  // a pinned mirror of the state, written after every trial, and reads it once per chunk of blocks
+  d.lm = s->lm.as<LmState>();
+  d.lm_host = s->h_lm;
+  d.lm_log = reinterpret_cast<LmLog*>(s->lm.as<char>() + sizeof(LmState) + 64 - (sizeof(LmState) % 8));
+  d.partial = s->partial.as<double>();
 
   std::vector<uint8_t> level(E, 0);
   std::vector<int> act, pose_h(P), pt_h(L), pose_of_h, pt_of_h, pt_start, ps_start, ps_edges, blk_i, blk_j, pair_start, ph_of_k, cursor,
@@ -1566,7 +1853,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
 
   // one g2o initializeOptimization(level 0) + optimize(iterations) round
   const bool timing = getenv("ASD_TIMING") != nullptr;
-  auto run_round = [&](int iterations, bool robust, double* chi_out, int* iters_out) -> int {
+  auto run_round = [&](int round_idx, int iterations, bool robust, double* chi_out, int* iters_out) -> int {
     const auto t_round = std::chrono::steady_clock::now();
     int n_trials = 0;
     // ---- active structure (sparse_optimizer.cpp:206-267, 166-190), on the host
@@ -1663,100 +1950,79 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     const int gE = (Ea + 255) / 256, gL = (nLa + 255) / 256, gP = std::max((nPf + 255) / 256, 1);
     const int n = 6 * nPf;
 
-    auto active_chi2 = [&](double* out) -> int {
-      hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
-      ASD_HIP_CHECK(ctx, hipGetLastError());
-      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      double sum = 0;
-      for (int i = 0; i < gE; ++i) sum += s->h_partial[i];
-      *out = sum;
-      return ASD_OK;
-    };
-
-    double lambda = -1, ni = 2;
-    int nBad = 0, done = 0;
-    double currentChi = 0;
-    for (int it = 0; it < iterations; ++it) {
-      // computeActiveErrors + activeRobustChi2 (levenberg.cpp:70-76).  After the first iteration the loop is only
-      // re-entered behind an ACCEPTED trial, whose k_ba_error pass already left the edge errors and their robust
-      // sum at exactly this estimate (same kernel, same state, same reduction order): reuse it.
-      if (it == 0 && (r2 = active_chi2(&currentChi)) != ASD_OK) return r2;
-      const double iniChi = currentChi;
-      // buildSystem
-      if (it == 0) ASD_HIP_CHECK(ctx, hipMemsetAsync(s->misc.p, 0, 64, st));
+    d.gE = gE; d.gL = gL; d.gP = gP;
+    // ---- the round on the device.  One "block" = one Levenberg trial as the device sees it: [linearise group -- runs only when
+    // the state says a new iteration starts] [solve: Dinv, Y, Schur, dense solve, back-substitution, pose update] [errors at the
+    // trial estimate] [control: accept / reject, next lambda, end of iteration / round] [restore -- runs only after a reject].
+    // Blocks are enqueued ahead; the host reads the mirrored state once per chunk.  The first chunk is as long as the previous
+    // LocalBA's round of the same index took (same map, similar problem), so the usual round needs one synchronisation.
+    auto enqueue_block = [&]() -> int {
       hipLaunchKernelGGL(k_ba_linearize, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
       if (nPf > 0) hipLaunchKernelGGL(k_ba_reduce_pose, dim3(nPf), dim3(256), 0, st, d);
       hipLaunchKernelGGL(k_ba_reduce_point, dim3(gL), dim3(256), 0, st, d);
-      ASD_HIP_CHECK(ctx, hipGetLastError());
-      if (it == 0) {  // computeLambdaInit: tau * max |diag(H)| over poses and landmarks
-        ASD_HIP_CHECK(ctx, hipMemcpyAsync(reinterpret_cast<char*>(s->h_misc) + 16, s->misc.as<char>() + 8, 8, hipMemcpyDeviceToHost, st));
-        ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        double md;
-        memcpy(&md, reinterpret_cast<char*>(s->h_misc) + 16, 8);
-        lambda = 1e-5 * md;
-        ni = 2;
-        nBad = 0;
-      }
-      double rho = 0;
-      int qmax = 0;
-      do {
-        // setLambda + solve (Schur) + update + computeActiveErrors, all enqueued back to back
-        hipLaunchKernelGGL(k_ba_point_dinv, dim3(gL), dim3(256), 0, st, d, lambda);
-        if (nPf > 0) {
-          hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
-          hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, st, d, sb, lambda);
-          if (nPf <= 32) {
-            const size_t nbk = (size_t)(nPf * (nPf + 1) / 2);
-            const size_t lds = nbk * 36 * sizeof(double) + (2 * 192 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
-            static bool chol_attr = false;
-            if (!chol_attr) {
-              ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
-              chol_attr = true;
-            }
-            hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(kCholThreads), lds, st, d.A, d.bs, d.x, n, d.status);
-          } else {
-            hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, d.A, d.bs, d.x, n, d.status);
-          }
+      hipLaunchKernelGGL(k_ba_point_dinv, dim3(gL), dim3(256), 0, st, d);
+      if (nPf > 0) {
+        hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, st, d, sb);
+        const size_t nbk = (size_t)(nPf * (nPf + 1) / 2);
+        static AsdPerDeviceOnce attr_set;   // the dynamic-LDS attribute is per device
+        if (attr_set.need(ctx->cfg.device)) {
+          ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_chol_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+          ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr_set.done(ctx->cfg.device);
         }
-        hipLaunchKernelGGL(k_ba_backsub, dim3(gL), dim3(256), 0, st, d, lambda);
-        hipLaunchKernelGGL(k_ba_update_pose, dim3(gP), dim3(256), 0, st, d, lambda, d.scale_off + gL);
-        hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
-        ASD_HIP_CHECK(ctx, hipGetLastError());
-        ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        const bool ok2 = nPf == 0 || s->h_misc[0] == 1;
-        double tempChi = 0, scale = 0;
-        for (int i = 0; i < gE; ++i) tempChi += s->h_partial[i];
-        for (int i = 0; i < gP; ++i) scale += s->h_partial[d.scale_off + gL + i];  // poses first, then landmarks
-        for (int i = 0; i < gL; ++i) scale += s->h_partial[d.scale_off + i];
-        if (getenv("ASD_BA_DEBUG")) fprintf(stderr, "[ba] it=%d q=%d lambda=%.6e cur=%.9e temp=%.9e scale=%.6e ok=%d nPf=%d nLa=%d Ea=%d nblk=%d\n", it, qmax, lambda, currentChi, tempChi, scale, (int)ok2, nPf, nLa, Ea, nblk);
-        if (!ok2) tempChi = std::numeric_limits<double>::max();
-        rho = currentChi - tempChi;
-        scale += 1e-3;
-        rho /= scale;
-        if (rho > 0 && std::isfinite(tempChi)) {
-          double alpha = 1. - std::pow((2 * rho - 1), 3);
-          alpha = std::min(alpha, 2. / 3.);
-          lambda *= std::max(1. / 3., alpha);
-          ni = 2;
-          currentChi = tempChi;
+        static const bool old_chol = getenv("ASD_BA_CHOL") != nullptr;   // A/B: the round-2 Cholesky kernel
+        if (nPf <= kSolveMaxBlocks && !old_chol) {
+          const size_t lds = (nbk * 36 + (size_t)(kSolveMaxBlocks - 1) * 36 + 192 + (kSolveThreads / 64) * 36 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
+          hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(kSolveThreads), lds, st, d.A, d.bs, d.x, n, d.lm);
+        } else if (nPf <= 32) {
+          const size_t lds = nbk * 36 * sizeof(double) + (2 * 192 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
+          hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(kCholThreads), lds, st, d.A, d.bs, d.x, n, d.lm);
         } else {
-          lambda *= ni;
-          ni *= 2;
-          hipLaunchKernelGGL(k_ba_restore, dim3(std::max(gL, gP)), dim3(256), 0, st, d);  // _optimizer->pop()
+          hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, d.A, d.bs, d.x, n, d.lm);
         }
-        qmax++;
-        ++n_trials;
-      } while (rho < 0 && qmax < 10);
-      ++done;
-      if (qmax == 10 || rho == 0) break;
-      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-      if (nBad >= 3) break;
+      }
+      hipLaunchKernelGGL(k_ba_backsub, dim3(gL), dim3(256), 0, st, d);
+      hipLaunchKernelGGL(k_ba_update_pose, dim3(gP), dim3(256), 0, st, d, d.scale_off + gL);
+      hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 0);
+      hipLaunchKernelGGL(k_ba_lm_control, dim3(1), dim3(kLmThreads), 0, st, d);
+      hipLaunchKernelGGL(k_ba_restore, dim3(std::max(gL, gP)), dim3(256), 0, st, d);
+      ASD_HIP_CHECK(ctx, hipGetLastError());
+      return ASD_OK;
+    };
+    // computeActiveErrors + activeRobustChi2 at the round's first estimate (levenberg.cpp:70-76), state reset
+    hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 1);
+    hipLaunchKernelGGL(k_ba_lm_begin, dim3(1), dim3(kLmThreads), 0, st, d, iterations);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    int& predicted = s->lm_blocks[round_idx];
+    int chunk = predicted > 0 ? predicted : iterations;
+    int done = 0;
+    for (int guard = 0; guard < 64 && iterations > 0; ++guard) {
+      for (int b = 0; b < chunk; ++b) if ((r2 = enqueue_block()) != ASD_OK) return r2;
+      n_trials += chunk;
+      // activeRobustChi2() from the stored edge errors behind every chunk: if the round ended inside it, its report is already there
+      hipLaunchKernelGGL(k_ba_chi2_stored, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, s->h_partial);
+      ASD_HIP_CHECK(ctx, hipGetLastError());
+      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      if (s->h_lm->done) break;
+      chunk = 2;
+    }
+    if (iterations > 0 && !s->h_lm->done) { ctx->set_error("asd_local_ba: the Levenberg state did not finish"); return ASD_ERR_NUMERIC; }
+    done = s->h_lm->iters_done;
+    predicted = s->h_lm->trials;
+    if (getenv("ASD_BA_DEBUG")) {
+      std::vector<LmLog> lg(kLmLogCap);
+      ASD_HIP_CHECK(ctx, hipMemcpy(lg.data(), d.lm_log, sizeof(LmLog) * kLmLogCap, hipMemcpyDeviceToHost));
+      for (int q = 0; q < std::min(s->h_lm->trials, kLmLogCap); ++q)
+        fprintf(stderr, "[ba] trial %d lambda=%.6e cur=%.9e temp=%.9e scale=%.6e nPf=%d nLa=%d Ea=%d nblk=%d\n", q, lg[q].lambda, lg[q].cur, lg[q].temp, lg[q].scale, nPf, nLa, Ea, nblk);
+      fprintf(stderr, "[ba] round %d: %d iterations, %d trials, %d blocks enqueued\n", round_idx, done, s->h_lm->trials, n_trials);
     }
     *iters_out = done;
-    // report the active (robust) chi2 from the stored edge errors, like activeRobustChi2() would
-    hipLaunchKernelGGL(k_ba_chi2_stored, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
-    ASD_HIP_CHECK(ctx, hipGetLastError());
-    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (iterations <= 0) {   // no block ran: report the chi2 of the stored errors as they stand
+      hipLaunchKernelGGL(k_ba_chi2_stored, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, s->h_partial);
+      ASD_HIP_CHECK(ctx, hipGetLastError());
+      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
     double sum = 0;
     for (int i = 0; i < gE; ++i) sum += s->h_partial[i];
     *chi_out = sum;
@@ -1771,7 +2037,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
 
   d.scale_off = nblk_e;
   // optimizer.initializeOptimization(); optimizer.optimize(its_first)           (Optimizer.cc:601-602)
-  rc = run_round(pr->its_first, true, &res->chi2_first, &res->iters_first);
+  rc = run_round(0, pr->its_first, true, &res->chi2_first, &res->iters_first);
   if (rc != ASD_OK) return rc;
   // outlier gating: chi2 > 5.991 || !isDepthPositive -> level 1; robust kernels off  (Optimizer.cc:612-631)
   hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>());
@@ -1785,7 +2051,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     level[e] = bad ? 1 : 0;
   }
   // optimizer.initializeOptimization(0); optimizer.optimize(its_second)         (Optimizer.cc:647-648)
-  rc = run_round(pr->its_second, false, &res->chi2_second, &res->iters_second);
+  rc = run_round(1, pr->its_second, false, &res->chi2_second, &res->iters_second);
   if (rc != ASD_OK) return rc;
   hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>());
   ASD_HIP_CHECK(ctx, hipGetLastError());

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,14 @@
       return ASD_ERR_HIP;                                                                 \
     }                                                                                     \
   } while (0)
+
+// hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device only: one bit per device ordinal says whether this
+// process has asked for it there (contexts on different devices of one process launch the same kernels)
+struct AsdPerDeviceOnce {
+  std::atomic<uint64_t> bits{0};
+  bool need(int dev) const { return !((bits.load(std::memory_order_acquire) >> (dev & 63)) & 1); }
+  void done(int dev) { bits.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 // Grow-only device buffer.  asd_ctx::scratch is the per-call workspace of entry points that need temporary device
 // arrays (one API call at a time per context, so one arena is enough); carve() hands out 256-B aligned pieces.

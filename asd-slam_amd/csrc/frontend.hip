@@ -843,7 +843,6 @@ struct AsyncExtract {
   AsyncJob jobs[kSlots];     // ring: job of submission s lives in jobs[s % kSlots]
   uint64_t submitted = 0, started = 0, waited = 0;  // counters: submitted >= started >= waited
   uint64_t last_view = ~0ull;                       // submission index of the most recently waited job
-  bool x_shared = false;                            // ctx->stream_x is the process-wide CU-masked stream: never destroyed
 };
 
 static void async_worker(asd_ctx* ctx) {
@@ -901,10 +900,9 @@ void frontend_async_shutdown(asd_ctx* ctx) {
   for (auto& S : ax->slots) slot_free(S);
   if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
   if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
-  const bool x_shared = ax->x_shared;
   delete ax;
   ctx->ax = nullptr;
-  if (ctx->stream_x && !x_shared) (void)hipStreamDestroy(ctx->stream_x);
+  if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
   ctx->stream_x = nullptr;
 }
 
@@ -926,19 +924,17 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
   if (rc != ASD_OK) return rc;
   (void)hipSetDevice(ctx->cfg.device);
   if (!ctx->ax) {
-    // Without a CU mask: lowest stream priority for ASDNet (the latency-critical tracking kernels on ctx->stream go first), the
-    // small front-half kernels get the middle priority so they slot in between the conv workgroups.  Default:
-    // 32 CUs (the last 32 mask bits: one XCD's worth) are kept out of the ASDNet stream (hipExtStreamCreateWithCUMask; ASD_EXTRACT_RESERVE_CUS=<n> changes the number, 0 = no
-    // mask and stream priorities instead): the tracking stream's single-workgroup kernels want 70-100 KB of LDS on one CU, and with
-    // ASDNet workgroups (50-70 KB each, two or three per CU) refilling every CU as soon as one drains they wait tens of
-    // microseconds for a CU with enough free LDS.  History of this measurement: with the six-product ASDNet (0.80 ms) on the
-    // critical path, a masked stream ran ASDNet 9 % slower whatever the mask and frames/s did not move (round 1: 720-750 either
-    // way; round 2: 711 / 722 / 750 with 8 / 16 / 32 CUs reserved against 757 without).  With the three-product ASDNet (0.62 ms, the
-    // extractor has slack) and LocalBA on its own lane the tracking chain is the critical path, and the reservation pays:
-    // 958-960 frames/s without, 991 / 1000-1015 / 1013 with 8 / 16 / 32 CUs reserved (ASDNet 0.61 -> 0.65-0.67 ms).  Re-measured at the
-    // end of round 2 (everything else in place): 993 / 1135-1151 / 1147 / 1161-1177 / 1159 frames/s with 8 / 16 / 24 / 32 / 48, ASDNet
-    // 0.61 / 0.62-0.63 / 0.62 / 0.63 / 0.70 ms: 32 it is.
-    // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
+    // Streams of the extractor: ASDNet (back half) at the LOWEST priority -- the latency-critical tracking kernels on ctx->stream
+    // go first --, the front half's fifteen small kernels at the HIGHEST: beside ASDNet at equal priority every one of them waited
+    // 20-60 us for its turn (rocprofv3: k_resize 4 -> 20-66 us), the front half stretched from 0.35 to 0.75 ms and the ASDNet
+    // queue idled waiting for it.
+    // NO CU-masked stream (round 3).  Rounds 1-2 ran ASDNet on a stream made with hipExtStreamCreateWithCUMask that left 32 CUs to
+    // the tracking stream (+6 % frames/s when re-measured in round 3: 980-1006 against 931-942).  ROCm 7.2 cannot tear such a stream
+    // down: destroyed, the process deadlocks at exit (main thread in __hip_module_dtor on a HIP mutex, an HSA event thread in an
+    // ioctl; round 2 also saw hipStreamDestroy itself hang); leaked, rocprofiler-sdk's static destructor segfaults inside
+    // libhsa-runtime64 when the process was profiled.  Both reproduce without this library (tools/ubench/masked_stream_exit.hip,
+    // tools/diag/masked_stream_py.py; profiles/r03_teardown_diagnostics.txt), so the mechanism is gone rather than worked around;
+    // ASD_EXTRACT_RESERVE_CUS is ignored.  The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
     // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
     // will ever take (asd_extract_wait would block forever).
     int prio_least = 0, prio_greatest = 0;
@@ -947,42 +943,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     AsyncExtract* ax = new AsyncExtract();
     hipStream_t sx = nullptr;
     auto build = [&]() -> int {
-      int reserve = 32;
-      if (const char* e = getenv("ASD_EXTRACT_RESERVE_CUS")) reserve = atoi(e);
-      if (reserve > 0 && reserve < ctx->num_cu / 2) {
-        uint32_t mask[16] = {};
-        const int words = (ctx->num_cu + 31) / 32;
-        // the LAST `reserve` mask bits; measured alternatives at 16 CUs: the first 16 bits 961 frames/s, every 16th bit 973-991 (ASDNet
-        // 0.94 ms: a mask that takes CUs out of every XCD unbalances it), every 16th with rotating low bits 1013, against 1123-1158
-        for (int cu = 0; cu < ctx->num_cu - reserve; ++cu) mask[cu / 32] |= 1u << (cu % 32);
-        // hipStreamDestroy of a CU-masked stream hangs now and then on this ROCm (found with a step trace of asd_ctx_destroy: one
-        // in ~6 teardowns, always inside that call, after the stream had been synchronised).  The masked stream is therefore
-        // created once per (device, mask) and process and never destroyed; contexts of one process share it, which orders their
-        // ASDNet passes among each other -- they would share the matrix cores anyway.
-        {
-          static std::mutex cache_m;
-          static std::map<std::pair<int, int>, hipStream_t> cache;
-          std::lock_guard<std::mutex> l(cache_m);
-          auto it = cache.find({ctx->cfg.device, reserve});
-          if (it == cache.end()) {
-            ASD_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&sx, words, mask));
-            cache[{ctx->cfg.device, reserve}] = sx;
-          } else {
-            sx = it->second;
-          }
-          ax->x_shared = true;
-        }
-        // only the ASDNet stream is masked: two CU-masked streams are served by ONE hardware queue whatever their masks
-        // (rocprofv3: same Queue_Id; the next frame's front half ran only after the previous frame's ASDNet had drained, which
-        // costs the extractor the overlap of its two halves).  The front half's stream gets the HIGHEST priority instead: its
-        // fifteen kernels are a few microseconds of small workgroups each, but beside ASDNet at equal priority every one of them
-        // waited 20-60 us for its turn (rocprofv3: k_resize 4 -> 20-66 us, k_fast_score 11 -> 54), the front half stretched
-        // from 0.35 to 0.75 ms and the ASDNet queue idled 0.4 ms per frame waiting for it: 932-954 -> 1017-1023 frames/s
-        ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_greatest));
-      } else {
+      static const bool front_mid = getenv("ASD_FRONT_PRIO_MID") != nullptr;   // A/B only
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
-      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, prio_mid));
-      }
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, front_mid ? prio_mid : prio_greatest));
       ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners));
       for (int i = 0; i < kSlots; ++i) {
         int r;
@@ -997,7 +960,7 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
       for (auto& S : ax->slots) slot_free(S);
       if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
       if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
-      if (sx && !ax->x_shared) (void)hipStreamDestroy(sx);
+      if (sx) (void)hipStreamDestroy(sx);
       delete ax;
       return rc;
     }
@@ -1034,13 +997,15 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
 static AsyncJob* wait_oldest(asd_ctx* ctx, int* rc) {
   AsyncExtract* ax = ctx->ax;
   AsyncJob* a;
+  bool back;
   {
     std::unique_lock<std::mutex> l(ax->m);
     if (ax->waited == ax->submitted) { ctx->set_error("asd_extract_wait: nothing was submitted"); *rc = ASD_ERR_INVALID; return nullptr; }
     a = &ax->jobs[ax->waited % kSlots];
     ax->cv.wait(l, [&] { return a->state == AsyncJob::BACK || a->state == AsyncJob::DONE; });
+    back = a->state == AsyncJob::BACK;   // (read under the lock: the worker writes the state under it)
   }
-  if (a->state == AsyncJob::BACK) {   // only this thread moves a job from BACK to DONE
+  if (back) {   // only this thread moves a job from BACK to DONE
     (void)hipSetDevice(ctx->cfg.device);
     const int frc = extract_finish(ctx, ax->slots[a->slot], a->job.n, a->kps.data(), nullptr);
     std::lock_guard<std::mutex> l(ax->m);
@@ -1050,11 +1015,11 @@ static AsyncJob* wait_oldest(asd_ctx* ctx, int* rc) {
   {
     std::lock_guard<std::mutex> l(ax->m);
     ++ax->waited;
+    if (a->job.rc == ASD_OK) ax->last_view = ax->waited - 1;   // submission index of the job handed over (asd_extract_last_view reads it under the lock)
   }
   if (a->job.rc != ASD_OK) { *rc = a->job.rc; return nullptr; }
   ctx->last_n = a->job.n;
   ctx->d_desc_last = ax->slots[a->slot].d_desc;
-  ax->last_view = ax->waited - 1;   // submission index of the job just handed over (asd_extract_last_view)
   *rc = ASD_OK;
   return a;
 }

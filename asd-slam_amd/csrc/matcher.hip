@@ -703,7 +703,7 @@ inline void transform(const float* T, const float* X, float* out) {
 }
 
 struct MatcherState {
-  int q_cap = 0, cand_cap = 0, qdesc_cap = 0;
+  int q_cap = 0, cand_cap = 0, h_cand_cap = 0, qdesc_cap = 0;   // cand_cap: device candidate buffers; h_cand_cap: their pinned host twins (host replay only)
   int last_total[4] = {1 << 15, 1 << 15, 1 << 15, 1 << 15};  // candidates the previous search of each kind produced
   WinQuery *d_queries = nullptr, *h_queries = nullptr;   // h_* pinned
   int *d_q_off = nullptr, *d_q_cnt = nullptr, *d_total = nullptr, *d_idx = nullptr;
@@ -742,17 +742,31 @@ int ensure_queries(asd_ctx* ctx, MatcherState* m, int nq) {
   m->q_cap = cap;
   return ASD_OK;
 }
-int ensure_cands(asd_ctx* ctx, MatcherState* m, int n) {
-  if (n <= m->cand_cap) return ASD_OK;
-  const int cap = std::max(n * 3 / 2, 1 << 18);
-  if (m->d_idx) { (void)hipFree(m->d_idx); (void)hipFree(m->d_dist); (void)hipFree(m->d_meta); (void)hipHostFree(m->h_idx); (void)hipHostFree(m->h_dist); }
+// device candidate buffers (k_window_search's output, k_resolve's input): 12 B per candidate
+int ensure_cands_dev(asd_ctx* ctx, MatcherState* m, size_t n) {
+  if (n <= (size_t)m->cand_cap) return ASD_OK;
+  if (n > ((size_t)1 << 30)) { ctx->set_error("candidate buffers: %zu entries asked for", n); return ASD_ERR_CAPACITY; }
+  const size_t cap = std::max(n + n / 2, (size_t)1 << 18);
+  if (m->d_idx) { (void)hipFree(m->d_idx); (void)hipFree(m->d_dist); (void)hipFree(m->d_meta); }
+  m->d_idx = nullptr; m->d_dist = nullptr; m->d_meta = nullptr;
   m->cand_cap = 0;
-  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_idx, (size_t)cap * sizeof(int)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_dist, (size_t)cap * sizeof(float)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_meta, (size_t)cap * sizeof(unsigned)));
-  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_idx, (size_t)cap * sizeof(int)));
-  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_dist, (size_t)cap * sizeof(float)));
-  m->cand_cap = cap;
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_idx, cap * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_dist, cap * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_meta, cap * sizeof(unsigned)));
+  m->cand_cap = (int)std::min(cap, (size_t)0x7fffffff);
+  return ASD_OK;
+}
+// ... and their pinned host twins, which only the host replay (window_search) reads
+int ensure_cands(asd_ctx* ctx, MatcherState* m, int n) {
+  int rc = ensure_cands_dev(ctx, m, (size_t)n);
+  if (rc != ASD_OK) return rc;
+  if (m->cand_cap <= m->h_cand_cap) return ASD_OK;
+  if (m->h_idx) { (void)hipHostFree(m->h_idx); (void)hipHostFree(m->h_dist); }
+  m->h_idx = nullptr; m->h_dist = nullptr;
+  m->h_cand_cap = 0;
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_idx, (size_t)m->cand_cap * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_dist, (size_t)m->cand_cap * sizeof(float)));
+  m->h_cand_cap = m->cand_cap;
   return ASD_OK;
 }
 int ensure_qdesc(asd_ctx* ctx, MatcherState* m, int n) {
@@ -884,10 +898,15 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
   // `complete` synchronises, handles a candidate-buffer overflow (grow, enqueue again) and unpacks.  With `defer` the caller gets
   // `complete` back instead of having it run (asd_track_async / asd_track_finish); `chain` must then outlive it.
   if (asd_track_busy(ctx, "matcher call")) return ASD_ERR_INVALID;
-  int rc = ensure_cands(ctx, m, 1);
+  const int n_cur = F.n;
+  // A deferred completion (asd_track_async) runs after the caller may have rewritten bank rows and other frame slots
+  // (include/asd_slam.h allows asd_bank_put* / asd_frame_set in between), so it must never have to search again: the candidate
+  // buffers are sized for the worst case up front -- a query's list holds at most every keypoint of the frame -- and an
+  // overflow at completion is an error, not a retry.  (12 B x nq x n_cur: 96 MB at 4000 x 2000; 288 GB of HBM make that a non-issue.)
+  const bool deferred = defer != nullptr;
+  int rc = ensure_cands_dev(ctx, m, deferred ? std::max((size_t)nq * (size_t)std::max(n_cur, 1), (size_t)1) : (size_t)1);
   if (rc != ASD_OK) return rc;
   hipStream_t st = ctx->stream;
-  const int n_cur = F.n;
   const AsdFrameSlot* Fp = &F;
   {
     AsdXfer &up = ctx->up, &down = ctx->down;
@@ -940,11 +959,11 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     a.mirror = zero_copy ? down.host<int>(o_out) : nullptr;
     const size_t lds = resolve_lds_bytes(KIND, n_cur, nq);
     auto launch = [&](auto kern) -> hipError_t {
-      static bool attr_set = false;   // per instantiation: more than 64 KB of dynamic LDS has to be asked for once
-      if (!attr_set) {
+      static AsdPerDeviceOnce attr_set;   // per instantiation and device: more than 64 KB of dynamic LDS has to be asked for once
+      if (attr_set.need(ctx->cfg.device)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.done(ctx->cfg.device);
       }
       hipLaunchKernelGGL(kern, dim3(1), dim3(kResolveThreads), lds, st, a);
       return hipGetLastError();
@@ -974,8 +993,12 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_chain));
       const int total = h_out[n_cur + 1];
       m->last_total[KIND] = total;
+      if (total > m->cand_cap && deferred) {   // cannot happen with the worst-case sizing above; never search again over state the caller may have changed
+        ctx->set_error("asd_track_finish: %d candidates overflowed the %d-entry buffers of a deferred stage", total, m->cand_cap);
+        return ASD_ERR_CAPACITY;
+      }
       if (total > m->cand_cap && round == 0) {  // the candidate buffers overflowed (k_resolve did not run): grow and search again
-        if ((rc = ensure_cands(ctx, m, total)) != ASD_OK) return rc;
+        if ((rc = ensure_cands_dev(ctx, m, (size_t)total)) != ASD_OK) return rc;
         *ctx->up.host<int>(o_total) = 0;
         if ((rc = attempt()) != ASD_OK) return rc;
         continue;
@@ -1215,9 +1238,9 @@ int asd_distinctive_descriptor_batch(asd_ctx* ctx, int32_t n_sets, const int32_t
   if (e == hipSuccess) e = hipMemcpyAsync(ds, set_start, (size_t)(n_sets + 1) * sizeof(int), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)n_sets * sizeof(int), st);
   if (e == hipSuccess) {
-    static bool attr = false;
+    static AsdPerDeviceOnce attr;
     const size_t lds = (size_t)(kDistinctMax * 132 + kDistinctMax * (kDistinctMax + 1) + kDistinctMax) * sizeof(float);
-    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (attr.need(ctx->cfg.device)) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr.done(ctx->cfg.device); }
     // one launch per run of map points that fit a workgroup (normally a single launch over all of them)
     for (int s = 0; s < n_sets;) {
       if (set_start[s + 1] - set_start[s] > kDistinctMax) { ++s; continue; }

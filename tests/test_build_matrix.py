@@ -10,8 +10,7 @@ from tests.conftest import ROOT
 
 CASES = [
     ({"ASD_RESULT_COPY": "1", "ASD_UPLOAD_COPY": "1"}, ["tests/test_track_chain.py", "tests/test_matcher.py::test_host_and_device_replay_agree"]),
-    ({"ASD_EXTRACT_RESERVE_CUS": "0"}, ["tests/test_frontend.py", "tests/test_bench_host.py"]),
-    ({"ASD_EXTRACT_RESERVE_CUS": "64"}, ["tests/test_bench_host.py"]),
+    ({"ASD_FRONT_PRIO_MID": "1"}, ["tests/test_bench_host.py"]),
 ]
 
 

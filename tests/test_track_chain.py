@@ -282,3 +282,49 @@ def test_split_phase_rules(hip, synth):
     again = hip.track_motion_model(0, 1, n, has, Xw, mp_desc, T, K, 15.0, pose0)
     for a, b in zip(again, ref):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_deferred_stage_never_searches_again(pkg, synth):
+    """A candidate-buffer overflow used to be handled at asd_track_finish by searching again -- over bank rows and frame slots the
+    caller may have rewritten in between (include/asd_slam.h allows asd_bank_put* / asd_frame_set there).  A deferred stage now sizes
+    the candidate buffers for the worst case before it enqueues (a query's list holds at most every keypoint of the frame), so its
+    completion never retries.  Fresh contexts (candidate buffers at their initial 262144 entries), a search radius whose lists
+    exceed that, and the bank rows overwritten between the armed call and asd_track_finish: same bits as the synchronous call."""
+    n, th = 2000, 170.0
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 4242)
+    pose0 = _pose7(pose_T(rv=(0.012, -0.018, 0.006), t=(0.12, -0.04, 0.33)))
+    rows = np.arange(n, dtype=np.int32)
+    # the lists really overflow the initial buffers: count the window candidates of every query (ORBmatcher.cc:1376-1383)
+    Xc = Xw.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3].astype(np.float64)
+    u = K[0] * Xc[:, 0] / Xc[:, 2] + K[2]
+    v = K[1] * Xc[:, 1] / Xc[:, 2] + K[3]
+    total = 0
+    for i in np.nonzero(has)[0]:
+        r = th * SCALES[kl["octave"][i]]
+        lv = (kc["octave"] >= kl["octave"][i] - 1) & (kc["octave"] <= kl["octave"][i] + 1)
+        total += int((lv & (np.abs(kc["x"] - u[i]) < r) & (np.abs(kc["y"] - v[i]) < r)).sum())
+    assert total > 300000, total
+
+    def ctx():
+        h = pkg.AsdHip(n_features=2000, max_width=1241, max_height=376, max_patches=4096)
+        h.frame_set(0, kc, dc, BOUNDS)
+        h.frame_set(1, kl, dl, BOUNDS)
+        h.bank_put(0, mp_desc)
+        return h
+    a = ctx()
+    try:
+        exp = a.track_motion_model(0, 1, n, has, Xw, rows, T, K, th, pose0, True)   # synchronous: grows and searches again, nothing changes meanwhile
+    finally:
+        a.close()
+    assert exp[1] > 100
+    b = ctx()
+    try:
+        assert b.track_motion_model(0, 1, n, has, Xw, rows, T, K, th, pose0, True, split=True) is None
+        b.bank_put(0, np.ascontiguousarray(mp_desc[::-1]))    # the rows the pending stage matched against are rewritten ...
+        b.frame_set(2, kl, dl, BOUNDS)                         # ... and another slot is filled, as the next frame's construction does
+        got = b.track_finish()
+    finally:
+        b.close()
+    for x, y in zip(got, exp):
+        np.testing.assert_array_equal(x, y)
