@@ -710,6 +710,8 @@ struct LmState {
 struct LmLog { double lambda, cur, temp, scale; };   // one record per trial (ASD_BA_DEBUG, tests)
 constexpr int kLmLogCap = 128;
 
+constexpr int kPoseSplit = 8;   // workgroups that share one pose's edge sum (k_ba_reduce_pose)
+
 struct BaDev {
   // problem
   int P, L, E;
@@ -718,6 +720,7 @@ struct BaDev {
   const int* e_pt; const int* e_ps;  // [E]
   const double* obs; const double* info;  // [E][2], [E]
   double* err;                       // [E][2]
+  const uint8_t* lvl;                // [E] g2o level of the edge in the running round: 1 = moved out by the outlier gating (Optimizer.cc:612-631)
   double fx, fy, cx, cy;
   // active structure of the current round
   int Ea, nPf, nLa;
@@ -737,6 +740,7 @@ struct BaDev {
   double* ck;   // [Ea][6]   B * db
   // per vertex
   double* Hpp;  // [nPf][27]
+  double* HppPart;  // [nPf][kPoseSplit][27] partial sums of k_ba_reduce_pose
   double* Hll;  // [nLa][9]
   double* Dinv; // [nLa][6]
   double* db;   // [nLa][3]
@@ -772,11 +776,13 @@ __global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust, int alway
   double part[1] = {0.0};
   if (k < d.Ea) {
     const int e = d.act[k];
-    ba_project_error(d, e);
-    const double c = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
-    double r0 = c, r1;
-    if (robust) huber(c, huber_delta(), r0, r1);
-    part[0] = r0;
+    if (!d.lvl[e]) {   // level-1 edges are outside the optimisation: their stored error stays as last computed, they add nothing
+      ba_project_error(d, e);
+      const double c = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
+      double r0 = c, r1;
+      if (robust) huber(c, huber_delta(), r0, r1);
+      part[0] = r0;
+    }
   }
   block_reduce<1>(part, red, out);
   if (threadIdx.x == 0) d.partial[blockIdx.x] = out[0];
@@ -788,6 +794,17 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev d, int robust) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= d.Ea) return;
   const int e = d.act[k];
+  if (d.lvl[e]) {   // a level-1 edge keeps its place in the round-1 structure and contributes exact zeros to every sum it is part of
+    double* hl = d.Hl + (size_t)k * 9;
+    for (int q = 0; q < 9; ++q) hl[q] = 0.0;
+    if (d.pose_h[d.e_ps[e]] >= 0) {
+      double* hc = d.Hc + (size_t)k * 27;
+      for (int q = 0; q < 27; ++q) hc[q] = 0.0;
+      double* b = d.Bk + (size_t)k * 18;
+      for (int q = 0; q < 18; ++q) b[q] = 0.0;
+    }
+    return;
+  }
   const Pose7 T = d.pose[d.e_ps[e]];
   double Xc[3], R[9], Jc[12], Jp[6];
   pose_map(T, d.pts + 3 * d.e_pt[e], Xc);
@@ -824,29 +841,35 @@ __device__ inline void atomic_max_pos_double(unsigned long long* addr, double v)
   atomicMax(addr, (unsigned long long)__double_as_longlong(v));
 }
 
-// Hpp_i, bp_i = segmented sum over the pose's edges with a fixed shape: thread-strided partial sums,
-// then the fixed-order block reduction (bit-reproducible).
+// Hpp_i, bp_i = segmented sum over the pose's edges with a fixed shape, in two stages: kPoseSplit workgroups per pose take the
+// edges i = s, s + kPoseSplit, ... of its list (thread-strided partial sums, fixed-order block reduction), a second kernel adds the
+// kPoseSplit partials in index order.  Bit-reproducible.  (One workgroup per pose -- 24 workgroups reading 6 MB of per-edge blocks --
+// took 16 us per iteration.)
 __global__ __launch_bounds__(256) void k_ba_reduce_pose(BaDev d) {
   __shared__ double red[4 * 32], out[27];
   if (d.lm->done || !d.lm->need_lin) return;
-  const int h = blockIdx.x;
+  const int h = blockIdx.x / kPoseSplit, sp = blockIdx.x % kPoseSplit;
   const int b = d.ps_start[h], e = d.ps_start[h + 1];
   double acc[27];
 #pragma unroll
   for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-  for (int i = b + threadIdx.x; i < e; i += 256) {
+  for (int i = b + sp * 256 + threadIdx.x; i < e; i += 256 * kPoseSplit) {
     const double* hc = d.Hc + (size_t)d.ps_edges[i] * 27;
 #pragma unroll
     for (int q = 0; q < 27; ++q) acc[q] += hc[q];
   }
   block_reduce<27>(acc, red, out);
-  if (threadIdx.x < 27) {
-    const int t = threadIdx.x;
-    const double s = out[t];
-    d.Hpp[(size_t)h * 27 + t] = s;
-    // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
-    if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(&d.lm->maxdiag_bits, fabs(s));
-  }
+  if (threadIdx.x < 27) d.HppPart[((size_t)h * kPoseSplit + sp) * 27 + threadIdx.x] = out[threadIdx.x];
+}
+__global__ __launch_bounds__(64) void k_ba_reduce_pose2(BaDev d) {
+  if (d.lm->done || !d.lm->need_lin) return;
+  const int h = blockIdx.x, t = threadIdx.x;
+  if (t >= 27) return;
+  double s = 0.0;
+  for (int sp = 0; sp < kPoseSplit; ++sp) s += d.HppPart[((size_t)h * kPoseSplit + sp) * 27 + t];
+  d.Hpp[(size_t)h * 27 + t] = s;
+  // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
+  if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(&d.lm->maxdiag_bits, fabs(s));
 }
 
 __global__ __launch_bounds__(256) void k_ba_reduce_point(BaDev d) {
@@ -1107,7 +1130,7 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
 // chain of ~14 dependent fp64 instructions (pivot update, 1/sqrt with two Newton steps, column scaling) at ~44 cycles a link --
 // plus a 21-link forward substitution per panel row.  The inverse of a symmetric 6x6 from two 3x3 cofactor inverses (P, then the
 // Schur complement S = R - Q P^-1 Q^T) has two reciprocals on its critical path instead of six inverse square roots (~36 links),
-// every wave computes it redundantly from LDS (nothing to broadcast, no barrier in front of the panel), and the panel / trailing
+// one wave computes it from LDS, and the panel / trailing
 // update / both substitutions become 6-term dot products with no triangular dependency inside a block.
 // Positive definiteness (linear_solver_dense.h:96 fails on a non-positive LDLT pivot) is checked on the leading minors of P and S.
 __device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double (&o)[6]) {
@@ -1168,7 +1191,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
   const int nblk = nb * (nb + 1) / 2;
   double* Tp = L + (size_t)nblk * 36;                 // [nb - 1][36] panel T_I of the current step
   double* xs = Tp + (size_t)(kSolveMaxBlocks - 1) * 36;   // [192] right-hand side / solution
-  double* Ww = xs + 192;                              // [16 waves][36] every wave's copy of the pivot block's inverse
+  double* Ww = xs + 192;                              // [36] the pivot block's inverse (+ padding)
   int& ok = *reinterpret_cast<int*>(Ww + (kSolveThreads / 64) * 36);
   short2* tri = reinterpret_cast<short2*>(Ww + (kSolveThreads / 64) * 36 + 2);  // [nblk] packed lower-triangle index -> (I, J)
 #define LB(I, J) (L + ((size_t)((I) * ((I) + 1) / 2 + (J))) * 36)
@@ -1183,18 +1206,22 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
   }
   for (int i = t; i < n; i += nt) xs[i] = bs[i];
   __syncthreads();
-  double* myW = Ww + wave * 36;
+  double* myW = Ww;   // the pivot block's inverse, shared by the workgroup
   for (int jb = 0; jb < nb; ++jb) {
-    // every wave inverts the pivot block for itself (same bits in every wave) and keeps it in its own LDS rows
-    double W[36];
-    const bool good = inv6_sym(LB(jb, jb), W);
-    if (lane < 36) {
-      double v = 0.0;
+    // ONE wave inverts the pivot block (the fp64 pipe of a SIMD retires one wave-instruction per ~8 cycles however many waves feed
+    // it: sixteen waves inverting redundantly -- the first form of this kernel, 104 us -- queue up four deep on every SIMD)
+    if (wave == 0) {
+      double W[36];
+      const bool good = inv6_sym(LB(jb, jb), W);
+      if (lane < 36) {
+        double v = 0.0;
 #pragma unroll
-      for (int q = 0; q < 36; ++q) v = lane == q ? W[q] : v;   // static register indices
-      myW[lane] = v;
+        for (int q = 0; q < 36; ++q) v = lane == q ? W[q] : v;   // static register indices
+        myW[lane] = v;
+      }
+      if (lane == 0 && !good) ok = 0;
     }
-    if (t == 0 && !good) ok = 0;
+    __syncthreads();
     const int m = nb - jb - 1;
     // panel: T_I = A_Ij W
     for (int idx = t; idx < m * 36; idx += nt) {
@@ -1405,7 +1432,10 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, int partial_off
       u[r] = d.x[6 * h + r];
       part[0] += u[r] * (lambda * u[r] + d.Hpp[(size_t)h * 27 + 21 + r]);
     }
-    d.pose[p] = pose_oplus(d.pose[p], u);
+    // (a pose whose edges were all moved to level 1 is no active vertex in g2o: its step is exactly zero here, and exp(0) * T would
+    // still re-normalise the quaternion)
+    const bool zero = u[0] == 0 && u[1] == 0 && u[2] == 0 && u[3] == 0 && u[4] == 0 && u[5] == 0;
+    if (!zero) d.pose[p] = pose_oplus(d.pose[p], u);
   }
   block_reduce<1>(part, red, out);
   if (threadIdx.x == 0) d.partial[partial_off + blockIdx.x] = out[0];
@@ -1508,10 +1538,12 @@ __global__ __launch_bounds__(256) void k_ba_chi2_stored(BaDev d, int robust, dou
   double part[1] = {0.0};
   if (k < d.Ea) {
     const int e = d.act[k];
-    const double c = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
-    double r0 = c, r1;
-    if (robust) huber(c, huber_delta(), r0, r1);
-    part[0] = r0;
+    if (!d.lvl[e]) {
+      const double c = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
+      double r0 = c, r1;
+      if (robust) huber(c, huber_delta(), r0, r1);
+      part[0] = r0;
+    }
   }
   block_reduce<1>(part, red, out);
   if (threadIdx.x == 0) sums[blockIdx.x] = out[0];
@@ -1544,6 +1576,7 @@ struct DevBuf {
 };
 
 struct BaState {
+  DevBuf lvl, HppPart;
   DevBuf pose, pose_bak, pts, pts_bak, e_pt, e_ps, obs, info, err, act, pose_h, pt_h, pose_of_h, pt_of_h, pt_start,
       ps_start, ps_edges, Bk, Hc, Hl, Yk, ck, Hpp, Hll, Dinv, db, x, A, bs, misc, partial, blk_i, blk_j, pair_start,
       pairs, chi2, dpos;
@@ -1603,7 +1636,7 @@ void ba_free(asd_ctx* ctx) {
   }
   DevBuf* all[] = {&s->pose, &s->pose_bak, &s->pts, &s->pts_bak, &s->e_pt, &s->e_ps, &s->obs, &s->info, &s->err, &s->act,
                    &s->pose_h, &s->pt_h, &s->pose_of_h, &s->pt_of_h, &s->pt_start, &s->ps_start, &s->ps_edges, &s->Bk,
-                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm,
+                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm, &s->lvl, &s->HppPart,
                    &s->partial, &s->blk_i, &s->blk_j, &s->pair_start, &s->pairs, &s->chi2, &s->dpos, &s->po_Xw,
                    &s->po_obs, &s->po_info, &s->po_err, &s->po_level, &s->po_outlier, &s->po_pose, &s->pc_n};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
@@ -1795,7 +1828,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ENS(Bk, (size_t)E * 18 * 8); ENS(Hc, (size_t)E * 27 * 8); ENS(Hl, (size_t)E * 9 * 8); ENS(Yk, (size_t)E * 18 * 8);
   ENS(ck, (size_t)E * 6 * 8); ENS(Hpp, (size_t)P * 27 * 8); ENS(Hll, (size_t)L * 9 * 8); ENS(Dinv, (size_t)L * 6 * 8);
   ENS(db, (size_t)L * 3 * 8); ENS(x, ((size_t)6 * P + 3 * L) * 8); ENS(A, (size_t)36 * P * P * 8); ENS(bs, (size_t)6 * P * 8);
-  ENS(misc, 64); ENS(chi2, (size_t)E * 8); ENS(dpos, (size_t)E);
+  ENS(misc, 64); ENS(chi2, (size_t)E * 8); ENS(dpos, (size_t)E); ENS(lvl, (size_t)E); ENS(HppPart, (size_t)P * kPoseSplit * 27 * 8);
   const int nblk_e = (E + 255) / 256, nblk_l = (L + 255) / 256, nblk_p = (P + 255) / 256;
   const size_t npartial = (size_t)nblk_e + nblk_l + nblk_p + 8;
   ENS(partial, npartial * 8);
@@ -1822,6 +1855,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->obs.p, pr->e_obs, (size_t)E * 16, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->info.p, pr->e_info, (size_t)E * 8, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemsetAsync(s->err.p, 0, (size_t)E * 16, st));
+  ASD_HIP_CHECK(ctx, hipMemsetAsync(s->lvl.p, 0, (size_t)E, st));
   ASD_HIP_CHECK(ctx, hipEventRecord(ev0, st));
 
   BaDev d{};
@@ -1829,7 +1863,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   d.pose = s->pose.as<Pose7>(); d.pose_bak = s->pose_bak.as<Pose7>();
   d.pts = s->pts.as<double>(); d.pts_bak = s->pts_bak.as<double>();
   d.e_pt = s->e_pt.as<int>(); d.e_ps = s->e_ps.as<int>(); d.obs = s->obs.as<double>(); d.info = s->info.as<double>();
-  d.err = s->err.as<double>();
+  d.err = s->err.as<double>(); d.lvl = s->lvl.as<uint8_t>(); d.HppPart = s->HppPart.as<double>();
   d.fx = pr->K[0]; d.fy = pr->K[1]; d.cx = pr->K[2]; d.cy = pr->K[3];
   d.act = s->act.as<int>(); d.pose_h = s->pose_h.as<int>(); d.pt_h = s->pt_h.as<int>();
   d.pose_of_h = s->pose_of_h.as<int>(); d.pt_of_h = s->pt_of_h.as<int>(); d.pt_start = s->pt_start.as<int>();
@@ -1853,22 +1887,31 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
 
   // one g2o initializeOptimization(level 0) + optimize(iterations) round
   const bool timing = getenv("ASD_TIMING") != nullptr;
+  // The active structure (sparse_optimizer.cpp:206-267, 166-190) is built ONCE, for the first round (every edge at level 0).  The
+  // second round (Optimizer.cc:647: initializeOptimization(0) after the outlier gating) runs over the same structure with the
+  // level-1 edges masked: such an edge keeps its place and contributes exact zeros (k_ba_linearize, k_ba_error), a landmark that
+  // lost all its edges gets a zero step, and x + 0.0 == x, so every sum equals the sum over the compacted lists g2o would build --
+  // without the second host pass over the edges and its uploads (0.45 ms per LocalBA).
+  int nPf = 0, nLa = 0, Ea = 0, nblk = 0;
+  std::chrono::steady_clock::time_point t_prep;
   auto run_round = [&](int round_idx, int iterations, bool robust, double* chi_out, int* iters_out) -> int {
     const auto t_round = std::chrono::steady_clock::now();
     int n_trials = 0;
-    // ---- active structure (sparse_optimizer.cpp:206-267, 166-190), on the host
+    int r2;
+    if (round_idx == 0) {
+    // ---- active structure, on the host
     std::vector<uint8_t> pa(P, 0), la(L, 0);
     for (int e = 0; e < E; ++e)
       if (!level[e]) { pa[pr->e_pose[e]] = 1; la[pr->e_point[e]] = 1; }
     pose_of_h.clear(); pt_of_h.clear();
     for (int p = 0; p < P; ++p) { pose_h[p] = -1; if (pa[p] && !pr->fixed[p]) { pose_h[p] = (int)pose_of_h.size(); pose_of_h.push_back(p); } }
     for (int l = 0; l < L; ++l) { pt_h[l] = -1; if (la[l]) { pt_h[l] = (int)pt_of_h.size(); pt_of_h.push_back(l); } }
-    const int nPf = (int)pose_of_h.size(), nLa = (int)pt_of_h.size();
+    nPf = (int)pose_of_h.size(); nLa = (int)pt_of_h.size();
     // active edges grouped by landmark (CSR), inside a landmark ordered by pose h-index (fixed poses first)
     pt_start.assign(nLa + 1, 0);
     for (int e = 0; e < E; ++e) if (!level[e]) ++pt_start[pt_h[pr->e_point[e]] + 1];
     for (int h = 0; h < nLa; ++h) pt_start[h + 1] += pt_start[h];
-    const int Ea = pt_start[nLa];
+    Ea = pt_start[nLa];
     act.assign(Ea, 0);
     ph_of_k.assign(std::max(Ea, 1), -1);  // pose h-index of the k-th active edge (-1 = fixed pose)
     {
@@ -1927,8 +1970,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         }
       }
     }
-    const int nblk = (int)blk_i.size();
-    int r2;
+    nblk = (int)blk_i.size();
     if ((r2 = s->blk_i.ensure(ctx, (size_t)std::max(nblk, 1) * 4)) || (r2 = s->blk_j.ensure(ctx, (size_t)std::max(nblk, 1) * 4)) ||
         (r2 = s->pair_start.ensure(ctx, (size_t)(nblk + 1) * 4)) || (r2 = s->pairs.ensure(ctx, pairs.size() * 8)))
       return r2;
@@ -1942,7 +1984,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     UP(pair_start, pair_start); UP(pairs, pairs);
 #undef UP
     d.Ea = Ea; d.nPf = nPf; d.nLa = nLa;
-    const auto t_prep = std::chrono::steady_clock::now();
+    }   // round_idx == 0
+    t_prep = std::chrono::steady_clock::now();
     SchurBlocks sb{s->blk_i.as<int>(), s->blk_j.as<int>(), s->pair_start.as<int>(), s->pairs.as<int2>()};
     *iters_out = 0;
     *chi_out = 0;
@@ -1958,7 +2001,10 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     // LocalBA's round of the same index took (same map, similar problem), so the usual round needs one synchronisation.
     auto enqueue_block = [&]() -> int {
       hipLaunchKernelGGL(k_ba_linearize, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
-      if (nPf > 0) hipLaunchKernelGGL(k_ba_reduce_pose, dim3(nPf), dim3(256), 0, st, d);
+      if (nPf > 0) {
+        hipLaunchKernelGGL(k_ba_reduce_pose, dim3(nPf * kPoseSplit), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_ba_reduce_pose2, dim3(nPf), dim3(64), 0, st, d);
+      }
       hipLaunchKernelGGL(k_ba_reduce_point, dim3(gL), dim3(256), 0, st, d);
       hipLaunchKernelGGL(k_ba_point_dinv, dim3(gL), dim3(256), 0, st, d);
       if (nPf > 0) {
@@ -2050,6 +2096,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     res->edge_outlier1[e] = bad ? 1 : 0;
     level[e] = bad ? 1 : 0;
   }
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->lvl.p, level.data(), (size_t)E, hipMemcpyHostToDevice, st));
   // optimizer.initializeOptimization(0); optimizer.optimize(its_second)         (Optimizer.cc:647-648)
   rc = run_round(1, pr->its_second, false, &res->chi2_second, &res->iters_second);
   if (rc != ASD_OK) return rc;

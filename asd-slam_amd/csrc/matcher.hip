@@ -378,6 +378,9 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
   const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
   const int total = *a.total;
   if (total > a.cap) {   // truncated lists: the host grows the buffers and searches again
+    // the match table is still written (no match anywhere): a fused chain behind this kernel gathers its edges from it, and
+    // stale rows would send PoseOptimization out of the position table's bounds
+    for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, -1);
     if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
     return;
   }
