@@ -18,14 +18,14 @@
 //   k_ba_error      edge-parallel residual + robust cost            -> per-block partial sums
 //   k_ba_linearize  edge-parallel Jacobians, Huber weight, per-edge blocks (Hpp/Hll/Hpl parts)
 //   k_ba_reduce_*   per-pose / per-landmark segmented sums (CSR built once per round on the host)
-//   k_ba_point_dinv landmark-parallel (Hll + lambda I)^-1, B*Dinv, B*db
+//   k_ba_edge_y     edge-parallel (Hll + lambda I)^-1 (recomputed per edge), Y = B*Dinv, c = B*db
 //   k_ba_schur      one workgroup per upper 6x6 block: Hpp + lambda I - sum_l (B Dinv) B^T  (dense)
 //   k_ba_chol       blocked Cholesky + triangular solves in one workgroup
-//   k_ba_backsub    landmark-parallel xl = Dinv (bl - B^T xp), point update, gain-ratio partials
+//   k_ba_step       landmark-parallel xl = Dinv (bl - B^T xp) + pose-parallel oplus into the TRIAL buffer, gain-ratio partials
 // The Levenberg accept/reject logic (optimization_algorithm_levenberg.cpp:61-189) runs ON THE DEVICE since round 3: the scalars
 // live in LmState, a one-thread kernel (k_ba_lm_control) behind every trial takes the decision the host used to take after a
 // synchronisation, and every other kernel reads lambda / "is this step needed" from that state -- a step whose answer is no
-// exits at once.  The host enqueues whole iterations ("blocks" = linearise group + trial group + control + restore) ahead and
+// exits at once.  The host enqueues whole iterations ("blocks" = linearise group + trial group + control) ahead and
 // synchronises once per chunk of blocks instead of once per trial.
 #include <algorithm>
 #include <chrono>
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(1024) void k_pose_edges(PoseEdgesArgs a) {
 struct LmState {
   double lambda, ni, currentChi, iniChi, rho;
   unsigned long long maxdiag_bits;   // max |diag(H)| over poses and landmarks as the bit pattern of a non-negative double
-  int it, qmax, nBad, done, need_lin, restore, trials, iters_done, chol_ok, iterations, first, pad_;
+  int it, qmax, nBad, done, need_lin, cur, trials, iters_done, chol_ok, iterations, first, pad_;   // cur: which of the two estimate buffers holds the accepted estimate
 };
 struct LmLog { double lambda, cur, temp, scale; };   // one record per trial (ASD_BA_DEBUG, tests)
 constexpr int kLmLogCap = 128;
@@ -715,8 +715,10 @@ constexpr int kPoseSplit = 8;   // workgroups that share one pose's edge sum (k_
 struct BaDev {
   // problem
   int P, L, E;
-  Pose7* pose; Pose7* pose_bak;      // [P]
-  double* pts; double* pts_bak;      // [L][3]
+  // the estimate is double buffered: [lm->cur] = the accepted estimate, [1 - lm->cur] = the trial (solve + oplus of the accepted one).
+  // Accepting a trial flips lm->cur, rejecting it does nothing: no backup / restore passes (g2o's push / pop, sparse_optimizer.cpp:422-435)
+  Pose7* pose[2];                    // [P]
+  double* pts[2];                    // [L][3]
   const int* e_pt; const int* e_ps;  // [E]
   const double* obs; const double* info;  // [E][2], [E]
   double* err;                       // [E][2]
@@ -761,9 +763,9 @@ __device__ inline double lm_lambda(const LmState* lm) {
   return lm->first ? 1e-5 * __longlong_as_double((long long)lm->maxdiag_bits) : lm->lambda;
 }
 
-__device__ inline void ba_project_error(const BaDev& d, int e) {
+__device__ inline void ba_project_error(const BaDev& d, int e, int buf) {
   double Xc[3];
-  pose_map(d.pose[d.e_ps[e]], d.pts + 3 * d.e_pt[e], Xc);
+  pose_map(d.pose[buf][d.e_ps[e]], d.pts[buf] + 3 * d.e_pt[e], Xc);
   d.err[2 * e] = d.obs[2 * e] - (Xc[0] / Xc[2] * d.fx + d.cx);
   d.err[2 * e + 1] = d.obs[2 * e + 1] - (Xc[1] / Xc[2] * d.fy + d.cy);
 }
@@ -772,12 +774,13 @@ __device__ inline void ba_project_error(const BaDev& d, int e) {
 __global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust, int always) {
   __shared__ double red[4 * 32], out[1];
   if (!always && d.lm->done) return;
+  const int buf = always ? d.lm->cur : 1 - d.lm->cur;   // the round's first pass looks at the accepted estimate, every other at the trial
   const int k = blockIdx.x * 256 + threadIdx.x;
   double part[1] = {0.0};
   if (k < d.Ea) {
     const int e = d.act[k];
     if (!d.lvl[e]) {   // level-1 edges are outside the optimisation: their stored error stays as last computed, they add nothing
-      ba_project_error(d, e);
+      ba_project_error(d, e, buf);
       const double c = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
       double r0 = c, r1;
       if (robust) huber(c, huber_delta(), r0, r1);
@@ -805,9 +808,10 @@ __global__ __launch_bounds__(256) void k_ba_linearize(BaDev d, int robust) {
     }
     return;
   }
-  const Pose7 T = d.pose[d.e_ps[e]];
+  const int cur = d.lm->cur;
+  const Pose7 T = d.pose[cur][d.e_ps[e]];
   double Xc[3], R[9], Jc[12], Jp[6];
-  pose_map(T, d.pts + 3 * d.e_pt[e], Xc);
+  pose_map(T, d.pts[cur] + 3 * d.e_pt[e], Xc);
   quat_to_rot(T, R);
   const double x = Xc[0], y = Xc[1], z = Xc[2];
   const double tmp[6] = {d.fx, 0, -x / z * d.fx, 0, d.fy, -y / z * d.fy};
@@ -845,21 +849,34 @@ __device__ inline void atomic_max_pos_double(unsigned long long* addr, double v)
 // edges i = s, s + kPoseSplit, ... of its list (thread-strided partial sums, fixed-order block reduction), a second kernel adds the
 // kPoseSplit partials in index order.  Bit-reproducible.  (One workgroup per pose -- 24 workgroups reading 6 MB of per-edge blocks --
 // took 16 us per iteration.)
-__global__ __launch_bounds__(256) void k_ba_reduce_pose(BaDev d) {
+// one launch, two kinds of workgroup: [0, nPf * kPoseSplit) the first stage of the pose sums, the rest the landmark sums
+__global__ __launch_bounds__(256) void k_ba_reduce(BaDev d) {
   __shared__ double red[4 * 32], out[27];
   if (d.lm->done || !d.lm->need_lin) return;
-  const int h = blockIdx.x / kPoseSplit, sp = blockIdx.x % kPoseSplit;
-  const int b = d.ps_start[h], e = d.ps_start[h + 1];
-  double acc[27];
+  const int npose_blk = d.nPf * kPoseSplit;
+  if ((int)blockIdx.x < npose_blk) {
+    const int h = blockIdx.x / kPoseSplit, sp = blockIdx.x % kPoseSplit;
+    const int b = d.ps_start[h], e = d.ps_start[h + 1];
+    double acc[27];
 #pragma unroll
-  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-  for (int i = b + sp * 256 + threadIdx.x; i < e; i += 256 * kPoseSplit) {
-    const double* hc = d.Hc + (size_t)d.ps_edges[i] * 27;
+    for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+    for (int i = b + sp * 256 + threadIdx.x; i < e; i += 256 * kPoseSplit) {
+      const double* hc = d.Hc + (size_t)d.ps_edges[i] * 27;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) acc[q] += hc[q];
+      for (int q = 0; q < 27; ++q) acc[q] += hc[q];
+    }
+    block_reduce<27>(acc, red, out);
+    if (threadIdx.x < 27) d.HppPart[((size_t)h * kPoseSplit + sp) * 27 + threadIdx.x] = out[threadIdx.x];
+    return;
   }
-  block_reduce<27>(acc, red, out);
-  if (threadIdx.x < 27) d.HppPart[((size_t)h * kPoseSplit + sp) * 27 + threadIdx.x] = out[threadIdx.x];
+  const int h = ((int)blockIdx.x - npose_blk) * 256 + threadIdx.x;
+  if (h >= d.nLa) return;
+  double s[9];
+  for (int q = 0; q < 9; ++q) s[q] = 0.0;
+  for (int k = d.pt_start[h]; k < d.pt_start[h + 1]; ++k)
+    for (int q = 0; q < 9; ++q) s[q] += d.Hl[(size_t)k * 9 + q];
+  for (int q = 0; q < 9; ++q) d.Hll[(size_t)h * 9 + q] = s[q];
+  atomic_max_pos_double(&d.lm->maxdiag_bits, fmax(fabs(s[0]), fmax(fabs(s[3]), fabs(s[5]))));
 }
 __global__ __launch_bounds__(64) void k_ba_reduce_pose2(BaDev d) {
   if (d.lm->done || !d.lm->need_lin) return;
@@ -872,36 +889,16 @@ __global__ __launch_bounds__(64) void k_ba_reduce_pose2(BaDev d) {
   if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(&d.lm->maxdiag_bits, fabs(s));
 }
 
-__global__ __launch_bounds__(256) void k_ba_reduce_point(BaDev d) {
-  if (d.lm->done || !d.lm->need_lin) return;
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= d.nLa) return;
-  double s[9];
-  for (int q = 0; q < 9; ++q) s[q] = 0.0;
-  for (int k = d.pt_start[h]; k < d.pt_start[h + 1]; ++k)
-    for (int q = 0; q < 9; ++q) s[q] += d.Hl[(size_t)k * 9 + q];
-  for (int q = 0; q < 9; ++q) d.Hll[(size_t)h * 9 + q] = s[q];
-  atomic_max_pos_double(&d.lm->maxdiag_bits, fmax(fabs(s[0]), fmax(fabs(s[3]), fabs(s[5]))));
-}
-
-// per landmark: Dinv = (Hll + lambda I)^-1, db = Dinv bl, and for its free-pose edges Y = B Dinv, c = B db
-__global__ __launch_bounds__(256) void k_ba_point_dinv(BaDev d) {
-  if (d.lm->done) return;
-  const double lambda = lm_lambda(d.lm);
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= d.nLa) return;
-  const double* H = d.Hll + (size_t)h * 9;
+// per landmark: Dinv = (Hll + lambda I)^-1 (symmetric 3x3 by cofactors) and db = Dinv bl.  Evaluated where it is needed (per edge in
+// k_ba_edge_y, per landmark in k_ba_backsub) instead of by a kernel of its own: forty flops against a launch, and the same
+// instructions give the same bits in both places.
+__device__ inline void point_dinv(const double* H, double lambda, double (&I)[9], double (&dbv)[3]) {
   const double a = H[0] + lambda, b = H[1], c = H[2], dd = H[3] + lambda, e = H[4], f = H[5] + lambda;
   const double c00 = dd * f - e * e, c01 = c * e - b * f, c02 = b * e - c * dd;
   const double id = 1.0 / (a * c00 + b * c01 + c * c02);
-  const double I[9] = {c00 * id, c01 * id, c02 * id, c01 * id, (a * f - c * c) * id, (b * c - a * e) * id,
-                       c02 * id, (b * c - a * e) * id, (a * dd - b * b) * id};
-  double* Di = d.Dinv + (size_t)h * 6;
-  Di[0] = I[0]; Di[1] = I[1]; Di[2] = I[2]; Di[3] = I[4]; Di[4] = I[5]; Di[5] = I[8];
-  const double bl[3] = {H[6], H[7], H[8]};
-  double dbv[3];
-  for (int r = 0; r < 3; ++r) dbv[r] = I[r * 3] * bl[0] + I[r * 3 + 1] * bl[1] + I[r * 3 + 2] * bl[2];
-  for (int r = 0; r < 3; ++r) d.db[(size_t)h * 3 + r] = dbv[r];
+  I[0] = c00 * id; I[1] = c01 * id; I[2] = c02 * id; I[3] = c01 * id; I[4] = (a * f - c * c) * id; I[5] = (b * c - a * e) * id;
+  I[6] = c02 * id; I[7] = (b * c - a * e) * id; I[8] = (a * dd - b * b) * id;
+  for (int r = 0; r < 3; ++r) dbv[r] = I[r * 3] * H[6] + I[r * 3 + 1] * H[7] + I[r * 3 + 2] * H[8];
 }
 
 // Y_k = B_k Dinv_l and c_k = B_k (Dinv_l bl) for every active edge to a free pose: one lane per edge (the per-landmark
@@ -913,9 +910,8 @@ __global__ __launch_bounds__(256) void k_ba_edge_y(BaDev d) {
   const int e = d.act[k];
   if (d.pose_h[d.e_ps[e]] < 0) return;
   const int h = d.pt_h[d.e_pt[e]];
-  const double* Di = d.Dinv + (size_t)h * 6;
-  const double I[9] = {Di[0], Di[1], Di[2], Di[1], Di[3], Di[4], Di[2], Di[4], Di[5]};
-  const double dbv[3] = {d.db[(size_t)h * 3], d.db[(size_t)h * 3 + 1], d.db[(size_t)h * 3 + 2]};
+  double I[9], dbv[3];
+  point_dinv(d.Hll + (size_t)h * 9, lm_lambda(d.lm), I, dbv);
   const double* B = d.Bk + (size_t)k * 18;
   double* Y = d.Yk + (size_t)k * 18;
   double* cc = d.ck + (size_t)k * 6;
@@ -1182,18 +1178,34 @@ __device__ inline bool inv6_sym(const double* A, double (&W)[36]) {
   return ok;
 }
 
-constexpr int kSolveThreads = 1024, kSolveMaxBlocks = 31;
+constexpr int kSolveThreads = 1024, kSolveMaxBlocks = 30;
+// Schedule of a step j (two barriers):
+//   [panel]   T_I = A_Ij W_j for I > j, one thread per ROW of a block (six independent dot products: the fp64 latency of one chain hides
+//             behind the other five); the same phase moves the PREVIOUS step's panel into A's place (nobody reads A_I,j-1 any more)
+//   barrier
+//   [update]  A_IK -= T_I A_Kj^T, again a row per thread.  Wave 0 takes the next pivot block A_j+1,j+1 first and inverts it at once
+//             (look-ahead) while the other fifteen waves do the rest of the trailing matrix: the ~37 dependent fp64 instructions of the
+//             inverse (~2k cycles) are the critical path of the whole factorisation and now run beside the update instead of after it
+//   barrier
+__device__ inline void solve_store_inverse(const double (&W)[36], double* dst, int lane) {
+  if (lane < 36) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 36; ++q) v = lane == q ? W[q] : v;   // static register indices
+    dst[lane] = v;
+  }
+}
 __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __restrict__ A, const double* __restrict__ bs,
                                                                 double* __restrict__ x, int n, LmState* lm) {
   extern __shared__ __attribute__((aligned(16))) double L[];
   if (lm->done) return;
   const int t = threadIdx.x, nt = blockDim.x, nb = n / 6, wave = t >> 6, lane = t & 63;
   const int nblk = nb * (nb + 1) / 2;
-  double* Tp = L + (size_t)nblk * 36;                 // [nb - 1][36] panel T_I of the current step
-  double* xs = Tp + (size_t)(kSolveMaxBlocks - 1) * 36;   // [192] right-hand side / solution
-  double* Ww = xs + 192;                              // [36] the pivot block's inverse (+ padding)
-  int& ok = *reinterpret_cast<int*>(Ww + (kSolveThreads / 64) * 36);
-  short2* tri = reinterpret_cast<short2*>(Ww + (kSolveThreads / 64) * 36 + 2);  // [nblk] packed lower-triangle index -> (I, J)
+  double* Tp0 = L + (size_t)nblk * 36;                          // two panels [nb - 1][36]: T_I of the current and of the previous step
+  double* xs = Tp0 + (size_t)2 * (kSolveMaxBlocks - 1) * 36;    // [192] right-hand side / solution
+  double* Ww = xs + 192;                                        // [2][36] inverse of the current / next pivot block
+  int& ok = *reinterpret_cast<int*>(Ww + 72);
+  short2* tri = reinterpret_cast<short2*>(Ww + 74);             // [nblk] packed lower-triangle index -> (I, J)
 #define LB(I, J) (L + ((size_t)((I) * ((I) + 1) / 2 + (J))) * 36)
   for (int I = t; I < nb; I += nt)
     for (int J = 0; J <= I; ++J) tri[I * (I + 1) / 2 + J] = make_short2((short)I, (short)J);
@@ -1206,61 +1218,91 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
   }
   for (int i = t; i < n; i += nt) xs[i] = bs[i];
   __syncthreads();
-  double* myW = Ww;   // the pivot block's inverse, shared by the workgroup
+  if (wave == 0) {   // the first pivot block
+    double W[36];
+    const bool good = inv6_sym(LB(0, 0), W);
+    solve_store_inverse(W, Ww, lane);
+    if (lane == 0 && !good) ok = 0;
+  }
+  __syncthreads();
   for (int jb = 0; jb < nb; ++jb) {
-    // ONE wave inverts the pivot block (the fp64 pipe of a SIMD retires one wave-instruction per ~8 cycles however many waves feed
-    // it: sixteen waves inverting redundantly -- the first form of this kernel, 104 us -- queue up four deep on every SIMD)
-    if (wave == 0) {
-      double W[36];
-      const bool good = inv6_sym(LB(jb, jb), W);
-      if (lane < 36) {
-        double v = 0.0;
-#pragma unroll
-        for (int q = 0; q < 36; ++q) v = lane == q ? W[q] : v;   // static register indices
-        myW[lane] = v;
-      }
-      if (lane == 0 && !good) ok = 0;
-    }
-    __syncthreads();
     const int m = nb - jb - 1;
-    // panel: T_I = A_Ij W
-    for (int idx = t; idx < m * 36; idx += nt) {
-      const int I = jb + 1 + idx / 36, e = idx % 36, r = e / 6, c = e % 6;
+    const double* Wc = Ww + (jb & 1) * 36;
+    double* Tp = Tp0 + (size_t)(jb & 1) * (kSolveMaxBlocks - 1) * 36;
+    // ---- panel rows: T_I[r][:] = A_Ij[r][:] W
+    if (t < m * 6) {
+      const int I = jb + 1 + t / 6, r = t % 6;
       const double* a = LB(I, jb) + r * 6;
-      double s2 = 0.0;
+      double av[6], o[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s2 += a[k] * myW[k * 6 + c];
-      Tp[idx] = s2;
+      for (int k = 0; k < 6; ++k) av[k] = a[k];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) o[c] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) o[c] += av[k] * Wc[k * 6 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) Tp[(t / 6) * 36 + r * 6 + c] = o[c];
     }
-    __syncthreads();
-    // trailing update A_IK -= T_I A_Kj^T (I >= K > j) and the right-hand side rows below
-    const int mblk = m * (m + 1) / 2;
-    for (int idx = t; idx < mblk * 36 + m * 6; idx += nt) {
-      if (idx < mblk * 36) {
-        const int bq = idx / 36, e = idx % 36;
-        const short2 ik = tri[bq];
-        const int r = e / 6, c = e % 6;
-        const double* ti = Tp + ik.x * 36 + r * 6;
-        const double* ak = LB(jb + 1 + ik.y, jb) + c * 6;
-        double s2 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s2 += ti[k] * ak[k];
-        LB(jb + 1 + ik.x, jb + 1 + ik.y)[e] -= s2;
-      } else {
-        const int row = idx - mblk * 36;
-        const double* ti = Tp + (row / 6) * 36 + (row % 6) * 6;
-        double s2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s2 += ti[c] * xs[6 * jb + c];
-        xs[6 * (jb + 1) + row] -= s2;
+    // ... and the previous step's panel / pivot inverse take their places for the backward substitution (threads of the upper waves)
+    if (jb > 0) {
+      const double* Tq = Tp0 + (size_t)((jb - 1) & 1) * (kSolveMaxBlocks - 1) * 36;
+      const int mp = m + 1;
+      for (int idx = nt - 1 - t; idx < mp * 36 + 36; idx += nt) {
+        if (idx < mp * 36) LB(jb + idx / 36, jb - 1)[idx % 36] = Tq[idx];
+        else LB(jb - 1, jb - 1)[idx - mp * 36] = Ww[((jb - 1) & 1) * 36 + idx - mp * 36];
       }
     }
     __syncthreads();
-    // T_I takes A_Ij's place (backward substitution), W the pivot block's
-    for (int idx = t; idx < m * 36; idx += nt) LB(jb + 1 + idx / 36, jb)[idx % 36] = Tp[idx];
-    if (t < 36) LB(jb, jb)[t] = myW[t];
+    // ---- trailing update by rows; wave 0: next pivot block first, then its inverse (look-ahead)
+    const int mblk = m * (m + 1) / 2;
+    auto update_row = [&](int bq, int r) {   // row r of block (jb+1+ik.x, jb+1+ik.y)
+      const short2 ik = tri[bq];
+      const double* ti = Tp + ik.x * 36 + r * 6;
+      const double* ak = LB(jb + 1 + ik.y, jb);
+      double tv[6], o[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) tv[k] = ti[k];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s2 += tv[k] * ak[c * 6 + k];
+        o[c] = s2;
+      }
+      double* dst = LB(jb + 1 + ik.x, jb + 1 + ik.y) + r * 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[c] -= o[c];
+    };
+    if (wave == 0) {
+      if (m > 0) {
+        if (lane < 6) update_row(0, lane);            // block (jb+1, jb+1) = tri index 0
+        double W[36];
+        const bool good = inv6_sym(LB(jb + 1, jb + 1), W);
+        solve_store_inverse(W, Ww + ((jb + 1) & 1) * 36, lane);
+        if (lane == 0 && !good) ok = 0;
+      }
+    } else {
+      const int items = (mblk - 1) * 6 + m * 6;       // the other blocks' rows, then the right-hand side rows
+      for (int idx = t - 64; idx < items; idx += nt - 64) {
+        if (idx < (mblk - 1) * 6) {
+          update_row(1 + idx / 6, idx % 6);
+        } else {
+          const int row = idx - (mblk - 1) * 6;
+          const double* ti = Tp + (row / 6) * 36 + (row % 6) * 6;
+          double s2 = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) s2 += ti[c] * xs[6 * jb + c];
+          xs[6 * (jb + 1) + row] -= s2;
+        }
+      }
+    }
     __syncthreads();
   }
+  // the last pivot's inverse (its panel is empty)
+  if (t < 36) LB(nb - 1, nb - 1)[t] = Ww[((nb - 1) & 1) * 36 + t];
+  __syncthreads();
   // y_j = W_j z_j, then x_j = y_j - sum_{I > j} T_Ij^T x_I right-looking from the last block
   double yv = 0.0;
   if (t < n) {
@@ -1384,49 +1426,47 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
   if (t == 0) lm->chol_ok = ok;
 }
 
-// xl = Dinv (bl - B^T xp); backup + update of the point; gain-ratio partial sum_j x_j (lambda x_j + b_j)
-__global__ __launch_bounds__(256) void k_ba_backsub(BaDev d) {
+// The step applied: one launch, two kinds of workgroup.  [0, gL): xl = Dinv (bl - B^T xp) and the trial point = accepted point + xl;
+// [gL, gL + gP): the trial pose = exp(xp) * accepted pose (VertexSE3Expmap::oplusImpl).  Both write the TRIAL buffer and leave the
+// accepted estimate alone; each workgroup also leaves its part of the gain-ratio denominator sum_j x_j (lambda x_j + b_j).
+__global__ __launch_bounds__(256) void k_ba_step(BaDev d) {
   __shared__ double red[4 * 32], out[1];
   if (d.lm->done) return;
   const double lambda = lm_lambda(d.lm);
-  const int h = blockIdx.x * 256 + threadIdx.x;
+  const int cur = d.lm->cur, nxt = 1 - cur;
   double part[1] = {0.0};
-  if (h < d.nLa) {
-    const double* H = d.Hll + (size_t)h * 9;
-    double cl[3] = {H[6], H[7], H[8]};
-    for (int k = d.pt_start[h]; k < d.pt_start[h + 1]; ++k) {
-      const int ph = d.pose_h[d.e_ps[d.act[k]]];
-      if (ph < 0) continue;
-      const double* B = d.Bk + (size_t)k * 18;
-      const double* xp = d.x + 6 * ph;
-      for (int c = 0; c < 3; ++c)
-        for (int r = 0; r < 6; ++r) cl[c] -= B[r * 3 + c] * xp[r];
+  if ((int)blockIdx.x < d.gL) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h < d.nLa) {
+      const double* H = d.Hll + (size_t)h * 9;
+      double cl[3] = {H[6], H[7], H[8]};
+      for (int k = d.pt_start[h]; k < d.pt_start[h + 1]; ++k) {
+        const int ph = d.pose_h[d.e_ps[d.act[k]]];
+        if (ph < 0) continue;
+        const double* B = d.Bk + (size_t)k * 18;
+        const double* xp = d.x + 6 * ph;
+        for (int c = 0; c < 3; ++c)
+          for (int r = 0; r < 6; ++r) cl[c] -= B[r * 3 + c] * xp[r];
+      }
+      double I[9], dbv[3];
+      point_dinv(H, lambda, I, dbv);
+      const double xl[3] = {I[0] * cl[0] + I[1] * cl[1] + I[2] * cl[2], I[1] * cl[0] + I[4] * cl[1] + I[5] * cl[2],
+                            I[2] * cl[0] + I[5] * cl[1] + I[8] * cl[2]};
+      const int l = d.pt_of_h[h];
+      for (int r = 0; r < 3; ++r) {
+        d.x[6 * d.nPf + 3 * h + r] = xl[r];
+        d.pts[nxt][3 * l + r] = d.pts[cur][3 * l + r] + xl[r];
+        part[0] += xl[r] * (lambda * xl[r] + H[6 + r]);
+      }
     }
-    const double* Di = d.Dinv + (size_t)h * 6;
-    const double xl[3] = {Di[0] * cl[0] + Di[1] * cl[1] + Di[2] * cl[2], Di[1] * cl[0] + Di[3] * cl[1] + Di[4] * cl[2],
-                          Di[2] * cl[0] + Di[4] * cl[1] + Di[5] * cl[2]};
-    const int l = d.pt_of_h[h];
-    for (int r = 0; r < 3; ++r) {
-      d.x[6 * d.nPf + 3 * h + r] = xl[r];
-      d.pts_bak[3 * l + r] = d.pts[3 * l + r];
-      d.pts[3 * l + r] += xl[r];
-      part[0] += xl[r] * (lambda * xl[r] + H[6 + r]);
-    }
+    block_reduce<1>(part, red, out);
+    if (threadIdx.x == 0) d.partial[d.scale_off + blockIdx.x] = out[0];
+    return;
   }
-  block_reduce<1>(part, red, out);
-  if (threadIdx.x == 0) d.partial[d.scale_off + blockIdx.x] = out[0];
-}
-
-// pose update (oplus) with backup; pose part of the gain-ratio denominator into partial[offset + block]
-__global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, int partial_off) {
-  __shared__ double red[4 * 32], out[1];
-  if (d.lm->done) return;
-  const double lambda = lm_lambda(d.lm);
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  double part[1] = {0.0};
+  const int pb = (int)blockIdx.x - d.gL;
+  const int h = pb * 256 + threadIdx.x;
   if (h < d.nPf) {
     const int p = d.pose_of_h[h];
-    d.pose_bak[p] = d.pose[p];
     double u[6];
     for (int r = 0; r < 6; ++r) {
       u[r] = d.x[6 * h + r];
@@ -1435,18 +1475,10 @@ __global__ __launch_bounds__(256) void k_ba_update_pose(BaDev d, int partial_off
     // (a pose whose edges were all moved to level 1 is no active vertex in g2o: its step is exactly zero here, and exp(0) * T would
     // still re-normalise the quaternion)
     const bool zero = u[0] == 0 && u[1] == 0 && u[2] == 0 && u[3] == 0 && u[4] == 0 && u[5] == 0;
-    if (!zero) d.pose[p] = pose_oplus(d.pose[p], u);
+    d.pose[nxt][p] = zero ? d.pose[cur][p] : pose_oplus(d.pose[cur][p], u);
   }
   block_reduce<1>(part, red, out);
-  if (threadIdx.x == 0) d.partial[partial_off + blockIdx.x] = out[0];
-}
-
-// _optimizer->pop() after a rejected trial: k_ba_lm_control says whether the trial just evaluated was one
-__global__ __launch_bounds__(256) void k_ba_restore(BaDev d) {
-  if (!d.lm->restore) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < d.nPf) { const int p = d.pose_of_h[i]; d.pose[p] = d.pose_bak[p]; }
-  if (i < d.nLa) { const int l = d.pt_of_h[i]; for (int r = 0; r < 3; ++r) d.pts[3 * l + r] = d.pts_bak[3 * l + r]; }
+  if (threadIdx.x == 0) d.partial[d.scale_off + d.gL + pb] = out[0];
 }
 
 // ---- Levenberg control on the device (optimization_algorithm_levenberg.cpp:61-189) ----------------------------------------
@@ -1475,7 +1507,7 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin(BaDev d, int iterati
   for (int i = 0; i < d.gE; ++i) sum += sh[i];
   S.lambda = -1; S.ni = 2; S.currentChi = sum; S.iniChi = sum; S.rho = 0;
   S.maxdiag_bits = 0;
-  S.it = 0; S.qmax = 0; S.nBad = 0; S.done = iterations <= 0 ? 1 : 0; S.need_lin = 1; S.restore = 0; S.trials = 0; S.iters_done = 0;
+  S.it = 0; S.qmax = 0; S.nBad = 0; S.done = iterations <= 0 ? 1 : 0; S.need_lin = 1; S.cur = d.lm->cur & 1; S.trials = 0; S.iters_done = 0;   // (cur carries over from the previous round)
   S.chol_ok = 1; S.iterations = iterations; S.first = 1; S.pad_ = 0;
   *d.lm = S;
   *d.lm_host = S;
@@ -1491,7 +1523,7 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_control(BaDev d) {
     S.lambda = 1e-5 * __longlong_as_double((long long)S.maxdiag_bits);
     S.ni = 2; S.nBad = 0; S.first = 0;
   }
-  S.need_lin = 0; S.restore = 0;
+  S.need_lin = 0;
   double tempChi = 0, scale = 0;
   for (int i = 0; i < d.gE; ++i) tempChi += sh[i];
   if (d.nPf > 0) for (int i = 0; i < d.gP; ++i) scale += sh[d.scale_off + d.gL + i];   // poses first, then landmarks
@@ -1508,10 +1540,10 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_control(BaDev d) {
     S.lambda *= fmax(1. / 3., alpha);
     S.ni = 2;
     S.currentChi = tempChi;
+    S.cur ^= 1;      // the trial estimate becomes the accepted one (_optimizer->discardTop())
   } else {
     S.lambda *= S.ni;
-    S.ni *= 2;
-    S.restore = 1;   // _optimizer->pop(): k_ba_restore, the next launch
+    S.ni *= 2;       // (_optimizer->pop(): the accepted estimate was never touched)
   }
   S.rho = rho;
   S.qmax++;
@@ -1550,13 +1582,22 @@ __global__ __launch_bounds__(256) void k_ba_chi2_stored(BaDev d, int robust, dou
 }
 
 // final per-edge outputs: chi2 from the stored error, isDepthPositive from the current estimate
-__global__ __launch_bounds__(256) void k_ba_edge_report(BaDev d, double* chi2, uint8_t* depth_pos) {
+// gate != null: the outlier gating between the rounds as well (Optimizer.cc:612-631): chi2 > 5.991 || !isDepthPositive -> level 1
+__global__ __launch_bounds__(256) void k_ba_edge_report(BaDev d, double* chi2, uint8_t* depth_pos, uint8_t* gate_lvl, uint8_t* gate_out) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= d.E) return;
-  chi2[e] = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
+  const int cur = d.lm->cur;
+  const double c = (d.err[2 * e] * d.err[2 * e] + d.err[2 * e + 1] * d.err[2 * e + 1]) * d.info[e];
+  chi2[e] = c;
   double Xc[3];
-  pose_map(d.pose[d.e_ps[e]], d.pts + 3 * d.e_pt[e], Xc);
-  depth_pos[e] = Xc[2] > 0.0 ? 1 : 0;
+  pose_map(d.pose[cur][d.e_ps[e]], d.pts[cur] + 3 * d.e_pt[e], Xc);
+  const uint8_t dp = Xc[2] > 0.0 ? 1 : 0;
+  depth_pos[e] = dp;
+  if (gate_lvl) {
+    const uint8_t bad = (c > 5.991 || !dp) ? 1 : 0;
+    gate_lvl[e] = bad;
+    gate_out[e] = bad;
+  }
 }
 
 // ---------------------------------------------------------------- host state
@@ -1577,6 +1618,7 @@ struct DevBuf {
 
 struct BaState {
   DevBuf lvl, HppPart;
+  DevBuf out1;
   DevBuf pose, pose_bak, pts, pts_bak, e_pt, e_ps, obs, info, err, act, pose_h, pt_h, pose_of_h, pt_of_h, pt_start,
       ps_start, ps_edges, Bk, Hc, Hl, Yk, ck, Hpp, Hll, Dinv, db, x, A, bs, misc, partial, blk_i, blk_j, pair_start,
       pairs, chi2, dpos;
@@ -1636,7 +1678,7 @@ void ba_free(asd_ctx* ctx) {
   }
   DevBuf* all[] = {&s->pose, &s->pose_bak, &s->pts, &s->pts_bak, &s->e_pt, &s->e_ps, &s->obs, &s->info, &s->err, &s->act,
                    &s->pose_h, &s->pt_h, &s->pose_of_h, &s->pt_of_h, &s->pt_start, &s->ps_start, &s->ps_edges, &s->Bk,
-                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm, &s->lvl, &s->HppPart,
+                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm, &s->lvl, &s->HppPart, &s->out1,
                    &s->partial, &s->blk_i, &s->blk_j, &s->pair_start, &s->pairs, &s->chi2, &s->dpos, &s->po_Xw,
                    &s->po_obs, &s->po_info, &s->po_err, &s->po_level, &s->po_outlier, &s->po_pose, &s->pc_n};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
@@ -1828,7 +1870,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ENS(Bk, (size_t)E * 18 * 8); ENS(Hc, (size_t)E * 27 * 8); ENS(Hl, (size_t)E * 9 * 8); ENS(Yk, (size_t)E * 18 * 8);
   ENS(ck, (size_t)E * 6 * 8); ENS(Hpp, (size_t)P * 27 * 8); ENS(Hll, (size_t)L * 9 * 8); ENS(Dinv, (size_t)L * 6 * 8);
   ENS(db, (size_t)L * 3 * 8); ENS(x, ((size_t)6 * P + 3 * L) * 8); ENS(A, (size_t)36 * P * P * 8); ENS(bs, (size_t)6 * P * 8);
-  ENS(misc, 64); ENS(chi2, (size_t)E * 8); ENS(dpos, (size_t)E); ENS(lvl, (size_t)E); ENS(HppPart, (size_t)P * kPoseSplit * 27 * 8);
+  ENS(misc, 64); ENS(chi2, (size_t)E * 8); ENS(dpos, (size_t)E); ENS(lvl, (size_t)E); ENS(out1, (size_t)E); ENS(HppPart, (size_t)P * kPoseSplit * 27 * 8);
   const int nblk_e = (E + 255) / 256, nblk_l = (L + 255) / 256, nblk_p = (P + 255) / 256;
   const size_t npartial = (size_t)nblk_e + nblk_l + nblk_p + 8;
   ENS(partial, npartial * 8);
@@ -1848,8 +1890,12 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     hp[p] = Pose7{q[0], q[1], q[2], q[3], q[4], q[5], q[6]};
     quat_normalize(hp[p].qx, hp[p].qy, hp[p].qz, hp[p].qw);
   }
+  // both estimate buffers start as the input (vertices no trial writes -- fixed poses, landmarks without an active edge -- must read the same in both)
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->pose.p, hp.data(), (size_t)P * sizeof(Pose7), hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->pts.p, pr->points, (size_t)L * 24, hipMemcpyHostToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->pose_bak.p, s->pose.p, (size_t)P * sizeof(Pose7), hipMemcpyDeviceToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->pts_bak.p, s->pts.p, (size_t)L * 24, hipMemcpyDeviceToDevice, st));
+  ASD_HIP_CHECK(ctx, hipMemsetAsync(s->lm.p, 0, sizeof(LmState), st));   // lm->cur = 0
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->e_pt.p, pr->e_point, (size_t)E * 4, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->e_ps.p, pr->e_pose, (size_t)E * 4, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->obs.p, pr->e_obs, (size_t)E * 16, hipMemcpyHostToDevice, st));
@@ -1860,8 +1906,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
 
   BaDev d{};
   d.P = P; d.L = L; d.E = E;
-  d.pose = s->pose.as<Pose7>(); d.pose_bak = s->pose_bak.as<Pose7>();
-  d.pts = s->pts.as<double>(); d.pts_bak = s->pts_bak.as<double>();
+  d.pose[0] = s->pose.as<Pose7>(); d.pose[1] = s->pose_bak.as<Pose7>();
+  d.pts[0] = s->pts.as<double>(); d.pts[1] = s->pts_bak.as<double>();
   d.e_pt = s->e_pt.as<int>(); d.e_ps = s->e_ps.as<int>(); d.obs = s->obs.as<double>(); d.info = s->info.as<double>();
   d.err = s->err.as<double>(); d.lvl = s->lvl.as<uint8_t>(); d.HppPart = s->HppPart.as<double>();
   d.fx = pr->K[0]; d.fy = pr->K[1]; d.cx = pr->K[2]; d.cy = pr->K[3];
@@ -1996,17 +2042,13 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     d.gE = gE; d.gL = gL; d.gP = gP;
     // ---- the round on the device.  One "block" = one Levenberg trial as the device sees it: [linearise group -- runs only when
     // the state says a new iteration starts] [solve: Dinv, Y, Schur, dense solve, back-substitution, pose update] [errors at the
-    // trial estimate] [control: accept / reject, next lambda, end of iteration / round] [restore -- runs only after a reject].
+    // trial estimate] [control: accept / reject (= flip the estimate buffers or not), next lambda, end of iteration / round].
     // Blocks are enqueued ahead; the host reads the mirrored state once per chunk.  The first chunk is as long as the previous
     // LocalBA's round of the same index took (same map, similar problem), so the usual round needs one synchronisation.
     auto enqueue_block = [&]() -> int {
       hipLaunchKernelGGL(k_ba_linearize, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
-      if (nPf > 0) {
-        hipLaunchKernelGGL(k_ba_reduce_pose, dim3(nPf * kPoseSplit), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_ba_reduce_pose2, dim3(nPf), dim3(64), 0, st, d);
-      }
-      hipLaunchKernelGGL(k_ba_reduce_point, dim3(gL), dim3(256), 0, st, d);
-      hipLaunchKernelGGL(k_ba_point_dinv, dim3(gL), dim3(256), 0, st, d);
+      hipLaunchKernelGGL(k_ba_reduce, dim3(nPf * kPoseSplit + gL), dim3(256), 0, st, d);
+      if (nPf > 0) hipLaunchKernelGGL(k_ba_reduce_pose2, dim3(nPf), dim3(64), 0, st, d);
       if (nPf > 0) {
         hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, st, d, sb);
@@ -2019,7 +2061,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         }
         static const bool old_chol = getenv("ASD_BA_CHOL") != nullptr;   // A/B: the round-2 Cholesky kernel
         if (nPf <= kSolveMaxBlocks && !old_chol) {
-          const size_t lds = (nbk * 36 + (size_t)(kSolveMaxBlocks - 1) * 36 + 192 + (kSolveThreads / 64) * 36 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
+          const size_t lds = (nbk * 36 + (size_t)2 * (kSolveMaxBlocks - 1) * 36 + 192 + 72 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
           hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(kSolveThreads), lds, st, d.A, d.bs, d.x, n, d.lm);
         } else if (nPf <= 32) {
           const size_t lds = nbk * 36 * sizeof(double) + (2 * 192 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
@@ -2028,11 +2070,9 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
           hipLaunchKernelGGL(k_ba_chol, dim3(1), dim3(1024), 0, st, d.A, d.bs, d.x, n, d.lm);
         }
       }
-      hipLaunchKernelGGL(k_ba_backsub, dim3(gL), dim3(256), 0, st, d);
-      hipLaunchKernelGGL(k_ba_update_pose, dim3(gP), dim3(256), 0, st, d, d.scale_off + gL);
+      hipLaunchKernelGGL(k_ba_step, dim3(gL + gP), dim3(256), 0, st, d);
       hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 0);
       hipLaunchKernelGGL(k_ba_lm_control, dim3(1), dim3(kLmThreads), 0, st, d);
-      hipLaunchKernelGGL(k_ba_restore, dim3(std::max(gL, gP)), dim3(256), 0, st, d);
       ASD_HIP_CHECK(ctx, hipGetLastError());
       return ASD_OK;
     };
@@ -2085,28 +2125,22 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   // optimizer.initializeOptimization(); optimizer.optimize(its_first)           (Optimizer.cc:601-602)
   rc = run_round(0, pr->its_first, true, &res->chi2_first, &res->iters_first);
   if (rc != ASD_OK) return rc;
-  // outlier gating: chi2 > 5.991 || !isDepthPositive -> level 1; robust kernels off  (Optimizer.cc:612-631)
-  hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>());
+  // outlier gating: chi2 > 5.991 || !isDepthPositive -> level 1; robust kernels off  (Optimizer.cc:612-631) -- on the device, no
+  // host round trip between the rounds; the flags travel back with the final results
+  hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>(), s->lvl.as<uint8_t>(), s->out1.as<uint8_t>());
   ASD_HIP_CHECK(ctx, hipGetLastError());
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_chi2, s->chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_depth_pos, s->dpos.p, (size_t)E, hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  for (int e = 0; e < E; ++e) {
-    const bool bad = res->edge_chi2[e] > 5.991 || !res->edge_depth_pos[e];
-    res->edge_outlier1[e] = bad ? 1 : 0;
-    level[e] = bad ? 1 : 0;
-  }
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->lvl.p, level.data(), (size_t)E, hipMemcpyHostToDevice, st));
   // optimizer.initializeOptimization(0); optimizer.optimize(its_second)         (Optimizer.cc:647-648)
   rc = run_round(1, pr->its_second, false, &res->chi2_second, &res->iters_second);
   if (rc != ASD_OK) return rc;
-  hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>());
+  hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>(), (uint8_t*)nullptr, (uint8_t*)nullptr);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ASD_HIP_CHECK(ctx, hipEventRecord(ev1, st));
+  const int fin = s->h_lm->cur & 1;   // the buffer that holds the accepted estimate (mirrored at the round's last synchronisation)
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_chi2, s->chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_depth_pos, s->dpos.p, (size_t)E, hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(hp.data(), s->pose.p, (size_t)P * sizeof(Pose7), hipMemcpyDeviceToHost, st));
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(pr->points, s->pts.p, (size_t)L * 24, hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_outlier1, s->out1.p, (size_t)E, hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(hp.data(), fin ? s->pose_bak.p : s->pose.p, (size_t)P * sizeof(Pose7), hipMemcpyDeviceToHost, st));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(pr->points, fin ? s->pts_bak.p : s->pts.p, (size_t)L * 24, hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(ms, ev0, ev1));
   for (int p = 0; p < P; ++p) {
