@@ -551,8 +551,64 @@ __device__ inline void split8_f16(const f32x4& v0, const f32x4& v1, float scale,
   pl = __builtin_bit_cast(u32x4, l);
 }
 
+// ---- tile queue + CU reservation in software ----------------------------------------------------------------------------
+// The tracking stream's single-workgroup kernels (k_pose_opt, k_resolve: 50-100 KB of LDS, latency-bound) run 20-30 % slower when
+// they share their CU with ASDNet workgroups, and wait for a CU with room when ASDNet has filled the chip.  Rounds 1-2 kept 32 CUs
+// out of ASDNet's reach with a CU-masked stream -- which ROCm 7.2 cannot tear down ("Teardown").  The same effect
+// without a special stream: the conv layers are PERSISTENT launches (about as many workgroups as fit the chip) whose workgroups
+// pull tiles = (patch, band) from a counter in HBM; a workgroup that finds itself on a reserved CU (s_getreg HW_ID / XCC_ID) leaves
+// without taking a tile.  Which tile a workgroup computes never affects the tile's result, so placement changes nothing but
+// speed; the LAST workgroup of the grid ignores the reservation and drains the queue, so every tile is computed even if every
+// other workgroup were to land on reserved CUs.  Single-workgroup launches on an otherwise free XCD go to XCC 0 / SE 0
+// (tools/ubench/cu_census.hip): mode 1 reserves exactly that shader engine (8 of 256 CUs).
+// MEASURED AND NOT ADOPTED (round 3, tools/ab_reserve.sh, in-line LocalBA, one box): one workgroup per tile 1069 frames/s (ASDNet
+// 0.582 ms); persistent without reservation 998 (0.604 ms); reserving XCC 0 / SE 0: 1000-1004, all of XCC 0: 983, half of SE 0 in
+// every XCC: 1010, two SEs of XCC 0: 1003.  Persistent workgroups hold their CUs for a whole layer (~100 us) where the
+// occupancy-based form frees a slot every few microseconds, so the tracking kernels wait longer for room, and under load their
+// single workgroups evidently do not land on the reserved CUs.  The form stays behind ASD_ASDNET_PERSIST=1 / ASD_ASDNET_RESERVE=<mode>
+// (tested: tests/test_build_matrix.py); the default is one workgroup per tile.
+__device__ inline bool asd_cu_reserved(int mode) {
+  if (mode == 0) return false;
+  unsigned hw, xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const unsigned se = (hw >> 13) & 0x7, cu = (hw >> 8) & 0xf;
+  xcc &= 0xf;
+  if (mode == 1) return xcc == 0 && se == 0;          // one shader engine of XCC 0: 8 CUs
+  if (mode == 2) return xcc == 0;                      // all of XCC 0: 32 CUs
+  if (mode == 3) return se == 0 && cu >= 4;            // the upper half of SE 0 in every XCC: 32 CUs
+  if (mode == 4) return xcc == 0 && se <= 1;           // two shader engines of XCC 0: 16 CUs
+  return false;
+}
+struct TileQueue {
+  int* counter;   // zeroed before the launch; null = one tile per workgroup, blockIdx.x (the non-persistent form)
+  int ntiles;
+  int reserve;    // asd_cu_reserved mode
+};
+// next tile of this workgroup or -1; `slot` is a __shared__ int.  Ends with a barrier: the previous tile's LDS is free afterwards.
+__device__ inline int tile_first(const TileQueue& q, int* slot) {
+  if (!q.counter) return blockIdx.x;
+  if (threadIdx.x == 0) {
+    int tl = -1;
+    if (blockIdx.x == gridDim.x - 1 || !asd_cu_reserved(q.reserve)) tl = atomicAdd(q.counter, 1);
+    *slot = tl >= 0 && tl < q.ntiles ? tl : -1;
+  }
+  __syncthreads();
+  return *slot;
+}
+__device__ inline int tile_next(const TileQueue& q, int* slot) {
+  if (!q.counter) return -1;
+  __syncthreads();   // every wave is done with the tile's LDS and with *slot
+  if (threadIdx.x == 0) {
+    const int tl = atomicAdd(q.counter, 1);
+    *slot = tl < q.ntiles ? tl : -1;
+  }
+  __syncthreads();
+  return *slot;
+}
+
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
-__global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
+__device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
                                                          unsigned long long* __restrict__ stamps, float in_scale, float out_scale) {
@@ -561,11 +617,16 @@ __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_co
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   constexpr int NTH = C::NTH, MT = C::MT, NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_b[];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // Inside the persistent launch this body is a loop body.  Everything below that depends only on the lane (operand offsets, the
+  // weight stream's addresses) is loop invariant, and hoisted out of the tile loop it stays live across the whole body: 93 -> 240
+  // VGPRs for conv3, spills in conv2.  The thread index is therefore made opaque per tile, so each tile recomputes what it needs.
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, li = lane & 31;
   constexpr int BANDS = C::HO / ROWS;
-  const int patch = (blockIdx.x / BANDS) * PP, band = blockIdx.x % BANDS;
+  const int patch = (bid / BANDS) * PP, band = bid % BANDS;
   const int r0 = band * ROWS;
 
   // MFMA shape: 32x32x16 -> lane = (k-half h, row/col li of 32), one sub-tile per 32x32 tile; 16x16x32 -> lane = (k-group of
@@ -816,7 +877,7 @@ __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_co
   if (stamps) {
     asm volatile("s_nop 0" ::"v"(acc[NA - 1][NB - 1][0]));  // the last MFMA has retired before the closing stamp
     const unsigned long long e_c = __builtin_amdgcn_s_memtime(), e_r = __builtin_amdgcn_s_memrealtime();
-    if (t == 0) { stamps[2 * blockIdx.x] = e_c - st_c; stamps[2 * blockIdx.x + 1] = e_r - st_r; }
+    if (t == 0) { stamps[2 * bid] = e_c - st_c; stamps[2 * bid + 1] = e_r - st_r; }
   }
   // ---- epilogue: bias (folded BN) + ReLU, NHWC f32 store.  Lane owns one cout column and AR pixel rows of each sub-tile
   // (32x32: rows (r & 3) + 8 (r >> 2) + 4 h; 16x16: rows 4 kg + r)
@@ -837,6 +898,16 @@ __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_co
       }
     }
   }
+}
+
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
+__global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1, int n,
+                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale, TileQueue tq) {
+  __shared__ int tile_slot;
+  for (int tile = tile_first(tq, &tile_slot); tile >= 0; tile = tile_next(tq, &tile_slot))
+    conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP>(tile, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1069,7 +1140,7 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
 hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
                           const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr,
-                          float in_scale = 1.f, float out_scale = 1.f) {
+                          float in_scale = 1.f, float out_scale = 1.f, int* tq_counter = nullptr, int reserve = 0, int num_cu = 256) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP>;
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
@@ -1083,9 +1154,13 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
     if (e != hipSuccess) return e;
     attr_set.done(dev_);
   }
-  if (grid_out) *grid_out = ((n + PP - 1) / PP) * (C::HO / ROWS);
-  hipLaunchKernelGGL(kern, dim3(((n + PP - 1) / PP) * (C::HO / ROWS)), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,
-                     in_scale, out_scale);
+  const int ntiles = ((n + PP - 1) / PP) * (C::HO / ROWS);
+  if (grid_out) *grid_out = ntiles;
+  // persistent form: as many workgroups as fit the chip (LDS-limited, at most three per CU as the occupancy-based form ran)
+  const int per_cu = std::max(1, std::min(3, (160 * 1024) / (lds + 64)));
+  const int grid = tq_counter ? std::min(ntiles, num_cu * per_cu) : ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,
+                     in_scale, out_scale, TileQueue{tq_counter, ntiles, reserve});
   return hipGetLastError();
 }
 
@@ -1164,6 +1239,9 @@ int asdnet_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_part, (size_t)FC_SK * npad * 128 * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_patches, np * 1024));
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_desc, np * 128 * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_tq, 16 * sizeof(int)));
+  if (const char* e = getenv("ASD_ASDNET_RESERVE")) ctx->cu_reserve = atoi(e);
+  if (const char* e = getenv("ASD_ASDNET_PERSIST")) ctx->asdnet_persist = atoi(e) != 0;
   return ASD_OK;
 }
 
@@ -1172,6 +1250,7 @@ void asdnet_free(asd_ctx* ctx) {
   if (ctx->d_part) (void)hipFree(ctx->d_part);
   if (ctx->d_patches) (void)hipFree(ctx->d_patches);
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+  if (ctx->d_tq) (void)hipFree(ctx->d_tq);
   if (ctx->d_w1) (void)hipFree(ctx->d_w1);
   for (int i = 0; i < 7; ++i) {
     if (ctx->d_bias[i]) (void)hipFree(ctx->d_bias[i]);
@@ -1264,10 +1343,14 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
   // ASD_ASDNET_MATH=f16x2: two fp16 pieces per operand, three products (kActScale and the per-layer weight scale are undone in the epilogue)
   const bool p2 = ctx->net_pieces == 2;
+  // persistent launches: one tile counter per layer, zeroed here on the forward's own stream
+  int* const tq = ctx->asdnet_persist ? ctx->d_tq : nullptr;
+  if (tq) ASD_HIP_CHECK(ctx, hipMemsetAsync(tq, 0, 16 * sizeof(int), st));
 #define X3_LAUNCH(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                       \
   (p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,               \
-                                     1.f / (kActScale * ctx->wx2_scale[l]))                                                                \
-      : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p))
+                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu)           \
+      : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, 1.f, 1.f,                \
+                                     tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu))
   if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L2S_CFG, true, 1, d_patches, a1, ctx->d_w1, ctx->d_bias[0])));
   else ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   PROF_MARK(2);

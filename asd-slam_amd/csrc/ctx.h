@@ -141,6 +141,9 @@ struct asd_ctx {
   int net_split = 1;            // ASD_ASDNET_MATH: 1 = split-bf16 kernels where a layer has one, 0 = f32 MFMA everywhere
   float* d_act[2] = {};         // ping-pong NHWC activations
   float* d_part = nullptr;      // split-K partials of the last layer
+  int* d_tq = nullptr;          // tile counters of the persistent conv launches of one forward (asdnet.hip, TileQueue), one per layer
+  int cu_reserve = 0;           // asd_cu_reserved mode of the persistent conv launches (ASD_ASDNET_RESERVE at asd_ctx_create)
+  bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
   uint8_t* d_patches = nullptr; // [max_patches][1024]
   float* d_desc = nullptr;      // [max_patches][128] descriptors of the last asd_extract / asd_describe
   float* d_desc_last = nullptr; // device descriptors asd_frame_set(desc == NULL) adopts: last asd_extract or last waited submission
