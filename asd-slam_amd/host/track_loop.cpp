@@ -68,7 +68,11 @@ struct asd_track_handle {
   std::vector<float> desc_sync;
   std::vector<float> uv, Xw, Xw2, nrm, dist, maxd, mind, proj, vc;
   std::vector<uint8_t> has, in_view, occ, outl;
-  std::vector<float> cur_Xw;
+  std::vector<float> cur_Xw, Xs, ns, mind_s, maxd_s;   // the selected local points' tables (UpdateLocalMap stand-in)
+  std::vector<int32_t> sel;
+  std::vector<uint8_t> keep, in_frame;
+  std::vector<double> ba_obs;   // the keyframe's observations (nominal + deterministic per-keyframe displacement)
+  float T1[16];
   std::vector<int32_t> rows, m1, m2, level;
   std::vector<double> Xd, obs, info;
   std::vector<double> ba_poses, ba_points, ba_chi2;
@@ -214,7 +218,37 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
   return ASD_OK;
 }
 
-static int submit_ba(asd_track_handle* h, asd_track_stats* st);
+static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t);
+
+// What Tracking does between its two stages (Tracking.cc:695-714, 725-726, 811-823): drop the matches PoseOptimization marked as
+// outliers, take the optimised pose as the frame's pose, and put the local map together from what is not in the frame already --
+// here: the candidates (the last frame's points + their displaced copies) that no kept match refers to.  Fills keep / occ / cur_Xw,
+// sel and the selected tables, T1; returns the number of selected points.  Mirrors bench.py's track_step line by line.
+static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t* outl1, const double* pose1) {
+  h->keep.assign(n, 0); h->occ.assign(n, 0);
+  h->in_frame.assign((size_t)2 * nl, 0);
+  h->cur_Xw.assign((size_t)3 * n, 0.f);
+  int nmatch = 0;
+  for (int j = 0; j < n; ++j) {
+    const int i = h->m1[j];
+    nmatch += i >= 0;
+    const int src = i >= 0 ? i : 0;
+    for (int k = 0; k < 3; ++k) h->cur_Xw[3 * j + k] = h->Xw[3 * src + k];
+    if (i >= 0 && !outl1[j]) { h->keep[j] = 1; h->occ[j] = 1; h->in_frame[i] = 1; }
+  }
+  if (nmatch >= 3) (void)asd_pose7_to_tcw(pose1, h->T1);
+  else memcpy(h->T1, h->T, sizeof h->T1);
+  h->sel.clear();
+  for (int i = 0; i < 2 * nl; ++i) if (!h->in_frame[i]) h->sel.push_back(i);
+  const int ns = (int)h->sel.size();
+  h->Xs.resize((size_t)3 * ns); h->ns.resize((size_t)3 * ns); h->mind_s.resize(ns); h->maxd_s.resize(ns);
+  for (int q = 0; q < ns; ++q) {
+    const int i = h->sel[q];
+    for (int k = 0; k < 3; ++k) { h->Xs[3 * q + k] = h->Xw2[3 * i + k]; h->ns[3 * q + k] = h->nrm[3 * i + k]; }
+    h->mind_s[q] = h->mind[i]; h->maxd_s[q] = h->maxd[i];
+  }
+  return ns;
+}
 
 static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::vector<int>& next, asd_track_stats* st) {
   asd_ctx* ctx = h->ctx;
@@ -267,20 +301,17 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
     st->m1 = n1; st->has_m1 = 1;
     seg(3);
-    // ---- Tracking::TrackLocalMap's numeric body, enqueued (Tracking.cc:725-736, 803-851)
-    h->occ.resize(n);
-    h->cur_Xw.assign((size_t)3 * n, 0.f);
-    for (int j = 0; j < n; ++j) {
-      h->occ[j] = h->m1[j] >= 0;
-      if (h->m1[j] >= 0) for (int k = 0; k < 3; ++k) h->cur_Xw[3 * j + k] = h->Xw[3 * h->m1[j] + k];
-    }
+    // ---- between the stages: outlier matches dropped, the optimised pose becomes the frame's pose, the local map is put together
+    const int nsel = select_local_points(h, n, nl, h->outl.data(), pose);
+    n2p = nsel;
+    // ---- Tracking::TrackLocalMap's numeric body, enqueued (Tracking.cc:725-736, 803-851), from the motion-model stage's pose
     h->m2.assign(n, -1);
     h->outl2.resize(n);
-    memcpy(h->c2_pose, h->pose0, sizeof h->c2_pose);
+    memcpy(h->c2_pose, pose, sizeof h->c2_pose);
     h->c2_n2 = 0; h->c2_ninl = 0;
     seg(7);
     if ((rc = asd_track_async(ctx)) != ASD_OK) return rc;
-    if ((rc = asd_track_local_points_bank(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->rows.data(), h->T,
+    if ((rc = asd_track_local_points_bank(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->sel.data(), h->T1,
                                           h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose, h->m2.data(), &h->c2_n2,
                                           h->outl2.data(), &h->c2_ninl)) != ASD_OK)
       return rc;
@@ -290,7 +321,7 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
   h->last_kps.assign(kps, kps + n);
   h->last_slot = cur;
   h->have_last = true;
-  if (do_ba && h->async_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;   // (in line: after the stage has finished, below)
+  if (do_ba && h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;   // (in line: after the stage has finished, below)
   seg(7);
   if (!next.empty() && next[0] == t + 1) {
     std::vector<int> after(next.begin() + 1, next.end());
@@ -304,11 +335,11 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
     st->m2 = h->c2_n2; st->has_m2 = 1;
     int nedge = 0;
-    for (int j = 0; j < n; ++j) nedge += h->m1[j] >= 0 || h->m2[j] >= 0;
+    for (int j = 0; j < n; ++j) nedge += h->keep[j] || h->m2[j] >= 0;
     if (nedge >= 3) { st->inliers = h->c2_ninl; st->has_inliers = 1; }
     seg(6);
   }
-  if (do_ba && !h->async_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;   // asd_local_ba uses the context's stream: no stage outstanding
+  if (do_ba && !h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;   // asd_local_ba uses the context's stream: no stage outstanding
   ++h->steps;
   return ASD_OK;
 }
@@ -390,7 +421,8 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     h->m1.assign(n, -1);
     int32_t n1 = 0;
     auto dev = [&](int i, const char* stage) { float ms = 0.f; if (asd_last_stage_ms(ctx, stage, &ms) == ASD_OK) h->kern_ms[i] += ms; };
-    auto pose_opt = [&](const std::vector<int>& sel, auto point_of, int32_t* ninl) -> int {
+    // PoseOptimization over the keypoints `sel` from `pose_io` (in: start, out: optimum); outl_k[j] per KEYPOINT
+    auto pose_opt = [&](const std::vector<int>& sel, auto point_of, double* pose_io, uint8_t* outl_k, int32_t* ninl) -> int {
       const int m = (int)sel.size();
       h->Xd.resize((size_t)3 * m); h->obs.resize((size_t)2 * m); h->info.resize(m); h->outl.resize(m);
       for (int q = 0; q < m; ++q) {
@@ -400,19 +432,34 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
         h->obs[2 * q] = (double)kps[j].x; h->obs[2 * q + 1] = (double)kps[j].y;
         h->info[q] = h->inv_sigma2[kps[j].octave];
       }
-      double pose[7];
-      memcpy(pose, h->pose0, sizeof pose);
-      return asd_pose_optimize(ctx, pose, m, h->Xd.data(), h->obs.data(), h->info.data(), h->K64, h->outl.data(), ninl);
+      const int r = asd_pose_optimize(ctx, pose_io, m, h->Xd.data(), h->obs.data(), h->info.data(), h->K64, h->outl.data(), ninl);
+      if (r == ASD_OK && outl_k) for (int q = 0; q < m; ++q) outl_k[sel[q]] = h->outl[q];
+      return r;
     };
+    // attributes of the candidate map points (they exist before the frame is tracked): the last frame's points plus a displaced copy
+    const int n2all = 2 * nl;
+    h->Xw2.resize((size_t)3 * n2all); h->nrm.resize((size_t)3 * n2all); h->dist.resize(n2all); h->maxd.resize(n2all); h->mind.resize(n2all);
+    for (int i = 0; i < nl; ++i)
+      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
+    for (int i = 0; i < n2all; ++i) {
+      const float* P = &h->Xw2[3 * i];
+      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
+      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
+      h->dist[i] = nn;
+      const int lv = lk[i % nl].octave;
+      h->maxd[i] = nn * h->scale32[lv];
+      h->mind[i] = h->maxd[i] / h->scale32[7];
+    }
     std::vector<int> sel;
+    std::vector<uint8_t> outl1(n, 0);
+    double pose1[7];
+    memcpy(pose1, h->pose0, sizeof pose1);
+    seg(7);
     if (h->fused) {
       // Tracking::TrackWithMotionModel's numeric body in one submission (Tracking.cc:664-723)
-      double pose[7];
-      memcpy(pose, h->pose0, sizeof pose);
       int32_t ninl = 0;
-      h->outl.resize(n);
       if ((rc = asd_track_motion_model_bank(ctx, cur, h->last_slot, h->has.data(), h->Xw.data(), h->rows.data(), h->T, h->K32, 15.0f, 1, nullptr,
-                                            pose, h->m1.data(), &n1, h->outl.data(), &ninl)) != ASD_OK)
+                                            pose1, h->m1.data(), &n1, outl1.data(), &ninl)) != ASD_OK)
         return rc;
       st->m1 = n1; st->has_m1 = 1;
       seg(2);
@@ -428,69 +475,54 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       for (int j = 0; j < n; ++j) if (h->m1[j] >= 0) sel.push_back(j);
       if (sel.size() >= 3) {
         int32_t ninl = 0;
-        if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, &ninl)) != ASD_OK) return rc;
+        if ((rc = pose_opt(sel, [&](int j) { return &h->Xw[3 * h->m1[j]]; }, pose1, outl1.data(), &ninl)) != ASD_OK) return rc;
       }
       dev(1, "ba");
       seg(3);
     }
-    // local map: the last frame's points plus a jittered copy
-    const int n2p = 2 * nl;
-    h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
-    for (int i = 0; i < nl; ++i)
-      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
-    for (int i = 0; i < n2p; ++i) {
-      const float* P = &h->Xw2[3 * i];
-      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
-      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
-      h->dist[i] = nn;
-      const int lv = lk[i % nl].octave;
-      h->maxd[i] = nn * h->scale32[lv];
-      h->mind[i] = h->maxd[i] / h->scale32[7];
-    }
-    h->in_view.resize(n2p); h->proj.resize((size_t)2 * n2p); h->level.resize(n2p); h->vc.resize(n2p);
+    // between the stages: outlier matches dropped, the optimised pose becomes the frame's pose, the local map is put together
+    const int nsel = select_local_points(h, n, nl, outl1.data(), pose1);
+    h->in_view.resize(nsel); h->proj.resize((size_t)2 * nsel); h->level.resize(nsel); h->vc.resize(nsel);
     seg(7);
     if (!h->fused) {   // fused: isInFrustum / PredictScale / search windows are made on the device inside asd_track_local_points
-      if ((rc = asd_frustum(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->T, h->K32, 0.5f, h->in_view.data(),
+      if ((rc = asd_frustum(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->T1, h->K32, 0.5f, h->in_view.data(),
                             h->proj.data(), h->level.data(), h->vc.data())) != ASD_OK)
         return rc;
     }
     seg(4);
-    h->occ.resize(n);
-    for (int j = 0; j < n; ++j) h->occ[j] = h->m1[j] >= 0;
     h->m2.assign(n, -1);
     int32_t n2 = 0;
     if (h->fused) {
       // Tracking::TrackLocalMap's numeric body (SearchLocalPoints: frustum loop + matcher, then PoseOptimization; Tracking.cc:725-736, 803-851)
-      h->cur_Xw.assign((size_t)3 * n, 0.f);
       int nedge = 0;
-      for (int j = 0; j < n; ++j)
-        if (h->m1[j] >= 0) { for (int k = 0; k < 3; ++k) h->cur_Xw[3 * j + k] = h->Xw[3 * h->m1[j] + k]; }
       double pose[7];
-      memcpy(pose, h->pose0, sizeof pose);
+      memcpy(pose, pose1, sizeof pose);
       int32_t ninl = 0;
       h->outl.resize(n);
-      if ((rc = asd_track_local_points_bank(ctx, cur, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data(), h->rows.data(), h->T,
+      if ((rc = asd_track_local_points_bank(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->sel.data(), h->T1,
                                             h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, pose, h->m2.data(), &n2,
                                             h->outl.data(), &ninl)) != ASD_OK)
         return rc;
       st->m2 = n2; st->has_m2 = 1;
       dev(2, "match");
       seg(5);
-      for (int j = 0; j < n; ++j) nedge += h->m1[j] >= 0 || h->m2[j] >= 0;
+      for (int j = 0; j < n; ++j) nedge += h->keep[j] || h->m2[j] >= 0;
       if (nedge >= 3) { st->inliers = ninl; st->has_inliers = 1; }
       seg(6);
     } else {
-      if ((rc = asd_match_project_points_bank(ctx, cur, n2p, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->rows.data(),
+      if ((rc = asd_match_project_points_bank(ctx, cur, nsel, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->sel.data(),
                                               h->occ.data(), 1.0f, 0.8f, h->m2.data(), &n2, nullptr)) != ASD_OK)
         return rc;
       st->m2 = n2; st->has_m2 = 1;
       dev(2, "match");
       seg(5);
       sel.clear();
-      for (int j = 0; j < n; ++j) if (h->m1[j] >= 0 || h->m2[j] >= 0) sel.push_back(j);
+      for (int j = 0; j < n; ++j) if (h->keep[j] || h->m2[j] >= 0) sel.push_back(j);
       if (sel.size() >= 3) {
         int32_t ninl = 0;
-        if ((rc = pose_opt(sel, [&](int j) { return h->m1[j] >= 0 ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * std::max(h->m2[j], 0)]; }, &ninl)) != ASD_OK)
+        double pose[7];
+        memcpy(pose, pose1, sizeof pose);
+        if ((rc = pose_opt(sel, [&](int j) { return h->keep[j] ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * h->sel[std::max(h->m2[j], 0)]]; }, pose, nullptr, &ninl)) != ASD_OK)
           return rc;
         st->inliers = ninl; st->has_inliers = 1;
       }
@@ -498,7 +530,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       seg(6);
     }
   }
-  if (do_ba && (rc = submit_ba(h, st)) != ASD_OK) return rc;
+  if (do_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;
   seg(7);
   h->last_kps.assign(kps, kps + n);
   h->last_slot = cur;
@@ -508,8 +540,10 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
 }
 
 
-// LocalBA at a keyframe: on the lane (collected later) or in line
-static int submit_ba(asd_track_handle* h, asd_track_stats* st) {
+// LocalBA at a keyframe: in line (the reference's order) or on the optional lane (collected later).  The problem of keyframe number
+// t / kf_interval = the nominal problem with every observation displaced by a deterministic +-0.1 px (bench.py,
+// ba_problem_for_keyframe: same integer hash, same double arithmetic): a real map changes between keyframes.
+static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
   asd_ctx* ctx = h->ctx;
   int rc;
   if ((rc = collect_ba(h, nullptr, -1)) != ASD_OK) return rc;   // the previous keyframe's run (its buffers are reused below)
@@ -517,8 +551,18 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st) {
   h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
   h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);
   h->ba_chi2.assign(B.n_edges, 0.0); h->ba_dpos.assign(B.n_edges, 0); h->ba_out1.assign(B.n_edges, 0);
+  h->ba_obs.resize((size_t)2 * B.n_edges);
+  const uint32_t kf = (uint32_t)(t / h->kf_interval);
+  for (uint32_t i = 0; i < (uint32_t)(2 * B.n_edges); ++i) {
+    uint32_t x = i * 2654435761u + kf * 40503u + 12345u;
+    x ^= x >> 15;
+    x *= 2246822519u;
+    x ^= x >> 13;
+    const double u = (double)((x >> 8) & 0xFFFFu);
+    h->ba_obs[i] = B.e_obs[i] + (u / 65536.0 - 0.5) * 0.2;
+  }
   h->ba_p = B;
-  h->ba_p.poses = h->ba_poses.data(); h->ba_p.points = h->ba_points.data();
+  h->ba_p.poses = h->ba_poses.data(); h->ba_p.points = h->ba_points.data(); h->ba_p.e_obs = h->ba_obs.data();
   memset(&h->ba_r, 0, sizeof h->ba_r);
   h->ba_r.edge_chi2 = h->ba_chi2.data(); h->ba_r.edge_depth_pos = h->ba_dpos.data(); h->ba_r.edge_outlier1 = h->ba_out1.data();
   const auto b0 = std::chrono::steady_clock::now();

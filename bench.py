@@ -214,12 +214,31 @@ class Workload:
         self.frames = [synth.scene_frame(t + 3 * seed_offset) for t in range(N_FRAMES)]
 
 
-def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
-    """One frame through extract -> M1 -> P1 -> frustum/M2 -> P1 (-> LocalBA).  `be` is a backend
-    (HIP or CPU restatement) exposing the same operations.  ExtractDesc of the NEXT frame does not depend
-    on this frame's tracking, so the HIP backend reads ahead (asd_extract_submit, own streams + worker thread: the
-    replay knows its next images, Examples/Monocular/kitti.cc:116-155) as soon as this frame's descriptors are
-    adopted; every frame still goes through every stage."""
+def ba_problem_for_keyframe(ba, kf):
+    """The LocalBA problem of keyframe number kf: the nominal problem with every observation moved by a deterministic
+    +-0.1 px that depends on (edge, keyframe) -- a real map changes between keyframes, so no two runs are the same problem (the
+    number of Levenberg trials then varies too).  Integer hash in uint32 arithmetic, mirrored term by term in host/track_loop.cpp."""
+    E = len(ba["e_point"])
+    i = np.arange(2 * E, dtype=np.uint32)
+    with np.errstate(over="ignore"):
+        h = i * np.uint32(2654435761) + np.uint32(kf) * np.uint32(40503) + np.uint32(12345)
+        h ^= h >> np.uint32(15)
+        h = h * np.uint32(2246822519)
+        h ^= h >> np.uint32(13)
+    u = ((h >> np.uint32(8)) & np.uint32(0xFFFF)).astype(np.float64)
+    p = dict(ba)
+    p["e_obs"] = np.ascontiguousarray(ba["e_obs"], np.float64) + ((u / 65536.0 - 0.5) * 0.2).reshape(E, 2)
+    return p
+
+
+def track_step(be, wl, image_handle, last, do_ba, next_handles=(), t=0):
+    """One frame through extract -> TrackWithMotionModel body (M1 + P1) -> UpdateLocalMap stand-in -> TrackLocalMap body (isInFrustum +
+    M2 + P1) (-> LocalBA, in line).  `be` is a backend (HIP or CPU restatement) exposing the same operations.  ExtractDesc of the NEXT
+    frame does not depend on this frame's tracking, so the HIP backend reads ahead (asd_extract_submit, own streams + worker thread:
+    the replay knows its next images, Examples/Monocular/kitti.cc:116-155) as soon as this frame's descriptors are adopted; every frame
+    still goes through every stage.  Data flow between the stages as in the reference: the local-map stage starts from the pose
+    the motion-model stage optimised and works on the matches it kept (Tracking.cc:693-714, 725-736); the local map is put together
+    AFTER the motion-model stage, from its matches (UpdateLocalMap, Tracking.cc:726)."""
     kps, desc = be.extract(image_handle)   # results stay valid through the next step (own arrays / library views)
     cur = be.make_frame(kps, desc)
     if next_handles:
@@ -227,56 +246,71 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=()):
     stats = {"n_kp": len(kps)}
     if last is not None:
         lk, ld, lframe = last
+        nl, n_cur = len(lk), len(kps)
         uv = wl.predicted_uv(lk) if hasattr(wl, "predicted_uv") else predicted_uv(lk)
         Xw = backproject_identity(wl.K32, uv, 20.0)
-        has = np.ones(len(lk), np.uint8)
+        has = np.ones(nl, np.uint8)
         # map point descriptors: the HIP backend keeps them in the device-resident bank (rows 0..n-1 = the last
-        # frame's descriptors, rows n..2n-1 = the same again for the jittered copy), the CPU backend gets the table
+        # frame's descriptors, rows n..2n-1 = the same again for the displaced copy), the CPU backend gets the table
         be.set_map_descriptors(lframe, ld)
-        fused = getattr(be, "fused", False)   # search + claim replay + PoseOptimization as one submission (asd_track_*)
-        if fused:
-            m1, n1 = be.track_motion_model(cur, lframe, len(kps), has, Xw, wl.T, wl.K32, 15.0, wl.pose0)[:2]
-        else:
-            m1, n1 = be.match_frame(cur, lframe, len(kps), has, Xw, ld, wl.T, wl.K32, 15.0)
-        j = np.nonzero(m1 >= 0)[0]
-        stats["m1"] = int(n1)
-        if len(j) >= 3 and not fused:
-            obs = np.stack([kps["x"][j], kps["y"][j]], 1).astype(np.float64)
-            be.pose_opt(wl.pose0, Xw[m1[j]].astype(np.float64), obs, wl.inv_sigma2[kps["octave"][j]], wl.K64)
-        # local map: the last frame's points plus a second, jittered copy (~2x keypoints, like a local map)
+        # attributes of the map points around the frame (they exist before the frame is tracked: MapPoint::mWorldPos, mNormalVector,
+        # mfMin/MaxDistance): the last frame's points plus a second, displaced copy (~2x keypoints, like a local map)
         Xw2 = np.concatenate([Xw, Xw + np.float32(0.02)])
-        d2 = (ld, ld)
-        n = Xw2 / np.linalg.norm(Xw2, axis=1, keepdims=True)
+        nrm = (Xw2 / np.linalg.norm(Xw2, axis=1, keepdims=True)).astype(np.float32)
         dist = np.linalg.norm(Xw2, axis=1).astype(np.float32)
         lv = np.concatenate([lk["octave"], lk["octave"]])
         maxd = dist * wl.scale32[lv]            # f32 * f32, mirrored term by term in host/track_loop.cpp
         mind = maxd / wl.scale32[7]
-        occ = (m1 >= 0).astype(np.uint8)
-        fr = None if fused else be.frustum(cur, Xw2, n.astype(np.float32), mind, maxd, wl.T, wl.K32)
+        fused = getattr(be, "fused", False)   # search + claim replay + PoseOptimization as one submission (asd_track_*)
+        # ---- TrackWithMotionModel (Tracking.cc:664-723): SearchByProjection against the last frame, PoseOptimization
+        outl1 = np.zeros(n_cur, np.uint8)
+        pose1 = wl.pose0.copy()
+        if fused:
+            m1, n1, pose1, outl1, _ = be.track_motion_model(cur, lframe, n_cur, has, Xw, wl.T, wl.K32, 15.0, wl.pose0)
+        else:
+            m1, n1 = be.match_frame(cur, lframe, n_cur, has, Xw, ld, wl.T, wl.K32, 15.0)
+            j = np.nonzero(m1 >= 0)[0]
+            if len(j) >= 3:
+                obs = np.stack([kps["x"][j], kps["y"][j]], 1).astype(np.float64)
+                pose1, o, _ = be.pose_opt(wl.pose0, Xw[m1[j]].astype(np.float64), obs, wl.inv_sigma2[kps["octave"][j]], wl.K64)
+                outl1[j] = o
+        stats["m1"] = int(n1)
+        keep = (m1 >= 0) & (outl1 == 0)       # Tracking.cc:695-714: matches the optimisation marked as outliers are dropped
+        # the frame's pose from here on = the optimised one (mCurrentFrame.SetPose, Optimizer.cc:405-407)
+        T1 = be.pose7_to_tcw(pose1) if (m1 >= 0).sum() >= 3 else wl.T
+        # ---- UpdateLocalMap stand-in (Tracking.cc:726, 907-): the local points = the candidates that are not in the frame already
+        # (SearchLocalPoints skips those, Tracking.cc:811-823)
+        in_frame = np.zeros(2 * nl, bool)
+        in_frame[m1[keep]] = True
+        sel = np.nonzero(~in_frame)[0].astype(np.int32)
+        occ = keep.astype(np.uint8)
+        cur_Xw = Xw[np.maximum(m1, 0)]
+        # ---- TrackLocalMap (Tracking.cc:725-736): isInFrustum + SearchByProjection(frame, points) + PoseOptimization from pose1
         if fused:   # frustum test, level prediction and search windows on the device too (asd_track_local_points)
-            m2, n2, _, _, ninl = be.track_local_points(cur, len(kps), Xw2, n.astype(np.float32), mind, maxd, occ, Xw[np.maximum(m1, 0)],
-                                                       1.0, 0.8, wl.T, wl.K32, wl.pose0)
+            m2, n2, _, _, ninl = be.track_local_points(cur, n_cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], sel, occ, cur_Xw, 1.0, 0.8, T1, wl.K32, pose1)
             stats["m2"] = int(n2)
-            if ((m1 >= 0) | (m2 >= 0)).sum() >= 3:
+            if (keep | (m2 >= 0)).sum() >= 3:
                 stats["inliers"] = int(ninl)
         else:
-            m2, n2 = be.match_points(cur, len(kps), fr, d2, occ, 1.0, 0.8)
+            fr = be.frustum(cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], T1, wl.K32)
+            m2, n2 = be.match_points(cur, n_cur, fr, (ld, ld), sel, occ, 1.0, 0.8)
             stats["m2"] = int(n2)
-            jj = np.nonzero((m1 >= 0) | (m2 >= 0))[0]
+            jj = np.nonzero(keep | (m2 >= 0))[0]
             if len(jj) >= 3:
-                X = np.where((m1[jj] >= 0)[:, None], Xw[np.maximum(m1[jj], 0)], Xw2[np.maximum(m2[jj], 0)])
+                X = np.where(keep[jj][:, None], Xw[np.maximum(m1[jj], 0)], Xw2[sel[np.maximum(m2[jj], 0)]])
                 obs = np.stack([kps["x"][jj], kps["y"][jj]], 1).astype(np.float64)
-                _, _, ninl = be.pose_opt(wl.pose0, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
+                _, _, ninl = be.pose_opt(pose1, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
                 stats["inliers"] = int(ninl)
     if do_ba:
+        prob = ba_problem_for_keyframe(wl.ba, t // KF_INTERVAL)
         if getattr(be, "async_ba", False):
             # variant only (--lane-ba): LocalBA on the library's lane, beside the next frames' tracking -- NOT the reference's order
             # (Tracking.cc:797 -> LocalMapping.cc:89 is an in-line call): submitted here, collected before the next submission
             be.local_ba_collect()
-            be.local_ba_submit(wl.ba)
+            be.local_ba_submit(prob)
             stats["ba_submitted"] = True
         else:
-            r = be.local_ba(wl.ba)
+            r = be.local_ba(prob)
             stats["ba_chi2"] = float(r["chi2_second"])
     return (kps, desc, cur), stats
 
@@ -420,14 +454,17 @@ class HipBackend:
     def frustum(self, cur, Xw, normal, mind, maxd, T, K):
         return self.hip.frustum(cur, Xw, normal, mind, maxd, T, K)
 
-    def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
-        return self.hip.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], occ, th, ratio)
+    def match_points(self, cur, n_cur, fr, desc, sel, occ, th, ratio):
+        return self.hip.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[sel], occ, th, ratio)
 
     def track_motion_model(self, cur, last, n_cur, has, Xw, T, K, th, pose0):
         return self.hip.track_motion_model(cur, last, n_cur, has, Xw, self.rows[:len(has)], T, K, th, pose0, True)
 
-    def track_local_points(self, cur, n_cur, Xw, normal, mind, maxd, occ, cur_Xw, th, ratio, T, K, pose0):
-        return self.hip.track_local_points(cur, n_cur, Xw, normal, mind, maxd, self.rows[:len(Xw)], T, K, occ, cur_Xw, th, ratio, pose0)
+    def track_local_points(self, cur, n_cur, Xw, normal, mind, maxd, sel, occ, cur_Xw, th, ratio, T, K, pose0):
+        return self.hip.track_local_points(cur, n_cur, Xw, normal, mind, maxd, self.rows[sel], T, K, occ, cur_Xw, th, ratio, pose0)
+
+    def pose7_to_tcw(self, pose):
+        return self.hip.pose7_to_tcw(pose)
 
     def local_ba(self, prob):
         return self.hip.local_ba(prob)
@@ -493,8 +530,11 @@ class CpuBackend:
     def set_map_descriptors(self, last, ld):
         pass
 
-    def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
-        return self.orc.match_project_points(cur, fr[0], fr[1], fr[2], fr[3], np.concatenate(desc), occ, th, ratio)
+    def match_points(self, cur, n_cur, fr, desc, sel, occ, th, ratio):
+        return self.orc.match_project_points(cur, fr[0], fr[1], fr[2], fr[3], np.concatenate(desc)[sel], occ, th, ratio)
+
+    def pose7_to_tcw(self, pose):
+        return self.orc.pose7_to_tcw(pose)
 
     def local_ba(self, prob):
         return (self.ref or self.orc).local_ba(prob)
@@ -514,7 +554,7 @@ def run_steps_python(be, wl, t0, n, last, prefetch_beyond=False):
     for i in range(n):
         t = t0 + i
         nxt = [be.image(t + k) for k in range(1, LOOKAHEAD + 1) if (i + k < n or prefetch_beyond)]
-        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1), next_handles=nxt)
+        last, stats = track_step(be, wl, be.image(t), last, do_ba=(t % KF_INTERVAL == KF_INTERVAL - 1), next_handles=nxt, t=t)
     if getattr(be, "async_ba", False):   # the run ends with its LocalBA finished (and reported if the last step started it)
         r = be.local_ba_collect()
         if stats.pop("ba_submitted", False) and r is not None:
@@ -634,8 +674,11 @@ class StereoBackend:
     def frustum(self, cur, Xw, normal, mind, maxd, T, K):
         return self.L.frustum(cur, Xw, normal, mind, maxd, T, K)
 
-    def match_points(self, cur, n_cur, fr, desc, occ, th, ratio):
-        return self.L.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[:len(fr[0])], occ, th, ratio)
+    def match_points(self, cur, n_cur, fr, desc, sel, occ, th, ratio):
+        return self.L.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[sel], occ, th, ratio)
+
+    def pose7_to_tcw(self, pose):
+        return self.L.pose7_to_tcw(pose)
 
     def local_ba(self, prob):
         return self.L.local_ba(prob)
