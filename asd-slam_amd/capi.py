@@ -113,6 +113,9 @@ class AsdHip:
         if rc != 0:
             raise AsdError(rc, self.lib.asd_last_error(self.ctx).decode())
 
+    def last_error(self):
+        return self.lib.asd_last_error(self.ctx).decode()
+
     # ---- tables
     def scale_tables(self):
         n = self.n_levels

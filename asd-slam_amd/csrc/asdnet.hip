@@ -1064,8 +1064,16 @@ __global__ __launch_bounds__(256) void k_fc_x3(const float* __restrict__ act, co
 }
 
 // K3: sum split-K partials in fixed order (deterministic), folded BN bias, L2Norm (Utils.py:15-22).
+// calibration: max |x| over a buffer as float bits (non-negative floats order like their bit patterns; a NaN / inf sorts above)
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ p, size_t n, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, __float_as_uint(p[i]) & 0x7fffffffu);
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, const float* __restrict__ bias,
-                                                float* __restrict__ desc, int n, int npad) {
+                                                float* __restrict__ desc, int n, int npad, int* __restrict__ range_flag) {
   const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= n) return;
   float v0 = 0.f, v1 = 0.f;
@@ -1078,6 +1086,9 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
   float ss = v0 * v0 + v1 * v1;
   for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
   const float norm = sqrtf(ss + 1e-10f);
+  // a row that is not finite: an activation left the range of the two-piece fp16 operand form somewhere upstream (the kernels let
+  // the inf / NaN through on purpose).  The flag sits in pinned host memory; the synchronising entry points turn it into ASD_ERR_RANGE.
+  if (range_flag && lane == 0 && !(fabsf(ss) <= 3.0e38f)) *range_flag = 1;
   desc[(size_t)p * 128 + lane] = v0 / norm;
   desc[(size_t)p * 128 + lane + 64] = v1 / norm;
 }
@@ -1240,6 +1251,8 @@ int asdnet_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_patches, np * 1024));
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_desc, np * 128 * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_tq, 16 * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_range), 64));
+  *ctx->h_range = 0;
   if (const char* e = getenv("ASD_ASDNET_RESERVE")) ctx->cu_reserve = atoi(e);
   if (const char* e = getenv("ASD_ASDNET_PERSIST")) ctx->asdnet_persist = atoi(e) != 0;
   return ASD_OK;
@@ -1251,6 +1264,7 @@ void asdnet_free(asd_ctx* ctx) {
   if (ctx->d_patches) (void)hipFree(ctx->d_patches);
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
   if (ctx->d_tq) (void)hipFree(ctx->d_tq);
+  if (ctx->h_range) (void)hipHostFree(ctx->h_range);
   if (ctx->d_w1) (void)hipFree(ctx->d_w1);
   for (int i = 0; i < 7; ++i) {
     if (ctx->d_bias[i]) (void)hipFree(ctx->d_bias[i]);
@@ -1259,6 +1273,14 @@ void asdnet_free(asd_ctx* ctx) {
     if (ctx->d_wx2[i]) (void)hipFree(ctx->d_wx2[i]);
   }
 }
+
+// Range calibration of the two-piece fp16 operand form (kActScale = 16: an activation beyond 4094 is not representable).  64
+// synthetic patches -- uniform noise, step edges in four orientations, checkerboards of period 2 / 4 / 8, ramps, single dots: the
+// patterns that drive a conv stack hardest after the per-patch normalisation -- go through the network as loaded; the largest
+// |activation| of every layer is measured (conv1, which never reaches HBM, on the host from the same patches; conv2 .. conv6 by
+// k_absmax behind each layer).  Anything above kCalibLimit = 2048 (a factor two of headroom) switches the context to the
+// three-piece bf16 form, which has no range limit; asd_last_error / asd_asdnet_pieces report it.
+static int asdnet_calibrate(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7], const float* const bn_var[7], float eps);
 
 int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
                         const float* const bn_var[7], float eps) {
@@ -1322,12 +1344,12 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
     }
   }
   ctx->weights_loaded = true;
-  return ASD_OK;
+  return asdnet_calibrate(ctx, conv_w, bn_mean, bn_var, eps);
 }
 
 int asdnet_profile_collect_set(asd_ctx* ctx, int set);
 
-int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st) {
+int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag) {
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
   if (n < 0 || n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
   if (n == 0) return ASD_OK;
@@ -1353,21 +1375,29 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
                                      tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu))
   if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L2S_CFG, true, 1, d_patches, a1, ctx->d_w1, ctx->d_bias[0])));
   else ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
+  // calibration (asd_load_weights): the largest |activation| each layer hands to the next one
+#define CALIB(l, buf, elems) do { if (ctx->d_calib) { hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, buf, (size_t)n * (elems), ctx->d_calib + (l)); ASD_HIP_CHECK(ctx, hipGetLastError()); } } while (0)
+  CALIB(1, a1, 32 * 32 * 32);
   PROF_MARK(2);
   if (ctx->net_split & 2) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L3S_CFG, false, 2, a1, a0, nullptr, nullptr)));
   else
   ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
+  CALIB(2, a0, 16 * 16 * 64);
   PROF_MARK(3);
   if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L4S_CFG, false, 3, a0, a1, nullptr, nullptr)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
+  CALIB(3, a1, 16 * 16 * 64);
   PROF_MARK(4);
   if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L5S_CFG, false, 4, a1, a0, nullptr, nullptr)));
   else
   ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
+  CALIB(4, a0, 8 * 8 * 128);
   PROF_MARK(5);
   if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L6S_CFG, false, 5, a0, a1, nullptr, nullptr)));
   else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
 #undef X3_LAUNCH
+  CALIB(5, a1, 8 * 8 * 128);
+#undef CALIB
   PROF_MARK(6);
   if (ctx->net_split & 32)
     hipLaunchKernelGGL(k_fc_x3, dim3((npad + FCS_MP - 1) / FCS_MP, FC_SK), dim3(256), 0, st, a1, static_cast<const uint8_t*>(ctx->d_wx3[6]), ctx->d_part, n, npad);
@@ -1375,11 +1405,99 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
     hipLaunchKernelGGL(k_fc_mfma, dim3((npad / 32 + FC_MT - 1) / FC_MT, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   PROF_MARK(7);
-  hipLaunchKernelGGL(k_l2norm, dim3((n + 3) / 4), dim3(256), 0, st, ctx->d_part, ctx->d_bias[6], d_desc, n, npad);
+  hipLaunchKernelGGL(k_l2norm, dim3((n + 3) / 4), dim3(256), 0, st, ctx->d_part, ctx->d_bias[6], d_desc, n, npad, range_flag);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   PROF_MARK(8);
 #undef PROF_MARK
   if (prof) { ctx->prof_pending[pset] = true; ctx->prof_pending_n[pset] = n; ctx->prof_cur ^= 1; }
+  return ASD_OK;
+}
+
+static int asdnet_calibrate(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7], const float* const bn_var[7], float eps) {
+  ctx->calib_note.clear();
+  if (ctx->net_pieces != 2 || !(ctx->net_split & 31)) return ASD_OK;   // only the fp16 form has a range
+  if (const char* e = getenv("ASD_ASDNET_CALIBRATE")) if (atoi(e) == 0) return ASD_OK;   // tests of the run-time flag switch the guard at load off
+  constexpr int N = 64;
+  constexpr float kCalibLimit = 2048.f;
+  std::vector<uint8_t> pat((size_t)N * 1024);
+  uint32_t rng = 0x9e3779b9u;
+  auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+  for (int p = 0; p < N; ++p)
+    for (int y = 0; y < 32; ++y)
+      for (int x = 0; x < 32; ++x) {
+        int v;
+        const int kind = p % 8, var = p / 8;
+        switch (kind) {
+          case 0: v = (int)(rnd() & 255); break;                                              // uniform noise
+          case 1: v = (x < 8 + 2 * var) ? 20 : 235; break;                                     // vertical edge
+          case 2: v = (y < 8 + 2 * var) ? 235 : 20; break;                                     // horizontal edge
+          case 3: v = (x + y < 24 + 2 * var) ? 10 : 245; break;                                // diagonal edge
+          case 4: v = (((x >> (var % 3)) + (y >> (var % 3))) & 1) ? 255 : 0; break;            // checkerboard, period 2 / 4 / 8
+          case 5: v = (x * 255) / 31; break;                                                   // ramp
+          case 6: v = (x == 4 * var + 1 && y == 3 * var + 2) ? 255 : 0; break;                 // single dot (std -> tiny: large normalised peak)
+          default: v = 128 + (int)(rnd() & 3); break;                                          // almost flat
+        }
+        pat[(size_t)p * 1024 + y * 32 + x] = (uint8_t)v;
+      }
+  // conv1 on the host: input_norm (ASDNet.py:360-365) + 3x3 conv + folded BN + ReLU, its maximum only
+  float max1 = 0.f;
+  {
+    std::vector<float> inv(32), bias(32);
+    for (int c = 0; c < 32; ++c) { inv[c] = 1.0f / std::sqrt(bn_var[0][c] + eps); bias[c] = -bn_mean[0][c] * inv[c]; }
+    std::vector<float> in(34 * 34);
+    for (int p = 0; p < N; ++p) {
+      double s1 = 0, s2 = 0;
+      for (int i = 0; i < 1024; ++i) s1 += pat[(size_t)p * 1024 + i] / 255.0;
+      const double mean = s1 / 1024;
+      for (int i = 0; i < 1024; ++i) { const double d = pat[(size_t)p * 1024 + i] / 255.0 - mean; s2 += d * d; }
+      const double sd = std::sqrt(s2 / 1023) + 1e-7;
+      std::fill(in.begin(), in.end(), 0.f);
+      for (int y = 0; y < 32; ++y)
+        for (int x = 0; x < 32; ++x) in[(y + 1) * 34 + x + 1] = (float)((pat[(size_t)p * 1024 + y * 32 + x] / 255.0 - mean) / sd);
+      for (int c = 0; c < 32; ++c)
+        for (int y = 0; y < 32; ++y)
+          for (int x = 0; x < 32; ++x) {
+            float a = bias[c];
+            for (int k = 0; k < 9; ++k) a += in[(y + k / 3) * 34 + x + k % 3] * conv_w[0][c * 9 + k] * inv[c];
+            max1 = std::max(max1, a);
+          }
+    }
+  }
+  // conv2 .. conv6 on the device, as loaded
+  uint8_t* d_pat = nullptr;
+  unsigned* d_max = nullptr;
+  float* d_out = nullptr;
+  ASD_HIP_CHECK(ctx, hipMalloc(&d_pat, pat.size()));
+  ASD_HIP_CHECK(ctx, hipMalloc(&d_max, 8 * sizeof(unsigned)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)N * 128 * sizeof(float)));
+  int rc = ASD_OK;
+  unsigned hmax[8] = {};
+  do {
+    if (hipMemcpy(d_pat, pat.data(), pat.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_max, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = ASD_ERR_HIP; break; }
+    ctx->d_calib = d_max;
+    rc = asdnet_forward_device(ctx, d_pat, N, d_out, ctx->stream, nullptr);
+    ctx->d_calib = nullptr;
+    if (rc != ASD_OK) break;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(hmax, d_max, sizeof hmax, hipMemcpyDeviceToHost) != hipSuccess) rc = ASD_ERR_HIP;
+  } while (0);
+  (void)hipFree(d_pat); (void)hipFree(d_max); (void)hipFree(d_out);
+  if (rc != ASD_OK) { ctx->set_error("asd_load_weights: the range calibration pass failed"); return rc; }
+  float worst = max1;
+  int worst_layer = 1;
+  for (int l = 1; l <= 5; ++l) {
+    float v;
+    memcpy(&v, &hmax[l], 4);
+    if (!(v <= 3.0e38f)) v = INFINITY;
+    if (v > worst) { worst = v; worst_layer = l + 1; }
+  }
+  if (worst > kCalibLimit) {
+    ctx->net_pieces = 3;
+    char buf[256];
+    snprintf(buf, sizeof buf, "asd_load_weights: calibration found |activation| = %g behind conv%d (limit %g for the two-piece fp16 form): this context uses the three-piece bf16 form (asd_asdnet_pieces = 3)",
+             (double)worst, worst_layer, (double)kCalibLimit);
+    ctx->calib_note = buf;
+    ctx->set_error("%s", buf);
+  }
   return ASD_OK;
 }
 

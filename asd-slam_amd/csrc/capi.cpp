@@ -196,7 +196,7 @@ int asd_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* co
 int asd_describe_device(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc) {
   if (!ctx || (n > 0 && (!d_patches || !d_desc))) return ASD_ERR_INVALID;
   if (asd_extractor_busy(ctx, "asd_describe_device")) return ASD_ERR_INVALID;
-  return asdnet_forward_device(ctx, d_patches, n, d_desc, ctx->stream);
+  return asdnet_forward_device(ctx, d_patches, n, d_desc, ctx->stream, ctx->h_range);   // (no synchronisation here: asd_sync reports the flag)
 }
 
 int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc) {
@@ -208,13 +208,14 @@ int asd_describe(asd_ctx* ctx, const uint8_t* patches, int32_t n, float* desc) {
   (void)hipSetDevice(ctx->cfg.device);
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_patches, patches, (size_t)n * 1024, hipMemcpyHostToDevice, ctx->stream));
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc, ctx->stream);
+  *ctx->h_range = 0;
+  int rc = asdnet_forward_device(ctx, ctx->d_patches, n, ctx->d_desc, ctx->stream, ctx->h_range);
   if (rc != ASD_OK) return rc;
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(desc, ctx->d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_asdnet, ctx->ev0, ctx->ev1));
-  return ASD_OK;
+  return asd_range_status(ctx, ctx->h_range, "asd_describe");
 }
 
 int asd_describe_timed(asd_ctx* ctx, const uint8_t* d_patches, int32_t n, float* d_desc, int32_t reps, float* avg_ms) {
@@ -323,7 +324,7 @@ int asd_memcpy_d2h(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes) {
 int asd_sync(asd_ctx* ctx) {
   if (!ctx) return ASD_ERR_INVALID;
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  return ASD_OK;
+  return ctx->h_range ? asd_range_status(ctx, ctx->h_range, "asd_describe_device") : ASD_OK;
 }
 
 // Converter::toSE3Quat (Converter.cc:37-47) + SE3Quat(R,t) ctor (se3quat.h:58-60): Eigen

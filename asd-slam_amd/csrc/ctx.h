@@ -141,6 +141,9 @@ struct asd_ctx {
   int net_split = 1;            // ASD_ASDNET_MATH: 1 = split-bf16 kernels where a layer has one, 0 = f32 MFMA everywhere
   float* d_act[2] = {};         // ping-pong NHWC activations
   float* d_part = nullptr;      // split-K partials of the last layer
+  int* h_range = nullptr;       // pinned: set by k_l2norm when a descriptor of an asd_describe* call came out non-finite (fp16x2 range)
+  std::string calib_note;       // what asd_load_weights' calibration found (empty: nothing to report)
+  unsigned* d_calib = nullptr;  // calibration only: per-layer max |activation| as float bits (asdnet_forward_device fills it when set)
   int* d_tq = nullptr;          // tile counters of the persistent conv launches of one forward (asdnet.hip, TileQueue), one per layer
   int cu_reserve = 0;           // asd_cu_reserved mode of the persistent conv launches (ASD_ASDNET_RESERVE at asd_ctx_create)
   bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
@@ -236,11 +239,20 @@ inline size_t pose_chain_io_bytes(int n_cur) { return 64 + (size_t)n_cur + 64; }
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 
 // asdnet.hip
+// the fp16x2 range flag of a finished forward -> status (clears the flag)
+inline int asd_range_status(asd_ctx* ctx, int* flag, const char* who) {
+  if (!flag || !*flag) return ASD_OK;
+  *flag = 0;
+  ctx->set_error("%s: an ASDNet activation left the range of the two-piece fp16 operand form (|x| > 4094): the descriptors of this call are "
+                 "not valid.  ASD_ASDNET_MATH=bf16x3 (or f32) has no range limit", who);
+  return ASD_ERR_RANGE;
+}
 int asdnet_alloc(asd_ctx* ctx);
 void asdnet_free(asd_ctx* ctx);
 int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7],
                         const float* const bn_var[7], float eps);
 // enqueues one forward on `st` (the caller's stream or the extraction worker's); d_act / d_part are one set per context, so
 // forwards of one context must be ordered among themselves: asd_extractor_busy() guards the caller-side entry points
-int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st);
+// range_flag: pinned host int the L2-norm kernel sets to 1 when a descriptor row is not finite (null = no report)
+int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag = nullptr);
 int asdnet_profile_collect(asd_ctx* ctx);  // folds pending layer events into the totals (needs a synced stream)

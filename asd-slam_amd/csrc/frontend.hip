@@ -397,6 +397,7 @@ struct ExtractSlot {
   uint8_t* d_patches = nullptr;
   float* d_desc = nullptr;
   float *d_angles = nullptr, *h_angles = nullptr, *h_desc = nullptr;  // h_* pinned
+  int* h_range = nullptr;   // pinned, behind the angles: the forward's fp16x2 range flag (asdnet.hip, k_l2norm)
   hipEvent_t ev_begin = nullptr, ev_front = nullptr, ev_end = nullptr;
   bool owned = false;  // slot 0 aliases the ctx / FrontendState buffers
 };
@@ -473,7 +474,7 @@ int frontend_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_kps, np * sizeof(short4)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_kps, np * sizeof(short4)));
   ASD_HIP_CHECK(ctx, hipMalloc(&fe->d_angles, np * sizeof(float)));
-  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_angles, np * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_angles, (np + 16) * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_desc, np * 128 * sizeof(float)));
   return ASD_OK;
 }
@@ -624,7 +625,8 @@ static int slot_alloc(asd_ctx* ctx, ExtractSlot& S) {
   ASD_HIP_CHECK(ctx, hipMalloc(&S.d_patches, np * 1024));
   ASD_HIP_CHECK(ctx, hipMalloc(&S.d_desc, np * 128 * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipMalloc(&S.d_angles, np * sizeof(float)));
-  ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_angles, np * sizeof(float)));
+  ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_angles, (np + 16) * sizeof(float)));
+  S.h_range = reinterpret_cast<int*>(S.h_angles + np);
   ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_desc, np * 128 * sizeof(float)));
   S.owned = true;
   return ASD_OK;
@@ -753,7 +755,8 @@ static int extract_front(asd_ctx* ctx, const ExtractJob& J, ExtractSlot& S, hipS
 // E6: ASDNet on the slot's patches + read-back of angles and descriptors, all enqueued on `st` behind ev_front
 static int extract_back_enqueue(asd_ctx* ctx, ExtractSlot& S, int n, hipStream_t st) {
   ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, S.ev_front, 0));
-  const int rc = asdnet_forward_device(ctx, S.d_patches, n, S.d_desc, st);
+  if (S.h_range) *S.h_range = 0;   // (the slot's previous user was waited for before the slot came round again)
+  const int rc = asdnet_forward_device(ctx, S.d_patches, n, S.d_desc, st, S.h_range);
   if (rc != ASD_OK) return rc;
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_angles, S.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -767,7 +770,7 @@ static int extract_finish(asd_ctx* ctx, ExtractSlot& S, int n, asd_keypoint* kps
   if (desc) memcpy(desc, S.h_desc, (size_t)n * 128 * sizeof(float));  // else: the consumer reads the pinned staging itself
   for (int i = 0; i < n; ++i) kps[i].angle = S.h_angles[i];
   ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_extract, S.ev_begin, S.ev_end));
-  return ASD_OK;
+  return asd_range_status(ctx, S.h_range, "asd_extract");
 }
 
 static int extract_check(asd_ctx* ctx, const uint8_t* image, int32_t width, int32_t height, int32_t stride) {
@@ -792,6 +795,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   if (!S.d_patches) {  // slot 0 = the buffers asd_describe uses as well
     S.d_patches = ctx->d_patches; S.d_desc = ctx->d_desc;
     S.d_angles = fe->d_angles; S.h_angles = fe->h_angles; S.h_desc = fe->h_desc;
+    S.h_range = reinterpret_cast<int*>(fe->h_angles + ctx->cfg.max_patches);
   }
   if ((rc = slot_events(ctx, S)) != ASD_OK) return rc;
   ExtractJob J;

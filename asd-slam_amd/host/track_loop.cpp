@@ -16,15 +16,9 @@
 #include <deque>
 #include <vector>
 
-#include "../../include/asd_slam.h"
+#include "track_loop.h"
 
 extern "C" {
-
-typedef struct asd_track_stats {
-  int32_t n_kp, m1, m2, inliers;
-  double ba_chi2;
-  int32_t has_m1, has_m2, has_inliers, has_ba;
-} asd_track_stats;
 
 struct asd_track_handle {
   asd_ctx* ctx;
@@ -46,6 +40,7 @@ struct asd_track_handle {
   // construction (wait for its extraction, AssignFeaturesToGrid + descriptor adoption, read-ahead submission, descriptor-bank
   // rows, projected points), which the reference's Frame constructor does before tracking that frame
   bool split = true;
+  float drift_cx = 620.5f, drift_cy = 188.0f, drift_z = 1.003f, drift_dx = 3.0f, drift_dy = 0.2f;   // asd_track_set_drift
   int stop_after = -1;      // no read-ahead beyond this frame (-1 = unbounded)
   int prep_t = -1;          // the frame prepare_frame() has made ready (its grid sits in slot `slot`), -1 = none
   const asd_keypoint* prep_kps = nullptr;
@@ -108,6 +103,9 @@ asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* c
 void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on != 0; }
 void asd_track_set_async_ba(asd_track_handle* h, int32_t on) { if (h) h->async_ba = on != 0; }
 void asd_track_set_split(asd_track_handle* h, int32_t on) { if (h) h->split = on != 0; }
+void asd_track_set_drift(asd_track_handle* h, float cx, float cy, float z, float dx, float dy) {
+  if (h) { h->drift_cx = cx; h->drift_cy = cy; h->drift_z = z; h->drift_dx = dx; h->drift_dy = dy; }
+}
 
 // collect the outstanding LocalBA; its chi2 goes into *st only when the step that submitted it is the one st describes
 static int collect_ba(asd_track_handle* h, asd_track_stats* st, long st_step) {
@@ -197,11 +195,13 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
     const std::vector<asd_keypoint>& lk = h->last_kps;
     const int nl = (int)lk.size();
     const float fx = h->K32[0], fy = h->K32[1], cx = h->K32[2], cy = h->K32[3];
-    const float z = 1.003f, c3 = (float)(3 * 1.003), c02 = (float)(0.2 * 1.003), depth = 20.0f;
+    // (default drift: exactly bench.py's predicted_uv -- z = 1.003f, c3 = (float)(3 * 1.003), c02 = (float)(0.2 * 1.003))
+    const float z = h->drift_z, c3 = (float)((double)h->drift_dx * (double)(h->drift_z == 1.003f ? 1.003 : (double)h->drift_z)),
+                c02 = (float)((double)(h->drift_dy == 0.2f ? 0.2 : (double)h->drift_dy) * (double)(h->drift_z == 1.003f ? 1.003 : (double)h->drift_z)), depth = 20.0f;
     h->Xw.resize((size_t)3 * nl);
     for (int i = 0; i < nl; ++i) {
-      const float u = (lk[i].x - 620.5f) * z + 620.5f - c3;
-      const float v = (lk[i].y - 188.0f) * z + 188.0f - c02;
+      const float u = (lk[i].x - h->drift_cx) * z + h->drift_cx - c3;
+      const float v = (lk[i].y - h->drift_cy) * z + h->drift_cy - c02;
       h->Xw[3 * i + 0] = (u - cx) / fx * depth;
       h->Xw[3 * i + 1] = (v - cy) / fy * depth;
       h->Xw[3 * i + 2] = depth;
@@ -402,11 +402,13 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     const int nl = (int)lk.size();
     const float fx = h->K32[0], fy = h->K32[1], cx = h->K32[2], cy = h->K32[3];
     // predicted_uv + backproject_identity (depth 20), float32 like the numpy expressions
-    const float z = 1.003f, c3 = (float)(3 * 1.003), c02 = (float)(0.2 * 1.003), depth = 20.0f;
+    // (default drift: exactly bench.py's predicted_uv -- z = 1.003f, c3 = (float)(3 * 1.003), c02 = (float)(0.2 * 1.003))
+    const float z = h->drift_z, c3 = (float)((double)h->drift_dx * (double)(h->drift_z == 1.003f ? 1.003 : (double)h->drift_z)),
+                c02 = (float)((double)(h->drift_dy == 0.2f ? 0.2 : (double)h->drift_dy) * (double)(h->drift_z == 1.003f ? 1.003 : (double)h->drift_z)), depth = 20.0f;
     h->Xw.resize((size_t)3 * nl);
     for (int i = 0; i < nl; ++i) {
-      const float u = (lk[i].x - 620.5f) * z + 620.5f - c3;
-      const float v = (lk[i].y - 188.0f) * z + 188.0f - c02;
+      const float u = (lk[i].x - h->drift_cx) * z + h->drift_cx - c3;
+      const float v = (lk[i].y - h->drift_cy) * z + h->drift_cy - c02;
       h->Xw[3 * i + 0] = (u - cx) / fx * depth;
       h->Xw[3 * i + 1] = (v - cy) / fy * depth;
       h->Xw[3 * i + 2] = depth;

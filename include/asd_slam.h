@@ -42,7 +42,9 @@ typedef enum asd_status {
   ASD_ERR_HIP = -3,         /* a HIP call or kernel failed                                */
   ASD_ERR_NO_WEIGHTS = -4,  /* asd_load_weights was not called                            */
   ASD_ERR_CAPACITY = -5,    /* input exceeds the capacity given at asd_ctx_create         */
-  ASD_ERR_NUMERIC = -6      /* solver breakdown (non positive definite system)            */
+  ASD_ERR_NUMERIC = -6,     /* solver breakdown (non positive definite system)            */
+  ASD_ERR_RANGE = -7        /* ASDNet (two-piece fp16 operand form): an activation left fp16's range, the
+                               descriptors of this call are not valid (see asd_asdnet_pieces)            */
 } asd_status;
 
 typedef struct asd_ctx asd_ctx;
@@ -520,8 +522,13 @@ int32_t asd_asdnet_split_mask(const asd_ctx* ctx);
 /* How the split-operand 3x3 conv kernels carry an f32 operand (chosen at asd_ctx_create by ASD_ASDNET_MATH):
  *   2  ("f16x2", the default; "split" is an alias)  x 2^k = h + l with two fp16 terms (22 significant bits), the three products
  *      l h, h l, h h accumulated in f32 on the f16 matrix pipe; against a float64 forward the descriptors are as close as those
- *      of the f32 MFMA chain (tests/test_asdnet.py).  Activations must stay below 4094 in magnitude (BatchNorm keeps them O(1));
- *      beyond that the descriptor comes out NaN, never silently wrong.
+ *      of the f32 MFMA chain (tests/test_asdnet.py).  Activations must stay below 4094 in magnitude (BatchNorm keeps them O(1)).
+ *      Two guards: asd_load_weights runs a calibration batch (64 synthetic patches: noise, edges, checkerboards, ramps, dots)
+ *      and, if any layer's largest activation leaves less than a factor two of headroom (> 2048), switches this context to
+ *      the three-piece form below (asd_asdnet_pieces then reports 3, asd_last_error says why); and a descriptor that comes out
+ *      non-finite at run time raises a device flag: asd_describe / asd_extract* / asd_extract_wait* return ASD_ERR_RANGE for
+ *      that call (asd_describe_device, which does not synchronise, reports it from the next asd_sync) -- the reference's f32
+ *      libtorch path (ORBextractor.cc:1127-1132) has no such failure mode, so it is an error here, never a silent NaN.
  *   3  ("bf16x3")  exact sum of three bf16 terms, six products; no range restriction; 1.35x the ASDNet time of the default. */
 int32_t asd_asdnet_pieces(const asd_ctx* ctx);
 /* Raw handles for harnesses that keep inputs resident (bench.py): the ctx stream

@@ -215,32 +215,44 @@ def test_operand_forms_accuracy(hip, hip_f32, hip_bf16x3, synth, asdnet_golden, 
 
 
 @pytest.mark.gpu
-def test_f16x2_range_is_loud(pkg, synth):
-    """f16x2 carries activations * 16 in fp16: an activation beyond 4094 cannot be represented.  The kernels do not clamp: the
-    descriptor of such a patch is NaN (visible), and bf16x3 / f32 handle the same weights."""
-    import os
+def test_f16x2_range_is_an_error_not_a_nan(pkg, synth, monkeypatch):
+    """f16x2 carries activations * 16 in fp16: an activation beyond 4094 cannot be represented.  Two guards (include/asd_slam.h,
+    asd_asdnet_pieces): asd_load_weights' calibration batch notices weights that drive a layer past 2048 and switches the context to
+    bf16x3 (no range limit, results finite); and with that guard switched off (ASD_ASDNET_CALIBRATE=0, test only) the forward raises
+    the device flag: asd_describe and asd_extract return ASD_ERR_RANGE instead of NaN descriptors with ASD_OK."""
     layers = [list(l) for l in synth.asdnet_weights(0)]
     w0, m0, v0 = layers[0]
     layers[0] = (np.asarray(w0) * np.float32(1e4), m0, v0)   # conv1 outputs ~1e4 x a normalised activation (BN variance left as is)
     patches = synth.random_patches(8, seed=5)
     ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
     try:
-        ctx.load_weights(layers)
         assert ctx.asdnet_pieces() == 2
-        assert np.isnan(ctx.describe(patches)).any()
+        ctx.load_weights(layers)
+        assert ctx.asdnet_pieces() == 3                      # the calibration fell back ...
+        assert "calibration" in ctx.last_error()             # ... and says so
+        assert np.isfinite(ctx.describe(patches)).all()
+        ctx.load_weights(synth.asdnet_weights(0))            # ordinary weights: a context that fell back stays on bf16x3, still correct
+        assert np.isfinite(ctx.describe(patches)).all()
     finally:
         ctx.close()
-    old = os.environ.get("ASD_ASDNET_MATH")
-    os.environ["ASD_ASDNET_MATH"] = "bf16x3"
+    # ordinary weights pass the calibration
+    ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
     try:
-        ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+        ctx.load_weights(synth.asdnet_weights(0))
+        assert ctx.asdnet_pieces() == 2
     finally:
-        if old is None:
-            del os.environ["ASD_ASDNET_MATH"]
-        else:
-            os.environ["ASD_ASDNET_MATH"] = old
+        ctx.close()
+    # the run-time flag, with the guard at load switched off
+    monkeypatch.setenv("ASD_ASDNET_CALIBRATE", "0")
+    ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
     try:
         ctx.load_weights(layers)
+        assert ctx.asdnet_pieces() == 2
+        with pytest.raises(Exception, match="range"):
+            ctx.describe(patches)
+        with pytest.raises(Exception, match="range"):
+            ctx.extract(synth.scene_frame(0, w=640, h=240))
+        ctx.load_weights(synth.asdnet_weights(0))            # the flag does not stick: the next call with sane weights is fine
         assert np.isfinite(ctx.describe(patches)).all()
     finally:
         ctx.close()

@@ -78,3 +78,26 @@ def test_replay_tool_matches_the_binding(tmp_path, pkg, synth):
     # identity pose: twc = -(Rwc * tcw) prints as -0.000000000 with the reference's `fixed` stream too (System.cc:529)
     assert len(traj) == n and [abs(float(v)) for v in traj[0].split()[1:]] == [0.0] * 6 + [1.0]
     assert all(len(v.split(".")[1]) == 9 for v in traj[0].split()[1:]) and len(traj[0].split()[0].split(".")[1]) == 6
+
+
+@pytest.mark.gpu
+def test_replay_chain_carries_the_metric(tmp_path, synth):
+    """asd_replay --chain: the metric's per-frame chain (extract, grid, both tracking stages, in-line LocalBA every --max_step_KF frames)
+    over an image sequence read from disk, reported as one JSON line with bench.py's keys."""
+    import json
+    n = 24
+    seq, cam, weights, _ = _write_sequence(tmp_path, synth, n)
+    p = subprocess.run([TOOL, seq, cam, weights, "--chain", "--max_step_KF", "5", "--warmup", "4"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    j = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["metric"].startswith("frames/sec end-to-end tracking+LocalBA") and j["unit"] == "frames/s"
+    assert j["steps"] == n - 4 and j["warmup"] == 4 and j["value"] > 10 and abs(j["value"] * j["ms_per_step"] - 1000.0) < 1.0
+    assert j["config"]["local_ba"].startswith("in line (reference order)") and j["config"]["kf_interval"] == 5
+    assert j["roofline"]["achieved"] > 0 and 0 < j["roofline"]["frac"] < 1
+    ls = j["last_step"]
+    assert ls["n_kp"] >= 2000 and ls["m1"] > 300 and ls["inliers"] > 300    # a 3 px drift is inside the 15 px windows of the identity prediction
