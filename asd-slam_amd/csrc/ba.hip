@@ -265,6 +265,57 @@ __device__ inline double nr_rsqrt(double x) {
   return r;
 }
 
+// symmetric 3x3 / 6x6 inverses by cofactors and one Schur complement (shared by PoseOptimization's 6x6 solve and the LocalBA dense solve)
+__device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double (&o)[6]) {
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  const double m2 = a * d - b * b;
+  const double id = nr_rcp(det);
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id; o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = m2 * id;
+  return a > 0 && m2 > 0 && det > 0;
+}
+// A: symmetric 6x6, lower triangle valid, row-major [6][6]; W: full inverse [6][6]
+__device__ inline bool inv6_sym(const double* A, double (&W)[36]) {
+  double Pi[6], Si[6];
+  bool ok = inv3_sym(A[0], A[6], A[12], A[7], A[13], A[14], Pi);
+  const double PiF[9] = {Pi[0], Pi[1], Pi[2], Pi[1], Pi[3], Pi[4], Pi[2], Pi[4], Pi[5]};
+  double Q[9], U[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Q[r * 3 + c] = A[(3 + r) * 6 + c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) U[r * 3 + c] = Q[r * 3] * PiF[c] + Q[r * 3 + 1] * PiF[3 + c] + Q[r * 3 + 2] * PiF[6 + c];
+  double S[6];   // (0,0) (1,0) (2,0) (1,1) (2,1) (2,2) of R - U Q^T
+  {
+    int q = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = c; r < 3; ++r) S[q++] = A[(3 + r) * 6 + 3 + c] - (U[r * 3] * Q[c * 3] + U[r * 3 + 1] * Q[c * 3 + 1] + U[r * 3 + 2] * Q[c * 3 + 2]);
+  }
+  ok = inv3_sym(S[0], S[1], S[2], S[3], S[4], S[5], Si) && ok;
+  const double SiF[9] = {Si[0], Si[1], Si[2], Si[1], Si[3], Si[4], Si[2], Si[4], Si[5]};
+  double W21[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) W21[r * 3 + c] = -(SiF[r * 3] * U[c] + SiF[r * 3 + 1] * U[3 + c] + SiF[r * 3 + 2] * U[6 + c]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      W[r * 6 + c] = PiF[r * 3 + c] - (U[r] * W21[c] + U[3 + r] * W21[3 + c] + U[6 + r] * W21[6 + c]);
+      W[(3 + r) * 6 + c] = W21[r * 3 + c];
+      W[c * 6 + 3 + r] = W21[r * 3 + c];
+      W[(3 + r) * 6 + 3 + c] = SiF[r * 3 + c];
+    }
+  return ok;
+}
+
+
 // Where the solver keeps its edges.  MODE 0: [6][n] doubles in global memory (problems that do not fit LDS); MODE 1: the same
 // in LDS (50 B / edge with the flags); MODE 2: the compact LDS form, 35 B / edge -- X, Y, Z as doubles, the observation as
 // two floats and the information value as an index into a <= 16-entry table.  The host picks MODE 2 when every observation
@@ -375,7 +426,16 @@ __device__ inline void pose_pass(const PoseOptArgs& a, const EdgeStore<MODE>& E,
   }
   const long long c1 = a.debug ? clock64() : 0;
   if (a.debug && (threadIdx.x & 63) == 0) S.wend[threadIdx.x >> 6] = c1 - c0;
-  block_reduce<29, kPoseWaves>(acc, S.red, S.sums);
+  // per-wave totals (reduce-scatter: lane l ends with the wave's total of value l >> 1) into S.red[wave][32]; the cross-wave sum is
+  // pose_sums_wave0's, behind ONE barrier
+  {
+    double w[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) w[k] = k < 29 ? acc[k] : 0.0;
+    const double tot = wave_reduce_scatter32(w);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((lane & 1) == 0) S.red[wave * 32 + (lane >> 1)] = tot;
+  }
   if (threadIdx.x == 0) {
     ++S.npass;
     if (a.debug) {
@@ -384,6 +444,17 @@ __device__ inline void pose_pass(const PoseOptArgs& a, const EdgeStore<MODE>& E,
       for (int w = 0; w < kPoseWaves; ++w) mx = S.wend[w] > mx ? S.wend[w] : mx;
       S.dbg[0] += mx;
     }
+  }
+}
+// wave 0, after the barrier behind pose_pass: S.sums[k] = sum over the waves in wave order (what block_reduce did behind a second
+// barrier).  The only readers in the Levenberg loop are this wave's own lanes, in program order behind these stores.
+__device__ inline void pose_sums_wave0(PoseShared& S) {
+  const int lane = threadIdx.x & 63;
+  if (lane < 29) {
+    double s = S.red[lane];
+#pragma unroll
+    for (int w2 = 1; w2 < kPoseWaves; ++w2) s += S.red[w2 * 32 + lane];  // fixed order
+    S.sums[lane] = s;
   }
 }
 
@@ -426,8 +497,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     ne = *a.n_dev;
   }
   if ((gather || a.n_dev) && ne < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
-    if (threadIdx.x < 7) a.io[threadIdx.x] = a.pose0[threadIdx.x];
-    if (threadIdx.x == 7) a.io[7] = 0.0;
+    if (threadIdx.x == 0) {   // (static indices: a run-time index into the kernel arguments makes the compiler keep a private copy in scratch)
+#pragma unroll
+      for (int q = 0; q < 7; ++q) a.io[q] = a.pose0[q];
+      a.io[7] = 0.0;
+    }
     return;
   }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
@@ -479,7 +553,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     }
     for (int i = t; i < ne; i += kPoseThreads) E.isgi[i] = a.isgi[i];
     }
-    if (t < 16) S.isg_tab[t] = a.isg_tab[t];
+    if (t == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) S.isg_tab[q] = a.isg_tab[q];
+    }
   } else {
     if constexpr (MODE == 1) {
       E.soa = dyn;
@@ -513,82 +590,117 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     if (t == 0) { S.T = S.T0; S.npass = 0; for (int q = 0; q < 4; ++q) { S.cyc[q] = 0; S.dbg[q] = 0; } }  // every round restarts from the input pose (Optimizer.cc:337)
     __syncthreads();
     pose_pass(a, E, lvl, S, robust);
+    __syncthreads();
+    if (t < 64) pose_sums_wave0(S);
+    __syncthreads();
     const bool any_active = S.sums[28] > 0.5;
     if (any_active) {
-      // ---- g2o optimize(10): Levenberg (optimization_algorithm_levenberg.cpp:61-189)
-      int nBadIt = 0;
-      if (t == 0) S.sys_valid = 1;
-      __syncthreads();
-      for (int it = 0; it < 10; ++it) {
-        if (!S.sys_valid) pose_pass(a, E, lvl, S, robust);  // only after a non-finite trial
-        if (t == 0) {
-          S.currentChi = S.sums[27];
-          S.iniChi = S.sums[27];
-          pose_take_system(S);
-          if (it == 0) {
-            double md = 0;
-            for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[j * 7]), md);
-            S.lambda = 1e-5 * md;
-            S.ni = 2;
-          }
-          S.qmax = 0;
-          S.rho = 0;
+      // ---- g2o optimize(10): Levenberg (optimization_algorithm_levenberg.cpp:61-189) as a state machine run by thread 0 between
+      // the passes.  Two barriers per pass: one publishes the pose the pass evaluates (and whether there is a pass at all), one
+      // collects the per-wave sums; the cross-wave sum, the accept / reject decision, the 6x6 solve and the pose update all happen
+      // in wave 0 between them (the first form had four barriers per pass and took the sums through LDS twice).
+      //   phase 1 = the pass evaluates a trial pose, 2 = it re-evaluates the current pose (after an iteration that ended on a
+      //   rejected trial: the sums no longer describe the current estimate), 0 = the round's optimisation is over
+      int nBadIt = 0, it = 0;
+      auto begin_iteration = [&]() {   // thread 0: the sums hold the system at the current estimate
+        S.currentChi = S.sums[27];
+        S.iniChi = S.sums[27];
+        pose_take_system(S);
+        if (it == 0) {
+          double md = 0;
+          for (int j = 0; j < 6; ++j) md = fmax(fabs(S.H[j * 7]), md);
+          S.lambda = 1e-5 * md;
+          S.ni = 2;
         }
+        S.qmax = 0;
+        S.rho = 0;
+      };
+      auto next_trial = [&]() {        // thread 0: solve (H + lambda I) x = b, T <- exp(x) T
+        const long long c0 = a.debug ? clock64() : 0;
+        S.Tbak = S.T;
+        double Hl[36], W[36], x[6];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) Hl[q] = S.H[q];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Hl[j * 7] += S.lambda;
+        const bool ok = inv6_sym(Hl, W);   // positive definite <=> the leading minors checked inside are positive (the dense LDLT of g2o fails otherwise)
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          double acc2 = 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) acc2 += W[r * 6 + c] * S.b[c];
+          x[r] = ok ? acc2 : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) S.x[r] = x[r];
+        S.ok = ok ? 1 : 0;
+        const long long c1 = a.debug ? clock64() : 0;
+        if (ok) S.T = pose_oplus(S.T, x);
+        S.cont = 1;
+        if (a.debug) { S.cyc[2] += clock64() - c0; S.dbg[1] += c1 - c0; }
+      };
+      if (t == 0) { begin_iteration(); next_trial(); }
+      for (;;) {
+        __syncthreads();               // S.T / S.cont of thread 0
+        const int phase = S.cont;
+        if (phase == 0) break;
+        pose_pass(a, E, lvl, S, robust);
         __syncthreads();
-        do {
+        if (t < 64) {
+          pose_sums_wave0(S);
           if (t == 0) {
             const long long c0 = a.debug ? clock64() : 0;
-            S.Tbak = S.T;
-            for (int j = 0; j < 6; ++j) S.x[j] = 0;
-            S.ok = chol6_solve(S.H, S.lambda, S.b, S.x) ? 1 : 0;
-            const long long c1 = a.debug ? clock64() : 0;
-            if (S.ok) S.T = pose_oplus(S.T, S.x);
-            if (a.debug) { S.cyc[2] += clock64() - c0; S.dbg[1] += c1 - c0; }
-          }
-          __syncthreads();
-          pose_pass(a, E, lvl, S, robust);
-          if (t == 0) {
-            const long long c0 = a.debug ? clock64() : 0;
-            double tempChi = S.sums[27];
-            if (!S.ok) tempChi = 1.7976931348623157e308;
-            double rho = S.currentChi - tempChi;
-            double scale = 0;
-            for (int j = 0; j < 6; ++j) scale += S.x[j] * (S.lambda * S.x[j] + S.b[j]);
-            scale += 1e-3;
-            rho /= scale;
-            if (rho > 0 && isfinite(tempChi)) {
-              const double q = 2 * rho - 1;
-              double alpha = 1. - q * q * q;
-              alpha = fmin(alpha, 2. / 3.);
-              S.lambda *= fmax(1. / 3., alpha);
-              S.ni = 2;
-              S.currentChi = tempChi;
-              S.sys_valid = 1;  // sums hold the system at the accepted estimate
-            } else {
-              S.lambda *= S.ni;
-              S.ni *= 2;
-              S.T = S.Tbak;
-              S.sys_valid = 0;
+            bool fresh_system = phase == 2;   // the pass was a plain evaluation at the current pose: start the next iteration from it
+            bool over = false;
+            if (phase == 1) {
+              double tempChi = S.sums[27];
+              if (!S.ok) tempChi = 1.7976931348623157e308;
+              double rho = S.currentChi - tempChi;
+              double scale = 0;
+              for (int j = 0; j < 6; ++j) scale += S.x[j] * (S.lambda * S.x[j] + S.b[j]);
+              scale += 1e-3;
+              rho /= scale;
+              bool accepted = false;
+              if (rho > 0 && isfinite(tempChi)) {
+                const double q = 2 * rho - 1;
+                double alpha = 1. - q * q * q;
+                alpha = fmin(alpha, 2. / 3.);
+                S.lambda *= fmax(1. / 3., alpha);
+                S.ni = 2;
+                S.currentChi = tempChi;
+                accepted = true;       // the sums hold the system at the accepted estimate
+              } else {
+                S.lambda *= S.ni;
+                S.ni *= 2;
+                S.T = S.Tbak;
+              }
+              S.rho = rho;
+              S.qmax++;
+              if (!(rho < 0 && S.qmax < 10)) {   // the iteration is over (levenberg.cpp:98-146)
+                bool stop = S.qmax == 10 || rho == 0;
+                if (!stop) {
+                  if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) nBadIt++; else nBadIt = 0;
+                  if (nBadIt >= 3) stop = true;
+                }
+                ++it;
+                if (stop || it >= 10) over = true;
+                else if (accepted) fresh_system = true;
+                else { S.cont = 2; over = false; fresh_system = false; }   // next: a plain pass at the restored pose
+                if (!over && !accepted) { if (a.debug) S.cyc[3] += clock64() - c0; goto published; }
+              }
             }
-            S.rho = rho;
-            S.qmax++;
-            S.cont = (rho < 0 && S.qmax < 10) ? 1 : 0;
             if (a.debug) S.cyc[3] += clock64() - c0;
+            if (over) S.cont = 0;
+            else {
+              if (fresh_system) begin_iteration();
+              next_trial();
+            }
+          published:;
           }
-          __syncthreads();
-        } while (S.cont);
-        if (t == 0) {
-          int stop = 0;
-          if (S.qmax == 10 || S.rho == 0) stop = 1;
-          else {
-            if ((S.iniChi - S.currentChi) * 1e3 < S.iniChi) nBadIt++; else nBadIt = 0;
-            if (nBadIt >= 3) stop = 1;
-          }
-          S.stop = stop;
         }
-        __syncthreads();
-        if (S.stop) break;
       }
+    } else {
+      __syncthreads();
     }
     // ---- re-classification (Optimizer.cc:341-368)
     double nb[1] = {0.0};
@@ -1129,55 +1241,6 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
 // one wave computes it from LDS, and the panel / trailing
 // update / both substitutions become 6-term dot products with no triangular dependency inside a block.
 // Positive definiteness (linear_solver_dense.h:96 fails on a non-positive LDLT pivot) is checked on the leading minors of P and S.
-__device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double (&o)[6]) {
-  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-  const double det = a * c00 + b * c01 + c * c02;
-  const double m2 = a * d - b * b;
-  const double id = nr_rcp(det);
-  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id; o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = m2 * id;
-  return a > 0 && m2 > 0 && det > 0;
-}
-// A: symmetric 6x6, lower triangle valid, row-major [6][6]; W: full inverse [6][6]
-__device__ inline bool inv6_sym(const double* A, double (&W)[36]) {
-  double Pi[6], Si[6];
-  bool ok = inv3_sym(A[0], A[6], A[12], A[7], A[13], A[14], Pi);
-  const double PiF[9] = {Pi[0], Pi[1], Pi[2], Pi[1], Pi[3], Pi[4], Pi[2], Pi[4], Pi[5]};
-  double Q[9], U[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Q[r * 3 + c] = A[(3 + r) * 6 + c];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) U[r * 3 + c] = Q[r * 3] * PiF[c] + Q[r * 3 + 1] * PiF[3 + c] + Q[r * 3 + 2] * PiF[6 + c];
-  double S[6];   // (0,0) (1,0) (2,0) (1,1) (2,1) (2,2) of R - U Q^T
-  {
-    int q = 0;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int r = c; r < 3; ++r) S[q++] = A[(3 + r) * 6 + 3 + c] - (U[r * 3] * Q[c * 3] + U[r * 3 + 1] * Q[c * 3 + 1] + U[r * 3 + 2] * Q[c * 3 + 2]);
-  }
-  ok = inv3_sym(S[0], S[1], S[2], S[3], S[4], S[5], Si) && ok;
-  const double SiF[9] = {Si[0], Si[1], Si[2], Si[1], Si[3], Si[4], Si[2], Si[4], Si[5]};
-  double W21[9];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) W21[r * 3 + c] = -(SiF[r * 3] * U[c] + SiF[r * 3 + 1] * U[3 + c] + SiF[r * 3 + 2] * U[6 + c]);
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      W[r * 6 + c] = PiF[r * 3 + c] - (U[r] * W21[c] + U[3 + r] * W21[3 + c] + U[6 + r] * W21[6 + c]);
-      W[(3 + r) * 6 + c] = W21[r * 3 + c];
-      W[c * 6 + 3 + r] = W21[r * 3 + c];
-      W[(3 + r) * 6 + 3 + c] = SiF[r * 3 + c];
-    }
-  return ok;
-}
-
 constexpr int kSolveThreads = 1024, kSolveMaxBlocks = 30;
 // Schedule of a step j (two barriers):
 //   [panel]   T_I = A_Ij W_j for I > j, one thread per ROW of a block (six independent dot products: the fp64 latency of one chain hides

@@ -68,11 +68,22 @@ ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
   if (theta < 0.00001) {  // se3quat.h:237-243 (kept as is: R = I + W + W^2, V = R)
     for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
   } else {
-    double sn, cs;
-    sincos(theta, &sn, &cs);
-    const double it = itheta, it2 = it * it;
-    const double a = sn * it, b = (1 - cs) * it2;
-    const double c = (theta - sn) * it2 * it;
+    // a = sin(t)/t, b = (1 - cos t)/t^2, c = (t - sin t)/t^3.  Levenberg steps are small rotations: below 0.1 rad the three series in
+    // t^2 (seven terms: truncation < 1e-19 relative) are shorter dependency chains than sincos + the divisions -- this runs on one lane
+    // between two passes of PoseOptimization -- and free of the cancellation of 1 - cos t and t - sin t; beyond: the closed forms.
+    double a, b, c;
+    if (theta2 < 0.01) {
+      const double u = theta2;
+      a = 1.0 + u * (-1.0 / 6 + u * (1.0 / 120 + u * (-1.0 / 5040 + u * (1.0 / 362880 + u * (-1.0 / 39916800 + u * (1.0 / 6227020800.0))))));
+      b = 0.5 + u * (-1.0 / 24 + u * (1.0 / 720 + u * (-1.0 / 40320 + u * (1.0 / 3628800 + u * (-1.0 / 479001600 + u * (1.0 / 87178291200.0))))));
+      c = 1.0 / 6 + u * (-1.0 / 120 + u * (1.0 / 5040 + u * (-1.0 / 362880 + u * (1.0 / 39916800 + u * (-1.0 / 6227020800.0 + u * (1.0 / 1307674368000.0))))));
+    } else {
+      double sn, cs;
+      sincos(theta, &sn, &cs);
+      const double it = itheta, it2 = it * it;
+      a = sn * it; b = (1 - cs) * it2;
+      c = (theta - sn) * it2 * it;
+    }
     for (int i = 0; i < 9; ++i) {
       const double I = (i % 4 == 0 ? 1.0 : 0.0);
       R[i] = I + a * O[i] + b * O2[i];
