@@ -861,6 +861,7 @@ struct BaDev {
   double* x;    // [6 nPf + 3 nLa]
   // dense system
   double* A;    // [n][n]
+  double* Apack; // the same system as the solve kernel keeps it: lower triangle by 6x6 blocks, block (I, J <= I) at (I (I + 1) / 2 + J) * 36
   double* bs;   // [n]
   LmState* lm;        // device
   LmState* lm_host;   // pinned mirror, written by k_ba_lm_control / k_ba_lm_begin
@@ -1041,37 +1042,61 @@ struct SchurBlocks {
   const int* pair_start;               // [nblk+1]
   const int2* pairs;
 };
-__global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb) {
-  __shared__ double red[4 * 64], out[42];
+// Latency, not arithmetic, sets this kernel's time (6 M fp64 FMAs chip-wide): a diagonal block has ~1200 pairs whose operands sit
+// behind two dependent gathers (pair -> edge indices -> 2 x 144 B).  Round 2's form -- 256 threads walking the list five deep, then
+// the same workgroup walking the pose's ck list -- took 24 us.  Now: 512 threads, two pairs in flight per thread (indices of both
+// first, then all four operand blocks), and the right-hand side sums bs = bp - sum ck in workgroups of their own ([nblk, nblk + nPf)).
+constexpr int kSchurThreads = 512;
+__global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BaDev d, SchurBlocks sb, int nblk) {
+  __shared__ double red[(kSchurThreads / 64) * 64], out[64];
   if (d.lm->done) return;
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x >= nblk) {   // right-hand side of one pose
+    const int h = blockIdx.x - nblk;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = d.ps_start[h] + t; i < d.ps_start[h + 1]; i += kSchurThreads) {
+      const double* cc = d.ck + (size_t)d.ps_edges[i] * 6;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc[r] += cc[r];
+    }
+    block_reduce<6, kSchurThreads / 64>(acc, red, out);
+    if (t < 6) d.bs[6 * h + t] = d.Hpp[(size_t)h * 27 + 21 + t] - out[t];
+    return;
+  }
   const double lambda = lm_lambda(d.lm);
   const int blk = blockIdx.x, bi = sb.blk_i[blk], bj = sb.blk_j[blk];
   const int n = 6 * d.nPf;
-  double acc[42];
+  double acc[36];
 #pragma unroll
-  for (int q = 0; q < 42; ++q) acc[q] = 0.0;
-  for (int p = sb.pair_start[blk] + threadIdx.x; p < sb.pair_start[blk + 1]; p += 256) {
-    const int2 pr = sb.pairs[p];
-    const double* Y = d.Yk + (size_t)pr.x * 18;
-    const double* B = d.Bk + (size_t)pr.y * 18;
-    double y[18], bb[18];
+  for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+  const int pend = sb.pair_start[blk + 1];
+  for (int p0 = sb.pair_start[blk] + t; p0 < pend; p0 += 2 * kSchurThreads) {
+    const int p1 = p0 + kSchurThreads;
+    const bool two = p1 < pend;
+    const int2 pr0 = sb.pairs[p0], pr1 = sb.pairs[two ? p1 : p0];
+    const double* Y0 = d.Yk + (size_t)pr0.x * 18;
+    const double* B0 = d.Bk + (size_t)pr0.y * 18;
+    const double* Y1 = d.Yk + (size_t)pr1.x * 18;
+    const double* B1 = d.Bk + (size_t)pr1.y * 18;
+    double y0[18], b0[18], y1[18], b1[18];
 #pragma unroll
-    for (int q = 0; q < 18; ++q) { y[q] = Y[q]; bb[q] = B[q]; }
+    for (int q = 0; q < 18; ++q) { y0[q] = Y0[q]; b0[q] = B0[q]; y1[q] = Y1[q]; b1[q] = B1[q]; }
+    if (!two) {
+#pragma unroll
+      for (int q = 0; q < 18; ++q) y1[q] = 0.0;   // the second slot of a lone pair adds exact zeros
+    }
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) acc[r * 6 + c] += y[r * 3] * bb[c * 3] + y[r * 3 + 1] * bb[c * 3 + 1] + y[r * 3 + 2] * bb[c * 3 + 2];
+      for (int c = 0; c < 6; ++c) {
+        acc[r * 6 + c] += y0[r * 3] * b0[c * 3] + y0[r * 3 + 1] * b0[c * 3 + 1] + y0[r * 3 + 2] * b0[c * 3 + 2];
+        acc[r * 6 + c] += y1[r * 3] * b1[c * 3] + y1[r * 3 + 1] * b1[c * 3 + 1] + y1[r * 3 + 2] * b1[c * 3 + 2];
+      }
   }
-  if (bi == bj)
-    for (int i = d.ps_start[bi] + threadIdx.x; i < d.ps_start[bi + 1]; i += 256) {
-      const double* cc = d.ck + (size_t)d.ps_edges[i] * 6;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) acc[36 + r] += cc[r];
-    }
-  block_reduce<42>(acc, red, out);
-  if (threadIdx.x < 36) {
-    const int r = threadIdx.x / 6, c = threadIdx.x % 6;
-    double v = -out[threadIdx.x];
+  block_reduce<36, kSchurThreads / 64>(acc, red, out);
+  if (t < 36) {
+    const int r = t / 6, c = t % 6;
+    double v = -out[t];
     if (bi == bj) {
       const int rr = min(r, c), cc = max(r, c);
       const int q = rr * 6 - rr * (rr - 1) / 2 + (cc - rr);  // index in the upper-packed 6x6
@@ -1079,9 +1104,7 @@ __global__ __launch_bounds__(256) void k_ba_schur(BaDev d, SchurBlocks sb) {
     }
     d.A[(size_t)(6 * bi + r) * n + 6 * bj + c] = v;
     if (bi != bj) d.A[(size_t)(6 * bj + c) * n + 6 * bi + r] = v;
-  } else if (threadIdx.x < 42 && bi == bj) {
-    const int r = threadIdx.x - 36;
-    d.bs[6 * bi + r] = d.Hpp[(size_t)bi * 27 + 21 + r] - out[threadIdx.x];
+    d.Apack[((size_t)bj * (bj + 1) / 2 + bi) * 36 + c * 6 + r] = v;   // lower block (bj, bi) = this upper block transposed
   }
 }
 
@@ -1274,11 +1297,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
     for (int J = 0; J <= I; ++J) tri[I * (I + 1) / 2 + J] = make_short2((short)I, (short)J);
   if (t == 0) ok = 1;
   __syncthreads();
-  for (int idx = t; idx < nblk * 36; idx += nt) {
-    const int blk = idx / 36, e = idx % 36;
-    const short2 ij = tri[blk];
-    L[idx] = A[(size_t)(6 * ij.x + e / 6) * n + 6 * ij.y + e % 6];
-  }
+  for (int idx = t; idx < nblk * 36; idx += nt) L[idx] = A[idx];   // A = the packed lower triangle (k_ba_schur writes it in this layout)
   for (int i = t; i < n; i += nt) xs[i] = bs[i];
   __syncthreads();
   if (wave == 0) {   // the first pivot block
@@ -1681,7 +1700,9 @@ struct DevBuf {
 
 struct BaState {
   DevBuf lvl, HppPart;
-  DevBuf out1;
+  DevBuf out1, Apack, sblk;   // sblk: the round's structure arrays in one block (uploaded from the pinned h_sblk)
+  char* h_sblk = nullptr;
+  size_t h_sblk_cap = 0;
   DevBuf pose, pose_bak, pts, pts_bak, e_pt, e_ps, obs, info, err, act, pose_h, pt_h, pose_of_h, pt_of_h, pt_start,
       ps_start, ps_edges, Bk, Hc, Hl, Yk, ck, Hpp, Hll, Dinv, db, x, A, bs, misc, partial, blk_i, blk_j, pair_start,
       pairs, chi2, dpos;
@@ -1741,12 +1762,13 @@ void ba_free(asd_ctx* ctx) {
   }
   DevBuf* all[] = {&s->pose, &s->pose_bak, &s->pts, &s->pts_bak, &s->e_pt, &s->e_ps, &s->obs, &s->info, &s->err, &s->act,
                    &s->pose_h, &s->pt_h, &s->pose_of_h, &s->pt_of_h, &s->pt_start, &s->ps_start, &s->ps_edges, &s->Bk,
-                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm, &s->lvl, &s->HppPart, &s->out1,
+                   &s->Hc, &s->Hl, &s->Yk, &s->ck, &s->Hpp, &s->Hll, &s->Dinv, &s->db, &s->x, &s->A, &s->bs, &s->misc, &s->lm, &s->lvl, &s->HppPart, &s->out1, &s->Apack, &s->sblk,
                    &s->partial, &s->blk_i, &s->blk_j, &s->pair_start, &s->pairs, &s->chi2, &s->dpos, &s->po_Xw,
                    &s->po_obs, &s->po_info, &s->po_err, &s->po_level, &s->po_outlier, &s->po_pose, &s->pc_n};
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (s->h_partial) (void)hipHostFree(s->h_partial);
   if (s->h_lm) (void)hipHostFree(s->h_lm);
+  if (s->h_sblk) (void)hipHostFree(s->h_sblk);
   if (s->h_po) (void)hipHostFree(s->h_po);
   delete s;
   ctx->ba = nullptr;
@@ -1932,7 +1954,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ENS(ps_start, (size_t)(P + 1) * 4); ENS(ps_edges, (size_t)E * 4);
   ENS(Bk, (size_t)E * 18 * 8); ENS(Hc, (size_t)E * 27 * 8); ENS(Hl, (size_t)E * 9 * 8); ENS(Yk, (size_t)E * 18 * 8);
   ENS(ck, (size_t)E * 6 * 8); ENS(Hpp, (size_t)P * 27 * 8); ENS(Hll, (size_t)L * 9 * 8); ENS(Dinv, (size_t)L * 6 * 8);
-  ENS(db, (size_t)L * 3 * 8); ENS(x, ((size_t)6 * P + 3 * L) * 8); ENS(A, (size_t)36 * P * P * 8); ENS(bs, (size_t)6 * P * 8);
+  ENS(db, (size_t)L * 3 * 8); ENS(x, ((size_t)6 * P + 3 * L) * 8); ENS(A, (size_t)36 * P * P * 8); ENS(Apack, (size_t)18 * P * (P + 1) * 8); ENS(bs, (size_t)6 * P * 8);
   ENS(misc, 64); ENS(chi2, (size_t)E * 8); ENS(dpos, (size_t)E); ENS(lvl, (size_t)E); ENS(out1, (size_t)E); ENS(HppPart, (size_t)P * kPoseSplit * 27 * 8);
   const int nblk_e = (E + 255) / 256, nblk_l = (L + 255) / 256, nblk_p = (P + 255) / 256;
   const size_t npartial = (size_t)nblk_e + nblk_l + nblk_p + 8;
@@ -1979,7 +2001,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   d.ps_start = s->ps_start.as<int>(); d.ps_edges = s->ps_edges.as<int>();
   d.Bk = s->Bk.as<double>(); d.Hc = s->Hc.as<double>(); d.Hl = s->Hl.as<double>(); d.Yk = s->Yk.as<double>();
   d.ck = s->ck.as<double>(); d.Hpp = s->Hpp.as<double>(); d.Hll = s->Hll.as<double>(); d.Dinv = s->Dinv.as<double>();
-  d.db = s->db.as<double>(); d.x = s->x.as<double>(); d.A = s->A.as<double>(); d.bs = s->bs.as<double>();
+  d.db = s->db.as<double>(); d.x = s->x.as<double>(); d.A = s->A.as<double>(); d.Apack = s->Apack.as<double>(); d.bs = s->bs.as<double>();
   // status and the per-workgroup partial sums are read by the host after every trial: the kernels store them straight into
   // pinned host memory (a few hundred doubles), which removes two copy commands per trial from the lane's queue
   // the Levenberg scalars and the per-workgroup partial sums they are made of stay on the device (k_ba_lm_control); the host sees
@@ -2002,6 +2024,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   // lost all its edges gets a zero step, and x + 0.0 == x, so every sum equals the sum over the compacted lists g2o would build --
   // without the second host pass over the edges and its uploads (0.45 ms per LocalBA).
   int nPf = 0, nLa = 0, Ea = 0, nblk = 0;
+  size_t n_pairs_total = 0;
+  SchurBlocks sb{};
   std::chrono::steady_clock::time_point t_prep;
   auto run_round = [&](int round_idx, int iterations, bool robust, double* chi_out, int* iters_out) -> int {
     const auto t_round = std::chrono::steady_clock::now();
@@ -2066,8 +2090,33 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     blk_i.resize(nblk_all); blk_j.resize(nblk_all);
     for (int i = 0, q = 0; i < nPf; ++i)
       for (int j = i; j < nPf; ++j, ++q) { blk_i[q] = i; blk_j[q] = j; }
-    pairs.resize(std::max(pair_start[nblk_all], 1));
+    // ONE pinned block, ONE upload for the whole structure (eleven copies out of pageable vectors cost ~0.2 ms of the 0.45 ms this
+    // pass took): the pair lists -- the largest array -- are written straight into it
+    nblk = nblk_all;
+    const size_t npairs = (size_t)std::max(pair_start[nblk_all], 1);
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_act = place((size_t)std::max(Ea, 1) * 4), o_pose_h = place((size_t)P * 4), o_pt_h = place((size_t)L * 4),
+                 o_pose_of_h = place((size_t)std::max(nPf, 1) * 4), o_pt_of_h = place((size_t)std::max(nLa, 1) * 4), o_pt_start = place((size_t)(nLa + 1) * 4),
+                 o_ps_start = place((size_t)(nPf + 1) * 4), o_ps_edges = place(ps_edges.size() * 4), o_blk_i = place((size_t)std::max(nblk, 1) * 4),
+                 o_blk_j = place((size_t)std::max(nblk, 1) * 4), o_pair_start = place((size_t)(nblk + 1) * 4), o_pairs = place(npairs * 8);
+    if ((r2 = s->sblk.ensure(ctx, off)) != ASD_OK) return r2;
+    if (s->h_sblk_cap < off) {
+      if (s->h_sblk) (void)hipHostFree(s->h_sblk);
+      s->h_sblk = nullptr; s->h_sblk_cap = 0;
+      ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_sblk), off + off / 4));
+      s->h_sblk_cap = off + off / 4;
+    }
+    char* hb = s->h_sblk;
+    auto put = [&](size_t o, const std::vector<int>& v) { if (!v.empty()) memcpy(hb + o, v.data(), v.size() * 4); };
+    put(o_act, act); put(o_pose_h, pose_h); put(o_pt_h, pt_h); put(o_pose_of_h, pose_of_h); put(o_pt_of_h, pt_of_h); put(o_pt_start, pt_start);
+    put(o_ps_start, ps_start); put(o_ps_edges, ps_edges); put(o_pair_start, pair_start);
     {
+      int* bi_ = reinterpret_cast<int*>(hb + o_blk_i);
+      int* bj_ = reinterpret_cast<int*>(hb + o_blk_j);
+      for (int i = 0, q = 0; i < nPf; ++i)
+        for (int j = i; j < nPf; ++j, ++q) { bi_[q] = i; bj_[q] = j; }
+      int2* pp = reinterpret_cast<int2*>(hb + o_pairs);
       cursor.assign(pair_start.begin(), pair_start.end() - 1);
       for (int h = 0; h < nLa; ++h) {
         const int s1 = pt_start[h + 1];
@@ -2075,27 +2124,22 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         while (a < s1 && ph_of_k[a] < 0) ++a;
         for (; a < s1; ++a) {
           const int ro = row_off[ph_of_k[a]];
-          for (int b = a; b < s1; ++b) pairs[cursor[ro + ph_of_k[b]]++] = make_int2(a, b);
+          for (int b = a; b < s1; ++b) pp[cursor[ro + ph_of_k[b]]++] = make_int2(a, b);
         }
       }
     }
-    nblk = (int)blk_i.size();
-    if ((r2 = s->blk_i.ensure(ctx, (size_t)std::max(nblk, 1) * 4)) || (r2 = s->blk_j.ensure(ctx, (size_t)std::max(nblk, 1) * 4)) ||
-        (r2 = s->pair_start.ensure(ctx, (size_t)(nblk + 1) * 4)) || (r2 = s->pairs.ensure(ctx, pairs.size() * 8)))
-      return r2;
-#define UP(buf, vec) ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->buf.p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, st))
-    if (Ea > 0) UP(act, act);
-    UP(pose_h, pose_h); UP(pt_h, pt_h);
-    if (nPf > 0) UP(pose_of_h, pose_of_h);
-    if (nLa > 0) UP(pt_of_h, pt_of_h);
-    UP(pt_start, pt_start); UP(ps_start, ps_start); UP(ps_edges, ps_edges);
-    if (nblk > 0) { UP(blk_i, blk_i); UP(blk_j, blk_j); }
-    UP(pair_start, pair_start); UP(pairs, pairs);
-#undef UP
+    n_pairs_total = npairs;
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->sblk.p, hb, off, hipMemcpyHostToDevice, st));
+    char* db = s->sblk.as<char>();
+    d.act = reinterpret_cast<const int*>(db + o_act); d.pose_h = reinterpret_cast<const int*>(db + o_pose_h); d.pt_h = reinterpret_cast<const int*>(db + o_pt_h);
+    d.pose_of_h = reinterpret_cast<const int*>(db + o_pose_of_h); d.pt_of_h = reinterpret_cast<const int*>(db + o_pt_of_h);
+    d.pt_start = reinterpret_cast<const int*>(db + o_pt_start); d.ps_start = reinterpret_cast<const int*>(db + o_ps_start);
+    d.ps_edges = reinterpret_cast<const int*>(db + o_ps_edges);
+    sb = SchurBlocks{reinterpret_cast<const int*>(db + o_blk_i), reinterpret_cast<const int*>(db + o_blk_j), reinterpret_cast<const int*>(db + o_pair_start),
+                     reinterpret_cast<const int2*>(db + o_pairs)};
     d.Ea = Ea; d.nPf = nPf; d.nLa = nLa;
     }   // round_idx == 0
     t_prep = std::chrono::steady_clock::now();
-    SchurBlocks sb{s->blk_i.as<int>(), s->blk_j.as<int>(), s->pair_start.as<int>(), s->pairs.as<int2>()};
     *iters_out = 0;
     *chi_out = 0;
     if (Ea == 0) return ASD_OK;
@@ -2114,7 +2158,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
       if (nPf > 0) hipLaunchKernelGGL(k_ba_reduce_pose2, dim3(nPf), dim3(64), 0, st, d);
       if (nPf > 0) {
         hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_ba_schur, dim3(nblk), dim3(256), 0, st, d, sb);
+        hipLaunchKernelGGL(k_ba_schur, dim3(nblk + nPf), dim3(kSchurThreads), 0, st, d, sb, nblk);
         const size_t nbk = (size_t)(nPf * (nPf + 1) / 2);
         static AsdPerDeviceOnce attr_set;   // the dynamic-LDS attribute is per device
         if (attr_set.need(ctx->cfg.device)) {
@@ -2125,7 +2169,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         static const bool old_chol = getenv("ASD_BA_CHOL") != nullptr;   // A/B: the round-2 Cholesky kernel
         if (nPf <= kSolveMaxBlocks && !old_chol) {
           const size_t lds = (nbk * 36 + (size_t)2 * (kSolveMaxBlocks - 1) * 36 + 192 + 72 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
-          hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(kSolveThreads), lds, st, d.A, d.bs, d.x, n, d.lm);
+          hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(kSolveThreads), lds, st, d.Apack, d.bs, d.x, n, d.lm);
         } else if (nPf <= 32) {
           const size_t lds = nbk * 36 * sizeof(double) + (2 * 192 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
           hipLaunchKernelGGL(k_ba_chol_lds, dim3(1), dim3(kCholThreads), lds, st, d.A, d.bs, d.x, n, d.lm);
@@ -2178,7 +2222,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     if (timing) {
       const auto t_end = std::chrono::steady_clock::now();
       fprintf(stderr, "[ba round] structure %.0f us (Ea=%d nPf=%d nLa=%d pairs=%zu), %d iterations / %d trials in %.0f us\n",
-              std::chrono::duration<double, std::micro>(t_prep - t_round).count(), Ea, nPf, nLa, pairs.size(), done, n_trials,
+              std::chrono::duration<double, std::micro>(t_prep - t_round).count(), Ea, nPf, nLa, n_pairs_total, done, n_trials,
               std::chrono::duration<double, std::micro>(t_end - t_prep).count());
     }
     return ASD_OK;
