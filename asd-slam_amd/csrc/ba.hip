@@ -265,56 +265,81 @@ __device__ inline double nr_rsqrt(double x) {
   return r;
 }
 
-// symmetric 3x3 / 6x6 inverses by cofactors and one Schur complement (shared by PoseOptimization's 6x6 solve and the LocalBA dense solve)
-__device__ inline bool inv3_sym(double a, double b, double c, double d, double e, double f, double (&o)[6]) {
-  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
-  const double det = a * c00 + b * c01 + c * c02;
-  const double m2 = a * d - b * b;
-  const double id = nr_rcp(det);
-  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id; o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = m2 * id;
-  return a > 0 && m2 > 0 && det > 0;
-}
-// A: symmetric 6x6, lower triangle valid, row-major [6][6]; W: full inverse [6][6]
+// Inverse of a symmetric positive definite 6x6 (PoseOptimization's normal equations, the pivot blocks of the LocalBA solve).  It runs
+// on one wave between two barriers and is a chain of DEPENDENT fp64 instructions (~40 cycles a link), so what counts is the length of
+// that chain, not the flop count.  With A = [[P, Q^T], [Q, R]] (3x3 blocks), C = adj(P), dP = det(P):
+//   U' = Q C,  S' = dP R - U' Q^T  (= dP x the Schur complement),  C' = adj(S'),  dS' = det(S'),  G = C' U'
+//   W22 = (dP / dS') C',   W21 = -G / dS',   W11 = C / dP + U'^T G / (dP dS')
+// i.e. nothing waits for a quotient: the two reciprocals (1 / dP, 1 / dS': seed + two Newton steps each) run beside the 3x3 products,
+// ~22 links where inverting P, forming the Schur complement and inverting it one after the other has ~37 (and a Cholesky with
+// forward / backward substitution ~90).  The block is first scaled by the power of two that brings its largest diagonal entry to
+// [1, 2): the products of cofactors reach the twelfth power of the entries' magnitude (exact scaling: the result is bit for bit
+// what the unscaled formulas give where those do not overflow).  Positive definiteness <=> the leading minors of P and of S' are
+// positive (g2o's dense LDLT fails on a non-positive pivot, linear_solver_dense.h:96).
+// A: lower triangle valid, row-major [6][6]; W: full inverse [6][6]
 __device__ inline bool inv6_sym(const double* A, double (&W)[36]) {
-  double Pi[6], Si[6];
-  bool ok = inv3_sym(A[0], A[6], A[12], A[7], A[13], A[14], Pi);
-  const double PiF[9] = {Pi[0], Pi[1], Pi[2], Pi[1], Pi[3], Pi[4], Pi[2], Pi[4], Pi[5]};
-  double Q[9], U[9];
+  const double dmax = fmax(fmax(fmax(A[0], A[7]), fmax(A[14], A[21])), fmax(A[28], A[35]));
+  // 2^-floor(log2 dmax) from the exponent field (dmax > 0 for anything positive definite; otherwise the minors below say no)
+  const int ex = (int)((__double_as_longlong(dmax) >> 52) & 0x7ff);
+  const double sc = __longlong_as_double((long long)(2046 - ex) << 52);
+  const bool sane = dmax > 0 && ex > 0 && ex < 2046;
+  const double p00 = A[0] * sc, p10 = A[6] * sc, p20 = A[12] * sc, p11 = A[7] * sc, p21 = A[13] * sc, p22 = A[14] * sc;
+  double Q[9], R[6];   // R: (0,0) (1,0) (2,0) (1,1) (2,1) (2,2)
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Q[r * 3 + c] = A[(3 + r) * 6 + c];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) U[r * 3 + c] = Q[r * 3] * PiF[c] + Q[r * 3 + 1] * PiF[3 + c] + Q[r * 3 + 2] * PiF[6 + c];
-  double S[6];   // (0,0) (1,0) (2,0) (1,1) (2,1) (2,2) of R - U Q^T
+    for (int c = 0; c < 3; ++c) Q[r * 3 + c] = A[(3 + r) * 6 + c] * sc;
   {
     int q = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = c; r < 3; ++r) S[q++] = A[(3 + r) * 6 + 3 + c] - (U[r * 3] * Q[c * 3] + U[r * 3 + 1] * Q[c * 3 + 1] + U[r * 3 + 2] * Q[c * 3 + 2]);
+      for (int r = c; r < 3; ++r) R[q++] = A[(3 + r) * 6 + 3 + c] * sc;
   }
-  ok = inv3_sym(S[0], S[1], S[2], S[3], S[4], S[5], Si) && ok;
-  const double SiF[9] = {Si[0], Si[1], Si[2], Si[1], Si[3], Si[4], Si[2], Si[4], Si[5]};
-  double W21[9];
+  // C = adj(P) (symmetric), dP
+  const double c00 = p11 * p22 - p21 * p21, c01 = p20 * p21 - p10 * p22, c02 = p10 * p21 - p20 * p11;
+  const double c11 = p00 * p22 - p20 * p20, c12 = p10 * p20 - p00 * p21, c22 = p00 * p11 - p10 * p10;
+  const double dP = p00 * c00 + p10 * c01 + p20 * c02;
+  const double r1 = nr_rcp(dP);
+  const double CF[9] = {c00, c01, c02, c01, c11, c12, c02, c12, c22};
+  double U[9];   // U' = Q C
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) W21[r * 3 + c] = -(SiF[r * 3] * U[c] + SiF[r * 3 + 1] * U[3 + c] + SiF[r * 3 + 2] * U[6 + c]);
+    for (int c = 0; c < 3; ++c) U[r * 3 + c] = Q[r * 3] * CF[c] + Q[r * 3 + 1] * CF[3 + c] + Q[r * 3 + 2] * CF[6 + c];
+  double S[6];   // S' = dP R - U' Q^T: (0,0) (1,0) (2,0) (1,1) (2,1) (2,2)
+  {
+    int q = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = c; r < 3; ++r) { S[q] = dP * R[q] - (U[r * 3] * Q[c * 3] + U[r * 3 + 1] * Q[c * 3 + 1] + U[r * 3 + 2] * Q[c * 3 + 2]); ++q; }
+  }
+  const double s00 = S[0], s10 = S[1], s20 = S[2], s11 = S[3], s21 = S[4], s22 = S[5];
+  const double e00 = s11 * s22 - s21 * s21, e01 = s20 * s21 - s10 * s22, e02 = s10 * s21 - s20 * s11;
+  const double e11 = s00 * s22 - s20 * s20, e12 = s10 * s20 - s00 * s21, e22 = s00 * s11 - s10 * s10;
+  const double dS = s00 * e00 + s10 * e01 + s20 * e02;
+  const double r2 = nr_rcp(dS);
+  const double EF[9] = {e00, e01, e02, e01, e11, e12, e02, e12, e22};
+  double G[9];   // G = C' U'
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G[r * 3 + c] = EF[r * 3] * U[c] + EF[r * 3 + 1] * U[3 + c] + EF[r * 3 + 2] * U[6 + c];
+  const double k22 = dP * r2 * sc, k21 = -r2 * sc, k11a = r1 * sc, k11b = r1 * r2 * sc;   // (the input scale goes back in here)
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      W[r * 6 + c] = PiF[r * 3 + c] - (U[r] * W21[c] + U[3 + r] * W21[3 + c] + U[6 + r] * W21[6 + c]);
-      W[(3 + r) * 6 + c] = W21[r * 3 + c];
-      W[c * 6 + 3 + r] = W21[r * 3 + c];
-      W[(3 + r) * 6 + 3 + c] = SiF[r * 3 + c];
+      const double utg = U[r] * G[c] + U[3 + r] * G[3 + c] + U[6 + r] * G[6 + c];   // (U'^T G)[r][c]
+      W[r * 6 + c] = CF[r * 3 + c] * k11a + utg * k11b;
+      const double w21 = G[r * 3 + c] * k21;
+      W[(3 + r) * 6 + c] = w21;
+      W[c * 6 + 3 + r] = w21;
+      W[(3 + r) * 6 + 3 + c] = EF[r * 3 + c] * k22;
     }
-  return ok;
+  return sane && p00 > 0 && c22 > 0 && dP > 0 && s00 > 0 && e22 > 0 && dS > 0;
 }
-
 
 // Where the solver keeps its edges.  MODE 0: [6][n] doubles in global memory (problems that do not fit LDS); MODE 1: the same
 // in LDS (50 B / edge with the flags); MODE 2: the compact LDS form, 35 B / edge -- X, Y, Z as doubles, the observation as
@@ -659,7 +684,8 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
               double scale = 0;
               for (int j = 0; j < 6; ++j) scale += S.x[j] * (S.lambda * S.x[j] + S.b[j]);
               scale += 1e-3;
-              rho /= scale;
+              rho *= nr_rcp(scale);    // (the IEEE division is ~15 dependent instructions on this one lane; rho's sign, its zero and the
+                                       //  gain-ratio formula below are unaffected by the last ulp)
               bool accepted = false;
               if (rho > 0 && isfinite(tempChi)) {
                 const double q = 2 * rho - 1;

@@ -54,44 +54,15 @@ ASD_HD void pose_map(const Pose7& T, const double X[3], double out[3]) {  // SE3
   out[0] += T.tx; out[1] += T.ty; out[2] += T.tz;
 }
 
-// VertexSE3Expmap::oplusImpl: T <- SE3Quat::exp(u) * T, u = (omega, upsilon)
-ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
-  const double wx = u[0], wy = u[1], wz = u[2];
-  const double theta2 = wx * wx + wy * wy + wz * wz;
-  const double itheta = theta2 > 0 ? asd_rsqrt(theta2) : 0.0;
-  const double theta = theta2 * itheta;
-  const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-  double O2[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
-  double R[9], V[9];
-  if (theta < 0.00001) {  // se3quat.h:237-243 (kept as is: R = I + W + W^2, V = R)
-    for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
-  } else {
-    // a = sin(t)/t, b = (1 - cos t)/t^2, c = (t - sin t)/t^3.  Levenberg steps are small rotations: below 0.1 rad the three series in
-    // t^2 (seven terms: truncation < 1e-19 relative) are shorter dependency chains than sincos + the divisions -- this runs on one lane
-    // between two passes of PoseOptimization -- and free of the cancellation of 1 - cos t and t - sin t; beyond: the closed forms.
-    double a, b, c;
-    if (theta2 < 0.01) {
-      const double u = theta2;
-      a = 1.0 + u * (-1.0 / 6 + u * (1.0 / 120 + u * (-1.0 / 5040 + u * (1.0 / 362880 + u * (-1.0 / 39916800 + u * (1.0 / 6227020800.0))))));
-      b = 0.5 + u * (-1.0 / 24 + u * (1.0 / 720 + u * (-1.0 / 40320 + u * (1.0 / 3628800 + u * (-1.0 / 479001600 + u * (1.0 / 87178291200.0))))));
-      c = 1.0 / 6 + u * (-1.0 / 120 + u * (1.0 / 5040 + u * (-1.0 / 362880 + u * (1.0 / 39916800 + u * (-1.0 / 6227020800.0 + u * (1.0 / 1307674368000.0))))));
-    } else {
-      double sn, cs;
-      sincos(theta, &sn, &cs);
-      const double it = itheta, it2 = it * it;
-      a = sn * it; b = (1 - cs) * it2;
-      c = (theta - sn) * it2 * it;
-    }
-    for (int i = 0; i < 9; ++i) {
-      const double I = (i % 4 == 0 ? 1.0 : 0.0);
-      R[i] = I + a * O[i] + b * O2[i];
-      V[i] = I + b * O[i] + c * O2[i];
-    }
-  }
-  // Quaterniond(R)
-  double ex, ey, ez, ew;
+// VertexSE3Expmap::oplusImpl: T <- SE3Quat::exp(u) * T, u = (omega, upsilon)   (se3quat.h:223-257, types_six_dof_expmap.h:94-97)
+// This runs on ONE lane between two passes of PoseOptimization, so it is written for a short chain of dependent fp64 instructions:
+//  * theta < 1e-5 (the reference's small-angle branch, kept as is: R = I + W + W^2, V = R, then Quaterniond(R)) -- no 1/theta needed;
+//  * theta < 0.1: everything as series in theta^2 (seven terms: truncation < 1e-19 relative): the rotation's quaternion directly as
+//    (omega sin(theta/2)/theta, cos(theta/2)) -- the same rotation the reference reaches through R = I + a W + b W^2 and
+//    Quaterniond(R), without the trace / square root / normalisation chain and without the cancellation of 1 - cos theta -- and
+//    V = I + b W + c W^2 with b = (1 - cos t)/t^2, c = (t - sin t)/t^3;
+//  * beyond: the closed forms through sincos, as the reference.
+ASD_HD void rot_to_quat_eigen(const double R[9], double& ex, double& ey, double& ez, double& ew) {   // Eigen::Quaterniond(Matrix3d)
   const double tr = R[0] + R[4] + R[8];
   if (tr > 0) {
     const double rs = asd_rsqrt(tr + 1.0);
@@ -118,7 +89,47 @@ ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
       ew = (R[3] - R[1]) * s; ex = (R[2] + R[6]) * s; ey = (R[5] + R[7]) * s;
     }
   }
-  quat_normalize(ex, ey, ez, ew);
+}
+
+ASD_HD Pose7 pose_oplus(const Pose7& T, const double u[6]) {
+  const double wx = u[0], wy = u[1], wz = u[2];
+  const double theta2 = wx * wx + wy * wy + wz * wz;
+  const double O[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double O2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) O2[i * 3 + j] = O[i * 3] * O[j] + O[i * 3 + 1] * O[3 + j] + O[i * 3 + 2] * O[6 + j];
+  double V[9];
+  double ex, ey, ez, ew;
+  if (theta2 < 1e-10) {  // theta < 0.00001, se3quat.h:237-243 (kept as is: R = I + W + W^2, V = R)
+    double R[9];
+    for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    rot_to_quat_eigen(R, ex, ey, ez, ew);
+    quat_normalize(ex, ey, ez, ew);
+  } else if (theta2 < 0.01) {
+    const double q = theta2;
+    const double b = 0.5 + q * (-1.0 / 24 + q * (1.0 / 720 + q * (-1.0 / 40320 + q * (1.0 / 3628800 + q * (-1.0 / 479001600 + q * (1.0 / 87178291200.0))))));
+    const double c = 1.0 / 6 + q * (-1.0 / 120 + q * (1.0 / 5040 + q * (-1.0 / 362880 + q * (1.0 / 39916800 + q * (-1.0 / 6227020800.0 + q * (1.0 / 1307674368000.0))))));
+    const double sh = 0.5 + q * (-1.0 / 48 + q * (1.0 / 3840 + q * (-1.0 / 645120 + q * (1.0 / 185794560 + q * (-1.0 / 81749606400.0 + q * (1.0 / 51011754393600.0))))));
+    const double ch = 1.0 + q * (-1.0 / 8 + q * (1.0 / 384 + q * (-1.0 / 46080 + q * (1.0 / 10321920 + q * (-1.0 / 3715891200.0 + q * (1.0 / 1961990553600.0))))));
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * O[i] + c * O2[i];
+    ex = wx * sh; ey = wy * sh; ez = wz * sh; ew = ch;   // unit up to rounding (ch > 0: the sign convention of normalizeRotation holds)
+  } else {
+    const double itheta = asd_rsqrt(theta2);
+    const double theta = theta2 * itheta;
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    const double it2 = itheta * itheta;
+    const double a = sn * itheta, b = (1 - cs) * it2;
+    const double c = (theta - sn) * it2 * itheta;
+    double R[9];
+    for (int i = 0; i < 9; ++i) {
+      const double I = (i % 4 == 0 ? 1.0 : 0.0);
+      R[i] = I + a * O[i] + b * O2[i];
+      V[i] = I + b * O[i] + c * O2[i];
+    }
+    rot_to_quat_eigen(R, ex, ey, ez, ew);
+    quat_normalize(ex, ey, ez, ew);
+  }
   const double et[3] = {V[0] * u[3] + V[1] * u[4] + V[2] * u[5], V[3] * u[3] + V[4] * u[4] + V[5] * u[5],
                         V[6] * u[3] + V[7] * u[4] + V[8] * u[5]};
   const double tt[3] = {T.tx, T.ty, T.tz};
