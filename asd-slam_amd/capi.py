@@ -164,6 +164,13 @@ class AsdHip:
         self._chk(self.lib.asd_describe_timed(self.ctx, d_patches, n, d_desc, reps, C.byref(ms)))
         return ms.value
 
+    def debug_act6(self, n):
+        """test aid: conv6's output of the most recent forward, first n patches, f32 [n, 64, 128]"""
+        out = np.empty((n, 64, 128), np.float32)
+        self.lib.asd_debug_act6.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.lib.asd_debug_act6(self.ctx, n, _p(out)))
+        return out
+
     def describe_device(self, d_patches, n, d_desc):
         self._chk(self.lib.asd_describe_device(self.ctx, d_patches, n, d_desc))
 

@@ -551,6 +551,26 @@ __device__ inline void split8_f16(const f32x4& v0, const f32x4& v1, float scale,
   pl = __builtin_bit_cast(u32x4, l);
 }
 
+// Two-piece fp16 split of four f32 values x times the power of two s (an accumulator sub-tile's four couts of one pixel), packed as
+// the MFMA operands want them: h = (fp16(s x0), fp16(s x1)), (fp16(s x2), fp16(s x3)); l = the fp16 of (s x - h), the difference formed
+// unrounded inside the fma and rounded once -- the values split8_f16 produces, in 8 instructions (the compiler's code for the scalar
+// expression converts every h twice).  v_fma_mixhi_f16 keeps the low half of its destination; a VALU result written with a
+// destination half-select needs one wait state before a VALU reads it on gfx940-class chips, which the interleaved order provides
+// (the closing s_nop covers whatever the compiler schedules next).
+__device__ __forceinline__ void split4_mix(float x0, float x1, float x2, float x3, float s, uint32_t (&h)[2], uint32_t (&l)[2]) {
+  asm("v_fma_mixlo_f16 %0, %8, %4, 0\n\t"
+      "v_fma_mixlo_f16 %1, %8, %6, 0\n\t"
+      "v_fma_mixhi_f16 %0, %8, %5, 0\n\t"
+      "v_fma_mixhi_f16 %1, %8, %7, 0\n\t"
+      "v_fma_mixlo_f16 %2, %8, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %8, %6, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %8, %5, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %8, %7, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(h[0]), "=&v"(h[1]), "=&v"(l[0]), "=&v"(l[1])
+      : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(s));
+}
+
 // ---- tile queue + CU reservation in software ----------------------------------------------------------------------------
 // The tracking stream's single-workgroup kernels (k_pose_opt, k_resolve: 50-100 KB of LDS, latency-bound) run 20-30 % slower when
 // they share their CU with ASDNet workgroups, and wait for a CU with room when ASDNet has filled the chip.  Rounds 1-2 kept 32 CUs
@@ -607,7 +627,13 @@ __device__ inline int tile_next(const TileQueue& q, int* slot) {
   return *slot;
 }
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
+// PAIR (two-piece form only): activations travel between the layers as the fp16 pieces themselves -- per pixel and group of eight
+// channels 16 B of h then 16 B of l, [pixel][c/8][h | l][8], the pieces of kActScale * x: the LDS band's own layout and the same
+// 4 B per element as f32.  The producer's epilogue splits each value once (split4_mix); a consumer stages its band with plain 16-B
+// copies instead of splitting every value of band and halo again on the vector ALU.  Identical pieces, identical products: the
+// descriptors are bit-identical to the f32-activation form (tests/test_asdnet.py::test_pair_format_is_bit_identical).  The
+// accumulators are kept transposed for it (weights as the MFMA's row operand): a lane then owns four consecutive couts of one pixel.
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3, bool PAIR = false>
 __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
@@ -616,6 +642,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   // accumulators are multiplied by out_scale = 1 / (in_scale * the layer's weight scale) in the epilogue (powers of two: exact)
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   constexpr int NTH = C::NTH, MT = C::MT, NT = C::NT;
+  static_assert(!PAIR || (NP == 2 && ASD_X3_S16), "the pair format belongs to the two-piece form on the 16x16x32 shape");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_b[];
   // Inside the persistent launch this body is a loop body.  Everything below that depends only on the lane (operand offsets, the
   // weight stream's addresses) is loop invariant, and hoisted out of the tile loop it stays live across the whole body: 93 -> 240
@@ -628,6 +655,9 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   constexpr int BANDS = C::HO / ROWS;
   const int patch = (bid / BANDS) * PP, band = bid % BANDS;
   const int r0 = band * ROWS;
+  unsigned long long st_t0 = 0, st_t1 = 0;   // diagnostic stamps (stamps == nullptr in every product launch)
+  if (stamps) st_t0 = st_t1 = __builtin_amdgcn_s_memtime();
+#define X3_STAMP(k) do { if (stamps && t == 0) stamps[16 * bid + (k)] = __builtin_amdgcn_s_memtime() - st_t0; } while (0)
 
   // MFMA shape: 32x32x16 -> lane = (k-half h, row/col li of 32), one sub-tile per 32x32 tile; 16x16x32 -> lane = (k-group of
   // four, row/col of 16), SUB = 2 sub-tiles per tile side
@@ -679,6 +709,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(x[k]));
     float sum = (x[0] + x[1]) + (x[2] + x[3]);
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    X3_STAMP(9);
     if (lane == 0 && ld) red[wave] = sum;
     __syncthreads();
     const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
@@ -695,6 +726,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
         for (int k = 0; k < 4; ++k) pin[j * 36 + x0 + k + 1] = d[k] / sd;
     }
     __syncthreads();
+    if (stamps) st_t1 = __builtin_amdgcn_s_memtime();
     // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding).
     // item = (pixel, octet of 8 couts); a thread keeps its octet and holds its 72 weights + 8 biases in registers.
     // Same f32 operation order per output as K1 (bias, then the nine taps in order)
@@ -743,6 +775,41 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
         }
       }
     }
+  } else if constexpr (PAIR) {
+    // the band is a copy: item = (pixel, group of eight channels) = 32 B of pieces; pixels outside the map are zeros
+    const uint8_t* inb = static_cast<const uint8_t*>(in_) + (size_t)patch * HIN * HIN * CIN * 4;
+    constexpr int C8 = CIN / 8;
+    constexpr int NPIXB = C::INROWS * C::INCOLS;
+    static_assert(NTH % C8 == 0, "a thread keeps its channel group");
+    constexpr int PSTEP = NTH / C8;
+    constexpr int NROUND = (PP * NPIXB + PSTEP - 1) / PSTEP;
+    constexpr int SBATCH = 8;
+    const int c8 = t % C8, pix0 = t / C8;
+    for (int rb = 0; rb < ((ASD_X3_ABL & 2) ? 0 : NROUND); rb += SBATCH) {
+      u32x4 v0[SBATCH], v1[SBATCH];
+#pragma unroll
+      for (int b = 0; b < SBATCH; ++b) {
+        const int pixg = pix0 + (rb + b) * PSTEP;
+        const int pp = pixg / NPIXB, pix = pixg % NPIXB;
+        const int i = pix % C::INCOLS, j = pix / C::INCOLS;
+        const int iy = r0 * S - 1 + j, ix = i - 1;
+        v0[b] = u32x4{0, 0, 0, 0}; v1[b] = u32x4{0, 0, 0, 0};
+        if (rb + b < NROUND && pixg < PP * NPIXB && iy >= 0 && iy < HIN && ix >= 0 && ix < HIN && patch + pp < n) {
+          const uint8_t* src = inb + ((size_t)pp * HIN * HIN * CIN + ((size_t)iy * HIN + ix) * CIN + c8 * 8) * 4;
+          v0[b] = *reinterpret_cast<const u32x4*>(src);
+          v1[b] = *reinterpret_cast<const u32x4*>(src + 16);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < SBATCH; ++b) {
+        const int pixg = pix0 + (rb + b) * PSTEP;
+        if (rb + b < NROUND && pixg < PP * NPIXB) {
+          uint8_t* dst = smem_b + (pixg / NPIXB) * C::ACT_BYTES + (pixg % NPIXB) * C::PIXB + c8 * C::GRPB;
+          *reinterpret_cast<u32x4*>(dst) = v0[b];
+          *reinterpret_cast<u32x4*>(dst + 16) = v1[b];
+        }
+      }
+    }
   } else
   {
     const float* inp = static_cast<const float*>(in_) + (size_t)patch * HIN * HIN * CIN;
@@ -788,7 +855,9 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
       }
     }
   }
+  X3_STAMP(12);
   __syncthreads();
+  X3_STAMP(13);
 
   // accumulators: [A sub-tile][B sub-tile]; a sub-tile is 32x32 (16 floats per lane) or 16x16 (4 floats per lane)
   constexpr int NA = MT * SUB, AR = S16 ? 4 : 16;
@@ -816,6 +885,10 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   auto hf = [](const u32x4& v) { return __builtin_bit_cast(f16x8, v); };
   auto mma = [&](const u32x4& x, const u32x4& y, accv& c) {
     if constexpr ((ASD_X3_ABL & 8) != 0) { asm volatile("" ::"v"(x), "v"(y)); }  // tuning: operands fetched, no MFMA
+#ifdef ASD_PAIR_NOTRANS   // timing experiment only (results are wrong): the pair epilogue behind untransposed accumulators
+    else if constexpr (PAIR) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(x), hf(y), c, 0, 0, 0);
+#endif
+    else if constexpr (PAIR) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(y), hf(x), c, 0, 0, 0);   // transposed: rows = couts, columns = pixels
     else if constexpr (NP == 2 && S16) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(x), hf(y), c, 0, 0, 0);
     else if constexpr (NP == 2) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(hf(x), hf(y), c, 0, 0, 0);
     else if constexpr (S16) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(x), bf(y), c, 0, 0, 0);
@@ -877,10 +950,37 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   if (stamps) {
     asm volatile("s_nop 0" ::"v"(acc[NA - 1][NB - 1][0]));  // the last MFMA has retired before the closing stamp
     const unsigned long long e_c = __builtin_amdgcn_s_memtime(), e_r = __builtin_amdgcn_s_memrealtime();
-    if (t == 0) { stamps[2 * bid] = e_c - st_c; stamps[2 * bid + 1] = e_r - st_r; }
+    if (t == 0) { stamps[16 * bid] = e_c - st_c; stamps[16 * bid + 1] = e_r - st_r; stamps[16 * bid + 2] = st_t1 - st_t0; stamps[16 * bid + 3] = st_c - st_t1; stamps[16 * bid + 6] = st_t0; }
   }
   // ---- epilogue: bias (folded BN) + ReLU, NHWC f32 store.  Lane owns one cout column and AR pixel rows of each sub-tile
   // (32x32: rows (r & 3) + 8 (r >> 2) + 4 h; 16x16: rows 4 kg + r)
+  if constexpr (PAIR) {
+    // lane = (pixel lr of the sub-tile, couts 4 kg .. 4 kg + 3): bias, ReLU (a NaN passes), the split of kActScale * v, a swap with
+    // the neighbouring quarter-group and one 16-B store into [pixel][cout / 8][h | l][8]
+    uint8_t* opb = reinterpret_cast<uint8_t*>(out) + ((size_t)patch * C::HO + r0) * C::HO * COUT * 4;
+    for (int nb = 0; nb < NB; ++nb) {
+      const int co0 = wn * NT * 32 + nb * TW + 4 * kg;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co0);
+      for (int ma = 0; ma < NA; ++ma) {
+        const int m0 = wm * MT * 32 + ma * TW;
+        const int pp = PP > 1 ? m0 / C::M_PATCH : 0;
+        if (PP > 1 && patch + pp >= n) continue;
+        const int m = m0 + lr;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = acc[ma][nb][r] * out_scale + bv[r]; v[r] = x < 0.f ? 0.f : x; }
+        uint32_t hh[2], ll[2];
+        split4_mix(v[0], v[1], v[2], v[3], kActScale, hh, ll);
+        // v_permlane16_swap: the odd 16-lane rows of the first register trade places with the even rows of the second.  Lanes kg and
+        // kg ^ 1 hold the two halves of one group of eight couts; after the swap an even-kg lane holds the group's whole h piece
+        // (its own half, the partner's half), an odd-kg lane the whole l piece: one 16-B store per lane, 64 contiguous bytes per pixel
+        const auto s0 = __builtin_amdgcn_permlane16_swap(hh[0], ll[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(hh[1], ll[1], false, false);
+        uint8_t* o = opb + ((size_t)pp * C::HO * C::HO + (size_t)(m - pp * C::M_PATCH)) * COUT * 4 + (co0 >> 3) * 32 + (kg & 1) * 16;
+        if (!(ASD_X3_ABL & 4) || hh[0] == 0x12345u) *reinterpret_cast<u32x4*>(o) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+    }
+  } else {
   float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
   for (int nb = 0; nb < NB; ++nb) {
     const int co = wn * NT * 32 + nb * TW + lr;
@@ -898,16 +998,18 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
       }
     }
   }
+  }
+  if (stamps && t == 0) { const unsigned long long e = __builtin_amdgcn_s_memtime(); stamps[16 * bid + 5] = e - st_t0; stamps[16 * bid + 7] = e; }
 }
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3, bool PAIR = false>
 __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
                                                          unsigned long long* __restrict__ stamps, float in_scale, float out_scale, TileQueue tq) {
   __shared__ int tile_slot;
   for (int tile = tile_first(tq, &tile_slot); tile >= 0; tile = tile_next(tq, &tile_slot))
-    conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP>(tile, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale);
+    conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(tile, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1063,6 +1165,92 @@ __global__ __launch_bounds__(256) void k_fc_x3(const float* __restrict__ act, co
       }
 }
 
+// K2p: the same GEMM on the two-piece fp16 form (three products), reading conv6's output in the PAIR format: patch p's 8192
+// values are [k / 8][h | l][8] with k = pixel * 128 + channel -- exactly what conv6's epilogue wrote -- so a slab of 128 k is a
+// 512-B run per patch that goes to LDS as it is (row stride 528 B: an odd multiple of 16 B).  Weight image [k/32][piece 2][k-group
+// 4][cout 128][8 fp16], the folded weights times the layer's power of two (weight_scale_f16); out_scale = 1 / (kActScale * that).
+constexpr int FCP_ROWB = FCS_SLAB * 4 + 16;
+__global__ __launch_bounds__(256) void k_fc_x2(const uint8_t* __restrict__ act, const uint8_t* __restrict__ wimg,
+                                               float* __restrict__ part, int n, int npad, float out_scale) {
+  __shared__ __attribute__((aligned(16))) uint8_t sa[FCS_MP * FCP_ROWB];
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int kg = lane >> 4, lr = lane & 15;
+  const int p0 = blockIdx.x * FCS_MP, sk = blockIdx.y;
+  constexpr int KPER = 8192 / FC_SK, NSLAB = KPER / FCS_SLAB, NCH = KPER / 32;
+  constexpr int CHUNKB = 32 * 4 * 128;
+  const uint8_t* wl = wimg + (size_t)(sk * (KPER / 32)) * CHUNKB + ((size_t)kg * 128 + wave * 32 + lr) * 16;
+  auto load_b = [&](int c, u32x4 (&b)[2][2]) {
+    const uint8_t* wc = wl + (size_t)c * CHUNKB;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) b[nb][p] = *reinterpret_cast<const u32x4*>(wc + (size_t)p * 4 * 128 * 16 + nb * 256);
+  };
+  auto hf = [](const u32x4& v) { return __builtin_bit_cast(f16x8, v); };
+  u32x4 br[3][2][2];
+  load_b(0, br[0]);
+  load_b(1, br[1]);
+  f4 acc[4][2];
+  for (int ma = 0; ma < 4; ++ma)
+    for (int nb = 0; nb < 2; ++nb)
+      for (int r = 0; r < 4; ++r) acc[ma][nb][r] = 0.f;
+  int c = 0;
+  for (int slab = 0; slab < NSLAB; ++slab) {
+    const int k0 = sk * KPER + slab * FCS_SLAB;
+    __syncthreads();  // the previous slab has been consumed
+    {
+      u32x4 v0[4], v1[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int item = t + i * 256, row = item >> 4, g = item & 15;
+        int p = p0 + row;
+        if (p >= n) p = n - 1;
+        const uint8_t* src = act + (size_t)p * 32768 + (size_t)(k0 / 8 + g) * 32;
+        v0[i] = *reinterpret_cast<const u32x4*>(src);
+        v1[i] = *reinterpret_cast<const u32x4*>(src + 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int item = t + i * 256, row = item >> 4, g = item & 15;
+        uint8_t* dst = sa + row * FCP_ROWB + g * 32;
+        *reinterpret_cast<u32x4*>(dst) = v0[i];
+        *reinterpret_cast<u32x4*>(dst + 16) = v1[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cs = 0; cs < FCS_SLAB / 32; ++cs, ++c) {
+      auto step = [&](u32x4 (&bc)[2][2], u32x4 (&bn)[2][2]) {
+        load_b(c + 2 < NCH ? c + 2 : NCH - 1, bn);  // past the end: a redundant re-read instead of a branch
+#pragma unroll
+        for (int ma = 0; ma < 4; ++ma) {
+          const uint8_t* ap = sa + (ma * 16 + lr) * FCP_ROWB + (cs * 4 + kg) * 32;
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(ap), al = *reinterpret_cast<const u32x4*>(ap + 16);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {   // smallest products first: (l,h) (h,l) (h,h)
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(al), hf(bc[nb][0]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(ah), hf(bc[nb][1]), acc[ma][nb], 0, 0, 0);
+            acc[ma][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hf(ah), hf(bc[nb][0]), acc[ma][nb], 0, 0, 0);
+          }
+        }
+      };
+      const int slot = c % 3;
+      if (slot == 0) step(br[0], br[2]);
+      else if (slot == 1) step(br[1], br[0]);
+      else step(br[2], br[1]);
+    }
+  }
+  if (p0 >= npad) return;
+  float* op = part + ((size_t)sk * npad + p0) * 128;
+  for (int ma = 0; ma < 4; ++ma)
+    for (int nb = 0; nb < 2; ++nb)
+      for (int r = 0; r < 4; ++r) {
+        const int row = ma * 16 + 4 * kg + r;
+        if (p0 + row < npad) op[(size_t)row * 128 + wave * 32 + nb * 16 + lr] = acc[ma][nb][r] * out_scale;
+      }
+}
+
 // K3: sum split-K partials in fixed order (deterministic), folded BN bias, L2Norm (Utils.py:15-22).
 // calibration: max |x| over a buffer as float bits (non-negative floats order like their bit patterns; a NaN / inf sorts above)
 __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ p, size_t n, unsigned* __restrict__ out) {
@@ -1093,6 +1281,7 @@ __global__ __launch_bounds__(256) void k_l2norm(const float* __restrict__ part, 
   desc[(size_t)p * 128 + lane + 64] = v1 / norm;
 }
 
+constexpr bool kPairOK = ASD_X3_S16 != 0;   // the pair format's transposed epilogue is written for the 16x16x32 shape
 // layer configurations: <CIN, COUT, HIN, S, ROWS, WM, WN, KC, PP, RING> (L3: persistent form, no PP / RING)
 #define L2_CFG 32, 32, 32, 1, 4, 4, 1, 16, 1, 3
 #define L3_CFG 32, 64, 32, 2, 4, 2, 2, 16
@@ -1148,12 +1337,12 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
   return hipGetLastError();
 }
 
-template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3>
+template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3, bool PAIR = false>
 hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
                           const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr,
                           float in_scale = 1.f, float out_scale = 1.f, int* tq_counter = nullptr, int reserve = 0, int num_cu = 256) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
-  auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP>;
+  auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>;
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
   constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds <= 160 * 1024, "band does not fit LDS");
@@ -1255,6 +1444,7 @@ int asdnet_alloc(asd_ctx* ctx) {
   *ctx->h_range = 0;
   if (const char* e = getenv("ASD_ASDNET_RESERVE")) ctx->cu_reserve = atoi(e);
   if (const char* e = getenv("ASD_ASDNET_PERSIST")) ctx->asdnet_persist = atoi(e) != 0;
+  if (const char* e = getenv("ASD_ASDNET_PAIR")) ctx->net_pair = atoi(e) != 0;
   return ASD_OK;
 }
 
@@ -1329,6 +1519,20 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
           }
       if (!ctx->d_wx3[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wx3[l], x3.size() * sizeof(uint16_t)));
       ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wx3[l], x3.data(), x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      // the two-piece fp16 image for K2p: [k/32][piece 2][k-group 4][cout 128][8]
+      const float ws = weight_scale_f16(conv_w[6], (size_t)128 * 128 * 64, inv, (size_t)128 * 64);
+      ctx->wx2_scale[l] = ws;
+      std::vector<uint16_t> x2((size_t)8192 * 128 * 2, 0);
+      for (int px = 0; px < 64; ++px)
+        for (int c = 0; c < 128; ++c)
+          for (int co = 0; co < 128; ++co) {
+            const int k = px * 128 + c, c32 = k / 32, g = (k % 32) / 8, j = k % 8;
+            uint16_t pc[2];
+            split2_host(conv_w[6][((size_t)co * 128 + c) * 64 + px] * inv[co] * ws, pc[0], pc[1]);
+            for (int q = 0; q < 2; ++q) x2[((((size_t)c32 * 2 + q) * 4 + g) * 128 + co) * 8 + j] = pc[q];
+          }
+      if (!ctx->d_wx2[l]) ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_wx2[l], x2.size() * sizeof(uint16_t)));
+      ASD_HIP_CHECK(ctx, hipMemcpy(ctx->d_wx2[l], x2.data(), x2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     if (l < 6) {
       std::vector<uint16_t> x3;
@@ -1365,11 +1569,15 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   PROF_MARK(1);  // layer 0 (input_norm + conv1) is fused into conv2's band fill: no launch of its own
   // ASD_ASDNET_MATH=f16x2: two fp16 pieces per operand, three products (kActScale and the per-layer weight scale are undone in the epilogue)
   const bool p2 = ctx->net_pieces == 2;
+  // pair format between the layers: every layer on the two-piece kernels, and not the calibration pass (k_absmax reads f32)
+  const bool pair = kPairOK && p2 && (ctx->net_split & 63) == 63 && ctx->net_pair && !ctx->d_calib;
   // persistent launches: one tile counter per layer, zeroed here on the forward's own stream
   int* const tq = ctx->asdnet_persist ? ctx->d_tq : nullptr;
   if (tq) ASD_HIP_CHECK(ctx, hipMemsetAsync(tq, 0, 16 * sizeof(int), st));
 #define X3_LAUNCH(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                       \
-  (p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,               \
+  (pair ? launch_conv_x3<CFG, FUSE, 2, kPairOK>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,       \
+                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu)           \
+   : p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,               \
                                      1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu)           \
       : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, 1.f, 1.f,                \
                                      tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu))
@@ -1399,7 +1607,10 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   CALIB(5, a1, 8 * 8 * 128);
 #undef CALIB
   PROF_MARK(6);
-  if (ctx->net_split & 32)
+  if (pair)
+    hipLaunchKernelGGL(k_fc_x2, dim3((npad + FCS_MP - 1) / FCS_MP, FC_SK), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(a1),
+                       static_cast<const uint8_t*>(ctx->d_wx2[6]), ctx->d_part, n, npad, 1.f / (kActScale * ctx->wx2_scale[6]));
+  else if (ctx->net_split & 32)
     hipLaunchKernelGGL(k_fc_x3, dim3((npad + FCS_MP - 1) / FCS_MP, FC_SK), dim3(256), 0, st, a1, static_cast<const uint8_t*>(ctx->d_wx3[6]), ctx->d_part, n, npad);
   else
     hipLaunchKernelGGL(k_fc_mfma, dim3((npad / 32 + FC_MT - 1) / FC_MT, FC_SK), dim3(256), 0, st, a1, ctx->d_wimg[6], ctx->d_part, n, npad);
@@ -1564,6 +1775,25 @@ static int ablate_one(asd_ctx* ctx, int layer, int n, int reps, float* ms) {
   return ASD_OK;
 }
 
+// debug / test aid (not part of the C ABI header): the activation conv6 handed to the last layer in the most recent forward, first n
+// patches, as f32 [n][64 pixels][128 channels]; a context in the pair format returns (h + l) / kActScale (exact in f32).
+extern "C" int asd_debug_act6(asd_ctx* ctx, int n, float* out) {
+  if (n < 0 || n > ctx->cfg.max_patches) return ASD_ERR_CAPACITY;
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const bool pair = kPairOK && ctx->net_pieces == 2 && (ctx->net_split & 63) == 63 && ctx->net_pair;
+  if (!pair) { ASD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_act[1], (size_t)n * 8192 * 4, hipMemcpyDeviceToHost)); return ASD_OK; }
+  std::vector<uint16_t> raw((size_t)n * 8192 * 2);
+  ASD_HIP_CHECK(ctx, hipMemcpy(raw.data(), ctx->d_act[1], raw.size() * 2, hipMemcpyDeviceToHost));
+  for (size_t e = 0; e < (size_t)n * 8192; ++e) {
+    const size_t g = e / 8, j = e % 8;
+    _Float16 h, l;
+    memcpy(&h, &raw[g * 16 + j], 2);
+    memcpy(&l, &raw[g * 16 + 8 + j], 2);
+    out[e] = ((float)h + (float)l) / kActScale;
+  }
+  return ASD_OK;
+}
+
 // debug / tuning aid (not part of the C ABI header): in-kernel clock of a split-operand layer (MI355X_MICROARCH.md, DVFS item 6).
 // Runs the layer `reps` times back to back with stamps around the MFMA loop; returns the median over workgroups of the loop's
 // shader cycles and of shader cycles per 10 ns wall tick (x 0.1 = GHz).  Uses d_part as the stamp buffer.
@@ -1576,8 +1806,11 @@ extern "C" int asd_debug_x3_clock(asd_ctx* ctx, int layer, int n, int reps, doub
     unsigned long long* sp = r + 1 == reps ? stamps : nullptr;
     hipError_t e = hipErrorInvalidValue;
     const bool p2 = ctx->net_pieces == 2;
+    const bool pair = kPairOK && p2 && (ctx->net_split & 63) == 63 && ctx->net_pair;
 #define X3_CLK(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                          \
-  (p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, sp, &grid, kActScale,                       \
+  (pair ? launch_conv_x3<CFG, FUSE, 2, kPairOK>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, sp, &grid, kActScale,               \
+                                     1.f / (kActScale * ctx->wx2_scale[l]))                                                                \
+   : p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, sp, &grid, kActScale,                       \
                                      1.f / (kActScale * ctx->wx2_scale[l]))                                                                \
       : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p, sp, &grid))
     if (layer == 2) e = X3_CLK(L2S_CFG, true, 1, ctx->d_patches, a1, ctx->d_w1, ctx->d_bias[0]);
@@ -1589,15 +1822,25 @@ extern "C" int asd_debug_x3_clock(asd_ctx* ctx, int layer, int n, int reps, doub
     ASD_HIP_CHECK(ctx, e);
   }
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  if ((size_t)grid * 16 > (size_t)FC_SK * ((ctx->cfg.max_patches + 31) / 32 * 32) * 128 * sizeof(float)) return ASD_ERR_CAPACITY;
-  std::vector<unsigned long long> hs((size_t)grid * 2);
+  if ((size_t)grid * 128 > (size_t)FC_SK * ((ctx->cfg.max_patches + 31) / 32 * 32) * 128 * sizeof(float)) return ASD_ERR_CAPACITY;
+  std::vector<unsigned long long> hs((size_t)grid * 16);
   ASD_HIP_CHECK(ctx, hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
   std::vector<double> cyc(grid), rate(grid);
-  for (int i = 0; i < grid; ++i) { cyc[i] = (double)hs[2 * i]; rate[i] = hs[2 * i + 1] ? (double)hs[2 * i] / (double)hs[2 * i + 1] : 0.0; }
+  for (int i = 0; i < grid; ++i) { cyc[i] = (double)hs[16 * i]; rate[i] = hs[16 * i + 1] ? (double)hs[16 * i] / (double)hs[16 * i + 1] : 0.0; }
   std::nth_element(cyc.begin(), cyc.begin() + grid / 2, cyc.end());
   std::nth_element(rate.begin(), rate.begin() + grid / 2, rate.end());
   *loop_cycles = cyc[grid / 2];
   *ghz = rate[grid / 2] * 0.1;
+  // phases of a workgroup's life (medians, shader cycles): entry -> input ready for conv1 / staging, -> band staged, MFMA loop, whole
+  // life; ASD_X3_PHASES=1 prints them
+  if (getenv("ASD_X3_PHASES")) {
+    auto med = [&](int k) { std::vector<double> v(grid); for (int i = 0; i < grid; ++i) v[i] = (double)hs[16 * i + k]; std::nth_element(v.begin(), v.begin() + grid / 2, v.end()); return v[grid / 2]; };
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int i = 0; i < grid; ++i) { lo = std::min(lo, hs[16 * i + 6]); hi = std::max(hi, hs[16 * i + 7]); }
+    fprintf(stderr, "  layer %d: %d workgroups; prologue %.0f, staging %.0f, MFMA loop %.0f, whole life %.0f cycles (medians); kernel span %.0f cycles\n",
+            layer, grid, med(2), med(3), med(0), med(5), (double)(hi - lo));
+    fprintf(stderr, "     since entry: patch arrived %.0f, conv1 begins %.0f, staging loop done %.0f, barrier passed %.0f\n", med(9), med(11), med(12), med(13));
+  }
   return ASD_OK;
 }
 

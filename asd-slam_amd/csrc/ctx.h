@@ -146,6 +146,7 @@ struct asd_ctx {
   unsigned* d_calib = nullptr;  // calibration only: per-layer max |activation| as float bits (asdnet_forward_device fills it when set)
   int* d_tq = nullptr;          // tile counters of the persistent conv launches of one forward (asdnet.hip, TileQueue), one per layer
   int cu_reserve = 0;           // asd_cu_reserved mode of the persistent conv launches (ASD_ASDNET_RESERVE at asd_ctx_create)
+  bool net_pair = true;         // two-piece form: activations between the layers as the fp16 piece pairs themselves (ASD_ASDNET_PAIR=0: f32 NHWC)
   bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
   uint8_t* d_patches = nullptr; // [max_patches][1024]
   float* d_desc = nullptr;      // [max_patches][128] descriptors of the last asd_extract / asd_describe

@@ -215,6 +215,37 @@ def test_operand_forms_accuracy(hip, hip_f32, hip_bf16x3, synth, asdnet_golden, 
 
 
 @pytest.mark.gpu
+def test_pair_format_is_bit_identical(pkg, synth, asdnet_golden, monkeypatch):
+    """The default two-piece form hands activations from layer to layer as the fp16 piece pairs (h, l) of 16 x -- split once in the
+    producer's epilogue -- instead of f32 values every consumer splits again while staging (ASD_ASDNET_PAIR=0 restores that).  The
+    pieces are the same numbers either way, so the conv layers' results are the same bits; the last layer differs in arithmetic
+    (three fp16 products against six bf16 ones), so descriptors agree to the f32 chain's own rounding, not bit for bit."""
+    patches = np.concatenate([asdnet_golden["patches"], synth.random_patches(200, seed=21), np.full((3, 32, 32), 77, np.uint8)])
+    monkeypatch.setenv("ASD_ASDNET_PAIR", "0")
+    plain = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    monkeypatch.delenv("ASD_ASDNET_PAIR")
+    pair = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    try:
+        w = synth.asdnet_weights(int(asdnet_golden["weight_seed"]))
+        plain.load_weights(w)
+        pair.load_weights(w)
+        assert pair.asdnet_pieces() == 2 and plain.asdnet_pieces() == 2
+        a, b = pair.describe(patches), plain.describe(patches)
+        assert np.isfinite(a).all()
+        np.testing.assert_allclose(a, b, atol=5e-7, rtol=0)
+        np.testing.assert_allclose(a[:64], asdnet_golden["desc"], atol=DESC_ATOL, rtol=0)
+        # conv2 .. conv6 bit for bit: the activation conv6 hands to the last layer, decoded from the pair format
+        l6_pair, x = pair.debug_act6(8), plain.debug_act6(8)
+        h = (x * np.float32(16)).astype(np.float16)                    # the split the consumers of the f32 form perform
+        l = (x * np.float32(16) - h.astype(np.float32)).astype(np.float16)
+        np.testing.assert_array_equal(l6_pair, (h.astype(np.float32) + l.astype(np.float32)) / np.float32(16))
+        assert np.abs(l6_pair).max() > 0.1
+    finally:
+        plain.close()
+        pair.close()
+
+
+@pytest.mark.gpu
 def test_f16x2_range_is_an_error_not_a_nan(pkg, synth, monkeypatch):
     """f16x2 carries activations * 16 in fp16: an activation beyond 4094 cannot be represented.  Two guards (include/asd_slam.h,
     asd_asdnet_pieces): asd_load_weights' calibration batch notices weights that drive a layer past 2048 and switches the context to
