@@ -349,6 +349,8 @@ struct ResolveArgs {
   int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations
   int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches: the kernel stores its outputs there as
                               // well, so the host needs no copy command behind the chain (the device copy feeds the pose solver)
+  int ov_cap;                 // candidates beyond the register slots that the workgroup keeps in LDS (12 B each) instead of
+                              // reading them from L2 in every iteration; a longer tail than this falls back to the L2 reads
 };
 constexpr int kResolveThreads = 512, kResolveMaxQPT = 8;   // up to 4096 queries
 // SLOTS = candidates a thread keeps in registers (template parameter: 8, 16 or 24, i.e. up to 12288 candidates register resident;
@@ -373,6 +375,9 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
   unsigned* claim0 = reinterpret_cast<unsigned*>(lds_q + (KIND == 1 ? 2 : 1) * a.nq);
   unsigned* claim[2] = {claim0, claim0 + a.n_cur};
   uint8_t* oct_occ = reinterpret_cast<uint8_t*>(claim0 + 2 * a.n_cur);   // octave | 0x80 if occupied on entry
+  unsigned* ov_lo = reinterpret_cast<unsigned*>(oct_occ + (a.n_cur + 15) / 16 * 16);   // [ov_cap] the tail beyond the registers:
+  unsigned* ov_db = ov_lo + a.ov_cap;                                                  // key low word, distance bits, query
+  unsigned* ov_q = ov_db + a.ov_cap;
   __shared__ int n_written, hist[HISTO], keep[3], n_removed;
   const int t = threadIdx.x;
   const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
@@ -411,6 +416,18 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     cdb[i] = __float_as_uint(a.dist[c]);
     if (v) cqp[i / 2] = (cqp[i / 2] & ~(0xffffu << (16 * (i & 1)))) | ((meta & 0xffffu) << (16 * (i & 1)));
   }
+  // the tail of a long list (12 k candidates against 16 x 512 slots): staged once in LDS; an iteration then pays ~100 cycles per
+  // dependent access instead of an L2 round trip (measured: see DESIGN.md, claim replay)
+  const int n_ov = total - kResolveSlots * kResolveThreads;
+  const bool ov_lds = n_ov > 0 && n_ov <= a.ov_cap;
+  if (ov_lds)
+    for (int i = t; i < n_ov; i += kResolveThreads) {
+      const int c = kResolveSlots * kResolveThreads + i;
+      const unsigned meta = a.meta[c];
+      ov_lo[i] = (meta & 0xffff0000u) | (unsigned)a.idx[c];
+      ov_db[i] = __float_as_uint(a.dist[c]);
+      ov_q[i] = meta & 0xffffu;
+    }
 #define CQ(i) ((cqp[(i) / 2] >> (16 * ((i) & 1))) & 0xffffu)
   int pick[QPT];
   unsigned posmask = 0;
@@ -460,6 +477,22 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
         for (int i = 0; i < 8; ++i)
           if (CQ(g + i) != 0xffffu) take(CQ(g + i), clo[g + i], cdb[g + i], cl[i], w[i]);
       }
+      if (ov_lds) {   // beyond the registers, from LDS: four candidates' reads in flight
+        for (int i0 = t; i0 < n_ov; i0 += 4 * kResolveThreads) {
+          unsigned q[4], lo[4], db[4], cl[4];
+          unsigned long long w[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int k = min(i0 + i * kResolveThreads, n_ov - 1);
+            q[i] = ov_q[k]; lo[i] = ov_lo[k]; db[i] = ov_db[k];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { cl[i] = rd[lo[i] & 0xffffu]; w[i] = second ? key1[q[i]] : 0ull; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i0 + i * kResolveThreads < n_ov) take(q[i], lo[i], db[i], cl[i], w[i]);
+        }
+      } else
       for (int c0 = t + kResolveSlots * kResolveThreads; c0 < total; c0 += 4 * kResolveThreads) {   // beyond the registers: 12 loads in flight
         unsigned meta[4], lo[4], db[4];
 #pragma unroll
@@ -869,6 +902,13 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
 size_t resolve_lds_bytes(int kind, int n_cur, int nq) {
   return (size_t)(kind == 1 ? 2 : 1) * nq * 8 + (size_t)n_cur * 2 * sizeof(int) + (size_t)(n_cur + 15) / 16 * 16;
 }
+// room for the tail of the candidate lists in LDS (k_resolve, ov_cap): what the previous search of this kind produced beyond `slots`
+// register slots per thread, a quarter on top, as far as the 96 KB this kernel may ask for allow
+int resolve_overflow_cap(int kind, int n_cur, int nq, int last_total, int slots) {
+  const long long want = ((long long)last_total * 5 / 4 - (long long)slots * kResolveThreads + 511) / 512 * 512;
+  const long long room = ((long long)96 * 1024 - (long long)resolve_lds_bytes(kind, n_cur, nq)) / 12 / 512 * 512;
+  return (int)std::max<long long>(0, std::min(want, room));
+}
 bool replay_on_device(const MatcherState* m, int kind, int n_cur, int nq) {
   return !m->replay_host && n_cur > 0 && n_cur < 65536 && nq <= kResolveThreads * kResolveMaxQPT && resolve_lds_bytes(kind, n_cur, nq) <= 96 * 1024;
 }
@@ -945,7 +985,10 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     for (int i = 0; i < kChainTabs; ++i) d_tab[i] = has_tab[i] ? up.dev<void>(o_tab[i]) : nullptr;
     if (dev_queries && (rc = chain->prepare(up.dev<WinQuery>(o_q), d_tab)) != ASD_OK) return rc;
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
-    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
+    // (the "match" stage clock of asd_last_stage_ms: two timed event records per chain, each a barrier packet on the stream -- only
+    // when somebody asked for timings)
+    static const bool stage_timing = getenv("ASD_TIMING") != nullptr || getenv("ASD_STAGE_TIMING") != nullptr;
+    if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
     hipLaunchKernelGGL(k_window_search, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
                        d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta);
     ASD_HIP_CHECK(ctx, hipGetLastError());
@@ -960,7 +1003,11 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     a.pick = d_pick; a.match_cur = d_out; a.n_matches = d_out + n_cur;
     static const bool zero_copy = getenv("ASD_RESULT_COPY") == nullptr;   // results stored by the kernels straight into the pinned block
     a.mirror = zero_copy ? down.host<int>(o_out) : nullptr;
-    const size_t lds = resolve_lds_bytes(KIND, n_cur, nq);
+    // register-resident candidates per thread: 8, or 16 for long frame-to-frame lists (KIND 1 with 16 spills under the cap)
+    constexpr int kBig = KIND == 0 ? 16 : 8;
+    const bool small = m->last_total[KIND] <= 8 * kResolveThreads;
+    a.ov_cap = resolve_overflow_cap(KIND, n_cur, nq, m->last_total[KIND], small ? 8 : kBig);
+    const size_t lds = resolve_lds_bytes(KIND, n_cur, nq) + (size_t)a.ov_cap * 12;
     auto launch = [&](auto kern) -> hipError_t {
       static AsdPerDeviceOnce attr_set;   // per instantiation and device: more than 64 KB of dynamic LDS has to be asked for once
       if (attr_set.need(ctx->cfg.device)) {
@@ -971,12 +1018,9 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       hipLaunchKernelGGL(kern, dim3(1), dim3(kResolveThreads), lds, st, a);
       return hipGetLastError();
     };
-    // register-resident candidates per thread: 8, or 16 for long frame-to-frame lists (KIND 1 with 16 spills under the cap)
-    constexpr int kBig = KIND == 0 ? 16 : 8;
-    const bool small = m->last_total[KIND] <= 8 * kResolveThreads;
     if (nq <= 4 * kResolveThreads) { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, kBig>)); }
     else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
-    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+    if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
     if (chain) {
       if ((rc = chain->enqueue(d_out, d_tab, zero_copy ? down.host<void>(o_res) : down.dev<void>(o_res))) != ASD_OK) return rc;
       chain->h_result = down.host<void>(o_res);
@@ -1008,7 +1052,9 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       }
       break;
     }
-    ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+    static const bool stage_timing = getenv("ASD_TIMING") != nullptr || getenv("ASD_STAGE_TIMING") != nullptr;
+    if (stage_timing) ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
+    else ctx->ms_match = 0.f;
     memcpy(match_cur, h_out, (size_t)n_cur * sizeof(int));
     *n_matches = h_out[n_cur];
     static const bool timing = getenv("ASD_TIMING") != nullptr;
