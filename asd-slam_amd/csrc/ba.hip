@@ -1724,8 +1724,227 @@ struct DevBuf {
   template <typename T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+
+// ---------------------------------------------------------------- the active structure, built on the device
+// g2o's initializeOptimization + buildStructure (sparse_optimizer.cpp:206-267, 166-190; block_solver.hpp:117-300) as this solver
+// keeps it: h-indices of the free poses / active landmarks, the edges grouped by landmark and ordered by pose inside a landmark,
+// every free pose's edge list, and per upper block (i <= j) of the reduced system the list of edge pairs (a, b) that meet in it.
+// The host loop that made these tables (kept below: ASD_BA_STRUCT=host, and for more than 32 free poses) took 0.35-0.47 ms of the
+// 2.5 ms LocalBA with the device idle; the same tables come out of four small launches.  Every list is in the order the host
+// loop produces (landmark, then position inside the landmark), so the sums the solver forms over them are the same sums.
+struct BaStructDev {
+  int P, L, E;
+  const int* e_ps; const int* e_pt; const uint8_t* fixed;
+  int* pose_h; int* pt_h; int* pose_of_h; int* pt_of_h; int* pt_start; int* act;
+  int* ph_of_k;        // [E] pose h-index of the k-th edge in act order (-1: fixed pose)
+  int* cursor;         // [L + 1] scratch
+  unsigned* pt_mask;   // [L] bit i: the landmark has an edge to free pose i
+  int* pt_free0;       // [L] act position of the landmark's first edge to a free pose
+  int* ps_cnt;         // [32]
+  int* ps_start; int* ps_edges;
+  int* blk_i; int* blk_j; int* pair_cnt; int* pair_start; int2* pairs;
+  int* counts;         // pinned host [4]: nPf, nLa, Ea, pairs
+};
+constexpr int kStructThreads = 1024, kStructMaxP = 1024, kStructMaxFree = 32;
+
+__device__ inline int struct_excl_scan(int v, int* sh, int& total) {   // exclusive prefix of v over the 1024 threads; sh: [16]
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int x = v;
+  for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+  if (lane == 63) sh[w] = x;
+  __syncthreads();
+  if (w == 0) {
+    int q = lane < kStructThreads / 64 ? sh[lane] : 0;
+    for (int off = 1; off < 16; off <<= 1) { const int y = __shfl_up(q, off); if (lane >= off) q += y; }
+    if (lane < kStructThreads / 64) sh[lane] = q;
+  }
+  __syncthreads();
+  const int base = w ? sh[w - 1] : 0;
+  total = sh[kStructThreads / 64 - 1];
+  __syncthreads();
+  return base + x - v;
+}
+
+// The vertex tables and the landmark CSR in six small launches (edge-parallel where the work is per edge, one workgroup for the two
+// prefix sums); atomics only where the order does not matter -- flags, counts, and a scatter whose segments are sorted afterwards.
+// A single workgroup walking the 29 k edges seven times took 0.3 ms: three dependent L2 round trips per edge and pass.
+__global__ __launch_bounds__(256) void k_ba_struct_flags(BaStructDev a, int* pflag) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < a.E) { pflag[a.e_ps[e]] = 1; a.pt_h[a.e_pt[e]] = 1; }
+}
+// free poses in pose order, active landmarks in landmark order; the landmark counters cleared
+__global__ __launch_bounds__(kStructThreads) void k_ba_struct_vertices(BaStructDev a, const int* pflag) {
+  __shared__ int sh[16];
+  constexpr int NT = kStructThreads;
+  const int t = threadIdx.x;
+  if (t == 0) {
+    int h = 0;
+    for (int p = 0; p < a.P; ++p) {
+      int v = -1;
+      if (pflag[p] && !a.fixed[p]) { v = h; a.pose_of_h[h++] = p; }
+      a.pose_h[p] = v;
+    }
+    a.counts[0] = h;
+  }
+  if (t < kStructMaxFree) a.ps_cnt[t] = 0;
+  const int chunk = (a.L + NT - 1) / NT, l0 = min(t * chunk, a.L), l1 = min(l0 + chunk, a.L);
+  int c = 0;
+  for (int l = l0; l < l1; ++l) c += a.pt_h[l];
+  int nLa;
+  int base = struct_excl_scan(c, sh, nLa);
+  for (int l = l0; l < l1; ++l) {
+    if (a.pt_h[l]) { a.pt_h[l] = base; a.pt_of_h[base] = l; ++base; } else a.pt_h[l] = -1;
+  }
+  for (int h = t; h <= nLa; h += NT) a.pt_start[h] = 0;
+  if (t == 0) { a.counts[1] = nLa; a.cursor[a.L] = nLa; }   // cursor[L]: nLa for the kernels behind this one
+}
+__global__ __launch_bounds__(256) void k_ba_struct_count(BaStructDev a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < a.E) atomicAdd(&a.pt_start[a.pt_h[a.e_pt[e]] + 1], 1);
+}
+// counts -> offsets, in place: slot h + 1 is read and written by the thread that owns landmark h
+__global__ __launch_bounds__(kStructThreads) void k_ba_struct_offsets(BaStructDev a) {
+  __shared__ int sh[16];
+  constexpr int NT = kStructThreads;
+  const int t = threadIdx.x, nLa = a.cursor[a.L];
+  __syncthreads();
+  const int hchunk = (nLa + NT - 1) / NT, h0 = min(t * hchunk, nLa), h1 = min(h0 + hchunk, nLa);
+  int cs = 0;
+  for (int h = h0; h < h1; ++h) cs += a.pt_start[h + 1];
+  int Ea;
+  int run = struct_excl_scan(cs, sh, Ea);
+  for (int h = h0; h < h1; ++h) { const int n = a.pt_start[h + 1]; a.cursor[h] = run; run += n; a.pt_start[h + 1] = run; }
+  if (t == 0) a.counts[2] = Ea;
+}
+__global__ __launch_bounds__(256) void k_ba_struct_scatter(BaStructDev a) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < a.E) { const int k = atomicAdd(&a.cursor[a.pt_h[a.e_pt[e]]], 1); a.act[k] = e; }
+}
+// inside a landmark: by pose h-index (fixed poses, -1, first), equal poses in edge order = the host's stable insertion sort;
+// then the pose index of every position, the landmark's mask of free poses, where its free edges begin, the poses' edge counts
+__global__ __launch_bounds__(256) void k_ba_struct_sort(BaStructDev a) {
+  __shared__ int pcnt[kStructMaxFree];
+  const int t = threadIdx.x, h = blockIdx.x * 256 + t, nLa = a.cursor[a.L];
+  if (t < kStructMaxFree) pcnt[t] = 0;
+  __syncthreads();
+  if (h < nLa) {
+    const int s0 = a.pt_start[h], s1 = a.pt_start[h + 1];
+    for (int i = s0 + 1; i < s1; ++i) {
+      const int e = a.act[i], pe = a.pose_h[a.e_ps[e]];
+      int b = i - 1;
+      for (; b >= s0; --b) {
+        const int eb = a.act[b], pb = a.pose_h[a.e_ps[eb]];
+        if (pb < pe || (pb == pe && eb < e)) break;
+        a.act[b + 1] = eb;
+      }
+      a.act[b + 1] = e;
+    }
+    unsigned mask = 0;
+    int free0 = s1;
+    for (int i = s0; i < s1; ++i) {
+      const int pv = a.pose_h[a.e_ps[a.act[i]]];
+      a.ph_of_k[i] = pv;
+      if (pv >= 0) { free0 = min(free0, i); if (pv < kStructMaxFree) { mask |= 1u << pv; atomicAdd(&pcnt[pv], 1); } }
+    }
+    a.pt_mask[h] = mask;
+    a.pt_free0[h] = free0;
+  }
+  __syncthreads();
+  if (t < kStructMaxFree && pcnt[t]) atomicAdd(&a.ps_cnt[t], pcnt[t]);
+}
+
+// every free pose's edges (k indices) in k order: one workgroup per pose, an ordered compaction over the act list
+__global__ __launch_bounds__(256) void k_ba_struct_pose_edges(BaStructDev a, int Ea) {
+  __shared__ int wsum[4];
+  const int h = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int start = 0;
+  for (int q = 0; q < h; ++q) start += a.ps_cnt[q];
+  if (t == 0) { a.ps_start[h] = start; if (h == (int)gridDim.x - 1) a.ps_start[h + 1] = start + a.ps_cnt[h]; }
+  int run = start;
+  for (int k0 = 0; k0 < Ea; k0 += 256) {
+    const int k = k0 + t;
+    const bool f = k < Ea && a.ph_of_k[k] == h;
+    const unsigned long long bal = __ballot(f);
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int off = __popcll(bal & ((1ull << lane) - 1));
+    for (int q = 0; q < w; ++q) off += wsum[q];
+    if (f) a.ps_edges[run + off] = k;
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+}
+
+// the pair list of upper block q = (i <= j): landmarks in order, inside a landmark the host's nested loop (a, then b >= a).
+// FILL = false counts, FILL = true writes (its start = the counts of the blocks before it).  A landmark whose free edges go to
+// distinct poses (every real one: an observation per keyframe) finds its pair by two popcounts of its mask; one with repeated poses
+// walks its edge list like the host loop.
+constexpr int kPairThreads = 1024;
+template <bool FILL>
+__global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a, int nPf, int nLa, int nblk) {
+  constexpr int NW = kPairThreads / 64;
+  __shared__ int wsum[NW], red[kPairThreads];
+  const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  int i = 0, rem = q;
+  while (rem >= nPf - i) { rem -= nPf - i; ++i; }
+  const int j = i + rem;
+  int start = 0;
+  if (FILL) {
+    int part = 0;
+    for (int b = t; b < q; b += kPairThreads) part += a.pair_cnt[b];
+    red[t] = part;
+    __syncthreads();
+    for (int off = kPairThreads / 2; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+    start = red[0];
+    __syncthreads();
+    if (t == 0) { a.blk_i[q] = i; a.blk_j[q] = j; a.pair_start[q] = start; }
+  }
+  const unsigned bi = 1u << i, bj = 1u << j;
+  int run = start, total = 0;
+  for (int h0 = 0; h0 < nLa; h0 += kPairThreads) {
+    const int h = h0 + t;
+    int cnt = 0, f0 = 0, s1 = 0;
+    unsigned m = 0;
+    bool simple = true;
+    if (h < nLa) {
+      m = a.pt_mask[h];
+      if ((m & bi) && (m & bj)) {
+        f0 = a.pt_free0[h]; s1 = a.pt_start[h + 1];
+        simple = __popc(m) == s1 - f0;
+        if (simple) cnt = 1;
+        else
+          for (int x = f0; x < s1; ++x)
+            if (a.ph_of_k[x] == i)
+              for (int y = x; y < s1; ++y) cnt += a.ph_of_k[y] == j;
+      }
+    }
+    int xs = cnt;   // exclusive prefix of cnt over the workgroup
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(xs, off); if (lane >= off) xs += y; }
+    if (lane == 63) wsum[w] = xs;
+    __syncthreads();
+    int off = xs - cnt, all = 0;
+    for (int b = 0; b < NW; ++b) { if (b < w) off += wsum[b]; all += wsum[b]; }
+    if (FILL && cnt) {
+      int o = run + off;
+      if (simple) a.pairs[o] = make_int2(f0 + __popc(m & (bi - 1)), f0 + __popc(m & (bj - 1)));
+      else
+        for (int x = f0; x < s1; ++x)
+          if (a.ph_of_k[x] == i)
+            for (int y = x; y < s1; ++y)
+              if (a.ph_of_k[y] == j) a.pairs[o++] = make_int2(x, y);
+    }
+    run += all; total += all;
+    __syncthreads();
+  }
+  if (t == 0) {
+    if (!FILL) a.pair_cnt[q] = total;
+    else if (q == nblk - 1) { a.pair_start[nblk] = start + total; a.counts[3] = start + total; }
+  }
+}
+
 struct BaState {
-  DevBuf lvl, HppPart;
+  DevBuf lvl, HppPart, fixed_d;
+  int* h_counts = nullptr;      // pinned [4]: nPf, nLa, Ea, pairs of the structure built on the device
   DevBuf out1, Apack, sblk;   // sblk: the round's structure arrays in one block (uploaded from the pinned h_sblk)
   char* h_sblk = nullptr;
   size_t h_sblk_cap = 0;
@@ -1794,6 +2013,7 @@ void ba_free(asd_ctx* ctx) {
   for (DevBuf* b : all) if (b->p) (void)hipFree(b->p);
   if (s->h_partial) (void)hipHostFree(s->h_partial);
   if (s->h_lm) (void)hipHostFree(s->h_lm);
+  if (s->h_counts) (void)hipHostFree(s->h_counts);
   if (s->h_sblk) (void)hipHostFree(s->h_sblk);
   if (s->h_po) (void)hipHostFree(s->h_po);
   delete s;
@@ -1971,6 +2191,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   const int P = pr->n_poses, L = pr->n_points, E = pr->n_edges;
   (void)hipSetDevice(ctx->cfg.device);
   int rc;
+  const auto t_enter = std::chrono::steady_clock::now();
 #define ENS(buf, bytes) if ((rc = s->buf.ensure(ctx, (bytes))) != ASD_OK) return rc
   ENS(pose, (size_t)P * sizeof(Pose7)); ENS(pose_bak, (size_t)P * sizeof(Pose7));
   ENS(pts, (size_t)L * 24); ENS(pts_bak, (size_t)L * 24);
@@ -2013,6 +2234,9 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->info.p, pr->e_info, (size_t)E * 8, hipMemcpyHostToDevice, st));
   ASD_HIP_CHECK(ctx, hipMemsetAsync(s->err.p, 0, (size_t)E * 16, st));
   ASD_HIP_CHECK(ctx, hipMemsetAsync(s->lvl.p, 0, (size_t)E, st));
+  ENS(fixed_d, (size_t)std::max(P, 1));
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->fixed_d.p, pr->fixed, (size_t)P, hipMemcpyHostToDevice, st));
+  if (!s->h_counts) ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), 64));
   ASD_HIP_CHECK(ctx, hipEventRecord(ev0, st));
 
   BaDev d{};
@@ -2037,6 +2261,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   d.lm_log = reinterpret_cast<LmLog*>(s->lm.as<char>() + sizeof(LmState) + 64 - (sizeof(LmState) % 8));
   d.partial = s->partial.as<double>();
 
+  const auto t_uploaded = std::chrono::steady_clock::now();
   std::vector<uint8_t> level(E, 0);
   std::vector<int> act, pose_h(P), pt_h(L), pose_of_h, pt_of_h, pt_start, ps_start, ps_edges, blk_i, blk_j, pair_start, ph_of_k, cursor,
       row_off;
@@ -2057,6 +2282,67 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     const auto t_round = std::chrono::steady_clock::now();
     int n_trials = 0;
     int r2;
+    int n_free_max = 0;
+    for (int p = 0; p < P; ++p) n_free_max += !pr->fixed[p];
+    static const bool struct_host = getenv("ASD_BA_STRUCT") && !strcmp(getenv("ASD_BA_STRUCT"), "host");
+    const bool struct_dev = !struct_host && E > 0 && P <= kStructMaxP && n_free_max <= kStructMaxFree;
+    if (round_idx == 0 && struct_dev) {
+      // ---- active structure, on the device (k_ba_struct_*): the tables are carved out of one block sized by upper bounds
+      const int nblk_max = n_free_max * (n_free_max + 1) / 2;
+      const size_t pairs_cap = (size_t)E * (size_t)(n_free_max + 1) / 2 + 1;
+      size_t off = 0;
+      auto place = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+      const size_t o_act = place((size_t)E * 4), o_pose_h = place((size_t)P * 4), o_pt_h = place((size_t)L * 4), o_pose_of_h = place((size_t)P * 4),
+                   o_pt_of_h = place((size_t)L * 4), o_pt_start = place((size_t)(L + 1) * 4), o_ps_start = place((size_t)(P + 1) * 4),
+                   o_ps_edges = place((size_t)E * 4), o_blk_i = place((size_t)std::max(nblk_max, 1) * 4), o_blk_j = place((size_t)std::max(nblk_max, 1) * 4),
+                   o_pair_start = place((size_t)(nblk_max + 1) * 4), o_pairs = place(pairs_cap * 8), o_ph = place((size_t)E * 4),
+                   o_cursor = place((size_t)(L + 1) * 4), o_mask = place((size_t)L * 4), o_pscnt = place(kStructMaxFree * 4),
+                   o_paircnt = place((size_t)std::max(std::max(nblk_max, P), 1) * 4), o_free0 = place((size_t)L * 4);
+      if ((r2 = s->sblk.ensure(ctx, off)) != ASD_OK) return r2;
+      char* db = s->sblk.as<char>();
+      BaStructDev sd{};
+      sd.P = P; sd.L = L; sd.E = E;
+      sd.e_ps = d.e_ps; sd.e_pt = d.e_pt; sd.fixed = s->fixed_d.as<uint8_t>();
+      sd.pose_h = reinterpret_cast<int*>(db + o_pose_h); sd.pt_h = reinterpret_cast<int*>(db + o_pt_h);
+      sd.pose_of_h = reinterpret_cast<int*>(db + o_pose_of_h); sd.pt_of_h = reinterpret_cast<int*>(db + o_pt_of_h);
+      sd.pt_start = reinterpret_cast<int*>(db + o_pt_start); sd.act = reinterpret_cast<int*>(db + o_act);
+      sd.ph_of_k = reinterpret_cast<int*>(db + o_ph); sd.cursor = reinterpret_cast<int*>(db + o_cursor);
+      sd.pt_free0 = reinterpret_cast<int*>(db + o_free0);
+      sd.pt_mask = reinterpret_cast<unsigned*>(db + o_mask); sd.ps_cnt = reinterpret_cast<int*>(db + o_pscnt);
+      sd.ps_start = reinterpret_cast<int*>(db + o_ps_start); sd.ps_edges = reinterpret_cast<int*>(db + o_ps_edges);
+      sd.blk_i = reinterpret_cast<int*>(db + o_blk_i); sd.blk_j = reinterpret_cast<int*>(db + o_blk_j);
+      sd.pair_cnt = reinterpret_cast<int*>(db + o_paircnt); sd.pair_start = reinterpret_cast<int*>(db + o_pair_start);
+      sd.pairs = reinterpret_cast<int2*>(db + o_pairs);
+      sd.counts = s->h_counts;
+      s->h_counts[3] = 0;
+      {
+        int* pflag = sd.pair_cnt;   // [P] scratch until the pair kernels run (nblk_max >= P whenever a pose is free; else sized below)
+        const int gEs = (E + 255) / 256;
+        ASD_HIP_CHECK(ctx, hipMemsetAsync(sd.pt_h, 0, (size_t)L * 4, st));
+        ASD_HIP_CHECK(ctx, hipMemsetAsync(pflag, 0, (size_t)P * 4, st));
+        hipLaunchKernelGGL(k_ba_struct_flags, dim3(gEs), dim3(256), 0, st, sd, pflag);
+        hipLaunchKernelGGL(k_ba_struct_vertices, dim3(1), dim3(kStructThreads), 0, st, sd, pflag);
+        hipLaunchKernelGGL(k_ba_struct_count, dim3(gEs), dim3(256), 0, st, sd);
+        hipLaunchKernelGGL(k_ba_struct_offsets, dim3(1), dim3(kStructThreads), 0, st, sd);
+        hipLaunchKernelGGL(k_ba_struct_scatter, dim3(gEs), dim3(256), 0, st, sd);
+        hipLaunchKernelGGL(k_ba_struct_sort, dim3((L + 255) / 256), dim3(256), 0, st, sd);
+      }
+      ASD_HIP_CHECK(ctx, hipGetLastError());
+      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));   // the launch dimensions of everything that follows: nPf, nLa
+      nPf = s->h_counts[0]; nLa = s->h_counts[1]; Ea = s->h_counts[2];
+      nblk = nPf * (nPf + 1) / 2;
+      if (nPf > 0) {
+        hipLaunchKernelGGL(k_ba_struct_pose_edges, dim3(nPf), dim3(256), 0, st, sd, Ea);
+        hipLaunchKernelGGL(k_ba_struct_pairs<false>, dim3(nblk), dim3(kPairThreads), 0, st, sd, nPf, nLa, nblk);
+        hipLaunchKernelGGL(k_ba_struct_pairs<true>, dim3(nblk), dim3(kPairThreads), 0, st, sd, nPf, nLa, nblk);
+        ASD_HIP_CHECK(ctx, hipGetLastError());
+      }
+      d.act = sd.act; d.pose_h = sd.pose_h; d.pt_h = sd.pt_h; d.pose_of_h = sd.pose_of_h; d.pt_of_h = sd.pt_of_h;
+      d.pt_start = sd.pt_start; d.ps_start = sd.ps_start; d.ps_edges = sd.ps_edges;
+      sb = SchurBlocks{sd.blk_i, sd.blk_j, sd.pair_start, sd.pairs};
+      d.Ea = Ea; d.nPf = nPf; d.nLa = nLa;
+      n_pairs_total = 0;   // (on the device; read from the pinned counts when the round reports)
+    } else
     if (round_idx == 0) {
     // ---- active structure, on the host
     std::vector<uint8_t> pa(P, 0), la(L, 0);
@@ -2248,7 +2534,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     if (timing) {
       const auto t_end = std::chrono::steady_clock::now();
       fprintf(stderr, "[ba round] structure %.0f us (Ea=%d nPf=%d nLa=%d pairs=%zu), %d iterations / %d trials in %.0f us\n",
-              std::chrono::duration<double, std::micro>(t_prep - t_round).count(), Ea, nPf, nLa, n_pairs_total, done, n_trials,
+              std::chrono::duration<double, std::micro>(t_prep - t_round).count(), Ea, nPf, nLa, struct_dev ? (size_t)s->h_counts[3] : n_pairs_total, done, n_trials,
               std::chrono::duration<double, std::micro>(t_end - t_prep).count());
     }
     return ASD_OK;
@@ -2268,6 +2554,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   hipLaunchKernelGGL(k_ba_edge_report, dim3(nblk_e), dim3(256), 0, st, d, s->chi2.as<double>(), s->dpos.as<uint8_t>(), (uint8_t*)nullptr, (uint8_t*)nullptr);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ASD_HIP_CHECK(ctx, hipEventRecord(ev1, st));
+  const auto t_rounds = std::chrono::steady_clock::now();
   const int fin = s->h_lm->cur & 1;   // the buffer that holds the accepted estimate (mirrored at the round's last synchronisation)
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_chi2, s->chi2.p, (size_t)E * 8, hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(res->edge_depth_pos, s->dpos.p, (size_t)E, hipMemcpyDeviceToHost, st));
@@ -2281,6 +2568,11 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     q[0] = hp[p].qx; q[1] = hp[p].qy; q[2] = hp[p].qz; q[3] = hp[p].qw; q[4] = hp[p].tx; q[5] = hp[p].ty; q[6] = hp[p].tz;
   }
 #undef ENS
+  if (timing) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[ba call] buffers + problem upload %.0f us, rounds (structure, trials, gating) %.0f us, results %.0f us\n", us(t_enter, t_uploaded),
+            us(t_uploaded, t_rounds), us(t_rounds, std::chrono::steady_clock::now()));
+  }
   return ASD_OK;
 }
 

@@ -219,6 +219,35 @@ def test_hip_local_ba_edge_cases(hip, oracle, synth):
 
 
 @pytest.mark.gpu
+def test_local_ba_structure_on_device_equals_host_structure(pkg, synth, monkeypatch):
+    """The active structure of a LocalBA (h-indices, edges by landmark, pose edge lists, the Schur pair lists per block) is built by
+    device kernels (k_ba_struct*); ASD_BA_STRUCT=host keeps the host loop that used to build it.  Same tables in the same order ->
+    the solver forms the same sums: every output is bit-identical, on the nominal problem and on the awkward ones (landmarks seen
+    only by fixed keyframes, unobserved landmarks, a pose without edges, problems with one free pose)."""
+    probs = [synth.ba_problem(), synth.ba_problem(n_free=3, n_fixed=3, n_points=150, seed=12, outlier_frac=0.3),
+             synth.ba_problem(n_free=1, n_fixed=2, n_points=40, seed=3, obs_per_point=2), synth.ba_problem(n_free=30, n_fixed=4, n_points=900, seed=8)]
+    lonely = synth.ba_problem(n_free=4, n_fixed=2, n_points=120, seed=5)
+    keep = lonely["e_pose"] != 3                      # a free pose (ids 0, 1 are the fixed ones) loses every edge; the last ten landmarks are never observed
+    keep &= lonely["e_point"] < 110
+    for k in ("e_pose", "e_point", "e_obs", "e_info"):
+        lonely[k] = np.ascontiguousarray(lonely[k][keep])
+    probs.append(lonely)
+    monkeypatch.setenv("ASD_BA_STRUCT", "host")
+    host = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    monkeypatch.delenv("ASD_BA_STRUCT")
+    dev = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    try:
+        for prob in probs:
+            a, b = dev.local_ba(prob), host.local_ba(prob)
+            for k in ("poses", "points", "edge_chi2", "edge_outlier1", "edge_depth_pos"):
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+            assert (a["iters_first"], a["iters_second"], a["chi2_first"], a["chi2_second"]) == (b["iters_first"], b["iters_second"], b["chi2_first"], b["chi2_second"])
+    finally:
+        host.close()
+        dev.close()
+
+
+@pytest.mark.gpu
 def test_local_ba_lane_equals_inline_and_runs_beside_tracking(hip, synth):
     """asd_local_ba_submit / _wait: LocalBundleAdjustment on the library's optional lane (the reference itself calls it in line,
     Tracking.cc:797 -> LocalMapping.cc:89).  Same kernels in the same order on another stream:
