@@ -1854,23 +1854,24 @@ __global__ __launch_bounds__(256) void k_ba_struct_sort(BaStructDev a) {
 }
 
 // every free pose's edges (k indices) in k order: one workgroup per pose, an ordered compaction over the act list
-__global__ __launch_bounds__(256) void k_ba_struct_pose_edges(BaStructDev a, int Ea) {
-  __shared__ int wsum[4];
+__global__ __launch_bounds__(kStructThreads) void k_ba_struct_pose_edges(BaStructDev a, int Ea) {
+  constexpr int NT = kStructThreads, NW = NT / 64;
+  __shared__ int wsum[NW];
   const int h = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   int start = 0;
   for (int q = 0; q < h; ++q) start += a.ps_cnt[q];
   if (t == 0) { a.ps_start[h] = start; if (h == (int)gridDim.x - 1) a.ps_start[h + 1] = start + a.ps_cnt[h]; }
   int run = start;
-  for (int k0 = 0; k0 < Ea; k0 += 256) {
+  for (int k0 = 0; k0 < Ea; k0 += NT) {
     const int k = k0 + t;
     const bool f = k < Ea && a.ph_of_k[k] == h;
     const unsigned long long bal = __ballot(f);
     if (lane == 0) wsum[w] = __popcll(bal);
     __syncthreads();
-    int off = __popcll(bal & ((1ull << lane) - 1));
-    for (int q = 0; q < w; ++q) off += wsum[q];
+    int off = __popcll(bal & ((1ull << lane) - 1)), all = 0;
+    for (int q = 0; q < NW; ++q) { if (q < w) off += wsum[q]; all += wsum[q]; }
     if (f) a.ps_edges[run + off] = k;
-    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    run += all;
     __syncthreads();
   }
 }
@@ -2332,7 +2333,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
       nPf = s->h_counts[0]; nLa = s->h_counts[1]; Ea = s->h_counts[2];
       nblk = nPf * (nPf + 1) / 2;
       if (nPf > 0) {
-        hipLaunchKernelGGL(k_ba_struct_pose_edges, dim3(nPf), dim3(256), 0, st, sd, Ea);
+        hipLaunchKernelGGL(k_ba_struct_pose_edges, dim3(nPf), dim3(kStructThreads), 0, st, sd, Ea);
         hipLaunchKernelGGL(k_ba_struct_pairs<false>, dim3(nblk), dim3(kPairThreads), 0, st, sd, nPf, nLa, nblk);
         hipLaunchKernelGGL(k_ba_struct_pairs<true>, dim3(nblk), dim3(kPairThreads), 0, st, sd, nPf, nLa, nblk);
         ASD_HIP_CHECK(ctx, hipGetLastError());
