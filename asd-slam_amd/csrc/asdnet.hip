@@ -115,13 +115,13 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
     float s = (x[0] + x[1]) + (x[2] + x[3]);
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0 && ld) red[wave] = s;
-    __syncthreads();
+    asd_syncthreads();
     const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
     float d[4], ss = 0.f;
     for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
     if (lane == 0 && ld) red[4 + wave] = ss;
-    __syncthreads();
+    asd_syncthreads();
     const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
     if (ld) {
       const int idx = t * 4, y = idx >> 5, x0 = idx & 31;  // this thread's 4 pixels sit in row y
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       if (j >= 0 && j < ROWS + 4)
         for (int k = 0; k < 4; ++k) pin[j * 36 + x0 + k + 1] = d[k] / sd;
     }
-    __syncthreads();
+    asd_syncthreads();
     // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding).
     // item = (pixel, quad of 4 couts); NTH is a multiple of 8, so a thread keeps the same quad for all its items and
     // holds that quad's 36 weights + 4 biases in registers (they were 40 LDS reads per item before)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
       if (C::WQUADS >= NTH || t < C::WQUADS)
         *reinterpret_cast<f32x4*>(sw + ps * C::WCHUNK + (r * NTH + t) * 4) =
             *reinterpret_cast<const f32x4*>(wimg + (size_t)ps * C::WCHUNK + (r * NTH + t) * 4);
-  __syncthreads();
+  asd_syncthreads();
 
   f32x16 acc[C::MT][C::NT];
   for (int mt = 0; mt < C::MT; ++mt)
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         for (int r = 0; r < C::WREGS; ++r)
           if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
       }
-      if (!(ABL & 8)) __syncthreads();
+      if (!(ABL & 8)) asd_syncthreads();
     }
   } else {
     for (int s = 0; s < C::NSTAGE; ++s) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN) void k_conv_mfma(const void* __restri
         for (int r = 0; r < C::WREGS; ++r)
           if (C::WQUADS >= NTH || t < C::WQUADS) *reinterpret_cast<f32x4*>(swn + (r * NTH + t) * 4) = wreg[r];
       }
-      if (!(ABL & 8)) __syncthreads();
+      if (!(ABL & 8)) asd_syncthreads();
     }
   }
 
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
   STORE_TILE(sact0);
   for (int r = 0; r < C::WREGS; ++r)
     *reinterpret_cast<f32x4*>(sw + (r * 256 + t) * 4) = *reinterpret_cast<const f32x4*>(wimg + (r * 256 + t) * 4);
-  __syncthreads();
+  asd_syncthreads();
 
   const int h = lane >> 5, li = lane & 31;
   int abase[C::MT];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
         for (int r = 0; r < C::WREGS; ++r) *reinterpret_cast<f32x4*>(swn + (r * 256 + t) * 4) = wreg[r];
       }
       if (s == 1 && has_next) STORE_TILE(sact0 + (cur ^ 1) * C::ACT_FLOATS);
-      __syncthreads();
+      asd_syncthreads();
       ++g;
     }
     // epilogue: bias (folded BN) + ReLU, NHWC store; drains under the next tile's MFMAs
@@ -613,17 +613,17 @@ __device__ inline int tile_first(const TileQueue& q, int* slot) {
     if (blockIdx.x == gridDim.x - 1 || !asd_cu_reserved(q.reserve)) tl = atomicAdd(q.counter, 1);
     *slot = tl >= 0 && tl < q.ntiles ? tl : -1;
   }
-  __syncthreads();
+  asd_syncthreads();
   return *slot;
 }
 __device__ inline int tile_next(const TileQueue& q, int* slot) {
   if (!q.counter) return -1;
-  __syncthreads();   // every wave is done with the tile's LDS and with *slot
+  asd_syncthreads();   // every wave is done with the tile's LDS and with *slot
   if (threadIdx.x == 0) {
     const int tl = atomicAdd(q.counter, 1);
     *slot = tl < q.ntiles ? tl : -1;
   }
-  __syncthreads();
+  asd_syncthreads();
   return *slot;
 }
 
@@ -711,13 +711,13 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
     X3_STAMP(9);
     if (lane == 0 && ld) red[wave] = sum;
-    __syncthreads();
+    asd_syncthreads();
     const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
     float d[4], ss = 0.f;
     for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
     if (lane == 0 && ld) red[4 + wave] = ss;
-    __syncthreads();
+    asd_syncthreads();
     const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
     if (ld) {
       const int idx = t * 4, y = idx >> 5, x0 = idx & 31;  // this thread's 4 pixels sit in row y
@@ -725,7 +725,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
       if (j >= 0 && j < ROWS + 4)
         for (int k = 0; k < 4; ++k) pin[j * 36 + x0 + k + 1] = d[k] / sd;
     }
-    __syncthreads();
+    asd_syncthreads();
     if (stamps) st_t1 = __builtin_amdgcn_s_memtime();
     // conv1 output for rows r0-1 .. r0+ROWS, cols -1 .. 32 (zero outside the 32x32 map: conv2's padding).
     // item = (pixel, octet of 8 couts); a thread keeps its octet and holds its 72 weights + 8 biases in registers.
@@ -856,7 +856,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
     }
   }
   X3_STAMP(12);
-  __syncthreads();
+  asd_syncthreads();
   X3_STAMP(13);
 
   // accumulators: [A sub-tile][B sub-tile]; a sub-tile is 32x32 (16 floats per lane) or 16x16 (4 floats per lane)
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, 
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
   for (int st = 0; st < KPER / FC_KCH; ++st) {
     const int k0 = sk * KPER + st * FC_KCH;
-    __syncthreads();
+    asd_syncthreads();
     for (int idx = t; idx < FC_MT * 32 * (FC_KCH / 4); idx += 256) {
       const int c4 = idx % (FC_KCH / 4), row = idx / (FC_KCH / 4);
       int p = p0 + row;
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_fc_mfma(const float* __restrict__ act, 
       *reinterpret_cast<f32x4*>(sa + row * (FC_KCH + 4) + c4 * 4) =
           *reinterpret_cast<const f32x4*>(act + (size_t)p * 8192 + k0 + c4 * 4);
     }
-    __syncthreads();
+    asd_syncthreads();
     const float* wb = wimg + ((size_t)(k0 / 8) * 2 + h) * 128 * 4 + (wave * 32 + li) * 4;
 #pragma unroll 4
     for (int c8 = 0; c8 < FC_KCH / 8; ++c8) {
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256) void k_fc_x3(const float* __restrict__ act, co
   int c = 0;  // chunk index within this workgroup's k range
   for (int slab = 0; slab < NSLAB; ++slab) {
     const int k0 = sk * KPER + slab * FCS_SLAB;
-    __syncthreads();  // the previous slab has been consumed
+    asd_syncthreads();  // the previous slab has been consumed
     {
       // 64 rows x 16 groups of 8 k: four items per thread, loads first
       f32x4 v0[4], v1[4];
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_fc_x3(const float* __restrict__ act, co
         *reinterpret_cast<u32x4*>(dst + 32) = pl;
       }
     }
-    __syncthreads();
+    asd_syncthreads();
 #pragma unroll
     for (int cs = 0; cs < FCS_SLAB / 32; ++cs, ++c) {
       // ring slot of chunk c is c % 3; NSLAB * 4 chunks in all, the slot pattern repeats every 3 chunks, so index by (c % 3)
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_fc_x2(const uint8_t* __restrict__ act, 
   int c = 0;
   for (int slab = 0; slab < NSLAB; ++slab) {
     const int k0 = sk * KPER + slab * FCS_SLAB;
-    __syncthreads();  // the previous slab has been consumed
+    asd_syncthreads();  // the previous slab has been consumed
     {
       u32x4 v0[4], v1[4];
 #pragma unroll
@@ -1218,7 +1218,7 @@ __global__ __launch_bounds__(256) void k_fc_x2(const uint8_t* __restrict__ act, 
         *reinterpret_cast<u32x4*>(dst + 16) = v1[i];
       }
     }
-    __syncthreads();
+    asd_syncthreads();
 #pragma unroll
     for (int cs = 0; cs < FCS_SLAB / 32; ++cs, ++c) {
       auto step = [&](u32x4 (&bc)[2][2], u32x4 (&bn)[2][2]) {

@@ -89,8 +89,13 @@ __device__ inline void rs_step_swap(double (&v)[2 * M], double (&o)[M]) {
 __device__ inline double wave_reduce_scatter32(double (&v)[32]) {
   const int lane = threadIdx.x & 63;
   double a[16], b[8], c[4], d[2], e[1];
+#ifdef ASD_NO_PERMLANE_SWAP   // diagnostic build: the two widest steps by __shfl_xor as well
+  rs_step<16>(v, a, 32, (lane & 32) != 0);
+  rs_step<8>(a, b, 16, (lane & 16) != 0);
+#else
   rs_step_swap<16, 32>(v, a);
   rs_step_swap<8, 16>(a, b);
+#endif
   rs_step<4>(b, c, 8, (lane & 8) != 0);
   rs_step<2>(c, d, 4, (lane & 4) != 0);
   rs_step<1>(d, e, 2, (lane & 2) != 0);
@@ -120,14 +125,14 @@ __device__ inline void block_reduce(double (&v)[N], double* red, double* out /*[
     for (int k = 0; k < 64; ++k) w[k] = k < N ? v[k] : 0.0;
     const double tot = wave_reduce_scatter64(w);
     red[wave * 64 + lane] = tot;
-    __syncthreads();
+    asd_syncthreads();
     if (threadIdx.x < N) {
       double s = red[threadIdx.x];
 #pragma unroll
       for (int w2 = 1; w2 < NW; ++w2) s += red[w2 * 64 + threadIdx.x];
       out[threadIdx.x] = s;
     }
-    __syncthreads();
+    asd_syncthreads();
     return;
   }
   if constexpr (N <= 2) {
@@ -144,7 +149,7 @@ __device__ inline void block_reduce(double (&v)[N], double* red, double* out /*[
     const double tot = wave_reduce_scatter32(w);
     if ((lane & 1) == 0) red[wave * 32 + (lane >> 1)] = tot;
   }
-  __syncthreads();
+  asd_syncthreads();
   if (threadIdx.x < N) {
     const int k = threadIdx.x;
     double s = red[k];
@@ -152,7 +157,7 @@ __device__ inline void block_reduce(double (&v)[N], double* red, double* out /*[
     for (int w2 = 1; w2 < NW; ++w2) s += red[w2 * 32 + k];  // fixed order
     out[k] = s;
   }
-  __syncthreads();
+  asd_syncthreads();
 }
 
 // every loop fully unrolled: with run-time indices A[] and inv[] live in scratch memory (336 B per lane, ~1450 cycles per solve on
@@ -510,13 +515,13 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       const unsigned long long m = __ballot(has);
       if (lane == 0) g_cnt[c * kPoseWaves + wave] = __popcll(m);
     }
-    __syncthreads();
+    asd_syncthreads();
     if (threadIdx.x == 0) {
       int sum = 0;
       for (int i = 0; i < nchunks * kPoseWaves; ++i) { const int v = g_cnt[i]; g_cnt[i] = sum; sum += v; }
       g_cnt[kGatherChunks * kPoseWaves] = sum;
     }
-    __syncthreads();
+    asd_syncthreads();
     ne = g_cnt[kGatherChunks * kPoseWaves];
   } else if (a.n_dev) {   // the matches were made on the device (asd_track_*): the edge count is only known there
     ne = *a.n_dev;
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     S.T0 = T0;
     S.T = T0;
   }
-  __syncthreads();
+  asd_syncthreads();
   bool robust = true;
   int nBad = 0;
   bool flags_changed = true;   // did the previous round's re-classification change any flag?
@@ -613,11 +618,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     const bool repeat = round >= 1 && round <= 2 && !flags_changed;
     if (!repeat) {
     if (t == 0) { S.T = S.T0; S.npass = 0; for (int q = 0; q < 4; ++q) { S.cyc[q] = 0; S.dbg[q] = 0; } }  // every round restarts from the input pose (Optimizer.cc:337)
-    __syncthreads();
+    asd_syncthreads();
     pose_pass(a, E, lvl, S, robust);
-    __syncthreads();
+    asd_syncthreads();
     if (t < 64) pose_sums_wave0(S);
-    __syncthreads();
+    asd_syncthreads();
     const bool any_active = S.sums[28] > 0.5;
     if (any_active) {
       // ---- g2o optimize(10): Levenberg (optimization_algorithm_levenberg.cpp:61-189) as a state machine run by thread 0 between
@@ -666,11 +671,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       };
       if (t == 0) { begin_iteration(); next_trial(); }
       for (;;) {
-        __syncthreads();               // S.T / S.cont of thread 0
+        asd_syncthreads();               // S.T / S.cont of thread 0
         const int phase = S.cont;
         if (phase == 0) break;
         pose_pass(a, E, lvl, S, robust);
-        __syncthreads();
+        asd_syncthreads();
         if (t < 64) {
           pose_sums_wave0(S);
           if (t == 0) {
@@ -726,7 +731,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
         }
       }
     } else {
-      __syncthreads();
+      asd_syncthreads();
     }
     // ---- re-classification (Optimizer.cc:341-368)
     double nb[1] = {0.0};
@@ -756,10 +761,10 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
         if (bad) nb[0] += 1.0;
       }
     }
-    flags_changed = __syncthreads_or(chg) != 0;
+    flags_changed = asd_syncthreads_or(chg) != 0;
     block_reduce<1, kPoseWaves>(nb, S.red, S.sums);
     nBad = (int)(S.sums[0] + 0.5);
-    __syncthreads();
+    asd_syncthreads();
     if (a.debug && t == 0)
       printf("[pose_opt] round %d: %d passes, nBad %d; cycles/pass: edges %lld (slowest wave %lld) reduce %lld solve+oplus %lld (solve %lld) accept %lld\n", round, S.npass,
              nBad, S.cyc[0] / S.npass, S.dbg[0] / S.npass, S.cyc[1] / S.npass, S.cyc[2] / S.npass, S.dbg[1] / S.npass, S.cyc[3] / S.npass);
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(1024) void k_pose_edges(PoseEdgesArgs a) {
   __shared__ int wave_tot[16], base;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) base = 0;
-  __syncthreads();
+  asd_syncthreads();
   for (int j0 = 0; j0 < a.n_cur; j0 += 1024) {
     const int j = j0 + t;
     int row = -1;
@@ -818,7 +823,7 @@ __global__ __launch_bounds__(1024) void k_pose_edges(PoseEdgesArgs a) {
     const bool has = mine || row >= 0;
     const unsigned long long m = __ballot(has);
     if (lane == 0) wave_tot[wave] = __popcll(m);
-    __syncthreads();
+    asd_syncthreads();
     int off = base;
     for (int w = 0; w < wave; ++w) off += wave_tot[w];
     if (has) {
@@ -831,9 +836,9 @@ __global__ __launch_bounds__(1024) void k_pose_edges(PoseEdgesArgs a) {
       E[3] = (double)k.x; E[4] = (double)k.y; E[5] = (double)a.inv_sigma2[oct];
       a.isgi[e] = (uint8_t)oct;
     }
-    __syncthreads();
+    asd_syncthreads();
     if (t == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wave_tot[w]; base += s; }
-    __syncthreads();
+    asd_syncthreads();
   }
   if (t == 0) *a.n_out = base;
 }
@@ -1156,14 +1161,14 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
   for (int I = t; I < nb; I += nt)
     for (int J = 0; J <= I; ++J) tri[I * (I + 1) / 2 + J] = make_short2((short)I, (short)J);
   if (t == 0) ok = 1;
-  __syncthreads();
+  asd_syncthreads();
   for (int idx = t; idx < nblk * 36; idx += nt) {
     const int blk = idx / 36, e = idx % 36;
     const short2 ij = tri[blk];
     L[idx] = A[(size_t)(6 * ij.x + e / 6) * n + 6 * ij.y + e % 6];
   }
   for (int i = t; i < n; i += nt) xs[i] = bs[i];
-  __syncthreads();
+  asd_syncthreads();
   for (int jb = 0; jb < nb; ++jb) {
     if (t == 0) {  // factor the diagonal block, forward-substitute its slice of the right-hand side: in registers
       double* ap = LB(jb, jb);
@@ -1206,7 +1211,7 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
       for (int q = 0; q < 6; ++q) { xs[6 * jb + q] = y[q]; invd[6 * jb + q] = iv[q]; }
       if (!good) ok = 0;
     }
-    __syncthreads();
+    asd_syncthreads();
     const double* Ljj = LB(jb, jb);
     const double* iv = invd + 6 * jb;
     // panel: every row below solves against Ljj^T
@@ -1222,7 +1227,7 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
       }
       for (int c = 0; c < 6; ++c) a[c] = v[c];
     }
-    __syncthreads();
+    asd_syncthreads();
     // trailing update: block (I,K), I >= K > jb, and the right-hand side rows below
     const int m = nb - jb - 1, mblk = m * (m + 1) / 2;
     for (int idx = t; idx < mblk * 36 + m * 6; idx += nt) {
@@ -1244,7 +1249,7 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
         xs[6 * I + r] -= s;
       }
     }
-    __syncthreads();
+    asd_syncthreads();
   }
   // backward substitution (L^T)
   for (int jb = nb - 1; jb >= 0; --jb) {
@@ -1265,7 +1270,7 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
 #pragma unroll
       for (int q = 0; q < 6; ++q) xs[6 * jb + q] = y[q];
     }
-    __syncthreads();
+    asd_syncthreads();
     for (int row = t; row < jb * 6; row += nt) {
       const int I = row / 6, r = row % 6;  // x_I -= L(jb,I)^T x_jb
       const double* a = LB(jb, I);
@@ -1273,7 +1278,7 @@ __global__ __launch_bounds__(kCholThreads) void k_ba_chol_lds(const double* __re
       for (int c = 0; c < 6; ++c) s += a[c * 6 + r] * xs[6 * jb + c];
       xs[6 * I + r] -= s;
     }
-    __syncthreads();
+    asd_syncthreads();
   }
 #undef LB
   for (int i = t; i < n; i += nt) x[i] = xs[i];
@@ -1322,17 +1327,17 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
   for (int I = t; I < nb; I += nt)
     for (int J = 0; J <= I; ++J) tri[I * (I + 1) / 2 + J] = make_short2((short)I, (short)J);
   if (t == 0) ok = 1;
-  __syncthreads();
+  asd_syncthreads();
   for (int idx = t; idx < nblk * 36; idx += nt) L[idx] = A[idx];   // A = the packed lower triangle (k_ba_schur writes it in this layout)
   for (int i = t; i < n; i += nt) xs[i] = bs[i];
-  __syncthreads();
+  asd_syncthreads();
   if (wave == 0) {   // the first pivot block
     double W[36];
     const bool good = inv6_sym(LB(0, 0), W);
     solve_store_inverse(W, Ww, lane);
     if (lane == 0 && !good) ok = 0;
   }
-  __syncthreads();
+  asd_syncthreads();
   for (int jb = 0; jb < nb; ++jb) {
     const int m = nb - jb - 1;
     const double* Wc = Ww + (jb & 1) * 36;
@@ -1362,7 +1367,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
         else LB(jb - 1, jb - 1)[idx - mp * 36] = Ww[((jb - 1) & 1) * 36 + idx - mp * 36];
       }
     }
-    __syncthreads();
+    asd_syncthreads();
     // ---- trailing update by rows; wave 0: next pivot block first, then its inverse (look-ahead)
     const int mblk = m * (m + 1) / 2;
     auto update_row = [&](int bq, int r) {   // row r of block (jb+1+ik.x, jb+1+ik.y)
@@ -1406,11 +1411,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
         }
       }
     }
-    __syncthreads();
+    asd_syncthreads();
   }
   // the last pivot's inverse (its panel is empty)
   if (t < 36) LB(nb - 1, nb - 1)[t] = Ww[((nb - 1) & 1) * 36 + t];
-  __syncthreads();
+  asd_syncthreads();
   // y_j = W_j z_j, then x_j = y_j - sum_{I > j} T_Ij^T x_I right-looking from the last block
   double yv = 0.0;
   if (t < n) {
@@ -1419,9 +1424,9 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
 #pragma unroll
     for (int k = 0; k < 6; ++k) yv += w[k] * xs[6 * j + k];
   }
-  __syncthreads();
+  asd_syncthreads();
   if (t < n) xs[t] = yv;
-  __syncthreads();
+  asd_syncthreads();
   for (int jb = nb - 1; jb >= 1; --jb) {
     if (t < jb * 6) {
       const int K = t / 6, c = t % 6;
@@ -1431,7 +1436,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_ba_solve_lds(const double* __
       for (int r = 0; r < 6; ++r) s2 += a[r * 6 + c] * xs[6 * jb + r];
       xs[t] -= s2;
     }
-    __syncthreads();
+    asd_syncthreads();
   }
 #undef LB
   for (int i = t; i < n; i += nt) x[i] = xs[i];
@@ -1447,7 +1452,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
   if (lm->done) return;
   const int t = threadIdx.x, nt = blockDim.x;
   if (t == 0) ok = 1;
-  __syncthreads();
+  asd_syncthreads();
   const int nb = n / 6;
   for (int jb = 0; jb < nb; ++jb) {
     const int j0 = jb * 6;
@@ -1471,7 +1476,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
         A[(size_t)(j0 + r) * n + j0 + c] = Ljj[r * 6 + c];
       }
     }
-    __syncthreads();
+    asd_syncthreads();
     // panel: rows below, L[i][j0..j0+5] = A[i][j0..] * Ljj^-T
     for (int i = j0 + 6 + t; i < n; i += nt) {
       double row[6];
@@ -1483,7 +1488,7 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
       }
       for (int c = 0; c < 6; ++c) A[(size_t)i * n + j0 + c] = row[c];
     }
-    __syncthreads();
+    asd_syncthreads();
     // trailing update (lower triangle incl. diagonal): A[i][k] -= sum_c L[i][j0+c] L[k][j0+c]
     const int m = n - j0 - 6;
     for (int idx = t; idx < m * m; idx += nt) {
@@ -1493,11 +1498,11 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
       for (int c = 0; c < 6; ++c) s += A[(size_t)i * n + j0 + c] * A[(size_t)k * n + j0 + c];
       A[(size_t)i * n + k] -= s;
     }
-    __syncthreads();
+    asd_syncthreads();
   }
   // forward substitution L y = bs (y kept in x)
   for (int i = t; i < n; i += nt) x[i] = bs[i];
-  __syncthreads();
+  asd_syncthreads();
   for (int jb = 0; jb < nb; ++jb) {
     const int j0 = jb * 6;
     if (t == 0)
@@ -1506,13 +1511,13 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
         for (int k = 0; k < r; ++k) s -= A[(size_t)(j0 + r) * n + j0 + k] * x[j0 + k];
         x[j0 + r] = s / A[(size_t)(j0 + r) * n + j0 + r];
       }
-    __syncthreads();
+    asd_syncthreads();
     for (int i = j0 + 6 + t; i < n; i += nt) {
       double s = 0.0;
       for (int c = 0; c < 6; ++c) s += A[(size_t)i * n + j0 + c] * x[j0 + c];
       x[i] -= s;
     }
-    __syncthreads();
+    asd_syncthreads();
   }
   // backward substitution L^T x = y
   for (int jb = nb - 1; jb >= 0; --jb) {
@@ -1523,13 +1528,13 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
         for (int k = r + 1; k < 6; ++k) s -= A[(size_t)(j0 + k) * n + j0 + r] * x[j0 + k];
         x[j0 + r] = s / A[(size_t)(j0 + r) * n + j0 + r];
       }
-    __syncthreads();
+    asd_syncthreads();
     for (int i = t; i < j0; i += nt) {
       double s = 0.0;
       for (int c = 0; c < 6; ++c) s += A[(size_t)(j0 + c) * n + i] * x[j0 + c];
       x[i] -= s;
     }
-    __syncthreads();
+    asd_syncthreads();
   }
   if (t == 0) lm->chol_ok = ok;
 }
@@ -1602,7 +1607,7 @@ constexpr int kLmThreads = 256, kLmMaxPartials = 2048;
 __device__ inline int lm_stage_partials(const BaDev& d, double* sh) {
   const int np = min(d.scale_off + d.gL + d.gP, kLmMaxPartials);
   for (int i = threadIdx.x; i < np; i += kLmThreads) sh[i] = d.partial[i];
-  __syncthreads();
+  asd_syncthreads();
   return np;
 }
 // start of a round: computeActiveErrors + activeRobustChi2 have just run (k_ba_error, always)
@@ -1752,16 +1757,16 @@ __device__ inline int struct_excl_scan(int v, int* sh, int& total) {   // exclus
   int x = v;
   for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
   if (lane == 63) sh[w] = x;
-  __syncthreads();
+  asd_syncthreads();
   if (w == 0) {
     int q = lane < kStructThreads / 64 ? sh[lane] : 0;
     for (int off = 1; off < 16; off <<= 1) { const int y = __shfl_up(q, off); if (lane >= off) q += y; }
     if (lane < kStructThreads / 64) sh[lane] = q;
   }
-  __syncthreads();
+  asd_syncthreads();
   const int base = w ? sh[w - 1] : 0;
   total = sh[kStructThreads / 64 - 1];
-  __syncthreads();
+  asd_syncthreads();
   return base + x - v;
 }
 
@@ -1807,7 +1812,7 @@ __global__ __launch_bounds__(kStructThreads) void k_ba_struct_offsets(BaStructDe
   __shared__ int sh[16];
   constexpr int NT = kStructThreads;
   const int t = threadIdx.x, nLa = a.cursor[a.L];
-  __syncthreads();
+  asd_syncthreads();
   const int hchunk = (nLa + NT - 1) / NT, h0 = min(t * hchunk, nLa), h1 = min(h0 + hchunk, nLa);
   int cs = 0;
   for (int h = h0; h < h1; ++h) cs += a.pt_start[h + 1];
@@ -1826,7 +1831,7 @@ __global__ __launch_bounds__(256) void k_ba_struct_sort(BaStructDev a) {
   __shared__ int pcnt[kStructMaxFree];
   const int t = threadIdx.x, h = blockIdx.x * 256 + t, nLa = a.cursor[a.L];
   if (t < kStructMaxFree) pcnt[t] = 0;
-  __syncthreads();
+  asd_syncthreads();
   if (h < nLa) {
     const int s0 = a.pt_start[h], s1 = a.pt_start[h + 1];
     for (int i = s0 + 1; i < s1; ++i) {
@@ -1849,7 +1854,7 @@ __global__ __launch_bounds__(256) void k_ba_struct_sort(BaStructDev a) {
     a.pt_mask[h] = mask;
     a.pt_free0[h] = free0;
   }
-  __syncthreads();
+  asd_syncthreads();
   if (t < kStructMaxFree && pcnt[t]) atomicAdd(&a.ps_cnt[t], pcnt[t]);
 }
 
@@ -1867,12 +1872,12 @@ __global__ __launch_bounds__(kStructThreads) void k_ba_struct_pose_edges(BaStruc
     const bool f = k < Ea && a.ph_of_k[k] == h;
     const unsigned long long bal = __ballot(f);
     if (lane == 0) wsum[w] = __popcll(bal);
-    __syncthreads();
+    asd_syncthreads();
     int off = __popcll(bal & ((1ull << lane) - 1)), all = 0;
     for (int q = 0; q < NW; ++q) { if (q < w) off += wsum[q]; all += wsum[q]; }
     if (f) a.ps_edges[run + off] = k;
     run += all;
-    __syncthreads();
+    asd_syncthreads();
   }
 }
 
@@ -1894,10 +1899,10 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a,
     int part = 0;
     for (int b = t; b < q; b += kPairThreads) part += a.pair_cnt[b];
     red[t] = part;
-    __syncthreads();
-    for (int off = kPairThreads / 2; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+    asd_syncthreads();
+    for (int off = kPairThreads / 2; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; asd_syncthreads(); }
     start = red[0];
-    __syncthreads();
+    asd_syncthreads();
     if (t == 0) { a.blk_i[q] = i; a.blk_j[q] = j; a.pair_start[q] = start; }
   }
   const unsigned bi = 1u << i, bj = 1u << j;
@@ -1922,7 +1927,7 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a,
     int xs = cnt;   // exclusive prefix of cnt over the workgroup
     for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(xs, off); if (lane >= off) xs += y; }
     if (lane == 63) wsum[w] = xs;
-    __syncthreads();
+    asd_syncthreads();
     int off = xs - cnt, all = 0;
     for (int b = 0; b < NW; ++b) { if (b < w) off += wsum[b]; all += wsum[b]; }
     if (FILL && cnt) {
@@ -1935,7 +1940,7 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a,
               if (a.ph_of_k[y] == j) a.pairs[o++] = make_int2(x, y);
     }
     run += all; total += all;
-    __syncthreads();
+    asd_syncthreads();
   }
   if (t == 0) {
     if (!FILL) a.pair_cnt[q] = total;

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_bow_descend(VocDev V, const float* __re
     const int ff = f0 + t / 128;
     s_feat[t / 128][t % 128] = ff < n ? desc[(size_t)ff * 128 + t % 128] : 0.f;
   }
-  __syncthreads();
+  asd_syncthreads();
   const int f = f0 + g;
   if (f >= n) return;  // whole groups leave together; the butterflies below stay inside one group
   const float* q = s_feat[g];

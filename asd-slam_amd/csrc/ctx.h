@@ -62,6 +62,18 @@ struct AsdDevBuf {
 // device-side copy kernel (matcher.hip): dst / src 16-B aligned, bytes % 16 == 0; src may be pinned host memory
 hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes);
 
+// Workgroup barrier with the wait for this wave's own LDS operations spelled out.  hipcc (ROCm 7.2) left the `s_waitcnt lgkmcnt(0)`
+// of __syncthreads() out in front of ONE barrier of k_pose_opt -- the head of the Levenberg loop, behind thread 0's store of the
+// "round over" flag: the other waves could pass the barrier and read the flag (or the trial pose) before the store had landed.
+// Invisible alone; beside the extractor's ASDNet workgroups, which keep the CU's LDS queues full, 1-3 PoseOptimization calls in a
+// thousand came back with a pose 1e-14..1e-12 off or a garbage inlier count (tools/diag/pose_determinism.py; found through a
+// flaky tests/test_bench_host.py).  Every barrier in the library is written through these two, and `make check-isa` checks that
+// every s_barrier in the device code has the wait directly in front of it.
+#if defined(__HIPCC__)
+#define asd_syncthreads() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+__device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __syncthreads_or(pred); }
+#endif
+
 struct AsdXfer {
   char* h = nullptr;
   char* d = nullptr;

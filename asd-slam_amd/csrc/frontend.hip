@@ -208,7 +208,7 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const int* __restrict__ cell
   __shared__ int carry_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (t == 0) carry_s = 0;
-  __syncthreads();
+  asd_syncthreads();
   for (int base = 0; base < ncells; base += 1024) {
     const int i = base + t;
     const int v = i < ncells ? (cell_count[i] & 0x7fffffff) : 0;
@@ -218,14 +218,14 @@ __global__ __launch_bounds__(1024) void k_cell_scan(const int* __restrict__ cell
       if (lane >= off) incl += o;
     }
     if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
+    asd_syncthreads();
     int wbase = 0;
     for (int w = 0; w < wave; ++w) wbase += wsum[w];
     const int carry = carry_s;
     if (i < ncells) cell_off[i] = carry + wbase + incl - v;
-    __syncthreads();
+    asd_syncthreads();
     if (t == 1023) carry_s = carry + wbase + incl;
-    __syncthreads();
+    asd_syncthreads();
   }
   if (t <= nlevels) {
     // level_start[l] = offset of the level's first cell; level_start[nlevels] = total
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_blur7(PyrDev P, const uint8_t* __restri
     for (int i = 0; i < 7; ++i) s += c_gauss[i] * row[xs[i]];
     rows[r][threadIdx.x & 63] = s;
   }
-  __syncthreads();
+  asd_syncthreads();
   for (int r = wq; r < 16; r += 4) {
     const int yy = y0 + r;
     if (yy >= L.h || x >= L.w) continue;

@@ -167,13 +167,13 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
     cnt = walk(0);
   }
   if (lane == 0) wg_cnt[wave] = cnt;
-  __syncthreads();
+  asd_syncthreads();
   if (threadIdx.x == 0) {
     int sum = 0;
     for (int w = 0; w < kSearchWaves; ++w) sum += wg_cnt[w];
     wg_base = sum ? atomicAdd(total, sum) : 0;
   }
-  __syncthreads();
+  asd_syncthreads();
   off = wg_base;
   for (int w = 0; w < wave; ++w) off += wg_cnt[w];
   if (cnt > 0) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const float* __restrict__ d
     const int r = idx >> 5, c = idx & 31;
     *reinterpret_cast<float4*>(sd + r * 132 + c * 4) = reinterpret_cast<const float4*>(desc + (size_t)(s0 + r) * 128)[c];
   }
-  __syncthreads();
+  asd_syncthreads();
   for (int p = t; p < n * n; p += 256) {
     const int i = p / n, j = p % n;
     float acc = 0.f;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const float* __restrict__ d
     }
     D[i * (n + 1) + j] = acc;
   }
-  __syncthreads();
+  asd_syncthreads();
   const int kth = (int)(0.5 * (n - 1));
   for (int p = t; p < n * n; p += 256) {
     const int i = p / n, j = p % n;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_distinctive(const float* __restrict__ d
     }
     if (rank == kth) med[i] = v;  // exactly one j per row has this rank
   }
-  __syncthreads();
+  asd_syncthreads();
   if (t == 0) {
     float best_median = 100;
     int best = 0;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void k_dist_matrix(const float* __restrict__ a
     const int ia = min(i0 + r, na - 1);
     sa[r][c] = reinterpret_cast<const float4*>(a + (size_t)ia * 128)[c];
   }
-  __syncthreads();
+  asd_syncthreads();
   const float4* brow = reinterpret_cast<const float4*>(b + (size_t)min(j, nb - 1) * 128);
   float acc[16];
 #pragma unroll
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     if (q < a.nq && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
     pick[k] = -1;
   }
-  __syncthreads();
+  asd_syncthreads();
   const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
   const unsigned th_bits = __float_as_uint(TH_HIGH);
   unsigned long long ts_it0 = ts1;
@@ -508,11 +508,11 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
     };
     scan(key1, false);
     const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
-    __syncthreads();
+    asd_syncthreads();
     const unsigned long long p2 = __builtin_amdgcn_s_memrealtime();
     if (KIND == 1) {   // phase 1b: the smallest key among the others = second best (value and level)
       scan(key2, true);
-      __syncthreads();
+      asd_syncthreads();
     }
     // phase 2: the owner of a query takes the winner and posts the claim
     int changed = 0;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
       if (p >= 0 && (posmask >> k & 1)) atomicMin(&wr[p], (tag_wr << 16) | (unsigned)q);
     }
     const unsigned long long p3 = __builtin_amdgcn_s_memrealtime();
-    const bool more = __syncthreads_or(changed) && it < max_it;
+    const bool more = asd_syncthreads_or(changed) && it < max_it;
     ph[0] += (int)(p1 - p0); ph[1] += (int)(p2 - p1); ph[2] += (int)(p3 - p2); ph[3] += (int)(__builtin_amdgcn_s_memrealtime() - p3);
     if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
     if (!more) break;
@@ -548,13 +548,13 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
   // ---- outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
   int* last = reinterpret_cast<int*>(claim0);
   for (int j = t; j < a.n_cur; j += kResolveThreads) last[j] = -1;
-  __syncthreads();
+  asd_syncthreads();
   int mine = 0;
 #pragma unroll
   for (int k = 0; k < QPT; ++k)
     if (pick[k] >= 0) { atomicMax(&last[pick[k]], t + k * kResolveThreads); ++mine; }
   if (mine) atomicAdd(&n_written, mine);
-  __syncthreads();
+  asd_syncthreads();
   for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, last[j]);
   if (KIND == 0 && a.check_ori) {
     int bin[QPT];
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
       bin[k] = b;
       atomicAdd(&hist[b], 1);
     }
-    __syncthreads();   // also orders the match_cur stores above before the removals below
+    asd_syncthreads();   // also orders the match_cur stores above before the removals below
     if (t == 0) {      // ComputeThreeMaxima (:1584-1625)
       int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
       for (int i = 0; i < HISTO; i++) {
@@ -582,14 +582,14 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
       else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
       keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
     }
-    __syncthreads();
+    asd_syncthreads();
     int removed = 0;
 #pragma unroll
     for (int k = 0; k < QPT; ++k)   // every write in a discarded bin clears the keypoint and is subtracted (:1437-1450)
       if (bin[k] >= 0 && bin[k] != keep[0] && bin[k] != keep[1] && bin[k] != keep[2]) { OUT(pick[k], -1); ++removed; }
     if (removed) atomicAdd(&n_removed, removed);
   }
-  __syncthreads();
+  asd_syncthreads();
   if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, *a.total); CNT(2, it + 1);
     // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs -- in units of 10 ns
     CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));

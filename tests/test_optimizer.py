@@ -144,6 +144,40 @@ def test_hip_pose_optimization_full_size(hip, oracle, synth):
 
 
 @pytest.mark.gpu
+def test_hip_pose_optimization_is_deterministic_beside_the_extractor(hip, synth):
+    """PoseOptimization runs as one workgroup that usually shares its CU with ASDNet workgroups of the read-ahead extractor.  With
+    the CU's LDS queues kept full by them, a barrier that does not wait for the wave's own LDS stores lets other waves read a stale
+    flag or pose: round 3 found 1-3 calls in a thousand coming back 1e-14..1e-12 off or with a garbage inlier count (hipcc had left
+    the wait out in front of one barrier; asd_syncthreads() in ctx.h now writes it out, `make check-isa` checks every barrier).  The
+    same problem solved 600 times beside a busy extractor must give the same bits every time (tools/diag/pose_determinism.py is the
+    long form of this test)."""
+    img = synth.scene_frame(0)
+    d_img = hip.device_alloc(img.size)
+    hip.h2d(d_img, img)
+    pp = synth.pose_problem(1140, seed=5, outlier_frac=0.15)
+    first, pending = None, 0
+    try:
+        for r in range(600):
+            while pending < 2:
+                hip.extract_submit(d_img, 1241, 376, 1241)
+                pending += 1
+            got = hip.pose_optimize(pp["pose"], pp["Xw"], pp["obs"], pp["info"], pp["K"])
+            if r % 3 == 0:
+                hip.extract_wait()
+                pending -= 1
+            if first is None:
+                first = (np.array(got[0]), np.array(got[1]), got[2])
+            else:
+                np.testing.assert_array_equal(got[0], first[0], err_msg=f"run {r}")
+                np.testing.assert_array_equal(got[1], first[1], err_msg=f"run {r}")
+                assert got[2] == first[2], f"run {r}"
+    finally:
+        while pending:
+            hip.extract_wait()
+            pending -= 1
+
+
+@pytest.mark.gpu
 def test_hip_pose_optimization_storage_forms(hip, oracle, synth):
     """The solver keeps its edges in one of three forms (ba.hip, EdgeStore): compact LDS (observations exactly f32 and
     <= 16 distinct information values: the reference's case, and every other test here), full f64 LDS, or global memory
