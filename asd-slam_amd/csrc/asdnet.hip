@@ -1835,11 +1835,9 @@ extern "C" int asd_debug_x3_clock(asd_ctx* ctx, int layer, int n, int reps, doub
   // life; ASD_X3_PHASES=1 prints them
   if (getenv("ASD_X3_PHASES")) {
     auto med = [&](int k) { std::vector<double> v(grid); for (int i = 0; i < grid; ++i) v[i] = (double)hs[16 * i + k]; std::nth_element(v.begin(), v.begin() + grid / 2, v.end()); return v[grid / 2]; };
-    unsigned long long lo = ~0ull, hi = 0;
-    for (int i = 0; i < grid; ++i) { lo = std::min(lo, hs[16 * i + 6]); hi = std::max(hi, hs[16 * i + 7]); }
-    fprintf(stderr, "  layer %d: %d workgroups; prologue %.0f, staging %.0f, MFMA loop %.0f, whole life %.0f cycles (medians); kernel span %.0f cycles\n",
-            layer, grid, med(2), med(3), med(0), med(5), (double)(hi - lo));
-    fprintf(stderr, "     since entry: patch arrived %.0f, conv1 begins %.0f, staging loop done %.0f, barrier passed %.0f\n", med(9), med(11), med(12), med(13));
+    fprintf(stderr, "  layer %d: %d workgroups; prologue %.0f, staging %.0f, MFMA loop %.0f, whole life %.0f cycles (medians)\n", layer, grid, med(2), med(3),
+            med(0), med(5));
+    if (layer == 2) fprintf(stderr, "     since entry: patch arrived %.0f, staging loop done %.0f, barrier passed %.0f\n", med(9), med(12), med(13));
   }
   return ASD_OK;
 }

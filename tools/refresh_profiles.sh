@@ -18,4 +18,12 @@ python3 tools/collect_mfma_util.py $O/pmc_clk $O/pmc_mfma > $O/asdnet_mfma_util.
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_clk $O/pmc_mfma
 python3 tools/time_asdnet.py 2000 20 > $O/time_asdnet.txt 2>&1
 ASD_TIMING=1 python3 tools/ba_times.py > $O/ba_times.txt 2>&1
-tail -3 $O/timeline.txt; tail -2 $O/time_asdnet.txt; tail -3 $O/ba_times.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ba -o ba -- python3 tools/ba_times.py > /dev/null 2>&1
+find $O/prof_ba -name "*kernel_trace.csv" -delete
+# what a workgroup of every conv layer spends its life on, at three load levels (in-kernel stamps)
+for n in 64 256 2000; do echo "n=$n"; ASD_X3_PHASES=1 python3 tools/x3_clock.py $n 2>&1; done > $O/asdnet_phases.txt
+# issue rates of one wave / of waves sharing a SIMD (VALU, MFMA, both)
+(tools/ubench/valu_rate; tools/ubench/mix_rate) > $O/issue_rates.txt 2>&1
+# PoseOptimization beside the extractor: one result over thousands of calls
+python3 tools/diag/pose_determinism.py 3000 beside > $O/pose_determinism.txt 2>&1
+tail -3 $O/timeline.txt; tail -2 $O/time_asdnet.txt; tail -3 $O/ba_times.txt; tail -2 $O/pose_determinism.txt

@@ -53,13 +53,16 @@ int main() {
     float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> h(17);
     (void)hipMemcpy(h.data(), dc, 16 * 8, hipMemcpyDeviceToHost);
+    // the stamps are the long run's (16x the instruction counts); the wall time is that launch's, by events
     double tm = 0, tv = 0;
     for (int w = 0; w < 4 * mw; ++w) tm += (double)h[w] / (4 * mw);
     for (int w = 4 * mw; w < 4 * (mw + vw); ++w) tv += (double)h[w] / (4 * vw);
     printf("%d MFMA + %d VALU waves per SIMD:", mw, vw);
-    if (mw) printf("  MFMA wave %.1f cycles per MFMA", tm / n_mfma);
-    if (vw) printf("  VALU wave %.1f cycles per v_fma_f32", tv / n_valu);
-    printf("  [wall %.1f us for a 16x longer run: %.0f ticks per us]\n", ms * 1e3, (double)std::max(h[0], h[4 * mw]) / (ms * 1e3));
+    if (mw) printf("  MFMA wave %.1f ticks per MFMA (%.1f per SIMD)", tm / (16.0 * n_mfma), tm / (16.0 * n_mfma) / mw);
+    if (vw) printf("  VALU wave %.1f ticks per v_fma_f32", tv / (16.0 * n_valu));
+    printf("  [%.0f us wall", ms * 1e3);
+    if (mw) printf(", %.1f M MFMA/s per SIMD = %.0f %% of the 2.5 PFLOP/s rate", mw * 16.0 * n_mfma / (ms * 1e3), mw * 16.0 * n_mfma / (ms * 1e3) / 149.3 * 100);
+    printf("]\n");
   }
   return 0;
 }
