@@ -905,7 +905,9 @@ def main():
         nprod = SPLIT_PRODUCTS[pieces]
         form = "2 fp16 terms, 3 f16 MFMA products" if pieces == 2 else "3 bf16 terms, 6 bf16 MFMA products"
         peak = PEAK_BF16_MFMA_TFLOPS / nprod
-        roof_kernel = f"k_conv_x3<32,32,32,1,8,4,1,1,true,{pieces}> (ASDNet input_norm+conv1+conv2; f32 operands split into {form} per multiply-add, f32 accumulate)"
+        pair = pieces == 2 and os.environ.get("ASD_ASDNET_PAIR", "1") != "0"
+        roof_kernel = (f"k_conv_x3<32,32,32,1,8,4,1,1,true,{pieces}{',true' if pair else ''}> (ASDNet input_norm+conv1+conv2; f32 operands split into {form} per "
+                       f"multiply-add, f32 accumulate{'; output stored as the fp16 piece pairs of 16 x, 4 B per element like f32' if pair else ''})")
         roof_extra = {"peak_basis": f"dense f16/bf16 MFMA {PEAK_BF16_MFMA_TFLOPS} TFLOP/s / {nprod} products",
                       "executed_16bit_tflops": nprod * achieved, "vs_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
     else:
