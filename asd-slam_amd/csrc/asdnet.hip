@@ -504,7 +504,8 @@ struct X3Cfg {
   static constexpr int ACT_BYTES = INROWS * INCOLS * PIXB;
   static constexpr int LDS_BYTES = PP * ACT_BYTES;
   static_assert((PIXB / 16) % 2 == 1, "pixel stride must be an odd multiple of 16 B");
-  static_assert(M_WG % (32 * WM) == 0 && COUT % (32 * WN) == 0 && CIN % KCH == 0 && HO % ROWS == 0, "tile split");
+  static constexpr int NCW = COUT / WN;               // couts per wave: a multiple of the MFMA tile width (16 or 32)
+  static_assert(M_WG % (32 * WM) == 0 && COUT % WN == 0 && NCW % (ASD_X3_S16 ? 16 : 32) == 0 && CIN % KCH == 0 && HO % ROWS == 0, "tile split");
   static_assert(PP == 1 || ROWS == HO, "several patches per workgroup only for whole-patch bands");
   static_assert(M_PATCH % 32 == 0, "32-pixel MFMA tiles must not straddle patches");
 };
@@ -641,7 +642,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   // NP = 3: bf16 pieces, six products (in_scale = out_scale = 1); NP = 2: fp16 pieces of x * in_scale, three products, the
   // accumulators are multiplied by out_scale = 1 / (in_scale * the layer's weight scale) in the epilogue (powers of two: exact)
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
-  constexpr int NTH = C::NTH, MT = C::MT, NT = C::NT;
+  constexpr int NTH = C::NTH, MT = C::MT, NCW = C::NCW;
   static_assert(!PAIR || (NP == 2 && ASD_X3_S16), "the pair format belongs to the two-piece form on the 16x16x32 shape");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem_b[];
   // Inside the persistent launch this body is a loop body.  Everything below that depends only on the lane (operand offsets, the
@@ -665,8 +666,8 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   constexpr int SUB = S16 ? 2 : 1, KG = C::KCH / 8, TW = 32 / SUB;
   const int kg = S16 ? lane >> 4 : h, lr = S16 ? lane & 15 : li;
   // ---- B operand stream: chunk c = tap * NC16 + c16, this lane's 8 k values of (piece, k-group kg, cout)
-  const uint8_t* wl = wimg + ((size_t)kg * COUT + wn * NT * 32 + lr) * 16;
-  constexpr int NB = NT * SUB;  // B sub-tiles of this wave
+  const uint8_t* wl = wimg + ((size_t)kg * COUT + wn * NCW + lr) * 16;
+  constexpr int NB = NCW / TW;  // B sub-tiles of this wave
   auto load_b = [&](int c, u32x4 (&b)[NB][NP]) {
     const uint8_t* wc = wl + (size_t)((ASD_X3_ABL & 1) ? (c & 1) : c) * C::CHUNKB;
 #pragma unroll
@@ -959,7 +960,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
     // the neighbouring quarter-group and one 16-B store into [pixel][cout / 8][h | l][8]
     uint8_t* opb = reinterpret_cast<uint8_t*>(out) + ((size_t)patch * C::HO + r0) * C::HO * COUT * 4;
     for (int nb = 0; nb < NB; ++nb) {
-      const int co0 = wn * NT * 32 + nb * TW + 4 * kg;
+      const int co0 = wn * NCW + nb * TW + 4 * kg;
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + co0);
       for (int ma = 0; ma < NA; ++ma) {
         const int m0 = wm * MT * 32 + ma * TW;
@@ -983,7 +984,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   } else {
   float* op = out + ((size_t)patch * C::HO + r0) * C::HO * COUT;
   for (int nb = 0; nb < NB; ++nb) {
-    const int co = wn * NT * 32 + nb * TW + lr;
+    const int co = wn * NCW + nb * TW + lr;
     const float bv = bias[co];
     for (int ma = 0; ma < NA; ++ma) {
       const int m0 = wm * MT * 32 + ma * TW;
@@ -1291,11 +1292,39 @@ constexpr bool kPairOK = ASD_X3_S16 != 0;   // the pair format's transposed epil
 // split-operand kernels: <CIN, COUT, HIN, S, ROWS, WM, WN, PP>
 // (two workgroups per CU each: one's band staging overlaps the other's MFMAs; whole-patch conv4 / two-patch conv6
 // workgroups at one per CU measured 189 / 168 us against 163 / 160)
-#define L2S_CFG 32, 32, 32, 1, 8, 4, 1, 1
-#define L3S_CFG 32, 64, 32, 2, 4, 2, 2, 1
-#define L4S_CFG 64, 64, 16, 1, 8, 2, 2, 1
-#define L5S_CFG 64, 128, 16, 2, 4, 1, 4, 1
-#define L6S_CFG 128, 128, 8, 1, 8, 1, 4, 1
+// Wave layout WM x WN (pixels x couts) of conv2 / conv3 / conv4.  A wave fetches the B operands (weights) of its own cout columns from
+// L1 / L2 and the A operands (activations) of its own pixels from LDS, so fewer couts per wave mean less weight stream through the CU's
+// vector-memory path and more LDS reads per MFMA.  Measured at N = 2000 (round 3, tools/build_variant.sh): conv3 as 1 x 4 (64 pixels x 16
+// couts per wave, no weight fetched twice in a workgroup) 104 -> 96 us -- the default; conv2 as 2 x 2 164 against 146 and conv4 as 1 x 4 103
+// against 96: there the doubled LDS traffic costs more than the halved weight stream saves.
+#ifndef ASD_L2_WMN
+#define ASD_L2_WMN 4, 1
+#endif
+#ifndef ASD_L3_WMN
+#if ASD_X3_S16
+#define ASD_L3_WMN 1, 4
+#else
+#define ASD_L3_WMN 2, 2     // (the 32x32x16 shape needs 32 couts per wave)
+#endif
+#endif
+#ifndef ASD_L4_WMN
+#define ASD_L4_WMN 2, 2
+#endif
+#define L2S_CFG 32, 32, 32, 1, 8, ASD_L2_WMN, 1
+#define L3S_CFG 32, 64, 32, 2, 4, ASD_L3_WMN, 1
+#define L4S_CFG 64, 64, 16, 1, 8, ASD_L4_WMN, 1
+// conv5: rows per band, WM, WN.  With two fp16 pieces the whole 16 x 16 input of a patch is 79 KB of LDS, so two whole-patch workgroups
+// fit a CU and every weight is fetched for 64 pixels instead of 32: 71 -> 66 us (round 2's three-piece form had room for one such
+// workgroup only and was slower that way).  Measured and not kept (N = 2000): 8-wave workgroups for conv4 / conv5 / conv6 (64 pixels x 16
+// couts per wave, two MFMA-issuing waves per SIMD and workgroup): 115 / 77 / 106 us against 97 / 71 / 95.
+#ifndef ASD_L5_RWMN
+#define ASD_L5_RWMN 8, 1, 4
+#endif
+#ifndef ASD_L6_WMN
+#define ASD_L6_WMN 1, 4
+#endif
+#define L5S_CFG 64, 128, 16, 2, ASD_L5_RWMN, 1
+#define L6S_CFG 128, 128, 8, 1, 8, ASD_L6_WMN, 1
 
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int KC, int PP = 1, int RING = 2, bool FUSE1 = false>
 hipError_t launch_conv(hipStream_t st, const void* in, const float* wimg, const float* bias, float* out, int n,
