@@ -1003,8 +1003,11 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   if (stamps && t == 0) { const unsigned long long e = __builtin_amdgcn_s_memtime(); stamps[16 * bid + 5] = e - st_t0; stamps[16 * bid + 7] = e; }
 }
 
+#ifndef ASD_L2_MINWG
+#define ASD_L2_MINWG 3   // conv2 (two-piece form): workgroups per CU the register allocation is held to
+#endif
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3, bool PAIR = false>
-__global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? 3 : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
+__global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? ASD_L2_MINWG : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
                                                          unsigned long long* __restrict__ stamps, float in_scale, float out_scale, TileQueue tq) {
@@ -1311,7 +1314,10 @@ constexpr bool kPairOK = ASD_X3_S16 != 0;   // the pair format's transposed epil
 #define ASD_L4_WMN 2, 2
 #endif
 #define L2S_CFG 32, 32, 32, 1, 8, ASD_L2_WMN, 1
-#define L3S_CFG 32, 64, 32, 2, 4, ASD_L3_WMN, 1
+#ifndef ASD_L3_ROWS
+#define ASD_L3_ROWS 4
+#endif
+#define L3S_CFG 32, 64, 32, 2, ASD_L3_ROWS, ASD_L3_WMN, 1
 #define L4S_CFG 64, 64, 16, 1, 8, ASD_L4_WMN, 1
 // conv5: rows per band, WM, WN.  With two fp16 pieces the whole 16 x 16 input of a patch is 79 KB of LDS, so two whole-patch workgroups
 // fit a CU and every weight is fetched for 64 pixels instead of 32: 71 -> 66 us (round 2's three-piece form had room for one such
