@@ -603,6 +603,22 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
 // k_window_search.  The arithmetic is asd_frustum's, operation for operation (f32 with the two double accumulations of the
 // reference; -ffp-contract=off; IEEE division and square root), and the level comes from comparisons with thresholds that the
 // host derived from its own logf (ctx.h, level_thr), so the queries are the ones the host would have written.
+// The upload of a fused chain rides in its first kernel: the blocks behind the query blocks copy the chain's pinned upload block to its
+// device twin (everything but the query table at its head, which the query blocks write), the query blocks read their own inputs from
+// the PINNED block.  One launch and ~10 us of dependent copy kernel less per stage; the kernels behind this one read the device twin.
+struct UploadTail {
+  const uint4* src; uint4* dst;   // pinned block, device twin
+  size_t first16, n16;            // 16-B words [first16, n16) are copied
+  int q_blocks;                   // blocks [0, q_blocks) make queries, the rest copy
+};
+__device__ inline bool upload_tail_block(const UploadTail& u) {
+  if ((int)blockIdx.x < u.q_blocks) return false;
+  const size_t nb = gridDim.x - u.q_blocks;
+  for (size_t i = u.first16 + (size_t)(blockIdx.x - u.q_blocks) * 256 + threadIdx.x; i < u.n16; i += nb * 256) u.dst[i] = u.src[i];
+  return true;
+}
+constexpr int kUploadTailBlocks = 64;
+
 struct FrustumArgs {
   int n, n_levels, bfactor;
   const float* Xw; const float* normal; const float* min_dist; const float* max_dist;
@@ -611,8 +627,10 @@ struct FrustumArgs {
   float fx, fy, cx, cy, min_x, max_x, min_y, max_y, cos_limit, th;
   float level_thr[ASD_MAX_LEVELS], scale[ASD_MAX_LEVELS];
   WinQuery* queries;
+  UploadTail up;
 };
 __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
+  if (upload_tail_block(a.up)) return;
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
@@ -657,8 +675,10 @@ struct ProjectArgs {
   float fx, fy, cx, cy, min_x, max_x, min_y, max_y, th;
   float scale[ASD_MAX_LEVELS];
   WinQuery* queries;
+  UploadTail up;
 };
 __global__ __launch_bounds__(256) void k_project_queries(ProjectArgs a) {
+  if (upload_tail_block(a.up)) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
@@ -924,7 +944,8 @@ struct ChainHook {
   size_t result_bytes = 0;            // room wanted in the result block
   // optional: the queries are made on the device from the uploaded tables (frustum test + window of every map point)
   // instead of being copied from m->h_queries; called after the upload, before the search
-  std::function<int(WinQuery* d_queries, void* const* d_tab)> prepare;
+  // (h_tab: the same tables inside the pinned upload block; tail: the copy the kernel carries, see UploadTail)
+  std::function<int(WinQuery* d_queries, void* const* d_tab, void* const* h_tab, const UploadTail& tail)> prepare;
   // enqueue the chain's kernels: match table, the uploaded tables, where the results go (all device pointers)
   std::function<int(const int* d_match, void* const* d_tab, void* d_result)> enqueue;
   const void* h_result = nullptr;     // out: the chain's results on the host after the call
@@ -980,10 +1001,20 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     int* d_cnt = m->d_q_off + nq;
     int* d_total = up.dev<int>(o_total);
     int rc;
-    ASD_HIP_CHECK(ctx, up.upload(st));
-    void* d_tab[kChainTabs];
-    for (int i = 0; i < kChainTabs; ++i) d_tab[i] = has_tab[i] ? up.dev<void>(o_tab[i]) : nullptr;
-    if (dev_queries && (rc = chain->prepare(up.dev<WinQuery>(o_q), d_tab)) != ASD_OK) return rc;
+    static const bool tail_upload = getenv("ASD_UPLOAD_SEPARATE") == nullptr;   // ASD_UPLOAD_SEPARATE=1: the upload as a launch of its own
+    const bool carried = dev_queries && tail_upload;
+    if (!carried) ASD_HIP_CHECK(ctx, up.upload(st));
+    void *d_tab[kChainTabs], *h_tab[kChainTabs];
+    for (int i = 0; i < kChainTabs; ++i) {
+      d_tab[i] = has_tab[i] ? up.dev<void>(o_tab[i]) : nullptr;
+      h_tab[i] = has_tab[i] ? (carried ? up.host<void>(o_tab[i]) : up.dev<void>(o_tab[i])) : nullptr;
+    }
+    if (dev_queries) {
+      // the query table is the block's first reservation: the copy starts behind it
+      const UploadTail tail{reinterpret_cast<const uint4*>(up.h), reinterpret_cast<uint4*>(up.d), carried ? ((size_t)nq * sizeof(WinQuery) + 255) / 256 * 16 : 0,
+                            carried ? (up.used + 15) / 16 : 0, 0};
+      if ((rc = chain->prepare(up.dev<WinQuery>(o_q), d_tab, h_tab, tail)) != ASD_OK) return rc;
+    }
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     // (the "match" stage clock of asd_last_stage_ms: two timed event records per chain, each a barrier packet on the stream -- only
     // when somebody asked for timings)
@@ -1590,12 +1621,14 @@ int track_motion_model_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
     pa.min_x = C->min_x; pa.max_x = C->max_x; pa.min_y = C->min_y; pa.max_y = C->max_y; pa.th = th;
     for (int l = 0; l < ASD_MAX_LEVELS; ++l) pa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f;
     const bool by_rows = mp_rows != nullptr;
-    chain->prepare = [ctx, pa, by_rows](WinQuery* d_queries, void* const* d_tab) -> int {
+    chain->prepare = [ctx, pa, by_rows](WinQuery* d_queries, void* const*, void* const* h_tab, const UploadTail& tail) -> int {
       ProjectArgs a = pa;
-      a.Xw = static_cast<const float*>(d_tab[0]); a.has_mp = static_cast<const uint8_t*>(d_tab[1]);
-      a.rows = by_rows ? static_cast<const int*>(d_tab[2]) : nullptr;
+      a.Xw = static_cast<const float*>(h_tab[0]); a.has_mp = static_cast<const uint8_t*>(h_tab[1]);
+      a.rows = by_rows ? static_cast<const int*>(h_tab[2]) : nullptr;
       a.queries = d_queries;
-      hipLaunchKernelGGL(k_project_queries, dim3((a.n + 255) / 256), dim3(256), 0, ctx->stream, a);
+      a.up = tail;
+      a.up.q_blocks = (a.n + 255) / 256;
+      hipLaunchKernelGGL(k_project_queries, dim3(a.up.q_blocks + (tail.n16 ? kUploadTailBlocks : 0)), dim3(256), 0, ctx->stream, a);
       ASD_HIP_CHECK(ctx, hipGetLastError());
       return ASD_OK;
     };
@@ -1710,13 +1743,15 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
   const bool by_rows = desc == nullptr;
   if (by_rows) { chain->src[6] = rows; chain->bytes[6] = (size_t)n_mp * 4; }
   chain->result_bytes = pose_chain_io_bytes(F->n);
-  chain->prepare = [ctx, fa, by_rows, n_mp](WinQuery* d_queries, void* const* d_tab) -> int {
+  chain->prepare = [ctx, fa, by_rows, n_mp](WinQuery* d_queries, void* const*, void* const* h_tab, const UploadTail& tail) -> int {
     FrustumArgs a = fa;
-    a.Xw = static_cast<const float*>(d_tab[0]); a.normal = static_cast<const float*>(d_tab[3]);
-    a.min_dist = static_cast<const float*>(d_tab[4]); a.max_dist = static_cast<const float*>(d_tab[5]);
-    a.rows = by_rows ? static_cast<const int*>(d_tab[6]) : nullptr;
+    a.Xw = static_cast<const float*>(h_tab[0]); a.normal = static_cast<const float*>(h_tab[3]);
+    a.min_dist = static_cast<const float*>(h_tab[4]); a.max_dist = static_cast<const float*>(h_tab[5]);
+    a.rows = by_rows ? static_cast<const int*>(h_tab[6]) : nullptr;
     a.queries = d_queries;
-    hipLaunchKernelGGL(k_frustum_queries, dim3((n_mp + 255) / 256), dim3(256), 0, ctx->stream, a);
+    a.up = tail;
+    a.up.q_blocks = (n_mp + 255) / 256;
+    hipLaunchKernelGGL(k_frustum_queries, dim3(a.up.q_blocks + (tail.n16 ? kUploadTailBlocks : 0)), dim3(256), 0, ctx->stream, a);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
