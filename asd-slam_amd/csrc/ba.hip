@@ -632,7 +632,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       //   phase 1 = the pass evaluates a trial pose, 2 = it re-evaluates the current pose (after an iteration that ended on a
       //   rejected trial: the sums no longer describe the current estimate), 0 = the round's optimisation is over
       int nBadIt = 0, it = 0;
-      auto begin_iteration = [&]() {   // thread 0: the sums hold the system at the current estimate
+      // (both lambdas are forced inline: as an out-of-line function next_trial takes the kernel's argument block by reference, which
+      //  makes the compiler keep a private copy of it in scratch -- 336 B per lane written at entry, every a.fx of the passes a scratch load)
+      auto begin_iteration = [&]() __attribute__((always_inline)) {   // thread 0: the sums hold the system at the current estimate
         S.currentChi = S.sums[27];
         S.iniChi = S.sums[27];
         pose_take_system(S);
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
         S.qmax = 0;
         S.rho = 0;
       };
-      auto next_trial = [&]() {        // thread 0: solve (H + lambda I) x = b, T <- exp(x) T
+      auto next_trial = [&]() __attribute__((always_inline)) {        // thread 0: solve (H + lambda I) x = b, T <- exp(x) T
         const long long c0 = a.debug ? clock64() : 0;
         S.Tbak = S.T;
         double Hl[36], W[36], x[6];
