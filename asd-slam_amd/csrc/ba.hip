@@ -532,6 +532,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       for (int q = 0; q < 7; ++q) a.io[q] = a.pose0[q];
       a.io[7] = 0.0;
     }
+    if (gather) {   // the per-keypoint form of the flags (below): all clear, and the edge count behind them
+      unsigned long long* og8 = reinterpret_cast<unsigned long long*>(a.io + 8);
+      const int nw = (a.g_ncur + 7) / 8;
+      for (int i = threadIdx.x; i < nw; i += kPoseThreads) og8[i] = 0ull;
+      if (threadIdx.x == 0) a.io[8 + nw] = (double)ne;
+    }
     return;
   }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
@@ -778,6 +784,39 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     a.io[0] = S.T.qx; a.io[1] = S.T.qy; a.io[2] = S.T.qz; a.io[3] = S.T.qw;
     a.io[4] = S.T.tx; a.io[5] = S.T.ty; a.io[6] = S.T.tz;
     a.io[7] = (double)nBad;
+  }
+  if (gather) {
+    // Fused chains: the flags go out per KEYPOINT (0 where the keypoint carries no edge) with the edge count behind them, so that the
+    // host's completion is two copies instead of a walk over the keypoints that rebuilds the edge order.  The edge of keypoint j is
+    // found as in the gather (prefix table g_cnt still in LDS); the flags are collected in LDS first -- the edge store is free now --
+    // and leave in 8-byte stores.
+    asd_syncthreads();
+    uint8_t* kpf = reinterpret_cast<uint8_t*>(dyn);
+    const int lane = t & 63, wave = t >> 6;
+    const int nchunks = (a.g_ncur + kPoseThreads - 1) / kPoseThreads;
+    uint8_t mine[kGatherChunks];
+#pragma unroll
+    for (int c = 0; c < kGatherChunks; ++c) {   // (read every edge's flag before the first store over the edge store: outl sits behind it, kpf in front)
+      mine[c] = 0;
+      if (c >= nchunks) continue;
+      const int j = c * kPoseThreads + t;
+      const bool has = j < a.g_ncur && ((a.g_hold && a.g_hold[j]) || a.g_src[j] >= 0);
+      const unsigned long long m = __ballot(has);
+      mine[c] = has ? outl[g_cnt[c * kPoseWaves + wave] + __popcll(m & ((1ull << lane) - 1))] : 0;
+    }
+    asd_syncthreads();
+#pragma unroll
+    for (int c = 0; c < kGatherChunks; ++c) {
+      const int j = c * kPoseThreads + t;
+      if (c < nchunks && j < (a.g_ncur + 7) / 8 * 8) kpf[j] = j < a.g_ncur ? mine[c] : 0;
+    }
+    asd_syncthreads();
+    unsigned long long* og8 = reinterpret_cast<unsigned long long*>(a.io + 8);
+    const unsigned long long* k8 = reinterpret_cast<const unsigned long long*>(kpf);
+    const int nw = (a.g_ncur + 7) / 8;
+    for (int i = t; i < nw; i += kPoseThreads) og8[i] = k8[i];
+    if (t == 0) a.io[8 + nw] = (double)ne;
+    return;
   }
   // outlier flags to the (pinned host) io block, eight per 8-byte store
   unsigned long long* og8 = reinterpret_cast<unsigned long long*>(a.io + 8);
@@ -2073,6 +2112,7 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
   else hipLaunchKernelGGL(k_pose_opt<0>, dim3(1), dim3(kPoseThreads), 0, st, a);
   ASD_HIP_CHECK(ctx, hipGetLastError());
+  ctx->pose_chain_kp_flags = mode == 2;   // the form of the flags in d_io: per keypoint + edge count (gather form), or per edge
   return ASD_OK;
 }
 

@@ -158,6 +158,7 @@ struct asd_ctx {
   unsigned* d_calib = nullptr;  // calibration only: per-layer max |activation| as float bits (asdnet_forward_device fills it when set)
   int* d_tq = nullptr;          // tile counters of the persistent conv launches of one forward (asdnet.hip, TileQueue), one per layer
   int cu_reserve = 0;           // asd_cu_reserved mode of the persistent conv launches (ASD_ASDNET_RESERVE at asd_ctx_create)
+  bool pose_chain_kp_flags = false;   // the last pose_chain_enqueue wrote its outlier flags per keypoint (gather form of k_pose_opt)
   bool net_pair = true;         // two-piece form: activations between the layers as the fp16 piece pairs themselves (ASD_ASDNET_PAIR=0: f32 NHWC)
   bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
   uint8_t* d_patches = nullptr; // [max_patches][1024]
@@ -247,7 +248,7 @@ void bow_free(asd_ctx* ctx);
 // ba.hip: PoseOptimization enqueued behind device-resident matches (fused tracking chains; see the definition)
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io);
-inline size_t pose_chain_io_bytes(int n_cur) { return 64 + (size_t)n_cur + 64; }
+inline size_t pose_chain_io_bytes(int n_cur) { return 64 + ((size_t)n_cur + 7) / 8 * 8 + 64; }   // pose[7], n_bad, flags (8-B words), edge count
 // capi.cpp
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 

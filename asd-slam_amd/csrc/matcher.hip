@@ -1566,6 +1566,16 @@ namespace {
 int finish_pose_chain(asd_ctx* ctx, const AsdFrameSlot& C, const std::function<const float*(int)>& point_of, bool chained, const double* h_io,
                       const double* Kd, double* pose7, uint8_t* outlier, int32_t* n_inliers) {
   const int n_cur = C.n;
+  if (chained && ctx->pose_chain_kp_flags) {
+    // the gather form of k_pose_opt hands the flags over per keypoint with the edge count behind them: no walk over the keypoints
+    const int ne = (int)(h_io[8 + (n_cur + 7) / 8] + 0.5);
+    memcpy(outlier, h_io + 8, (size_t)n_cur);
+    *n_inliers = 0;
+    if (ne < 3) return ASD_OK;   // Optimizer.cc:323-324 (the kernel left the pose as it was and cleared the flags)
+    memcpy(pose7, h_io, 56);
+    *n_inliers = ne - (int)(h_io[7] + 0.5);
+    return ASD_OK;
+  }
   std::vector<int> kp_of_edge;
   for (int j = 0; j < n_cur; ++j) { outlier[j] = 0; if (point_of(j)) kp_of_edge.push_back(j); }
   const int ne = (int)kp_of_edge.size();
