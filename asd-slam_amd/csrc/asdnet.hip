@@ -1324,7 +1324,11 @@ constexpr bool kPairOK = ASD_X3_S16 != 0;   // the pair format's transposed epil
 // workgroup only and was slower that way).  Measured and not kept (N = 2000): 8-wave workgroups for conv4 / conv5 / conv6 (64 pixels x 16
 // couts per wave, two MFMA-issuing waves per SIMD and workgroup): 115 / 77 / 106 us against 97 / 71 / 95.
 #ifndef ASD_L5_RWMN
+#if ASD_X3_S16
 #define ASD_L5_RWMN 8, 1, 4
+#else
+#define ASD_L5_RWMN 4, 1, 4     // (the 32x32x16 build keeps the 4-row bands: the whole-patch form costs it five more minutes of compile time)
+#endif
 #endif
 #ifndef ASD_L6_WMN
 #define ASD_L6_WMN 1, 4
