@@ -1001,7 +1001,8 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     int* d_cnt = m->d_q_off + nq;
     int* d_total = up.dev<int>(o_total);
     int rc;
-    static const bool tail_upload = getenv("ASD_UPLOAD_SEPARATE") == nullptr;   // ASD_UPLOAD_SEPARATE=1: the upload as a launch of its own
+    // ASD_UPLOAD_SEPARATE=1: the upload as a launch of its own; ASD_UPLOAD_COPY=1 (copy commands instead of copy kernels) implies it
+    static const bool tail_upload = getenv("ASD_UPLOAD_SEPARATE") == nullptr && getenv("ASD_UPLOAD_COPY") == nullptr;
     const bool carried = dev_queries && tail_upload;
     if (!carried) ASD_HIP_CHECK(ctx, up.upload(st));
     void *d_tab[kChainTabs], *h_tab[kChainTabs];

@@ -9,7 +9,7 @@ import pytest
 from tests.conftest import ROOT
 
 CASES = [
-    ({"ASD_RESULT_COPY": "1", "ASD_UPLOAD_COPY": "1", "ASD_UPLOAD_SEPARATE": "1"}, ["tests/test_track_chain.py", "tests/test_matcher.py::test_host_and_device_replay_agree"]),
+    ({"ASD_RESULT_COPY": "1", "ASD_UPLOAD_COPY": "1"}, ["tests/test_track_chain.py", "tests/test_matcher.py::test_host_and_device_replay_agree"]),
     ({"ASD_UPLOAD_SEPARATE": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_FRONT_PRIO_MID": "1"}, ["tests/test_bench_host.py"]),
     ({"ASD_ASDNET_PERSIST": "1", "ASD_ASDNET_RESERVE": "1"}, ["tests/test_asdnet.py", "tests/test_frontend.py::test_extract_kitti_size_bit_exact"]),
