@@ -26,4 +26,5 @@ for n in 64 256 2000; do echo "n=$n"; ASD_X3_PHASES=1 python3 tools/x3_clock.py 
 (tools/ubench/valu_rate; tools/ubench/mix_rate) > $O/issue_rates.txt 2>&1
 # PoseOptimization beside the extractor: one result over thousands of calls
 python3 tools/diag/pose_determinism.py 3000 beside > $O/pose_determinism.txt 2>&1
+python3 tools/diag/ba_determinism.py 600 >> $O/pose_determinism.txt 2>&1
 tail -3 $O/timeline.txt; tail -2 $O/time_asdnet.txt; tail -3 $O/ba_times.txt; tail -2 $O/pose_determinism.txt
