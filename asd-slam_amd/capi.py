@@ -52,6 +52,15 @@ def make_fv(node_of_kp):
     return fv, (ids, start, idx)
 
 
+class asd_track_frame_args(C.Structure):
+    _fields_ = [("slot_cur", C.c_int32), ("slot_last", C.c_int32), ("has_mp", C.c_void_p), ("Xw_last", C.c_void_p), ("last_rows", C.c_void_p),
+                ("last_cand", C.c_void_p), ("last_obs_positive", C.c_void_p), ("Tcw", C.c_void_p), ("th", C.c_float), ("check_orientation", C.c_int32),
+                ("n_cand", C.c_int32), ("cand_rows", C.c_void_p), ("cand_obs_positive", C.c_void_p), ("viewing_cos_limit", C.c_float),
+                ("th_local", C.c_float), ("nn_ratio", C.c_float), ("K", C.c_void_p), ("pose7", C.c_void_p), ("pose1", C.c_void_p),
+                ("match1", C.c_void_p), ("n_matches1", C.c_void_p), ("outlier1", C.c_void_p), ("n_inliers1", C.c_void_p),
+                ("match2", C.c_void_p), ("n_matches2", C.c_void_p), ("outlier2", C.c_void_p), ("n_inliers2", C.c_void_p)]
+
+
 class asd_ba_problem(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("poses", C.c_void_p), ("fixed", C.c_void_p), ("points", C.c_void_p),
@@ -375,6 +384,50 @@ class AsdHip:
             self._track_job = (match, n, pose, outl, ninl, n_cur)   # the library writes these at track_finish
             return None
         return match, n.value, pose, outl[:n_cur], ninl.value
+
+    def mpbank_put(self, first_row, Xw, normal, min_dist, max_dist):
+        Xw, normal, min_dist, max_dist = (_c(a, np.float32) for a in (Xw, normal, min_dist, max_dist))
+        self._chk(self.lib.asd_mpbank_put(self.ctx, first_row, len(min_dist), _p(Xw), _p(normal), _p(min_dist), _p(max_dist)))
+
+    def prep_async(self, on):
+        self._chk(self.lib.asd_prep_async(self.ctx, int(on)))
+
+    def track_frame(self, slot_cur, slot_last, n_cur, has_mp, Xw_last, last_rows, last_cand, Tcw, K, th, pose7, cand_rows, th_local, nn_ratio,
+                    cos_limit=0.5, check_ori=True, last_obs_positive=None, cand_obs_positive=None, split=False):
+        """asd_track_frame: both tracking stages as one submission -> dict(match1, n1, pose1, outlier1, n_inl1, match2, n2, pose, outlier2, n_inl2);
+        split=True: returns None once enqueued, track_frame_finish() returns the dict"""
+        a = asd_track_frame_args()
+        keep = dict(has=_c(has_mp, np.uint8), Xw=_c(Xw_last, np.float32), rows=_c(last_rows, np.int32),
+                    lc=None if last_cand is None else _c(last_cand, np.int32),
+                    o1=None if last_obs_positive is None else _c(last_obs_positive, np.uint8), T=_c(Tcw, np.float32),
+                    cr=_c(cand_rows, np.int32), o2=None if cand_obs_positive is None else _c(cand_obs_positive, np.uint8), K=_c(K, np.float32),
+                    pose=_c(pose7, np.float64).copy(), pose1=np.zeros(7, np.float64),
+                    m1=np.empty(n_cur, np.int32), m2=np.empty(n_cur, np.int32), out1=np.zeros(max(n_cur, 1), np.uint8), out2=np.zeros(max(n_cur, 1), np.uint8),
+                    n1=C.c_int32(), n2=C.c_int32(), i1=C.c_int32(), i2=C.c_int32())
+        adr = lambda x: None if x is None else x.ctypes.data
+        a.slot_cur, a.slot_last = slot_cur, slot_last
+        a.has_mp, a.Xw_last, a.last_rows, a.last_cand, a.last_obs_positive = adr(keep["has"]), adr(keep["Xw"]), adr(keep["rows"]), adr(keep["lc"]), adr(keep["o1"])
+        a.Tcw, a.th, a.check_orientation = adr(keep["T"]), th, int(check_ori)
+        a.n_cand, a.cand_rows, a.cand_obs_positive = len(keep["cr"]), adr(keep["cr"]), adr(keep["o2"])
+        a.viewing_cos_limit, a.th_local, a.nn_ratio, a.K = cos_limit, th_local, nn_ratio, adr(keep["K"])
+        a.pose7, a.pose1 = adr(keep["pose"]), adr(keep["pose1"])
+        a.match1, a.n_matches1, a.outlier1, a.n_inliers1 = adr(keep["m1"]), C.addressof(keep["n1"]), adr(keep["out1"]), C.addressof(keep["i1"])
+        a.match2, a.n_matches2, a.outlier2, a.n_inliers2 = adr(keep["m2"]), C.addressof(keep["n2"]), adr(keep["out2"]), C.addressof(keep["i2"])
+        if split:
+            self._chk(self.lib.asd_track_async(self.ctx))
+        self._chk(self.lib.asd_track_frame(self.ctx, C.byref(a)))
+        self._frame_job = (keep, n_cur)
+        return None if split else self._frame_result()
+
+    def _frame_result(self):
+        k, n_cur = self._frame_job
+        self._frame_job = None
+        return dict(match1=k["m1"], n1=k["n1"].value, pose1=k["pose1"], outlier1=k["out1"][:n_cur], n_inl1=k["i1"].value,
+                    match2=k["m2"], n2=k["n2"].value, pose=k["pose"], outlier2=k["out2"][:n_cur], n_inl2=k["i2"].value)
+
+    def track_frame_finish(self):
+        self._chk(self.lib.asd_track_finish(self.ctx))
+        return self._frame_result()
 
     def track_finish(self):
         """completes the asd_track_* call started with split=True -> (match_cur, n_matches, pose7, outlier, n_inliers)"""

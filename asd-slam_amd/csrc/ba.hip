@@ -228,6 +228,8 @@ struct PoseOptArgs {
   double* soa_g;        // [8][n] global scratch (used when the problem does not fit LDS)
   uint8_t* flags_g;     // [2n] global scratch: level, outlier
   double pose0[7];      // initial pose (by value: no read of host memory on the kernel's critical path)
+  const double* pose0_dev;  // non-null (asd_track_frame: the stage behind another PoseOptimization): the initial pose is read from here
+  double* io_dev;           // non-null: the result block is written here as well (device memory, for the kernels of the next stage)
   double isg_tab[16];   // MODE 2: the distinct information values ...
   const uint8_t* isgi;  // ... and each edge's index into them (device)
   double* io;           // out: pose[7], n_bad (as double), then outlier bytes at io + 8
@@ -529,14 +531,16 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   if ((gather || a.n_dev) && ne < 3) {   // Optimizer.cc:323-324: fewer than 3 correspondences -> pose untouched, nothing marked
     if (threadIdx.x == 0) {   // (static indices: a run-time index into the kernel arguments makes the compiler keep a private copy in scratch)
 #pragma unroll
-      for (int q = 0; q < 7; ++q) a.io[q] = a.pose0[q];
+      for (int q = 0; q < 7; ++q) { const double v = a.pose0_dev ? a.pose0_dev[q] : a.pose0[q]; a.io[q] = v; if (a.io_dev) a.io_dev[q] = v; }
       a.io[7] = 0.0;
+      if (a.io_dev) a.io_dev[7] = 0.0;
     }
     if (gather) {   // the per-keypoint form of the flags (below): all clear, and the edge count behind them
       unsigned long long* og8 = reinterpret_cast<unsigned long long*>(a.io + 8);
+      unsigned long long* od8 = reinterpret_cast<unsigned long long*>(a.io_dev + 8);
       const int nw = (a.g_ncur + 7) / 8;
-      for (int i = threadIdx.x; i < nw; i += kPoseThreads) og8[i] = 0ull;
-      if (threadIdx.x == 0) a.io[8 + nw] = (double)ne;
+      for (int i = threadIdx.x; i < nw; i += kPoseThreads) { og8[i] = 0ull; if (a.io_dev) od8[i] = 0ull; }
+      if (threadIdx.x == 0) { a.io[8 + nw] = (double)ne; if (a.io_dev) a.io_dev[8 + nw] = (double)ne; }
     }
     return;
   }
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   for (int i = t; i < ne; i += kPoseThreads) { lvl[i] = 0; outl[i] = 0; }
   if (t == 0) {
     Pose7 T0{a.pose0[0], a.pose0[1], a.pose0[2], a.pose0[3], a.pose0[4], a.pose0[5], a.pose0[6]};
+    if (a.pose0_dev) T0 = Pose7{a.pose0_dev[0], a.pose0_dev[1], a.pose0_dev[2], a.pose0_dev[3], a.pose0_dev[4], a.pose0_dev[5], a.pose0_dev[6]};
     quat_normalize(T0.qx, T0.qy, T0.qz, T0.qw);
     S.T0 = T0;
     S.T = T0;
@@ -784,6 +789,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     a.io[0] = S.T.qx; a.io[1] = S.T.qy; a.io[2] = S.T.qz; a.io[3] = S.T.qw;
     a.io[4] = S.T.tx; a.io[5] = S.T.ty; a.io[6] = S.T.tz;
     a.io[7] = (double)nBad;
+    if (a.io_dev) {
+      a.io_dev[0] = S.T.qx; a.io_dev[1] = S.T.qy; a.io_dev[2] = S.T.qz; a.io_dev[3] = S.T.qw;
+      a.io_dev[4] = S.T.tx; a.io_dev[5] = S.T.ty; a.io_dev[6] = S.T.tz;
+      a.io_dev[7] = (double)nBad;
+    }
   }
   if (gather) {
     // Fused chains: the flags go out per KEYPOINT (0 where the keypoint carries no edge) with the edge count behind them, so that the
@@ -816,6 +826,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     const int nw = (a.g_ncur + 7) / 8;
     for (int i = t; i < nw; i += kPoseThreads) og8[i] = k8[i];
     if (t == 0) a.io[8 + nw] = (double)ne;
+    if (a.io_dev) {
+      unsigned long long* od8 = reinterpret_cast<unsigned long long*>(a.io_dev + 8);
+      for (int i = t; i < nw; i += kPoseThreads) od8[i] = k8[i];
+      if (t == 0) a.io_dev[8 + nw] = (double)ne;
+    }
     return;
   }
   // outlier flags to the (pinned host) io block, eight per 8-byte store
@@ -2072,7 +2087,7 @@ void ba_free(asd_ctx* ctx) {
 // match table, k_pose_opt reads their count from the device -- so the chain needs ONE synchronisation, at its end.  The results
 // (pose, n_bad, outlier byte per edge in keypoint order) are copied to *h_io; the caller synchronises and unpacks them.
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
-                       const float* d_own, const double* pose7, const double* K, double* d_io) {
+                       const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev) {
   // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
   // inside the caller's one result block: no copy is enqueued here
   BaState* s = ba_state(ctx);
@@ -2099,7 +2114,9 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
     a.edges = s->po_Xw.as<double>(); a.isgi = s->po_Xw.as<uint8_t>() + idx_off;
   }
   for (int k = 0; k < 16; ++k) a.isg_tab[k] = k < ctx->cfg.n_levels ? (double)ctx->inv_sigma2[k] : 0.0;   // invSigma2 is a float in the reference (Optimizer.cc:300)
-  memcpy(a.pose0, pose7, 56);
+  if (pose7) memcpy(a.pose0, pose7, 56);
+  a.pose0_dev = d_pose0; a.io_dev = d_io_dev;
+  if ((d_pose0 || d_io_dev) && mode != 2) { ctx->set_error("pose chain: the device-side hand-over needs the LDS form of the solver (frame too large)"); return ASD_ERR_CAPACITY; }
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
   a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;
   a.use_lds = mode;

@@ -146,6 +146,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   if (!ctx) return ASD_ERR_INVALID;
   (void)hipSetDevice(ctx->cfg.device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream_prep) (void)hipStreamSynchronize(ctx->stream_prep);
   frontend_async_shutdown(ctx);
   asdnet_free(ctx);
   frontend_free(ctx);
@@ -163,6 +164,8 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   for (int set = 0; set < 2; ++set)
     for (int i = 0; i < 9; ++i) if (ctx->prof_ev[set][i]) (void)hipEventDestroy(ctx->prof_ev[set][i]);
+  if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+  if (ctx->stream_prep) (void)hipStreamDestroy(ctx->stream_prep);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return ASD_OK;

@@ -127,6 +127,9 @@ struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
   hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
+  hipStream_t stream_prep = nullptr; // asd_prep_async: frame construction (grid / descriptor / bank copies) beside the stages in flight
+  hipEvent_t ev_prep = nullptr;
+  bool prep_on = false;
   struct AsyncExtract* ax = nullptr;
   int num_cu = 256;
   std::string err;
@@ -230,6 +233,8 @@ struct asd_ctx {
   }
 };
 
+inline hipStream_t asd_prep_stream(asd_ctx* ctx) { return ctx->prep_on ? ctx->stream_prep : ctx->stream; }
+
 // frontend.hip
 int frontend_alloc(asd_ctx* ctx);
 void frontend_free(asd_ctx* ctx);
@@ -246,8 +251,13 @@ void ba_free(asd_ctx* ctx);
 void mapping_free(asd_ctx* ctx);
 void bow_free(asd_ctx* ctx);
 // ba.hip: PoseOptimization enqueued behind device-resident matches (fused tracking chains; see the definition)
+// d_pose0 (optional): the start pose on the device (the previous stage's result block), pose7 is then ignored; d_io_dev (optional): a
+// second copy of the result block in device memory for the kernels of a following stage (asd_track_frame)
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
-                       const float* d_own, const double* pose7, const double* K, double* d_io);
+                       const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
+                       double* d_io_dev = nullptr);
+// true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
+inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }
 inline size_t pose_chain_io_bytes(int n_cur) { return 64 + ((size_t)n_cur + 7) / 8 * 8 + 64; }   // pose[7], n_bad, flags (8-B words), edge count
 // capi.cpp
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);

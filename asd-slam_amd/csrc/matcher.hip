@@ -45,23 +45,40 @@ struct GridDev {
 // (segments may land in any order, each query's own list is in reference order), pass 2 writes
 // (candidate index, distance).  Arithmetic of the cell range / distance tests is the float
 // arithmetic of Frame.cc:226-265 verbatim.
+//
+// SORT = true (the device claim replay, k_resolve; round 4): the query's list leaves the kernel in PREFERENCE order instead -- ascending
+// (distance bits, position in Frame::GetFeaturesInArea order), which is the order the reference's strict `<` walks settle ties in
+// (ORBmatcher.cc:86-104, :1392-1404: the first candidate in visiting order wins among equal distances) -- with its four best entries
+// also in a compact per-query table.  The replay then needs the head of each list only: "best candidate no earlier map point holds"
+// is the first entry of the sorted list without such a claim, the second best the next one.  A wave ranks its list by counting
+// (rank of p = number of entries with a smaller key; keys are distinct because positions are): O(n^2 / 64) LDS broadcast reads for
+// lists of 6 entries on average.  Entries the replay can never pick are left out here: keypoints that hold a map point on entry
+// (`occ`, ORBmatcher.cc:84-88) and, with th_cut = TH_HIGH, candidates beyond it (frame-to-frame search: best-only, :1406).
 #ifndef ASD_SEARCH_WAVES
 #define ASD_SEARCH_WAVES 8
 #endif
 constexpr int kSearchWaves = ASD_SEARCH_WAVES;   // queries (waves) per workgroup
 constexpr int kSearchCols = 16;                  // fast path: windows of up to this many grid columns ...
 constexpr int kSearchList = 128;                 // ... and up to this many candidates per query
+constexpr int kTop = 4;                          // SORT: entries per query in the compact head table
+struct SortArgs {
+  const uint8_t* occ;      // [n_cur] or null: keypoints that cannot be matched (occupied on entry)
+  float th_cut;            // q_cnt counts the entries with distance <= th_cut (they are the list's head); +inf = all
+  uint16_t* top_idx;       // [nq][kTop] keypoint (0xffff = no entry)
+};
+template <bool SORT>
 __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
                                                        const float* __restrict__ qdesc, const float* __restrict__ cdesc,
                                                        int* __restrict__ q_off, int* __restrict__ q_cnt,
                                                        int* __restrict__ total, int cap, int* __restrict__ out_idx,
-                                                       float* __restrict__ out_dist, unsigned* __restrict__ out_meta = nullptr) {
+                                                       float* __restrict__ out_dist, unsigned* __restrict__ out_meta, SortArgs S) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * kSearchWaves + wave;
   // the waves of a workgroup reserve their segments with ONE atomicAdd (2000 same-address atomics, one per query, were a
   // serial chain through one L2 channel): every wave stays alive up to the barriers below, a query beyond nq counts as empty
   __shared__ int wg_cnt[kSearchWaves], wg_base;
   __shared__ int cand_l[kSearchWaves][kSearchList];
+  __shared__ unsigned dist_l[SORT ? kSearchWaves : 1][kSearchList];
   const bool live = q < nq;
   const WinQuery Q = live ? queries[q] : WinQuery{0.f, 0.f, 0.f, 0, 0, -1};
   int cnt = 0, off = 0;
@@ -83,7 +100,7 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
     if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) ok = false;
     return ok;
   };
-  auto score = [&](int idx, int p) {   // exact summation order of DescriptorDistance (sequential f32), candidate p of the list
+  auto distance = [&](int idx) {   // exact summation order of DescriptorDistance (sequential f32)
     const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)Q.qrow * 128);
     const float4* bb = reinterpret_cast<const float4*>(cdesc + (size_t)idx * 128);
     float sqd = 0.f;
@@ -96,9 +113,13 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
       d = x.z - y.z; sqd = sqd + d * d;
       d = x.w - y.w; sqd = sqd + d * d;
     }
+    return sqd;
+  };
+  auto score = [&](int idx, int p) {   // candidate p of the list, in list order
+    const float sqd = distance(idx);
     out_idx[off + p] = idx;
     out_dist[off + p] = sqd;
-    if (out_meta) out_meta[off + p] = ((unsigned)p << 16) | (unsigned)q;   // k_resolve: position in the list | query
+    if (out_meta) out_meta[off + p] = ((unsigned)p << 16) | (unsigned)q;   // position in the list | query
   };
   // the general walk (any window, any list length): one dependent chain cell range -> items -> keypoints per column and pass
   auto walk = [&](int pass) {
@@ -112,6 +133,7 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
         if (it < e) {
           idx = G.cell_items[it];
           ok = accept(G.kp[idx]);
+          if (SORT && ok && S.occ && S.occ[idx]) ok = false;
         }
         const unsigned long long m = __ballot(ok);
         if (pass == 1 && ok) {
@@ -150,6 +172,13 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
     float4 kpc[kSearchCols];
 #pragma unroll
     for (int c = 0; c < kSearchCols; ++c) kpc[c] = idxc[c] >= 0 ? G.kp[idxc[c]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SORT && S.occ) {   // keypoints occupied on entry never enter a list (one more batch of loads, in flight with the keypoints)
+      uint8_t oc[kSearchCols];
+#pragma unroll
+      for (int c = 0; c < kSearchCols; ++c) oc[c] = idxc[c] >= 0 ? S.occ[idxc[c]] : (uint8_t)0;
+#pragma unroll
+      for (int c = 0; c < kSearchCols; ++c) if (oc[c]) idxc[c] = -1;
+    }
     int pos = 0;
 #pragma unroll
     for (int c = 0; c < kSearchCols; ++c) {
@@ -176,15 +205,87 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
   asd_syncthreads();
   off = wg_base;
   for (int w = 0; w < wave; ++w) off += wg_cnt[w];
-  if (cnt > 0) {
-    if (fast) {
-      for (int p = lane; p < cnt; p += 64)
-        if (off + p < cap) score(cand_l[wave][p], p);
-    } else {
+  if (!SORT) {
+    if (cnt > 0) {
+      if (fast) {
+        for (int p = lane; p < cnt; p += 64)
+          if (off + p < cap) score(cand_l[wave][p], p);
+      } else {
+        (void)walk(1);
+      }
+    }
+    if (lane == 0 && live) { q_cnt[q] = cnt; q_off[q] = cnt ? off : 0; }
+    return;
+  }
+  // ---- SORT: the list in preference order + the compact head table
+  if (!live) return;
+  const bool fits = off + cnt <= cap;   // (an overflowing search is run again by the host: nothing of it is read)
+  int n_keep = 0, s_off = off;
+  auto put = [&](int base, int rank, int idx, float d) {
+    out_idx[base + rank] = idx;
+    out_dist[base + rank] = d;
+    if (rank < kTop) S.top_idx[(size_t)q * kTop + rank] = (uint16_t)idx;
+  };
+  if (cnt > 0 && fits) {
+    if (fast) {   // at most two candidates per lane, every key of the list in LDS
+      const bool v0 = lane < cnt, v1 = lane + 64 < cnt;
+      const int i0 = v0 ? cand_l[wave][lane] : 0, i1 = v1 ? cand_l[wave][lane + 64] : 0;
+      const float d0 = v0 ? distance(i0) : 0.f, d1 = v1 ? distance(i1) : 0.f;
+      const unsigned b0 = __float_as_uint(d0), b1 = __float_as_uint(d1);
+      if (v0) dist_l[wave][lane] = b0;
+      if (v1) dist_l[wave][lane + 64] = b1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      int r0 = 0, r1 = 0;
+      for (int i = 0; i < cnt; ++i) {
+        const unsigned di = dist_l[wave][i];
+        r0 += (di < b0) || (di == b0 && i < lane);
+        r1 += (di < b1) || (di == b1 && i < lane + 64);
+      }
+      if (v0) put(off, r0, i0, d0);
+      if (v1) put(off, r1, i1, d1);
+      n_keep = __popcll(__ballot(v0 && d0 <= S.th_cut)) + __popcll(__ballot(v1 && d1 <= S.th_cut));
+    } else {      // any length: the list is written in visiting order first, then ranked from there in chunks of kSearchList keys
       (void)walk(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      s_off = cap + off;   // the sorted copy lives in the buffers' second half
+      constexpr int R = 4;
+      for (int pb = 0; pb < cnt; pb += 64 * R) {
+        int pi[R], ii[R], rk[R]; unsigned bi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          pi[r] = pb + 64 * r + lane;
+          const int pc = min(pi[r], cnt - 1);
+          ii[r] = __hip_atomic_load(out_idx + off + pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bi[r] = __float_as_uint(__hip_atomic_load(out_dist + off + pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          rk[r] = 0;
+        }
+        for (int cbase = 0; cbase < cnt; cbase += kSearchList) {
+          __builtin_amdgcn_wave_barrier();
+          for (int i = lane; i < kSearchList; i += 64)
+            dist_l[wave][i] = cbase + i < cnt ? __float_as_uint(__hip_atomic_load(out_dist + off + cbase + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0xffffffffu;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+          const int m = min(kSearchList, cnt - cbase);
+          for (int i = 0; i < m; ++i) {
+            const unsigned di = dist_l[wave][i];
+#pragma unroll
+            for (int r = 0; r < R; ++r) rk[r] += (di < bi[r]) || (di == bi[r] && cbase + i < pi[r]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool v = pi[r] < cnt;
+          if (v) put(s_off, rk[r], ii[r], __uint_as_float(bi[r]));
+          n_keep += __popcll(__ballot(v && __uint_as_float(bi[r]) <= S.th_cut));
+        }
+      }
     }
   }
-  if (lane == 0 && live) { q_cnt[q] = cnt; q_off[q] = cnt ? off : 0; }
+  if (lane < kTop && lane >= (fits ? cnt : 0)) S.top_idx[(size_t)q * kTop + lane] = 0xffffu;
+  if (lane == 0) { q_cnt[q] = n_keep; q_off[q] = cnt ? s_off : 0; }
 }
 
 // Node-restricted search (BoW-guided matchers): query q is matched against the explicit candidate list
@@ -598,6 +699,248 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
 #undef OUT
 #undef CNT
 
+// ---- claim replay over SORTED lists (round 4; the default) -------------------------------------------------------------
+// Same recurrence, same fixed-point iteration, same claim tables as k_resolve above -- what changed is how a map point finds its
+// pick inside an iteration.  k_resolve keeps all ~12 k candidates in registers and lets every one of them bid for its query with a
+// 64-bit LDS atomicMin in EVERY iteration (24 candidates per thread, 13 iterations: 90 us on one workgroup).  k_window_search<true>
+// hands the lists over in preference order, so "the best candidate no earlier map point holds" is the first entry of the list whose
+// keypoint carries no such claim, and the second best (KIND 1) the next one.
+// KIND 0 (best only): "keypoint j is held against q" can only become true and never false again from one iteration to the next --
+// the smallest claimant of j finds everything in front of j in its list still held and j still free, so it picks j again -- hence a
+// map point's position in its list only ever advances.  A thread keeps (position, keypoint) of each of its queries; an iteration
+// reads that keypoint's claim, steps forward past held entries if it has to (each list entry is stepped over at most once in the
+// whole kernel: ~700 steps per frame instead of 12 k bids per iteration), posts the claim.
+// KIND 1 (best / second best with the ratio test): a pick can be withdrawn (the second best changing its level), so every iteration
+// walks from the head -- the four heads' keypoints are in registers, their claims come in one LDS round trip, and the distances /
+// levels of the two survivors in a second one for all of the thread's queries together.
+// The LDS round trips are what an iteration costs (the workgroup shares its CU with ASDNet workgroups that keep the LDS queues
+// full), so every phase issues its reads for all of the thread's queries before it uses any.
+struct Resolve2Args {
+  int nq, n_cur;
+  const int* q_off; const int* q_cnt; const int* idx; const float* dist;   // k_window_search<true>: sorted lists (q_cnt = the head that can be picked)
+  const uint16_t* top_idx;                                                  // [nq][kTop] the lists' heads (keypoints; 0xffff = none)
+  const int* total; int cap;
+  const uint8_t* obs_pos;     // [nq] or null
+  const float4* kp_cur;       // (x, y, octave bits, angle)
+  const float4* kp_last;      // KIND 0: query q = last-frame keypoint q
+  int check_ori;
+  float nn_ratio;
+  int* match_cur;             // out [n_cur]
+  int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations, [3..6] stamps
+  int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches
+  int stage_cap;              // list entries [0, stage_cap) are copied into LDS (2 B each, KIND 1: 6 B) for the walks beyond the heads
+};
+__host__ __device__ inline size_t resolve2_fixed_lds(int kind, int n_cur) {   // claim tables + angle table (KIND 0) / octave table (KIND 1)
+  return (size_t)n_cur * 8 + (kind == 0 ? (size_t)n_cur * 4 : ((size_t)n_cur + 15) / 16 * 16);
+}
+constexpr int kResolve2Threads = 1024;
+template <int KIND, int QPT>
+__global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
+#define OUT(i, v) do { const int v_ = (v); a.match_cur[i] = v_; if (a.mirror) a.mirror[i] = v_; } while (0)
+#define CNT(i, v) do { const int v_ = (v); a.n_matches[i] = v_; if (a.mirror) a.mirror[a.n_cur + (i)] = v_; } while (0)
+  constexpr int NT = kResolve2Threads;
+  extern __shared__ unsigned lds_c[];
+  unsigned* claim0 = lds_c;
+  unsigned* claim[2] = {claim0, claim0 + a.n_cur};
+  float* ang = reinterpret_cast<float*>(claim0 + 2 * a.n_cur);                       // KIND 0: the current frame's keypoint angles
+  uint8_t* octv = reinterpret_cast<uint8_t*>(claim0 + 2 * a.n_cur);                  // KIND 1: their octaves
+  char* tail = reinterpret_cast<char*>(lds_c) + resolve2_fixed_lds(KIND, a.n_cur);
+  float* sdist = reinterpret_cast<float*>(tail);                                     // KIND 1: [stage_cap]
+  uint16_t* sidx = reinterpret_cast<uint16_t*>(tail + (KIND == 1 ? (size_t)a.stage_cap * 4 : 0));   // [stage_cap]
+  __shared__ int n_written, hist[HISTO], n_removed, flag[3];
+  int* last = reinterpret_cast<int*>(tail + (size_t)a.stage_cap * (KIND == 1 ? 6 : 2));   // [n_cur] the last writer of every keypoint
+  const int t = threadIdx.x;
+  const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+  const int total = *a.total;
+  if (total > a.cap || total == 0) {   // truncated lists (the host grows the buffers and searches again) / nothing in any window:
+    // the match table is still written (no match anywhere) -- a fused chain behind this kernel gathers its edges from it
+    for (int j = t; j < a.n_cur; j += NT) OUT(j, -1);
+    if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
+    return;
+  }
+  // the thread's queries first (their loads are then in flight under the LDS fills below): list length and start, the heads
+  int cnt[QPT], pick[QPT], qoff[QPT];
+  uint2 tj[QPT];                        // the four heads' keypoints (16 bit each)
+  float ang_last[KIND == 0 ? QPT : 1];
+  unsigned posmask = 0;
+#pragma unroll
+  for (int k = 0; k < QPT; ++k) {
+    const int q = t + k * NT;
+    const bool v = q < a.nq;
+    const int qc = v ? q : 0;
+    cnt[k] = v ? a.q_cnt[qc] : 0;
+    qoff[k] = a.q_off[qc];
+    tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
+    if (KIND == 0) ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
+    if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
+    pick[k] = -1;
+  }
+  for (int j = t; j < 2 * a.n_cur; j += NT) claim0[j] = 0xffffffffu;
+  for (int j = t; j < a.n_cur; j += NT) last[j] = -1;
+  if (KIND == 0) { if (a.check_ori) for (int j = t; j < a.n_cur; j += NT) ang[j] = a.kp_cur[j].w; }
+  else for (int j = t; j < a.n_cur; j += NT) octv[j] = (uint8_t)(__float_as_int(a.kp_cur[j].z) & 0xff);
+  const int n_stage = min(total, a.stage_cap);
+  for (int i = t; i < n_stage; i += NT) { sidx[i] = (uint16_t)a.idx[i]; if (KIND == 1) sdist[i] = a.dist[i]; }
+  if (t == 0) { n_written = 0; n_removed = 0; flag[0] = 0; flag[1] = 0; flag[2] = 0; }
+  if (t < HISTO) hist[t] = 0;
+  auto top_j = [&](int k, int i) -> unsigned { return ((i < 2 ? tj[k].x : tj[k].y) >> (16 * (i & 1))) & 0xffffu; };
+  auto list_j = [&](int k, int i) -> int { const int pos = qoff[k] + i; return pos < n_stage ? (int)sidx[pos] : a.idx[pos]; };
+  int ptr[KIND == 0 ? QPT : 1], curj[KIND == 0 ? QPT : 1];   // KIND 0: position in the list and the keypoint there (-1: list exhausted)
+  if (KIND == 0) {
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) { ptr[k] = 0; curj[k] = cnt[k] > 0 ? (int)top_j(k, 0) : -1; }
+  }
+  asd_syncthreads();
+  const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+  const int max_it = a.nq + 2;
+  int it = 0, f_cur = 0;   // f_cur = it % 3
+  unsigned long long ts_it0 = ts1;
+  for (;; ++it) {
+    // read the claims of iteration it-1 (table it & 1, tag it), post this iteration's picks into the other table (tag it+1)
+    const unsigned* rd = claim[it & 1];
+    unsigned* wr = claim[(it + 1) & 1];
+    const unsigned tag_rd = (unsigned)(0xffff - it), tag_wr = (unsigned)(0xffff - (it + 1));
+    auto held = [&](unsigned c, int q) { return (c >> 16) == tag_rd && (c & 0xffffu) < (unsigned)q; };   // an earlier map point holds it
+    int changed = 0;
+    if (KIND == 0) {
+      unsigned c0[QPT];
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) c0[k] = curj[k] >= 0 ? rd[curj[k]] : 0u;
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) {
+        const int q = t + k * NT;
+        if (curj[k] >= 0 && held(c0[k], q)) {   // step forward, four entries per round trip
+          int j = -1;
+          while (j < 0 && ptr[k] + 1 < cnt[k]) {
+            int jj[4]; unsigned cc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) jj[i] = ptr[k] + 1 + i < cnt[k] ? (ptr[k] + 1 + i < kTop ? (int)top_j(k, min(ptr[k] + 1 + i, kTop - 1)) : list_j(k, ptr[k] + 1 + i)) : -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cc[i] = jj[i] >= 0 ? rd[jj[i]] : 0u;
+            int adv = 4;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) if (jj[i] >= 0 && !held(cc[i], q)) { j = jj[i]; adv = i + 1; }
+            ptr[k] += adv;
+          }
+          curj[k] = j;
+        }
+        changed |= curj[k] != pick[k];
+        pick[k] = curj[k];
+        if (curj[k] >= 0 && (posmask >> k & 1)) atomicMin(&wr[curj[k]], (tag_wr << 16) | (unsigned)q);
+      }
+    } else {
+      unsigned cl[QPT][kTop];
+#pragma unroll
+      for (int k = 0; k < QPT; ++k)
+#pragma unroll
+        for (int i = 0; i < kTop; ++i) cl[k][i] = (i < cnt[k]) ? rd[top_j(k, i)] : 0u;
+      int p[QPT], p2[QPT], i1[QPT], i2[QPT];
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) {
+        const int q = t + k * NT;
+        int found = 0;
+        p[k] = -1; p2[k] = -1; i1[k] = 0; i2[k] = 0;
+#pragma unroll
+        for (int i = 0; i < kTop; ++i) {
+          if (i >= cnt[k] || held(cl[k][i], q) || found >= 2) continue;
+          if (found == 0) { p[k] = (int)top_j(k, i); i1[k] = i; }
+          else { p2[k] = (int)top_j(k, i); i2[k] = i; }
+          ++found;
+        }
+        if (found < 2 && cnt[k] > kTop) {   // the heads did not settle it: on through the list (LDS copy, global beyond it)
+          for (int i = kTop; i < cnt[k] && found < 2; ++i) {
+            const int j = list_j(k, i);
+            if (held(rd[j], q)) continue;
+            if (found == 0) { p[k] = j; i1[k] = i; }
+            else { p2[k] = j; i2[k] = i; }
+            ++found;
+          }
+        }
+      }
+      // ORBmatcher.cc:106-112 (bestDist2 starts at 256, bestLevel2 at -1): distances and levels of the two survivors, all queries together
+      float best[QPT], best2[QPT];
+      int lvl[QPT], lvl2[QPT];
+      auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; return pos < n_stage ? sdist[pos] : a.dist[pos]; };
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) {
+        best[k] = p[k] >= 0 ? dist_at(k, i1[k]) : 0.f;
+        best2[k] = p2[k] >= 0 ? dist_at(k, i2[k]) : 256.f;
+        lvl[k] = p[k] >= 0 ? (int)octv[p[k]] : -1;
+        lvl2[k] = p2[k] >= 0 ? (int)octv[p2[k]] : -1;
+      }
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) {
+        const int q = t + k * NT;
+        int pk = p[k];
+        if (pk >= 0 && (!(best[k] <= TH_HIGH) || (lvl[k] == lvl2[k] && best[k] > a.nn_ratio * best2[k]))) pk = -1;
+        changed |= pk != pick[k];
+        pick[k] = pk;
+        if (pk >= 0 && (posmask >> k & 1)) atomicMin(&wr[pk], (tag_wr << 16) | (unsigned)q);
+      }
+    }
+    // "did any pick change" with ONE barrier (__syncthreads_or is three and a cross-lane reduction): a changed pick sets this
+    // iteration's flag word, thread 0 clears the next one's -- last read two barriers ago
+    if (changed) flag[f_cur] = 1;
+    const int f_next = f_cur == 2 ? 0 : f_cur + 1;
+    if (t == 0) flag[f_next] = 0;
+    asd_syncthreads();
+    const bool more = flag[f_cur] != 0 && it < max_it;
+    f_cur = f_next;
+    if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
+    if (!more) break;
+  }
+  const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
+  // ---- outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
+  int mine = 0;
+  int bin[QPT];
+#pragma unroll
+  for (int k = 0; k < QPT; ++k) {
+    bin[k] = -1;
+    if (pick[k] < 0) continue;
+    atomicMax(&last[pick[k]], t + k * NT);
+    ++mine;
+    if (KIND == 0 && a.check_ori) {
+      float rot = ang_last[k] - ang[pick[k]];   // ORBmatcher.cc:1419-1425
+      if (rot < 0.0) rot += 360.0f;
+      int b = (int)roundf(rot * (1.0f / HISTO));
+      if (b == HISTO) b = 0;
+      bin[k] = b;
+      atomicAdd(&hist[b], 1);
+    }
+  }
+  if (mine) atomicAdd(&n_written, mine);
+  asd_syncthreads();
+  if (KIND == 0 && a.check_ori) {
+    // ComputeThreeMaxima (:1584-1625), by every thread for itself (thirty broadcast reads instead of a barrier around thread 0)
+    int hs[HISTO];
+#pragma unroll
+    for (int i = 0; i < HISTO; i++) hs[i] = hist[i];
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+#pragma unroll
+    for (int i = 0; i < HISTO; i++) {
+      const int s = hs[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    int removed = 0;
+#pragma unroll
+    for (int k = 0; k < QPT; ++k)   // every write in a discarded bin clears the keypoint and is subtracted (:1437-1450)
+      if (bin[k] >= 0 && bin[k] != ind1 && bin[k] != ind2 && bin[k] != ind3) { last[pick[k]] = -1; ++removed; }
+    if (removed) atomicAdd(&n_removed, removed);
+    asd_syncthreads();
+  }
+  for (int j = t; j < a.n_cur; j += NT) OUT(j, last[j]);
+  if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, total); CNT(2, it + 1);
+    // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs, the first iteration -- in units of 10 ns
+    CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
+    for (int i = 7; i < 11; ++i) CNT(i, 0); }
+}
+#undef OUT
+#undef CNT
+
 // Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) + the search window of
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) (:60-70), one thread per map point, straight into the query table of
 // k_window_search.  The arithmetic is asd_frustum's, operation for operation (f32 with the two double accumulations of the
@@ -628,12 +971,56 @@ struct FrustumArgs {
   float level_thr[ASD_MAX_LEVELS], scale[ASD_MAX_LEVELS];
   WinQuery* queries;
   UploadTail up;
+  // asd_track_frame (the stage behind another one, nothing from the host in between): the frame pose comes from device memory
+  // (T_dev[16] + Ow[3], written by k_between), the map points are rows of the attribute bank (attr[row][8] = position, normal,
+  // min / max distance), candidates flagged in `skip` are in the frame already (Tracking.cc:811-823) and make no query, and every
+  // candidate's position is also written to xw_out[q] for the edges of the pose solver behind the search
+  const float* T_dev; const float* attr; const uint8_t* skip; float* xw_out;
 };
 __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
   if (upload_tail_block(a.up)) return;
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
+  if (a.attr) {   // bank form
+    const int row = a.rows[q];
+    const float4 A0 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row], A1 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row + 1];
+    a.xw_out[3 * (size_t)q] = A0.x; a.xw_out[3 * (size_t)q + 1] = A0.y; a.xw_out[3 * (size_t)q + 2] = A0.z;
+    if (!a.skip[q]) {
+      float T[16], Ow[3];
+      for (int i = 0; i < 16; ++i) T[i] = a.T_dev[i];
+      for (int i = 0; i < 3; ++i) Ow[i] = a.T_dev[16 + i];
+      const float P[3] = {A0.x, A0.y, A0.z}, Pn[3] = {A0.w, A1.x, A1.y};
+      const float min_dist = A1.z, max_dist = A1.w;
+      float Pc[3];
+      for (int r = 0; r < 3; ++r) {
+        const float t0 = T[r * 4 + 0] * P[0] + T[r * 4 + 1] * P[1] + T[r * 4 + 2] * P[2];
+        Pc[r] = (float)((double)t0 + (double)T[r * 4 + 3]);
+      }
+      bool ok = !(Pc[2] < 0.0f);
+      const float invz = 1.0f / Pc[2];
+      const float u = a.fx * Pc[0] * invz + a.cx, v = a.fy * Pc[1] * invz + a.cy;
+      if (u < a.min_x || u > a.max_x || v < a.min_y || v > a.max_y) ok = false;
+      const float maxD = 1.2f * max_dist, minD = 0.8f * min_dist;
+      const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+      const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
+      const float dist = (float)sqrt(nn);
+      if (dist < minD || dist > maxD) ok = false;
+      const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+      const float vc = (float)(dot / dist);
+      if (vc < a.cos_limit) ok = false;
+      if (ok) {
+        const float ratio = max_dist / dist;
+        int lvl = 0;
+        for (int k = 1; k < a.n_levels; ++k) lvl += ratio >= a.level_thr[k];
+        float r = vc > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
+        if (a.bfactor) r *= a.th;
+        Q = WinQuery{u, v, r * a.scale[lvl], lvl - 1, lvl, row};
+      }
+    }
+    a.queries[q] = Q;
+    return;
+  }
   const float* P = a.Xw + 3 * (size_t)q;
   float Pc[3];
   for (int r = 0; r < 3; ++r) {
@@ -700,6 +1087,70 @@ __global__ __launch_bounds__(256) void k_project_queries(ProjectArgs a) {
     }
   }
   a.queries[i] = Q;
+}
+
+// What Tracking does between its two stages, on the device (asd_track_frame): the matches PoseOptimization marked as outliers are
+// dropped (Tracking.cc:695-714), the optimised pose becomes the frame's pose (Optimizer.cc:405-407 -> Frame::SetPose: Tcw as
+// Converter::toCvMat(SE3Quat) gives it, mOw = -Rcw^T tcw, Frame.cc:150-158), and the map points the frame holds already are marked so
+// that SearchLocalPoints does not project them again (Tracking.cc:811-823).  One workgroup; inputs are the match table and the
+// result block of the motion-model stage in device memory, outputs feed k_frustum_queries, k_window_search and k_pose_opt of the
+// local-map stage.  The conversions are asd_pose7_to_tcw's and track_local_points_impl's expressions, operation for operation
+// (-ffp-contract=off), so the stage behind sees the bits a host in between would have handed it.
+struct BetweenArgs {
+  int n_cur, n_last, n_cand;
+  const int* match1;        // [n_cur] last-frame keypoint or -1
+  const double* io1;        // the motion-model stage's result block: pose[7], n_bad, outlier byte per keypoint, edge count
+  const float* Xw_last;     // [n_last][3]
+  const int* last_cand;     // [n_last] or null: candidate index of the map point last keypoint i holds
+  float T_pred[16];         // the pose the motion-model search projected with (kept when it made fewer than 3 matches)
+  uint8_t* occ;             // out [n_cur]: the keypoint keeps its map point
+  float* cur_Xw;            // out [n_cur][3]: that map point's position
+  uint8_t* skip;            // out [n_cand]
+  float* T1;                // out [19]: Tcw (row major 4x4), Ow
+};
+__global__ __launch_bounds__(1024) void k_between(BetweenArgs a) {
+  const int t = threadIdx.x;
+  __shared__ int s_nmatch;
+  if (t == 0) s_nmatch = 0;
+  for (int c = t; c < a.n_cand; c += 1024) a.skip[c] = 0;
+  asd_syncthreads();
+  const uint8_t* outl = reinterpret_cast<const uint8_t*>(a.io1 + 8);
+  int mine = 0;
+  for (int j = t; j < a.n_cur; j += 1024) {
+    const int i = a.match1[j];
+    mine += i >= 0;
+    const int src = i >= 0 ? i : 0;
+    for (int k = 0; k < 3; ++k) a.cur_Xw[3 * (size_t)j + k] = a.n_last > 0 ? a.Xw_last[3 * (size_t)src + k] : 0.f;
+    const bool keep = i >= 0 && !outl[j];
+    a.occ[j] = keep ? 1 : 0;
+    if (keep && a.last_cand) { const int c = a.last_cand[i]; if (c >= 0 && c < a.n_cand) a.skip[c] = 1; }
+  }
+  if (mine) atomicAdd(&s_nmatch, mine);
+  asd_syncthreads();
+  if (t == 0) {
+    float T[16];
+    if (s_nmatch >= 3) {   // asd_pose7_to_tcw
+      const double* p = a.io1;
+      const double x = p[0], y = p[1], z = p[2], w = p[3];
+      const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+      const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+      const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j];
+        T[i * 4 + 3] = (float)p[4 + i];
+      }
+      T[12] = T[13] = T[14] = 0.f;
+      T[15] = 1.f;
+    } else {
+      for (int i = 0; i < 16; ++i) T[i] = a.T_pred[i];
+    }
+    for (int i = 0; i < 16; ++i) a.T1[i] = T[i];
+    for (int i = 0; i < 3; ++i) {  // mOw = -mRcw.t()*mtcw (Frame.cc:157): transposed gemm accumulates in double
+      double sum = 0;
+      for (int k = 0; k < 3; ++k) sum += (double)T[k * 4 + i] * (double)T[k * 4 + 3];
+      a.T1[16 + i] = (float)(-1.0 * sum);
+    }
+  }
 }
 
 // ---- host helpers -------------------------------------------------------------------------
@@ -771,6 +1222,13 @@ struct MatcherState {
   float *d_qdesc = nullptr, *h_qdesc = nullptr;
   float* d_bank = nullptr;  // device-resident descriptor bank (MapPoint::mDescriptor rows)
   int bank_cap = 0;
+  // map-point attribute bank, same row ids: [row][8] = mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance (asd_mpbank_put)
+  float* d_attr = nullptr;
+  int attr_cap = 0;
+  float* h_attr[2] = {nullptr, nullptr};   // pinned staging, used alternately
+  size_t h_attr_cap[2] = {0, 0};
+  hipEvent_t ev_attr[2] = {nullptr, nullptr};
+  int attr_turn = 0;
   // device-side replay (k_resolve): pinned staging for flags in / matches out
   int* h_res = nullptr;      // [res_cap + 4] ints, then res_cap bytes of flags
   int res_cap = 0;
@@ -806,8 +1264,9 @@ int ensure_cands_dev(asd_ctx* ctx, MatcherState* m, size_t n) {
   if (m->d_idx) { (void)hipFree(m->d_idx); (void)hipFree(m->d_dist); (void)hipFree(m->d_meta); }
   m->d_idx = nullptr; m->d_dist = nullptr; m->d_meta = nullptr;
   m->cand_cap = 0;
-  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_idx, cap * sizeof(int)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_dist, cap * sizeof(float)));
+  // idx / dist twice over: k_window_search<true> writes the sorted copy of a list that took its slow path into the second half
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_idx, 2 * cap * sizeof(int)));
+  ASD_HIP_CHECK(ctx, hipMalloc(&m->d_dist, 2 * cap * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipMalloc(&m->d_meta, cap * sizeof(unsigned)));
   m->cand_cap = (int)std::min(cap, (size_t)0x7fffffff);
   return ASD_OK;
@@ -877,8 +1336,8 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
     ASD_HIP_CHECK(ctx, hipMemsetAsync(d_total, 0, sizeof(int), st));
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_window_search, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
-                       d_total, m->cand_cap, m->d_idx, m->d_dist);
+    hipLaunchKernelGGL(k_window_search<false>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, m->d_queries, nq, d_q, F.d_desc, d_off, d_cnt,
+                       d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, SortArgs{});
     ASD_HIP_CHECK(ctx, hipGetLastError());
     ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
     ASD_HIP_CHECK(ctx, hipMemcpyAsync(m->h_q, d_off, ((size_t)2 * nq + 1) * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -919,7 +1378,10 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
 // where the claim / ratio / histogram replay runs: on the device (k_resolve, default) or on the host over the copied-back
 // candidate lists (ASD_MATCH_REPLAY=host in the environment of asd_ctx_create; also taken when the tables would
 // not fit the workgroup's LDS or there are more than 4096 queries)
+// ASD_RESOLVE=bids: round 2/3's k_resolve (every candidate bids in every iteration) instead of the sorted-list replay, for A/B runs
+bool resolve_by_bids() { static const bool b = [] { const char* e = getenv("ASD_RESOLVE"); return e && !strcmp(e, "bids"); }(); return b; }
 size_t resolve_lds_bytes(int kind, int n_cur, int nq) {
+  if (!resolve_by_bids()) return resolve2_fixed_lds(kind, n_cur) + (size_t)n_cur * 4;   // k_resolve2: the two claim tables, angle / octave table, last-writer table
   return (size_t)(kind == 1 ? 2 : 1) * nq * 8 + (size_t)n_cur * 2 * sizeof(int) + (size_t)(n_cur + 15) / 16 * 16;
 }
 // room for the tail of the candidate lists in LDS (k_resolve, ov_cap): what the previous search of this kind produced beyond `slots`
@@ -978,9 +1440,10 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     if (chain) for (int i = 0; i < kChainTabs; ++i) extra += chain->bytes[i] + 256;
     ASD_HIP_CHECK(ctx, up.begin(st, (size_t)nq * sizeof(WinQuery) + 256 + (size_t)nq + (size_t)n_cur + 1024 + extra));
     ASD_HIP_CHECK(ctx, down.begin(st, ((size_t)n_cur + 16) * sizeof(int) + 256 + (chain ? chain->result_bytes : 0)));
-    ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4)));
+    ASD_HIP_CHECK(ctx, ctx->scratch.reserve(AsdDevBuf::padded((size_t)nq * 4) + AsdDevBuf::padded((size_t)nq * kTop * 2)));
   }
   int* d_pick = ctx->scratch.carve<int>(nq);
+  uint16_t* d_top_idx = ctx->scratch.carve<uint16_t>((size_t)nq * kTop);
   const bool dev_queries = chain && chain->prepare;
   const size_t o_q = dev_queries ? ctx->up.reserve((size_t)nq * sizeof(WinQuery)) : ctx->up.add(m->h_queries, (size_t)nq * sizeof(WinQuery));
   const size_t o_total = ctx->up.zeros(sizeof(int));
@@ -1021,8 +1484,42 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     // when somebody asked for timings)
     static const bool stage_timing = getenv("ASD_TIMING") != nullptr || getenv("ASD_STAGE_TIMING") != nullptr;
     if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-    hipLaunchKernelGGL(k_window_search, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
-                       d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta);
+    static const bool zero_copy = getenv("ASD_RESULT_COPY") == nullptr;   // results stored by the kernels straight into the pinned block
+    if (!resolve_by_bids()) {
+      // the lists in preference order (k_window_search<true>), the replay over their heads (k_resolve2)
+      SortArgs sa{KIND == 1 ? up.dev<uint8_t>(o_occ) : nullptr, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top_idx};
+      hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off,
+                         d_cnt, d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, sa);
+      ASD_HIP_CHECK(ctx, hipGetLastError());
+      Resolve2Args a{};
+      a.nq = nq; a.n_cur = n_cur;
+      a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.top_idx = d_top_idx;
+      a.total = d_total; a.cap = m->cand_cap;
+      a.obs_pos = has_obs ? up.dev<uint8_t>(o_obs) : nullptr;
+      a.kp_cur = F.d_kp; a.kp_last = kp_last;
+      a.check_ori = check_ori; a.nn_ratio = nn_ratio;
+      a.match_cur = d_out; a.n_matches = d_out + n_cur;
+      a.mirror = zero_copy ? down.host<int>(o_out) : nullptr;
+      // the sorted lists' copy in LDS (for queries whose four best are all held): what the previous search of this kind produced and
+      // a quarter on top, as far as the 96 KB this kernel may ask for allow; entries beyond it are read from global memory
+      const size_t fixed = resolve_lds_bytes(KIND, n_cur, nq), per = KIND == 1 ? 6 : 2;
+      a.stage_cap = (int)std::min<size_t>(((size_t)m->last_total[KIND] * 5 / 4 + 1023) / 1024 * 1024, ((size_t)96 * 1024 - fixed) / per / 8 * 8);
+      const size_t lds = fixed + (size_t)a.stage_cap * per;
+      auto launch = [&](auto kern) -> hipError_t {
+        static AsdPerDeviceOnce attr_set;   // per instantiation and device: more than 64 KB of dynamic LDS has to be asked for once
+        if (attr_set.need(ctx->cfg.device)) {
+          const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+          if (e != hipSuccess) return e;
+          attr_set.done(ctx->cfg.device);
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(kResolve2Threads), lds, st, a);
+        return hipGetLastError();
+      };
+      if (nq <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 2>));
+      else ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 4>));
+    } else {
+    hipLaunchKernelGGL(k_window_search<false>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
+                       d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta, SortArgs{});
     ASD_HIP_CHECK(ctx, hipGetLastError());
     ResolveArgs a{};
     a.nq = nq; a.n_cur = n_cur;
@@ -1033,7 +1530,6 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     a.kp_cur = F.d_kp; a.kp_last = kp_last;
     a.check_ori = check_ori; a.nn_ratio = nn_ratio;
     a.pick = d_pick; a.match_cur = d_out; a.n_matches = d_out + n_cur;
-    static const bool zero_copy = getenv("ASD_RESULT_COPY") == nullptr;   // results stored by the kernels straight into the pinned block
     a.mirror = zero_copy ? down.host<int>(o_out) : nullptr;
     // register-resident candidates per thread: 8, or 16 for long frame-to-frame lists (KIND 1 with 16 spills under the cap)
     constexpr int kBig = KIND == 0 ? 16 : 8;
@@ -1052,6 +1548,7 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     };
     if (nq <= 4 * kResolveThreads) { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, kBig>)); }
     else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
+    }
     if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
     if (chain) {
       if ((rc = chain->enqueue(d_out, d_tab, zero_copy ? down.host<void>(o_res) : down.dev<void>(o_res))) != ASD_OK) return rc;
@@ -1136,10 +1633,11 @@ void matcher_free(asd_ctx* ctx) {
   }
   if (ctx->matcher) {
     MatcherState* m = static_cast<MatcherState*>(ctx->matcher);
-    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_meta, m->d_qdesc, m->d_bank};
+    void* dev[] = {m->d_queries, m->d_q_off, m->d_idx, m->d_dist, m->d_meta, m->d_qdesc, m->d_bank, m->d_attr};
     for (void* p : dev) if (p) (void)hipFree(p);
-    void* host[] = {m->h_queries, m->h_q, m->h_idx, m->h_dist, m->h_qdesc, m->h_res};
+    void* host[] = {m->h_queries, m->h_q, m->h_idx, m->h_dist, m->h_qdesc, m->h_res, m->h_attr[0], m->h_attr[1]};
     for (void* p : host) if (p) (void)hipHostFree(p);
+    for (hipEvent_t e : m->ev_attr) if (e) (void)hipEventDestroy(e);
     delete m;
     ctx->matcher = nullptr;
   }
@@ -1170,7 +1668,7 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
     // the slot's pinned staging buffer is about to be rewritten: its previous copies (a frame or more ago) must have left it
     ASD_HIP_CHECK(ctx, hipEventSynchronize(F->ev_staged));
   }
-  hipStream_t st = ctx->stream;
+  hipStream_t st = asd_prep_stream(ctx);
   if (n > 0) {
     if (desc) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, desc, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, st));
     else ASD_HIP_CHECK(ctx, copy_rows(st, F->d_desc, ctx->d_desc_last, (size_t)n * 128 * sizeof(float)));
@@ -1858,6 +2356,188 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
 
 }
 
+// ---- both tracking stages of a frame as ONE submission (round 4) ------------------------------------------------------------
+// asd_track_motion_model_bank, then what Tracking does between its stages (outlier matches dropped, the optimised pose becomes
+// the frame's pose, map points the frame holds are left out of the local-map search: Tracking.cc:695-714, 725-726, 811-823) as a
+// device kernel (k_between), then asd_track_local_points_bank over the candidate rows of the attribute bank -- eight kernels back to
+// back on the context's stream, no host decision and no upload in between (the host's turn-around between the two submissions was
+// 50-60 us of an 0.7 ms frame, plus a 130 KB upload of gathered tables).  Same kernels and the same arithmetic as the two calls:
+// tests/test_track_chain.py holds the results to the same bits.
+namespace {
+int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<int()>* defer) {
+  AsdFrameSlot *C = slot_of(ctx, A.slot_cur), *L = slot_of(ctx, A.slot_last);
+  if (!C || !L || !A.has_mp || !A.Xw_last || !A.last_rows || !A.Tcw || !A.K || !A.cand_rows || A.n_cand < 1 || !A.pose7 || !A.pose1 || !A.match1 ||
+      !A.n_matches1 || !A.outlier1 || !A.n_inliers1 || !A.match2 || !A.n_matches2 || !A.outlier2 || !A.n_inliers2)
+    return ASD_ERR_INVALID;
+  if (asd_track_busy(ctx, "asd_track_frame")) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  const int nl = L->n, nc = C->n, ncand = A.n_cand;
+  if (nl < 1 || nc < 1 || !replay_on_device(m, 0, nc, nl) || !replay_on_device(m, 1, nc, ncand) || resolve_by_bids() || !pose_chain_lds_form(ctx, nc)) {
+    ctx->set_error("asd_track_frame: %d / %d keypoints, %d candidates are outside what the one-submission form handles (empty frame, more than "
+                   "%d queries, or tables beyond the workgroup's LDS): use asd_track_motion_model_bank + asd_track_local_points_bank", nc, nl, ncand,
+                   kResolve2Threads * 4);
+    return ASD_ERR_CAPACITY;
+  }
+  for (int i = 0; i < nl; ++i)
+    if (A.has_mp[i] && (A.last_rows[i] < 0 || A.last_rows[i] >= m->bank_cap)) { ctx->set_error("bank row %d out of range", A.last_rows[i]); return ASD_ERR_INVALID; }
+  for (int c = 0; c < ncand; ++c)
+    if (A.cand_rows[c] < 0 || A.cand_rows[c] >= m->bank_cap || A.cand_rows[c] >= m->attr_cap) { ctx->set_error("candidate row %d out of range (descriptor bank %d rows, attribute bank %d)", A.cand_rows[c], m->bank_cap, m->attr_cap); return ASD_ERR_INVALID; }
+  // nothing is searched twice here: the candidate buffers take the worst case up front (a list holds at most every keypoint)
+  int rc = ensure_cands_dev(ctx, m, (size_t)std::max(nl, ncand) * (size_t)nc);
+  if (rc != ASD_OK) return rc;
+  hipStream_t st = ctx->stream;
+  AsdXfer &up = ctx->up, &down = ctx->down;
+  const size_t io_bytes = pose_chain_io_bytes(nc);
+  ASD_HIP_CHECK(ctx, up.begin(st, (size_t)nl * sizeof(WinQuery) + (size_t)nl * (1 + 1 + 12 + 4 + 4) + (size_t)ncand * 5 + 16 * 256));
+  ASD_HIP_CHECK(ctx, down.begin(st, 2 * (((size_t)nc + 16) * sizeof(int) + 256 + io_bytes + 256)));
+  size_t need = 0;
+  auto pad = [](size_t b) { return AsdDevBuf::padded(b); };
+  need += pad((size_t)ncand * sizeof(WinQuery)) + 2 * pad((size_t)nl * 4) + 2 * pad((size_t)ncand * 4) + pad((size_t)nl * kTop * 2) + pad((size_t)ncand * kTop * 2) +
+          pad(nc) + pad((size_t)nc * 12) + pad(ncand) + pad((size_t)ncand * 12) + pad(32 * 4) + pad(io_bytes);
+  ASD_HIP_CHECK(ctx, ctx->scratch.reserve(need));
+  WinQuery* d_q2 = ctx->scratch.carve<WinQuery>(ncand);
+  int *d_off1 = ctx->scratch.carve<int>(nl), *d_cnt1 = ctx->scratch.carve<int>(nl), *d_off2 = ctx->scratch.carve<int>(ncand), *d_cnt2 = ctx->scratch.carve<int>(ncand);
+  uint16_t *d_top1 = ctx->scratch.carve<uint16_t>((size_t)nl * kTop), *d_top2 = ctx->scratch.carve<uint16_t>((size_t)ncand * kTop);
+  uint8_t* d_occ = ctx->scratch.carve<uint8_t>(nc);
+  float* d_curXw = ctx->scratch.carve<float>((size_t)nc * 3);
+  uint8_t* d_skip = ctx->scratch.carve<uint8_t>(ncand);
+  float* d_cXw = ctx->scratch.carve<float>((size_t)ncand * 3);
+  float* d_T1 = ctx->scratch.carve<float>(32);
+  double* d_io1 = reinterpret_cast<double*>(ctx->scratch.carve<char>(io_bytes));
+  // one upload block: the motion-model stage's query table (written on the device) first, the copy the kernel carries behind it
+  const size_t o_q1 = up.reserve((size_t)nl * sizeof(WinQuery));
+  const size_t o_tot1 = up.zeros(sizeof(int)), o_tot2 = up.zeros(sizeof(int));
+  const size_t o_obs1 = A.last_obs_positive ? up.add(A.last_obs_positive, nl) : 0, o_obs2 = A.cand_obs_positive ? up.add(A.cand_obs_positive, ncand) : 0;
+  const size_t o_has = up.add(A.has_mp, nl), o_Xw = up.add(A.Xw_last, (size_t)nl * 12), o_rows1 = up.add(A.last_rows, (size_t)nl * 4);
+  const size_t o_lc = A.last_cand ? up.add(A.last_cand, (size_t)nl * 4) : 0, o_crows = up.add(A.cand_rows, (size_t)ncand * 4);
+  const size_t o_out1 = down.reserve(((size_t)nc + 16) * sizeof(int)), o_res1 = down.reserve(io_bytes);
+  const size_t o_out2 = down.reserve(((size_t)nc + 16) * sizeof(int)), o_res2 = down.reserve(io_bytes);
+  const bool has_obs1 = A.last_obs_positive != nullptr, has_obs2 = A.cand_obs_positive != nullptr, has_lc = A.last_cand != nullptr;
+  const std::array<double, 4> Kd = {(double)A.K[0], (double)A.K[1], (double)A.K[2], (double)A.K[3]};
+
+  // ---- motion-model stage
+  {
+    ProjectArgs pa{};
+    pa.n = nl; pa.kp_last = L->d_kp;
+    memcpy(pa.T, A.Tcw, sizeof pa.T);
+    pa.fx = A.K[0]; pa.fy = A.K[1]; pa.cx = A.K[2]; pa.cy = A.K[3];
+    pa.min_x = C->min_x; pa.max_x = C->max_x; pa.min_y = C->min_y; pa.max_y = C->max_y; pa.th = A.th;
+    for (int l = 0; l < ASD_MAX_LEVELS; ++l) pa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f;
+    pa.Xw = up.host<float>(o_Xw); pa.has_mp = up.host<uint8_t>(o_has); pa.rows = up.host<int>(o_rows1);   // the query blocks read the pinned block
+    pa.queries = up.dev<WinQuery>(o_q1);
+    pa.up = UploadTail{reinterpret_cast<const uint4*>(up.h), reinterpret_cast<uint4*>(up.d), ((size_t)nl * sizeof(WinQuery) + 255) / 256 * 16, (up.used + 15) / 16,
+                       (nl + 255) / 256};
+    hipLaunchKernelGGL(k_project_queries, dim3(pa.up.q_blocks + kUploadTailBlocks), dim3(256), 0, st, pa);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+  }
+  auto resolve_launch = [&](auto kern, const Resolve2Args& a, size_t lds) -> hipError_t {
+    static AsdPerDeviceOnce attr_set;
+    if (attr_set.need(ctx->cfg.device)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set.done(ctx->cfg.device);
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(kResolve2Threads), lds, st, a);
+    return hipGetLastError();
+  };
+  auto search_resolve = [&](auto kind_tag, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in,
+                            const uint8_t* d_obs, const float4* kp_last, int check_ori, float nn_ratio, int* d_out, int* h_out) -> int {
+    constexpr int KIND = decltype(kind_tag)::value;
+    GridDev G{C->d_kp, C->d_cell_start, C->d_cell_items, C->min_x, C->min_y, C->inv_w, C->inv_h};
+    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top};
+    hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, d_q, nq, m->d_bank, C->d_desc, d_off, d_cnt,
+                       d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, sa);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    Resolve2Args a{};
+    a.nq = nq; a.n_cur = nc;
+    a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.top_idx = d_top;
+    a.total = d_total; a.cap = m->cand_cap;
+    a.obs_pos = d_obs;
+    a.kp_cur = C->d_kp; a.kp_last = kp_last;
+    a.check_ori = check_ori; a.nn_ratio = nn_ratio;
+    a.match_cur = d_out; a.n_matches = d_out + nc; a.mirror = h_out;
+    const size_t fixed = resolve_lds_bytes(KIND, nc, nq), per = KIND == 1 ? 6 : 2;
+    a.stage_cap = (int)std::min<size_t>(((size_t)m->last_total[KIND] * 5 / 4 + 1023) / 1024 * 1024, ((size_t)96 * 1024 - fixed) / per / 8 * 8);
+    const size_t lds = fixed + (size_t)a.stage_cap * per;
+    if (nq <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<KIND, 2>, a, lds));
+    else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<KIND, 4>, a, lds));
+    return ASD_OK;
+  };
+  if ((rc = search_resolve(std::integral_constant<int, 0>{}, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr,
+                           has_obs1 ? up.dev<uint8_t>(o_obs1) : nullptr, L->d_kp, A.check_orientation, 0.f, down.dev<int>(o_out1), down.host<int>(o_out1))) != ASD_OK)
+    return rc;
+  if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
+                               d_io1)) != ASD_OK)
+    return rc;
+  // ---- between the stages
+  {
+    BetweenArgs b{};
+    b.n_cur = nc; b.n_last = nl; b.n_cand = ncand;
+    b.match1 = down.dev<int>(o_out1); b.io1 = d_io1; b.Xw_last = up.dev<float>(o_Xw); b.last_cand = has_lc ? up.dev<int>(o_lc) : nullptr;
+    memcpy(b.T_pred, A.Tcw, sizeof b.T_pred);
+    b.occ = d_occ; b.cur_Xw = d_curXw; b.skip = d_skip; b.T1 = d_T1;
+    hipLaunchKernelGGL(k_between, dim3(1), dim3(1024), 0, st, b);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+  }
+  // ---- local-map stage
+  {
+    FrustumArgs fa{};
+    fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
+    fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
+    fa.min_x = C->min_x; fa.max_x = C->max_x; fa.min_y = C->min_y; fa.max_y = C->max_y;
+    fa.cos_limit = A.viewing_cos_limit; fa.th = A.th_local;
+    for (int l = 0; l < ASD_MAX_LEVELS; ++l) { fa.level_thr[l] = ctx->level_thr[l]; fa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f; }
+    fa.rows = up.dev<int>(o_crows); fa.queries = d_q2;
+    fa.up = UploadTail{nullptr, nullptr, 0, 0, (ncand + 255) / 256};
+    fa.T_dev = d_T1; fa.attr = m->d_attr; fa.skip = d_skip; fa.xw_out = d_cXw;
+    hipLaunchKernelGGL(k_frustum_queries, dim3((ncand + 255) / 256), dim3(256), 0, st, fa);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+  }
+  if ((rc = search_resolve(std::integral_constant<int, 1>{}, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, has_obs2 ? up.dev<uint8_t>(o_obs2) : nullptr,
+                           nullptr, 0, A.nn_ratio, down.dev<int>(o_out2), down.host<int>(o_out2))) != ASD_OK)
+    return rc;
+  if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr)) != ASD_OK)
+    return rc;
+  if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st));
+
+  asd_track_frame_args O = A;   // (only the output pointers are used below)
+  std::array<double, 7> p_in;
+  memcpy(p_in.data(), A.pose7, 56);
+  auto complete = [=]() -> int {
+    ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_chain));
+    const int *h1 = ctx->down.host<int>(o_out1), *h2 = ctx->down.host<int>(o_out2);
+    m->last_total[0] = h1[nc + 1]; m->last_total[1] = h2[nc + 1];
+    if (h1[nc + 1] > m->cand_cap || h2[nc + 1] > m->cand_cap) {   // cannot happen with the worst-case sizing above
+      ctx->set_error("asd_track_frame: %d / %d candidates overflowed the %d-entry buffers", h1[nc + 1], h2[nc + 1], m->cand_cap);
+      return ASD_ERR_CAPACITY;
+    }
+    auto unpack = [&](const int* h_out, const double* h_io, const double* p_start, int32_t* match, int32_t* n_matches, uint8_t* outlier, double* pose, int32_t* n_inl) {
+      memcpy(match, h_out, (size_t)nc * sizeof(int));
+      *n_matches = h_out[nc];
+      const int ne = (int)(h_io[8 + (nc + 7) / 8] + 0.5);
+      memcpy(outlier, h_io + 8, (size_t)nc);
+      memcpy(pose, ne < 3 ? p_start : h_io, 56);   // Optimizer.cc:323-324: fewer than 3 correspondences leave the pose alone
+      *n_inl = ne < 3 ? 0 : ne - (int)(h_io[7] + 0.5);
+    };
+    unpack(h1, ctx->down.host<double>(o_res1), p_in.data(), O.match1, O.n_matches1, O.outlier1, O.pose1, O.n_inliers1);
+    double p1[7];
+    memcpy(p1, O.pose1, 56);
+    unpack(h2, ctx->down.host<double>(o_res2), p1, O.match2, O.n_matches2, O.outlier2, O.pose7, O.n_inliers2);
+    ctx->ms_match = 0.f;
+    return ASD_OK;
+  };
+  if (defer) { *defer = complete; return ASD_OK; }
+  return complete();
+}
+}  // namespace
+
+int asd_track_frame(asd_ctx* ctx, const asd_track_frame_args* args) {
+  if (!args) return ASD_ERR_INVALID;
+  return run_track(ctx, [&](std::function<int()>* defer) { return track_frame_impl(ctx, *args, defer); });
+}
+
 int asd_track_async(asd_ctx* ctx) {
   if (!ctx) return ASD_ERR_INVALID;
   if (asd_track_busy(ctx, "asd_track_async")) return ASD_ERR_INVALID;
@@ -2264,7 +2944,67 @@ int asd_bank_put_from_frame(asd_ctx* ctx, int32_t slot, int32_t first_row, int32
   MatcherState* m = mstate(ctx);
   int rc = ensure_bank(ctx, m, first_row + n);
   if (rc != ASD_OK || n == 0) return rc;
-  ASD_HIP_CHECK(ctx, copy_rows(ctx->stream, m->d_bank + (size_t)first_row * 128, F->d_desc, (size_t)n * 512));
+  ASD_HIP_CHECK(ctx, copy_rows(asd_prep_stream(ctx), m->d_bank + (size_t)first_row * 128, F->d_desc, (size_t)n * 512));
+  return ASD_OK;
+}
+
+// MapPoint::{mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance} of rows [first_row, first_row + n) of the bank
+int asd_mpbank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* Xw, const float* normal, const float* min_dist, const float* max_dist) {
+  if (!ctx || first_row < 0 || n < 0 || (n > 0 && (!Xw || !normal || !min_dist || !max_dist))) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  if (first_row + n > m->attr_cap) {
+    const int cap = std::max((first_row + n) * 3 / 2, 16384);
+    float* nb = nullptr;
+    ASD_HIP_CHECK(ctx, hipMalloc(&nb, (size_t)cap * 32));
+    ASD_HIP_CHECK(ctx, hipDeviceSynchronize());   // (growth is rare: everything that reads or writes the old table has finished)
+    if (m->d_attr) { ASD_HIP_CHECK(ctx, hipMemcpy(nb, m->d_attr, (size_t)m->attr_cap * 32, hipMemcpyDeviceToDevice)); (void)hipFree(m->d_attr); }
+    m->d_attr = nb;
+    m->attr_cap = cap;
+  }
+  if (n == 0) return ASD_OK;
+  const int k = m->attr_turn ^= 1;
+  if (!m->ev_attr[k]) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&m->ev_attr[k], hipEventDisableTiming));
+  else ASD_HIP_CHECK(ctx, hipEventSynchronize(m->ev_attr[k]));   // this staging buffer's previous upload has left it
+  if (m->h_attr_cap[k] < (size_t)n * 32) {
+    if (m->h_attr[k]) (void)hipHostFree(m->h_attr[k]);
+    m->h_attr[k] = nullptr; m->h_attr_cap[k] = 0;
+    ASD_HIP_CHECK(ctx, hipHostMalloc(&m->h_attr[k], (size_t)n * 48));
+    m->h_attr_cap[k] = (size_t)n * 48;
+  }
+  float* h = m->h_attr[k];
+  for (int i = 0; i < n; ++i) {
+    float* r = h + 8 * (size_t)i;
+    r[0] = Xw[3 * i]; r[1] = Xw[3 * i + 1]; r[2] = Xw[3 * i + 2];
+    r[3] = normal[3 * i]; r[4] = normal[3 * i + 1]; r[5] = normal[3 * i + 2];
+    r[6] = min_dist[i]; r[7] = max_dist[i];
+  }
+  hipStream_t st = asd_prep_stream(ctx);
+  ASD_HIP_CHECK(ctx, copy_rows(st, m->d_attr + 8 * (size_t)first_row, h, (size_t)n * 32));
+  ASD_HIP_CHECK(ctx, hipEventRecord(m->ev_attr[k], st));
+  return ASD_OK;
+}
+
+// Frame construction beside the stages in flight: between asd_prep_async(ctx, 1) and asd_prep_async(ctx, 0) the device work of
+// asd_frame_set, asd_bank_put_from_frame and asd_mpbank_put goes to a second stream of the context instead of queueing behind the
+// outstanding asd_track_* stage; closing the bracket makes everything enqueued on the context's stream AFTERWARDS wait for it.
+int asd_prep_async(asd_ctx* ctx, int32_t on) {
+  if (!ctx) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  if (on) {
+    if (!ctx->stream_prep) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, hi));
+      ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    }
+    ctx->prep_on = true;
+    return ASD_OK;
+  }
+  if (!ctx->prep_on) return ASD_OK;
+  ctx->prep_on = false;
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_prep, ctx->stream_prep));
+  ASD_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prep, 0));
   return ASD_OK;
 }
 

@@ -288,6 +288,56 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
                                 float nn_ratio, const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur,
                                 int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
 
+/* Map-point attribute bank, the companion of the descriptor bank (same row ids): MapPoint::mWorldPos, mNormalVector,
+ * mfMinDistance, mfMaxDistance (MapPoint.cc:60-77, 340-391; rewritten by UpdateNormalAndDepth once per keyframe, read by
+ * Frame::isInFrustum for every local map point of every frame, Frame.cc:160-217).  Xw[n][3], normal[n][3], min_dist[n],
+ * max_dist[n] (raw values: isInFrustum's 0.8 / 1.2 factors are applied by the kernels).  The arrays are consumed on return. */
+int asd_mpbank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* Xw, const float* normal, const float* min_dist,
+                   const float* max_dist);
+
+/* Both tracking stages of a frame as ONE submission: asd_track_motion_model_bank, then -- on the device, where the host of
+ * the two-call form sits -- what Tracking does between them: matches PoseOptimization marked as outliers are dropped
+ * (Tracking.cc:695-714), the optimised pose becomes the frame's pose (Frame::SetPose, Frame.cc:150-158), the map points the
+ * frame holds now are left out of the local-map search (SearchLocalPoints' mnLastFrameSeen marks, Tracking.cc:811-823); then
+ * asd_track_local_points_bank over the candidates, from the motion-model stage's pose and kept matches.  The local map is
+ * passed as a SUPERSET known before the frame is tracked: n_cand rows of the attribute + descriptor bank (cand_rows), and per
+ * keypoint of the last frame the candidate index of the map point it holds (last_cand[i], -1 = not among the candidates;
+ * NULL = none is) -- a candidate whose map point ends up as a kept match of the motion-model stage makes no query.  Results
+ * are those of the two calls bit for bit, with match2[j] a CANDIDATE index.  pose7: in = SE3Quat of the predicted pose, out =
+ * the local-map stage's optimum; pose1 = the motion-model stage's.  The control flow stays with the caller as before: if the
+ * motion-model stage made too few matches (nmatches < 20, Tracking.cc:681-685) it discards match2 / pose7 and runs the retry
+ * with the separate calls.  Sizes beyond the one-submission form (more than 4096 last-frame keypoints or candidates, frames
+ * beyond the solver's LDS form) return ASD_ERR_CAPACITY: use the two calls.  Honours asd_track_async / asd_track_finish. */
+typedef struct asd_track_frame_args {
+  int32_t slot_cur, slot_last;
+  const uint8_t* has_mp;            /* [n_last] motion-model stage: as asd_track_motion_model_bank */
+  const float* Xw_last;             /* [n_last][3] */
+  const int32_t* last_rows;         /* [n_last] descriptor-bank rows */
+  const int32_t* last_cand;         /* [n_last] or NULL */
+  const uint8_t* last_obs_positive; /* [n_last] or NULL */
+  const float* Tcw;                 /* [16] predicted pose the motion-model search projects with */
+  float th;                         /* its window factor (15 mono, Tracking.cc:676-680) */
+  int32_t check_orientation;
+  int32_t n_cand;                   /* local-map stage: as asd_track_local_points_bank, attributes from the bank */
+  const int32_t* cand_rows;         /* [n_cand] rows of the attribute and descriptor banks */
+  const uint8_t* cand_obs_positive; /* [n_cand] or NULL */
+  float viewing_cos_limit, th_local, nn_ratio;
+  const float* K;                   /* fx fy cx cy */
+  double* pose7;                    /* [7] in / out */
+  double* pose1;                    /* [7] out */
+  int32_t *match1, *n_matches1; uint8_t* outlier1; int32_t* n_inliers1;   /* [n_cur] tables, as the stage calls return them */
+  int32_t *match2, *n_matches2; uint8_t* outlier2; int32_t* n_inliers2;
+} asd_track_frame_args;
+int asd_track_frame(asd_ctx* ctx, const asd_track_frame_args* args);
+
+/* Frame construction beside the stages in flight.  Between asd_prep_async(ctx, 1) and asd_prep_async(ctx, 0) the device
+ * work of asd_frame_set, asd_bank_put_from_frame and asd_mpbank_put is enqueued on a second stream of the context instead of
+ * behind the outstanding asd_track_* stage (the reference's Frame constructor runs before the frame is tracked, not after the
+ * previous one: Tracking.cc:96-118); closing the bracket orders everything enqueued on the context AFTERWARDS behind it.  The
+ * caller guarantees what ordering on one stream gave for free: nothing written inside the bracket (the frame slot, the bank
+ * rows) is read by a stage still in flight. */
+int asd_prep_async(asd_ctx* ctx, int32_t on);
+
 /* Split-phase execution of the asd_track_* calls.  asd_track_async(ctx) arms the NEXT asd_track_motion_model[_bank] /
  * asd_track_local_map[_bank] / asd_track_local_points[_bank] call on this context: it returns as soon as its work is enqueued
  * -- every INPUT array has been consumed by then and may be reused, the OUTPUT arrays (pose7, match_cur, n_matches,

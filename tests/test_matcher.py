@@ -291,6 +291,87 @@ def test_match_project_frame(hip, oracle, synth, n, th, ori):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,th", [(2000, 120.0), (700, 400.0)])
+def test_match_project_frame_long_lists(hip, oracle, synth, n, th):
+    """windows of more than 16 grid columns / more than 128 candidates: k_window_search<true> ranks such a list from its copy in
+    global memory (slow path), and the replay walks beyond the four heads it keeps in registers"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, 150 + n, sigma=0.4)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    obs = (np.random.default_rng(3).uniform(size=n) < 0.7).astype(np.uint8)
+    for flags in (None, obs):
+        got, ng = hip.match_project_frame(0, 1, n, has, Xw, mp_desc, T, K, th, True, obs_positive=flags)
+        exp, ne = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw, mp_desc,
+                                             T, K, th, True, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne and ng > 0
+
+
+def _crowded_case(synth, n, n_cur, seed):
+    """n map points aimed at n_cur << n current keypoints packed into a small region with near-identical descriptors: every
+    list is long, every head is contested, and most map points end up far down their list or empty-handed"""
+    kl, dl = make_frame(n, seed)
+    K = np.array(synth.KITTI_K, np.float32)
+    T = pose_T()
+    rng = np.random.default_rng(seed + 1)
+    kc, _ = make_frame(n_cur, seed + 5)
+    kc["x"] = rng.uniform(600, 660, n_cur).astype(np.float32)
+    kc["y"] = rng.uniform(170, 210, n_cur).astype(np.float32)
+    kc["octave"] = np.sort(rng.integers(2, 5, n_cur))
+    base = dl[0]
+    dc = perturbed_descriptors(np.repeat(base[None], n_cur, 0), 0.02, seed + 2)
+    aim = rng.integers(0, n_cur, n)
+    kl = kl.copy()
+    kl["octave"] = kc["octave"][aim]
+    uv = np.stack([kc["x"][aim], kc["y"][aim]], 1) + rng.uniform(-3, 3, (n, 2)).astype(np.float32)
+    Xw = backproject(T, K, uv, rng.uniform(5, 40, n))
+    has = np.ones(n, np.uint8)
+    mp_desc = perturbed_descriptors(np.repeat(base[None], n, 0), 0.02, seed + 3)
+    return kl, dl, kc, dc, Xw, has, mp_desc, T, K, aim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_cur,th", [(2000, 60, 15.0), (3000, 300, 10.0), (500, 7, 30.0)])
+def test_match_project_frame_crowded(hip, oracle, synth, n, n_cur, th):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, _ = _crowded_case(synth, n, n_cur, 400 + n)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    obs = (np.random.default_rng(5).uniform(size=n) < 0.6).astype(np.uint8)
+    for flags, ori in ((None, False), (obs, True), (np.ones(n, np.uint8), True)):
+        got, ng = hip.match_project_frame(0, 1, n_cur, has, Xw, mp_desc, T, K, th, ori, obs_positive=flags)
+        exp, ne = oracle.match_project_frame(oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS), has, Xw, mp_desc,
+                                             T, K, th, ori, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mp,n_cur,th", [(3000, 200, 5.0), (2500, 40, 12.0)])
+def test_match_project_points_crowded(hip, oracle, synth, n_mp, n_cur, th):
+    """the local-map search with every keypoint contested by many map points: second-best / ratio decisions deep in the lists"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, aim = _crowded_case(synth, n_mp, n_cur, 700 + n_mp)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    F = oracle.frame(kc, dc, BOUNDS)
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    nrm = Xw.astype(np.float64) - Ow
+    dist = np.linalg.norm(nrm, axis=1)
+    nrm = (nrm / dist[:, None]).astype(np.float32)
+    maxd = (dist * SCALES[kc["octave"][aim]]).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    in_view, proj, level, vc = hip.frustum(0, Xw, nrm, mind, maxd, T, K)
+    assert in_view.sum() > 0.8 * n_mp
+    rng = np.random.default_rng(9)
+    occupied = (rng.uniform(size=n_cur) < 0.2).astype(np.uint8)
+    obs = (rng.uniform(size=n_mp) < 0.6).astype(np.uint8)
+    for flags in (None, obs):
+        got, ng = hip.match_project_points(0, n_cur, in_view, proj, level, vc, mp_desc, occupied, th, 0.8, obs_positive=flags)
+        exp, ne = oracle.match_project_points(F, in_view, proj, level, vc, mp_desc, occupied, th, 0.8, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne
+        assert not ((got >= 0) & (occupied > 0)).any()
+
+
+@pytest.mark.gpu
 def test_match_project_frame_degenerate(hip, oracle, synth):
     kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, 300, 77)
     hip.frame_set(0, kc, dc, BOUNDS)

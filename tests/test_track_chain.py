@@ -328,3 +328,88 @@ def test_deferred_stage_never_searches_again(pkg, synth):
         b.close()
     for x, y in zip(got, exp):
         np.testing.assert_array_equal(x, y)
+
+
+def _frame_case(synth, n, seed):
+    """a tracked-frame situation: last frame + current frame (as _m1_case), and a local map = the last frame's points plus a displaced
+    copy of each (twice the keypoints, like bench.py's stand-in), every last keypoint holding candidate i"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n, seed)
+    Xw2 = np.concatenate([Xw, Xw + np.float32(0.02)])
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    d = Xw2.astype(np.float64) - Ow
+    dist = np.linalg.norm(d, axis=1)
+    nrm = (d / dist[:, None]).astype(np.float32)
+    lv = np.concatenate([kl["octave"], kl["octave"]])
+    maxd = (dist * SCALES[lv]).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    return kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,th,flags", [(2000, 15.0, False), (700, 30.0, True), (2, 15.0, False)])
+def test_track_frame_equals_the_two_stage_calls(hip, synth, n, th, flags):
+    """asd_track_frame (both stages + what Tracking does between them, one submission) against asd_track_motion_model_bank -> host ->
+    asd_track_local_points_bank: the same bits in every output"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd = _frame_case(synth, n, 900 + n)
+    n_cur = len(kc)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    base = 300
+    hip.bank_put(base, np.concatenate([mp_desc, mp_desc]))
+    hip.mpbank_put(base, Xw2, nrm, mind, maxd)
+    rows1 = np.arange(base, base + n, dtype=np.int32)
+    cand_rows = np.arange(base, base + 2 * n, dtype=np.int32)
+    rng = np.random.default_rng(4)
+    obs1 = (rng.uniform(size=n) < 0.8).astype(np.uint8) if flags else None
+    obs2 = (rng.uniform(size=2 * n) < 0.8).astype(np.uint8) if flags else None
+    last_cand = np.arange(n, dtype=np.int32)
+    if flags:
+        last_cand[::7] = -1            # map points that are not among the candidates
+    pose0 = _pose7(pose_T(rv=(0.012, -0.018, 0.006), t=(0.12, -0.04, 0.33)))
+    # ---- the two calls with the host in between (bench.py's track_step)
+    m1, n1, pose1, outl1, inl1 = hip.track_motion_model(0, 1, n_cur, has, Xw, rows1, T, K, th, pose0, True, obs_positive=obs1)
+    keep = (m1 >= 0) & (outl1 == 0)
+    T1 = hip.pose7_to_tcw(pose1) if (m1 >= 0).sum() >= 3 else T
+    in_frame = np.zeros(2 * n, bool)
+    lc = last_cand[m1[keep]]
+    in_frame[lc[lc >= 0]] = True
+    sel = np.nonzero(~in_frame)[0].astype(np.int32)
+    occ = keep.astype(np.uint8)
+    cur_Xw = Xw[np.maximum(m1, 0)]
+    m2, n2, pose2, outl2, inl2 = hip.track_local_points(0, n_cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], cand_rows[sel], T1, K, occ, cur_Xw, 1.0, 0.8,
+                                                        pose1, obs_positive=None if obs2 is None else obs2[sel])
+    # ---- one submission
+    for split in (False, True):
+        r = hip.track_frame(0, 1, n_cur, has, Xw, rows1, last_cand, T, K, th, pose0, cand_rows, 1.0, 0.8, last_obs_positive=obs1, cand_obs_positive=obs2,
+                            split=split)
+        if split:
+            assert r is None
+            hip.frame_set(2, kl, dl, BOUNDS)      # the next frame's construction may run meanwhile
+            r = hip.track_frame_finish()
+        np.testing.assert_array_equal(r["match1"], m1)
+        assert (r["n1"], r["n_inl1"]) == (n1, inl1)
+        np.testing.assert_array_equal(r["outlier1"], outl1)
+        np.testing.assert_array_equal(r["pose1"], pose1)
+        exp2 = np.where(m2 >= 0, sel[np.maximum(m2, 0)], -1)     # candidate index instead of index into the compacted list
+        np.testing.assert_array_equal(r["match2"], exp2)
+        assert (r["n2"], r["n_inl2"]) == (n2, inl2)
+        np.testing.assert_array_equal(r["outlier2"], outl2)
+        np.testing.assert_array_equal(r["pose"], pose2)
+    if n >= 700:
+        assert n1 > 0.3 * n and n2 > 0 and inl2 > 0.3 * n
+
+
+@pytest.mark.gpu
+def test_track_frame_refuses_what_it_cannot_chain(hip, synth):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd = _frame_case(synth, 300, 77)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    hip.bank_put(0, np.concatenate([mp_desc, mp_desc]))
+    hip.mpbank_put(0, Xw2, nrm, mind, maxd)
+    pose0 = _pose7(pose_T())
+    with pytest.raises(RuntimeError):        # candidate row beyond the banks
+        hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.arange(10_000_000, 10_000_600, dtype=np.int32), 1.0, 0.8)
+    with pytest.raises(RuntimeError):        # more candidates than one replay workgroup takes
+        hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.zeros(5000, np.int32), 1.0, 0.8)
+    r = hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.arange(600, dtype=np.int32), 1.0, 0.8)
+    assert r["n1"] > 0
