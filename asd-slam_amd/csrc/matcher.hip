@@ -2526,6 +2526,16 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     memcpy(p1, O.pose1, 56);
     unpack(h2, ctx->down.host<double>(o_res2), p1, O.match2, O.n_matches2, O.outlier2, O.pose7, O.n_inliers2);
     ctx->ms_match = 0.f;
+    static const bool timing = getenv("ASD_TIMING") != nullptr;
+    if (timing) {   // k_resolve2's own stamps (10 ns units), averaged over 200 frames
+      static double acc[2][5]; static long calls;
+      const int* hh[2] = {h1, h2};
+      for (int k = 0; k < 2; ++k) { acc[k][0] += hh[k][nc + 2]; for (int i = 0; i < 4; ++i) acc[k][1 + i] += 0.01 * hh[k][nc + 3 + i]; }
+      if (++calls % 200 == 0)
+        for (int k = 0; k < 2; ++k)
+          fprintf(stderr, "[track_frame resolve kind %d] %.1f iterations, %d candidates; staging %.1f us, iterations %.1f us (the first %.1f), outputs %.1f us\n", k,
+                  acc[k][0] / calls, hh[k][nc + 1], acc[k][1] / calls, acc[k][2] / calls, acc[k][4] / calls, acc[k][3] / calls);
+    }
     return ASD_OK;
   };
   if (defer) { *defer = complete; return ASD_OK; }

@@ -40,6 +40,16 @@ struct asd_track_handle {
   // construction (wait for its extraction, AssignFeaturesToGrid + descriptor adoption, read-ahead submission, descriptor-bank
   // rows, projected points), which the reference's Frame constructor does before tracking that frame
   bool split = true;
+  // both stages as ONE submission (asd_track_frame): the between-stage work (outlier drop, pose hand-over, local-map selection) runs on
+  // the device, the local map's attributes live in the bank, and the next frame is constructed on the context's second stream
+  // (asd_prep_async) beside the stages instead of behind them.  Needs three frame slots (the next frame's grid is written while the
+  // motion-model stage may still read the last frame's) and two alternating bank regions.
+  bool chain = true;
+  int bank_base = 0;        // first bank row of the map the prepared frame is tracked against
+  std::vector<int32_t> last_cand, cand_rows;
+  asd_track_frame_args fa;
+  int32_t f_n1 = 0, f_inl1 = 0, f_n2 = 0, f_inl2 = 0;
+  double f_pose[7], f_pose1[7];
   float drift_cx = 620.5f, drift_cy = 188.0f, drift_z = 1.003f, drift_dx = 3.0f, drift_dy = 0.2f;   // asd_track_set_drift
   int stop_after = -1;      // no read-ahead beyond this frame (-1 = unbounded)
   int prep_t = -1;          // the frame prepare_frame() has made ready (its grid sits in slot `slot`), -1 = none
@@ -103,6 +113,7 @@ asd_track_handle* asd_track_create(asd_ctx* ctx, int32_t n_frames, const void* c
 void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on != 0; }
 void asd_track_set_async_ba(asd_track_handle* h, int32_t on) { if (h) h->async_ba = on != 0; }
 void asd_track_set_split(asd_track_handle* h, int32_t on) { if (h) h->split = on != 0; }
+void asd_track_set_chain(asd_track_handle* h, int32_t on) { if (h) h->chain = on != 0; }
 void asd_track_set_drift(asd_track_handle* h, float cx, float cy, float z, float dx, float dy) {
   if (h) { h->drift_cx = cx; h->drift_cy = cy; h->drift_z = z; h->drift_dx = dx; h->drift_dy = dy; }
 }
@@ -171,7 +182,8 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
     if ((rc = asd_extract_device(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
     kps = h->kps.data();
   }
-  h->slot ^= 1;
+  const bool chain = h->fused && h->split && h->chain;
+  if (chain) h->slot = (h->slot + 1) % 3; else h->slot ^= 1;
   seg(7);
   if ((rc = asd_frame_set(ctx, h->slot, kps, nullptr, n, 0.f, (float)h->W, 0.f, (float)h->H)) != ASD_OK) return rc;
   seg(0);
@@ -191,7 +203,48 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
     }
   }
   seg(1);
-  if (h->have_last) {
+  if (h->have_last && chain) {
+    // the map this frame is tracked against, written beside the previous frame's stages: the other bank region (rows the stages in
+    // flight do not read) takes the last frame's points -- descriptors device to device, attributes from the host -- and a displaced copy
+    const std::vector<asd_keypoint>& lk = h->last_kps;
+    const int nl = (int)lk.size();
+    const float fx = h->K32[0], fy = h->K32[1], cx = h->K32[2], cy = h->K32[3];
+    const float z = h->drift_z, c3 = (float)((double)h->drift_dx * (double)(h->drift_z == 1.003f ? 1.003 : (double)h->drift_z)),
+                c02 = (float)((double)(h->drift_dy == 0.2f ? 0.2 : (double)h->drift_dy) * (double)(h->drift_z == 1.003f ? 1.003 : (double)h->drift_z)), depth = 20.0f;
+    h->Xw.resize((size_t)3 * nl);
+    for (int i = 0; i < nl; ++i) {
+      const float u = (lk[i].x - h->drift_cx) * z + h->drift_cx - c3;
+      const float v = (lk[i].y - h->drift_cy) * z + h->drift_cy - c02;
+      h->Xw[3 * i + 0] = (u - cx) / fx * depth;
+      h->Xw[3 * i + 1] = (v - cy) / fy * depth;
+      h->Xw[3 * i + 2] = depth;
+    }
+    h->has.assign(nl, 1);
+    const int n2p = 2 * nl;
+    h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
+    for (int i = 0; i < nl; ++i)
+      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
+    for (int i = 0; i < n2p; ++i) {
+      const float* P = &h->Xw2[3 * i];
+      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
+      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
+      h->dist[i] = nn;
+      const int lv = lk[i % nl].octave;
+      h->maxd[i] = nn * h->scale32[lv];
+      h->mind[i] = h->maxd[i] / h->scale32[7];
+    }
+    seg(7);
+    h->bank_base = h->bank_base ? 0 : 8192;
+    const int base = h->bank_base;
+    if (n2p > 8192) return ASD_ERR_CAPACITY;
+    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, base, nl)) != ASD_OK) return rc;
+    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, base + nl, nl)) != ASD_OK) return rc;
+    if ((rc = asd_mpbank_put(ctx, base, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data())) != ASD_OK) return rc;
+    h->rows.resize(nl); h->last_cand.resize(nl); h->cand_rows.resize(n2p);
+    for (int i = 0; i < nl; ++i) { h->rows[i] = base + i; h->last_cand[i] = i; }
+    for (int i = 0; i < n2p; ++i) h->cand_rows[i] = base + i;
+    seg(2);
+  } else if (h->have_last) {
     const std::vector<asd_keypoint>& lk = h->last_kps;
     const int nl = (int)lk.size();
     const float fx = h->K32[0], fy = h->K32[1], cx = h->K32[2], cy = h->K32[3];
@@ -340,6 +393,75 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     seg(6);
   }
   if (do_ba && !h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;   // asd_local_ba uses the context's stream: no stage outstanding
+  ++h->steps;
+  return ASD_OK;
+}
+
+// One frame with both stages as one submission (asd_track_frame) and the next frame constructed beside them (asd_prep_async).
+static int track_step_chain(asd_track_handle* h, int t, bool do_ba, const std::vector<int>& next, asd_track_stats* st) {
+  asd_ctx* ctx = h->ctx;
+  int rc;
+  auto tp = std::chrono::steady_clock::now();
+  auto seg = [&](int i) {
+    const auto now = std::chrono::steady_clock::now();
+    h->seg_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
+    tp = now;
+  };
+  if (h->prep_t != t && (rc = prepare_frame(h, t, next)) != ASD_OK) return rc;
+  tp = std::chrono::steady_clock::now();
+  const asd_keypoint* kps = h->prep_kps;
+  const int32_t n = h->prep_n;
+  const int cur = h->slot;
+  h->prep_t = -1;
+  memset(st, 0, sizeof *st);
+  st->n_kp = n;
+  const bool had_last = h->have_last;
+  if (had_last) {
+    h->m1.assign(n, -1); h->m2.assign(n, -1);
+    h->outl.assign(n, 0); h->outl2.assign(n, 0);
+    memcpy(h->f_pose, h->pose0, sizeof h->f_pose);
+    asd_track_frame_args& a = h->fa;
+    memset(&a, 0, sizeof a);
+    a.slot_cur = cur; a.slot_last = h->last_slot;
+    a.has_mp = h->has.data(); a.Xw_last = h->Xw.data(); a.last_rows = h->rows.data(); a.last_cand = h->last_cand.data();
+    a.Tcw = h->T; a.th = 15.0f; a.check_orientation = 1;
+    a.n_cand = (int32_t)h->cand_rows.size(); a.cand_rows = h->cand_rows.data();
+    a.viewing_cos_limit = 0.5f; a.th_local = 1.0f; a.nn_ratio = 0.8f; a.K = h->K32;
+    a.pose7 = h->f_pose; a.pose1 = h->f_pose1;
+    a.match1 = h->m1.data(); a.n_matches1 = &h->f_n1; a.outlier1 = h->outl.data(); a.n_inliers1 = &h->f_inl1;
+    a.match2 = h->m2.data(); a.n_matches2 = &h->f_n2; a.outlier2 = h->outl2.data(); a.n_inliers2 = &h->f_inl2;
+    if ((rc = asd_track_async(ctx)) != ASD_OK) return rc;
+    if ((rc = asd_track_frame(ctx, &a)) != ASD_OK) return rc;
+    seg(2);
+  }
+  // ---- beside the stages: this frame becomes the last frame, the next one is constructed on the second stream
+  h->last_kps.assign(kps, kps + n);
+  h->last_slot = cur;
+  h->have_last = true;
+  if (do_ba && h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;
+  seg(7);
+  if (!next.empty() && next[0] == t + 1) {
+    std::vector<int> after(next.begin() + 1, next.end());
+    after.push_back(next.back() + 1);
+    if ((int)after.size() > h->lookahead) after.resize(h->lookahead);
+    if (h->stop_after >= 0) while (!after.empty() && after.back() > h->stop_after) after.pop_back();
+    if ((rc = asd_prep_async(ctx, 1)) != ASD_OK) return rc;
+    rc = prepare_frame(h, t + 1, after);
+    const int rc2 = asd_prep_async(ctx, 0);
+    if (rc != ASD_OK) return rc;
+    if (rc2 != ASD_OK) return rc2;
+    tp = std::chrono::steady_clock::now();
+  }
+  if (had_last) {
+    if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
+    st->m1 = h->f_n1; st->has_m1 = 1;
+    st->m2 = h->f_n2; st->has_m2 = 1;
+    int nedge = 0;
+    for (int j = 0; j < n; ++j) nedge += (h->m1[j] >= 0 && !h->outl[j]) || h->m2[j] >= 0;
+    if (nedge >= 3) { st->inliers = h->f_inl2; st->has_inliers = 1; }
+    seg(6);
+  }
+  if (do_ba && !h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;
   ++h->steps;
   return ASD_OK;
 }
@@ -592,8 +714,9 @@ int asd_track_run(asd_track_handle* h, int32_t t0, int32_t n, int32_t prefetch_b
     h->stop_after = prefetch_beyond ? -1 : t0 + n - 1;   // the last frame a read-ahead submission may be made for
     const bool split = h->fused && h->split;
     if (!split && h->prep_t >= 0) { h->prep_t = -1; }    // (a frame prepared by the split step is simply prepared again)
-    const int rc = split ? track_step_split(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats)
-                         : track_step(h, t, t % h->kf_interval == h->kf_interval - 1, next, stats);
+    const bool ba_now = t % h->kf_interval == h->kf_interval - 1;
+    const int rc = split ? (h->chain ? track_step_chain(h, t, ba_now, next, stats) : track_step_split(h, t, ba_now, next, stats))
+                         : track_step(h, t, ba_now, next, stats);
     if (rc != ASD_OK) return rc;
   }
   return collect_ba(h, stats, h->steps - 1);   // the run ends with its LocalBA finished (and reported if the last step started it)

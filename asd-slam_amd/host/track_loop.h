@@ -28,6 +28,9 @@ void asd_track_destroy(asd_track_handle* h);
 void asd_track_set_fused(asd_track_handle* h, int32_t on);
 void asd_track_set_async_ba(asd_track_handle* h, int32_t on);   /* 1 = LocalBA on the optional lane (NOT the reference's order) */
 void asd_track_set_split(asd_track_handle* h, int32_t on);
+/* 1 (default, with fused + split): both stages as one submission (asd_track_frame), the next frame constructed on the context's second
+ * stream beside them (asd_prep_async); 0 = two submissions with the host in between */
+void asd_track_set_chain(asd_track_handle* h, int32_t on);
 /* where the stand-in map points of frame t land in frame t+1: u' = (u - cx) z + cx - dx z, v' = (v - cy) z + cy - dy z.  Default = the
  * synthetic stream of synth.scene_frame (cx 620.5, cy 188, z 1.003, dx 3, dy 0.2); a real sequence uses z = 1, dx = dy = 0. */
 void asd_track_set_drift(asd_track_handle* h, float cx, float cy, float z, float dx, float dy);

@@ -360,6 +360,7 @@ class NativeHost:
         self.lib.asd_track_set_fused(self.h, int(getattr(be, "fused", True)))
         self.lib.asd_track_set_async_ba(self.h, int(getattr(be, "async_ba", False)))
         self.lib.asd_track_set_split(self.h, int(getattr(be, "split", True)))
+        self.lib.asd_track_set_chain(self.h, int(getattr(be, "chain", True)))
         self.be = be
 
     def run(self, t0, n, prefetch_beyond):
@@ -791,6 +792,8 @@ def main():
                     help="kitti-mono = the headline configuration (BASELINE configs[2]); euroc-stereo = configs[3], a secondary line")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
     ap.add_argument("--no-split", action="store_true", help="C++ host: run each asd_track_* stage to completion before any other host work (no asd_track_async / asd_track_finish)")
+    ap.add_argument("--no-chain", action="store_true", help="C++ host: the two tracking stages as two submissions with the host in between (round 3's form) "
+                                                             "instead of one (asd_track_frame) with the next frame constructed on a second stream")
     ap.add_argument("--lane-ba", action="store_true",
                     help="variant: LocalBA on the library's lane (asd_local_ba_submit / _wait) beside the next frames, which then track against the "
                          "pre-BA map -- not the reference's order (Tracking.cc:797 -> LocalMapping.cc:89 runs it in line, the default here)")
@@ -827,6 +830,7 @@ def main():
     be.fused = not args.no_fuse
     be.async_ba = bool(args.lane_ba)
     be.split = not args.no_split
+    be.chain = not args.no_chain
     be.native = None
     if args.host == "cxx":
         try:
@@ -939,7 +943,11 @@ def main():
                        "host": "C++ host loop over the C ABI (asd-slam_amd/host/track_loop.cpp)" if args.host == "cxx" else "Python loop (ctypes)",
                        "stages": ("each asd_track_* stage run to completion" if (args.no_split or args.no_fuse or args.host != "cxx") else
                                   "split-phase (asd_track_async / asd_track_finish): the local-map tables are built under the motion-model stage, the next "
-                                  "frame is constructed (extraction hand-over, grid, descriptor adoption, read-ahead submission) under the local-map stage"),
+                                  "frame is constructed (extraction hand-over, grid, descriptor adoption, read-ahead submission) under the local-map stage"
+                                  if args.no_chain else
+                                  "one submission per frame (asd_track_frame: motion-model stage, the outlier drop / pose hand-over / local-map selection between "
+                                  "the stages on the device, local-map stage); the next frame is constructed (extraction hand-over, grid, descriptor adoption, "
+                                  "map rows of the banks, read-ahead submission) on the context's second stream beside it (asd_prep_async)"),
                        "local_ba": ("on the library's optional lane (asd_local_ba_submit at the keyframe, own thread + stream; later frames read "
                                     "the pre-BA map: NOT the reference's order); every run is collected inside the timed region" if args.lane_ba else
                                     "in line (reference order): asd_local_ba at the keyframe, before the next frame is tracked "
