@@ -1383,8 +1383,12 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>;
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
-  constexpr int lds = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
-  static_assert(lds <= 160 * 1024, "band does not fit LDS");
+  constexpr int lds0 = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
+  static_assert(lds0 <= 160 * 1024, "band does not fit LDS");
+  // ASD_X3_MAXWG=<k> (A/B): the LDS request is padded so that at most k of these workgroups share a CU (the rest of the CU -- LDS,
+  // registers, wave slots -- stays free for the tracking stream's kernels)
+  static const int maxwg = [] { const char* e = getenv("ASD_X3_MAXWG"); return e ? atoi(e) : 0; }();
+  const int lds = (maxwg >= 1 && maxwg <= 8) ? std::max(lds0, 160 * 1024 / (maxwg + 1) + 256) : lds0;
   static AsdPerDeviceOnce attr_set;   // per instantiation; the attribute belongs to the current device (the caller selected the context's)
   int dev_ = 0;
   (void)hipGetDevice(&dev_);

@@ -230,6 +230,8 @@ struct PoseOptArgs {
   double pose0[7];      // initial pose (by value: no read of host memory on the kernel's critical path)
   const double* pose0_dev;  // non-null (asd_track_frame: the stage behind another PoseOptimization): the initial pose is read from here
   double* io_dev;           // non-null: the result block is written here as well (device memory, for the kernels of the next stage)
+  const AsdBetweenArgs* between;   // device memory or null.  asd_track_frame, motion-model stage: the kernel ends with the work between the
+                                   // two stages (needs io_dev).  A pointer, not a member: a larger argument block costs the kernel a scratch copy
   double isg_tab[16];   // MODE 2: the distinct information values ...
   const uint8_t* isgi;  // ... and each edge's index into them (device)
   double* io;           // out: pose[7], n_bad (as double), then outlier bytes at io + 8
@@ -542,6 +544,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       for (int i = threadIdx.x; i < nw; i += kPoseThreads) { og8[i] = 0ull; if (a.io_dev) od8[i] = 0ull; }
       if (threadIdx.x == 0) { a.io[8 + nw] = (double)ne; if (a.io_dev) a.io_dev[8 + nw] = (double)ne; }
     }
+    if (a.between) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asd_syncthreads();
+      asd_between_body(*a.between, threadIdx.x, kPoseThreads);
+    }
     return;
   }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
@@ -830,6 +837,11 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       unsigned long long* od8 = reinterpret_cast<unsigned long long*>(a.io_dev + 8);
       for (int i = t; i < nw; i += kPoseThreads) od8[i] = k8[i];
       if (t == 0) a.io_dev[8 + nw] = (double)ne;
+    }
+    if (a.between) {   // the flags and the pose above are this workgroup's own stores: complete, then visible to all its waves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asd_syncthreads();
+      asd_between_body(*a.between, t, kPoseThreads);
     }
     return;
   }
@@ -2087,7 +2099,8 @@ void ba_free(asd_ctx* ctx) {
 // match table, k_pose_opt reads their count from the device -- so the chain needs ONE synchronisation, at its end.  The results
 // (pose, n_bad, outlier byte per edge in keypoint order) are copied to *h_io; the caller synchronises and unpacks them.
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
-                       const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev) {
+                       const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
+                       const AsdBetweenArgs* between) {
   // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
   // inside the caller's one result block: no copy is enqueued here
   BaState* s = ba_state(ctx);
@@ -2116,6 +2129,7 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   for (int k = 0; k < 16; ++k) a.isg_tab[k] = k < ctx->cfg.n_levels ? (double)ctx->inv_sigma2[k] : 0.0;   // invSigma2 is a float in the reference (Optimizer.cc:300)
   if (pose7) memcpy(a.pose0, pose7, 56);
   a.pose0_dev = d_pose0; a.io_dev = d_io_dev;
+  a.between = between;
   if ((d_pose0 || d_io_dev) && mode != 2) { ctx->set_error("pose chain: the device-side hand-over needs the LDS form of the solver (frame too large)"); return ASD_ERR_CAPACITY; }
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
   a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;

@@ -74,6 +74,76 @@ hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t byte
 __device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __syncthreads_or(pred); }
 #endif
 
+
+// What Tracking does between its two stages, on the device (asd_track_frame): the matches PoseOptimization marked as outliers are
+// dropped (Tracking.cc:695-714), the optimised pose becomes the frame's pose (Optimizer.cc:405-407 -> Frame::SetPose: Tcw as
+// Converter::toCvMat(SE3Quat) gives it, mOw = -Rcw^T tcw, Frame.cc:150-158), and the map points the frame holds already are marked so
+// that SearchLocalPoints does not project them again (Tracking.cc:811-823).  Runs as the tail of the motion-model stage's k_pose_opt (the
+// workgroup that has just written the flags and the pose); outputs feed k_frustum_queries, k_window_search and k_pose_opt of the
+// local-map stage.  The conversions are asd_pose7_to_tcw's and track_local_points_impl's expressions, operation for operation (the
+// caller compiles this with -ffp-contract=off semantics: every product below is rounded before it is added -- see the pragma), so the
+// stage behind sees the bits a host in between would have handed it.
+struct AsdBetweenArgs {
+  int n_cur, n_last, n_cand;
+  const int* match1;        // [n_cur] last-frame keypoint or -1
+  const double* io1;        // the motion-model stage's result block (device copy): pose[7], n_bad, outlier byte per keypoint, edge count
+  const float* Xw_last;     // [n_last][3]
+  const int* last_cand;     // [n_last] or null: candidate index of the map point last keypoint i holds
+  float T_pred[16];         // the pose the motion-model search projected with (kept when it made fewer than 3 matches)
+  uint8_t* occ;             // out [n_cur]: the keypoint keeps its map point
+  float* cur_Xw;            // out [n_cur][3]: that map point's position
+  uint8_t* skip;            // out [n_cand]
+  float* T1;                // out [19]: Tcw (row major 4x4), Ow
+};
+#if defined(__HIPCC__)
+// every thread of ONE workgroup (nt threads) calls this behind a barrier that follows the workgroup's stores to io1
+__device__ inline void asd_between_body(const AsdBetweenArgs& a_dev, const int t, const int nt) {
+#pragma clang fp contract(off)
+  const AsdBetweenArgs a = a_dev;
+  __shared__ int s_nmatch;
+  if (t == 0) s_nmatch = 0;
+  for (int c = t; c < a.n_cand; c += nt) a.skip[c] = 0;
+  asd_syncthreads();
+  const uint8_t* outl = reinterpret_cast<const uint8_t*>(a.io1 + 8);
+  int mine = 0;
+  for (int j = t; j < a.n_cur; j += nt) {
+    const int i = a.match1[j];
+    mine += i >= 0;
+    const int src = i >= 0 ? i : 0;
+    for (int k = 0; k < 3; ++k) a.cur_Xw[3 * (size_t)j + k] = a.n_last > 0 ? a.Xw_last[3 * (size_t)src + k] : 0.f;
+    const bool keep = i >= 0 && !outl[j];
+    a.occ[j] = keep ? 1 : 0;
+    if (keep && a.last_cand) { const int c = a.last_cand[i]; if (c >= 0 && c < a.n_cand) a.skip[c] = 1; }
+  }
+  if (mine) atomicAdd(&s_nmatch, mine);
+  asd_syncthreads();
+  if (t == 0) {
+    float T[16];
+    if (s_nmatch >= 3) {   // asd_pose7_to_tcw
+      const double* p = a.io1;
+      const double x = p[0], y = p[1], z = p[2], w = p[3];
+      const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+      const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+      const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j];
+        T[i * 4 + 3] = (float)p[4 + i];
+      }
+      T[12] = T[13] = T[14] = 0.f;
+      T[15] = 1.f;
+    } else {
+      for (int i = 0; i < 16; ++i) T[i] = a.T_pred[i];
+    }
+    for (int i = 0; i < 16; ++i) a.T1[i] = T[i];
+    for (int i = 0; i < 3; ++i) {  // mOw = -mRcw.t()*mtcw (Frame.cc:157): transposed gemm accumulates in double
+      double sum = 0;
+      for (int k = 0; k < 3; ++k) sum += (double)T[k * 4 + i] * (double)T[k * 4 + 3];
+      a.T1[16 + i] = (float)(-1.0 * sum);
+    }
+  }
+}
+#endif
+
 struct AsdXfer {
   char* h = nullptr;
   char* d = nullptr;
@@ -253,9 +323,10 @@ void bow_free(asd_ctx* ctx);
 // ba.hip: PoseOptimization enqueued behind device-resident matches (fused tracking chains; see the definition)
 // d_pose0 (optional): the start pose on the device (the previous stage's result block), pose7 is then ignored; d_io_dev (optional): a
 // second copy of the result block in device memory for the kernels of a following stage (asd_track_frame)
+// between (optional, with d_io_dev; DEVICE memory): the work between the two tracking stages as the kernel's tail (asd_between_body)
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
-                       double* d_io_dev = nullptr);
+                       double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr);
 // true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
 inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }
 inline size_t pose_chain_io_bytes(int n_cur) { return 64 + ((size_t)n_cur + 7) / 8 * 8 + 64; }   // pose[7], n_bad, flags (8-B words), edge count

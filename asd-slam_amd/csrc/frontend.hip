@@ -436,9 +436,12 @@ static void level_dims(const asd_ctx* ctx, int w, int h, int level, int* lw, int
   *lh = cv_round((float)h * s);
 }
 
-int frontend_alloc(asd_ctx* ctx) {
+// one complete set of front-half state (pyramid, score map, blurred pyramid, tables, corner staging, quadtree scratch): the context
+// owns one (ctx->fe: the synchronous entry points and the first extraction worker), the pipelined extractor a second one for its
+// second worker, so that two front halves can be in flight
+static int fe_alloc(asd_ctx* ctx, FrontendState** out) {
   FrontendState* fe = new FrontendState();
-  ctx->fe = fe;
+  *out = fe;
   fe->pool = new LevelPool(3);
   const int nl = ctx->cfg.n_levels, W = ctx->cfg.max_width, H = ctx->cfg.max_height;
   size_t bytes = 0, tx = 0, ty = 0;
@@ -478,9 +481,9 @@ int frontend_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipHostMalloc(&fe->h_desc, np * 128 * sizeof(float)));
   return ASD_OK;
 }
+int frontend_alloc(asd_ctx* ctx) { return fe_alloc(ctx, &ctx->fe); }
 
-void frontend_free(asd_ctx* ctx) {
-  FrontendState* fe = ctx->fe;
+static void fe_free(FrontendState* fe) {
   if (!fe) return;
   void* dev[] = {fe->d_pyr, fe->d_blur, fe->d_score, fe->d_xofs, fe->d_ialpha, fe->d_yofs, fe->d_ibeta, fe->d_cells,
                  fe->d_cell_count, fe->d_cell_off, fe->d_level_cell_start, fe->d_level_start,
@@ -492,12 +495,11 @@ void frontend_free(asd_ctx* ctx) {
     if (*e) (void)hipEventDestroy(*e);
   delete fe->pool;
   delete fe;
-  ctx->fe = nullptr;
 }
+void frontend_free(asd_ctx* ctx) { fe_free(ctx->fe); ctx->fe = nullptr; }
 
 // Tables that depend on the image size: level geometry, resize coefficients, FAST cells.
-static int configure_size(asd_ctx* ctx, int w, int h) {
-  FrontendState* fe = ctx->fe;
+static int configure_size(asd_ctx* ctx, FrontendState* fe, int w, int h) {
   if (fe->cfg_w == w && fe->cfg_h == h) return ASD_OK;
   const int nl = ctx->cfg.n_levels;
   if (!fe->consts_set) {
@@ -653,12 +655,11 @@ static void slot_free(ExtractSlot& S) {
 // E1-E5: pyramid, FAST, quadtree, orientation, blur, patch gather.  Fills kps (angle still 0) and leaves the
 // patches + angles in the slot; records S.ev_front on `st` after the last kernel.  Blocks the calling host
 // thread twice (corner counts, corner list) but never waits for anything outside `st`.
-static int extract_front(asd_ctx* ctx, const ExtractJob& J, ExtractSlot& S, hipStream_t st, hipEvent_t ev_corners,
+static int extract_front(asd_ctx* ctx, FrontendState* fe, const ExtractJob& J, ExtractSlot& S, hipStream_t st, hipEvent_t ev_corners,
                          asd_keypoint* kps, int32_t* n_out) {
   const int width = J.w, height = J.h, stride = J.stride;
-  int rc = configure_size(ctx, width, height);
+  int rc = configure_size(ctx, fe, width, height);
   if (rc != ASD_OK) return rc;
-  FrontendState* fe = ctx->fe;
   const PyrDev& P = fe->pyr;
   const int nl = P.nlevels;
   int quota[ASD_MAX_LEVELS];
@@ -801,7 +802,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   ExtractJob J;
   J.image = image; J.on_device = image_on_device; J.w = width; J.h = height; J.stride = stride; J.nfeat = n_features_override;
   int32_t n = 0;
-  if ((rc = extract_front(ctx, J, S, ctx->stream, ctx->ev2, kps, &n)) != ASD_OK) return rc;
+  if ((rc = extract_front(ctx, fe, J, S, ctx->stream, ctx->ev2, kps, &n)) != ASD_OK) return rc;
   *n_out = n;
   ctx->last_n = n;
   ctx->d_desc_last = S.d_desc;
@@ -836,20 +837,28 @@ struct AsyncJob {
   std::vector<asd_keypoint> kps;
 };
 
+// Two workers (round 4): a front half is ~0.5 ms of one host thread -- fifteen small launches that queue beside ASDNet, one wait for
+// the corner list, the quadtrees -- and enqueueing the back half another ~0.2 ms, so ONE worker turned a frame around every ~0.72 ms
+// while the ASDNet kernels of a frame take 0.56: the matrix cores idled 0.12 ms per frame waiting for the next patches (rocprofv3,
+// tools/extractor_timeline.py).  With a second set of front-half buffers two front halves are in flight; back halves are still
+// enqueued in submission order (back_next) on the one ASDNet stream.
+constexpr int kWorkers = 2;
 struct AsyncExtract {
-  std::thread th;
+  std::thread th[kWorkers];
   std::mutex m;
   std::condition_variable cv;
   bool stop = false;
-  hipStream_t stream_f = nullptr;
-  hipEvent_t ev_corners = nullptr;
+  hipStream_t stream_f[kWorkers] = {};
+  hipEvent_t ev_corners[kWorkers] = {};
+  FrontendState* fe[kWorkers] = {};   // fe[0] = ctx->fe, fe[1] owned here
   ExtractSlot slots[kSlots];
   AsyncJob jobs[kSlots];     // ring: job of submission s lives in jobs[s % kSlots]
   uint64_t submitted = 0, started = 0, waited = 0;  // counters: submitted >= started >= waited
+  uint64_t back_next = 0;                           // submission whose back half is enqueued next
   uint64_t last_view = ~0ull;                       // submission index of the most recently waited job
 };
 
-static void async_worker(asd_ctx* ctx) {
+static void async_worker(asd_ctx* ctx, int wk) {
   AsyncExtract* ax = ctx->ax;
   (void)hipSetDevice(ctx->cfg.device);
   // The worker only ENQUEUES: front half of the next queued frame (two host syncs + the host quadtree), then its back half
@@ -862,32 +871,40 @@ static void async_worker(asd_ctx* ctx) {
   long jobs = 0;
   for (;;) {
     AsyncJob* next = nullptr;
+    uint64_t seq = 0;
     const auto w0 = std::chrono::steady_clock::now();
     {
       std::unique_lock<std::mutex> l(ax->m);
       ax->cv.wait(l, [&] { return ax->stop || ax->started < ax->submitted; });
       if (ax->stop) return;
-      next = &ax->jobs[ax->started % kSlots];
+      seq = ax->started;
+      next = &ax->jobs[seq % kSlots];
       ++ax->started;
       next->state = AsyncJob::FRONT;
     }
     const auto w1 = std::chrono::steady_clock::now();
     ExtractSlot& S = ax->slots[next->slot];
     int32_t n = 0;
-    int rc = extract_front(ctx, next->job, S, ax->stream_f, ax->ev_corners, next->kps.data(), &n);
+    int rc = extract_front(ctx, ax->fe[wk], next->job, S, ax->stream_f[wk], ax->ev_corners[wk], next->kps.data(), &n);
     const auto w2 = std::chrono::steady_clock::now();
     next->job.n = n;
+    {   // back halves go onto the ASDNet stream in submission order, one thread at a time (asdnet_forward_device uses per-context state)
+      std::unique_lock<std::mutex> l(ax->m);
+      ax->cv.wait(l, [&] { return ax->stop || ax->back_next == seq; });
+      if (ax->stop) return;
+    }
     if (rc == ASD_OK && n > 0) rc = extract_back_enqueue(ctx, S, n, ctx->stream_x);
     if (timing) {
       const auto w3 = std::chrono::steady_clock::now();
       auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
       t_idle += us(w0, w1); t_front += us(w1, w2); t_back += us(w2, w3);
-      if (++jobs % 200 == 0) fprintf(stderr, "[extract worker] per frame: waiting for a job %.0f us, front half %.0f us, back half enqueue %.0f us\n", t_idle / jobs, t_front / jobs, t_back / jobs);
+      if (++jobs % 100 == 0) fprintf(stderr, "[extract worker %d] per frame: waiting for a job %.0f us, front half %.0f us, back half (turn + enqueue) %.0f us\n", wk, t_idle / jobs, t_front / jobs, t_back / jobs);
     }
     {
       std::lock_guard<std::mutex> l(ax->m);
       next->job.rc = rc;
       next->state = (rc != ASD_OK || n == 0) ? AsyncJob::DONE : AsyncJob::BACK;   // BACK: enqueued, the waiter synchronises
+      ++ax->back_next;
     }
     ax->cv.notify_all();
   }
@@ -898,12 +915,13 @@ void frontend_async_shutdown(asd_ctx* ctx) {
   AsyncExtract* ax = ctx->ax;
   { std::lock_guard<std::mutex> l(ax->m); ax->stop = true; }
   ax->cv.notify_all();
-  if (ax->th.joinable()) ax->th.join();
+  for (auto& th : ax->th) if (th.joinable()) th.join();
   if (ctx->stream_x) (void)hipStreamSynchronize(ctx->stream_x);
-  if (ax->stream_f) (void)hipStreamSynchronize(ax->stream_f);
+  for (hipStream_t st : ax->stream_f) if (st) (void)hipStreamSynchronize(st);
   for (auto& S : ax->slots) slot_free(S);
-  if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
-  if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
+  for (hipEvent_t e : ax->ev_corners) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t st : ax->stream_f) if (st) (void)hipStreamDestroy(st);
+  for (int w = 1; w < kWorkers; ++w) fe_free(ax->fe[w]);
   delete ax;
   ctx->ax = nullptr;
   if (ctx->stream_x) (void)hipStreamDestroy(ctx->stream_x);
@@ -949,8 +967,13 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     auto build = [&]() -> int {
       static const bool front_mid = getenv("ASD_FRONT_PRIO_MID") != nullptr;   // A/B only
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
-      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f, hipStreamDefault, front_mid ? prio_mid : prio_greatest));
-      ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners));
+      ax->fe[0] = ctx->fe;
+      for (int w = 0; w < kWorkers; ++w) {
+        ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f[w], hipStreamDefault, front_mid ? prio_mid : prio_greatest));
+        ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners[w]));
+        int r;
+        if (w > 0 && (r = fe_alloc(ctx, &ax->fe[w])) != ASD_OK) return r;
+      }
       for (int i = 0; i < kSlots; ++i) {
         int r;
         if ((r = slot_alloc(ctx, ax->slots[i])) != ASD_OK) return r;
@@ -962,15 +985,17 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     };
     if ((rc = build()) != ASD_OK) {
       for (auto& S : ax->slots) slot_free(S);
-      if (ax->ev_corners) (void)hipEventDestroy(ax->ev_corners);
-      if (ax->stream_f) (void)hipStreamDestroy(ax->stream_f);
+      for (hipEvent_t e : ax->ev_corners) if (e) (void)hipEventDestroy(e);
+      for (hipStream_t st : ax->stream_f) if (st) (void)hipStreamDestroy(st);
+      for (int w = 1; w < kWorkers; ++w) fe_free(ax->fe[w]);
       if (sx) (void)hipStreamDestroy(sx);
       delete ax;
       return rc;
     }
     ctx->stream_x = sx;
     ctx->ax = ax;
-    ax->th = std::thread(async_worker, ctx);
+    static const int n_workers = [] { const char* e = getenv("ASD_EXTRACT_WORKERS"); const int v = e ? atoi(e) : kWorkers; return v < 1 ? 1 : (v > kWorkers ? kWorkers : v); }();
+    for (int w = 0; w < n_workers; ++w) ax->th[w] = std::thread(async_worker, ctx, w);
   }
   AsyncExtract* ax = ctx->ax;
   if (ctx->adopt_pending) {

@@ -760,7 +760,8 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
   }
   // the thread's queries first (their loads are then in flight under the LDS fills below): list length and start, the heads
   int cnt[QPT], pick[QPT], qoff[QPT];
-  uint2 tj[QPT];                        // the four heads' keypoints (16 bit each)
+  constexpr int HD = KIND == 1 ? 2 : kTop;   // heads kept in registers (KIND 1: the lists are short and two settle nearly every query)
+  uint2 tj[QPT];                        // the heads' keypoints (16 bit each; KIND 1 uses .x only)
   float ang_last[KIND == 0 ? QPT : 1];
   unsigned posmask = 0;
 #pragma unroll
@@ -770,7 +771,8 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
     const int qc = v ? q : 0;
     cnt[k] = v ? a.q_cnt[qc] : 0;
     qoff[k] = a.q_off[qc];
-    tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
+    if (KIND == 1) tj[k] = make_uint2(*reinterpret_cast<const unsigned*>(a.top_idx + (size_t)qc * kTop), 0u);
+    else tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
     if (KIND == 0) ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
     if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
     pick[k] = -1;
@@ -829,11 +831,11 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
         if (curj[k] >= 0 && (posmask >> k & 1)) atomicMin(&wr[curj[k]], (tag_wr << 16) | (unsigned)q);
       }
     } else {
-      unsigned cl[QPT][kTop];
+      unsigned cl[QPT][HD];
 #pragma unroll
       for (int k = 0; k < QPT; ++k)
 #pragma unroll
-        for (int i = 0; i < kTop; ++i) cl[k][i] = (i < cnt[k]) ? rd[top_j(k, i)] : 0u;
+        for (int i = 0; i < HD; ++i) cl[k][i] = (i < cnt[k]) ? rd[top_j(k, i)] : 0u;
       int p[QPT], p2[QPT], i1[QPT], i2[QPT];
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
@@ -841,14 +843,14 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
         int found = 0;
         p[k] = -1; p2[k] = -1; i1[k] = 0; i2[k] = 0;
 #pragma unroll
-        for (int i = 0; i < kTop; ++i) {
+        for (int i = 0; i < HD; ++i) {
           if (i >= cnt[k] || held(cl[k][i], q) || found >= 2) continue;
           if (found == 0) { p[k] = (int)top_j(k, i); i1[k] = i; }
           else { p2[k] = (int)top_j(k, i); i2[k] = i; }
           ++found;
         }
-        if (found < 2 && cnt[k] > kTop) {   // the heads did not settle it: on through the list (LDS copy, global beyond it)
-          for (int i = kTop; i < cnt[k] && found < 2; ++i) {
+        if (found < 2 && cnt[k] > HD) {   // the heads did not settle it: on through the list (LDS copy, global beyond it)
+          for (int i = HD; i < cnt[k] && found < 2; ++i) {
             const int j = list_j(k, i);
             if (held(rd[j], q)) continue;
             if (found == 0) { p[k] = j; i1[k] = i; }
@@ -1089,70 +1091,7 @@ __global__ __launch_bounds__(256) void k_project_queries(ProjectArgs a) {
   a.queries[i] = Q;
 }
 
-// What Tracking does between its two stages, on the device (asd_track_frame): the matches PoseOptimization marked as outliers are
-// dropped (Tracking.cc:695-714), the optimised pose becomes the frame's pose (Optimizer.cc:405-407 -> Frame::SetPose: Tcw as
-// Converter::toCvMat(SE3Quat) gives it, mOw = -Rcw^T tcw, Frame.cc:150-158), and the map points the frame holds already are marked so
-// that SearchLocalPoints does not project them again (Tracking.cc:811-823).  One workgroup; inputs are the match table and the
-// result block of the motion-model stage in device memory, outputs feed k_frustum_queries, k_window_search and k_pose_opt of the
-// local-map stage.  The conversions are asd_pose7_to_tcw's and track_local_points_impl's expressions, operation for operation
-// (-ffp-contract=off), so the stage behind sees the bits a host in between would have handed it.
-struct BetweenArgs {
-  int n_cur, n_last, n_cand;
-  const int* match1;        // [n_cur] last-frame keypoint or -1
-  const double* io1;        // the motion-model stage's result block: pose[7], n_bad, outlier byte per keypoint, edge count
-  const float* Xw_last;     // [n_last][3]
-  const int* last_cand;     // [n_last] or null: candidate index of the map point last keypoint i holds
-  float T_pred[16];         // the pose the motion-model search projected with (kept when it made fewer than 3 matches)
-  uint8_t* occ;             // out [n_cur]: the keypoint keeps its map point
-  float* cur_Xw;            // out [n_cur][3]: that map point's position
-  uint8_t* skip;            // out [n_cand]
-  float* T1;                // out [19]: Tcw (row major 4x4), Ow
-};
-__global__ __launch_bounds__(1024) void k_between(BetweenArgs a) {
-  const int t = threadIdx.x;
-  __shared__ int s_nmatch;
-  if (t == 0) s_nmatch = 0;
-  for (int c = t; c < a.n_cand; c += 1024) a.skip[c] = 0;
-  asd_syncthreads();
-  const uint8_t* outl = reinterpret_cast<const uint8_t*>(a.io1 + 8);
-  int mine = 0;
-  for (int j = t; j < a.n_cur; j += 1024) {
-    const int i = a.match1[j];
-    mine += i >= 0;
-    const int src = i >= 0 ? i : 0;
-    for (int k = 0; k < 3; ++k) a.cur_Xw[3 * (size_t)j + k] = a.n_last > 0 ? a.Xw_last[3 * (size_t)src + k] : 0.f;
-    const bool keep = i >= 0 && !outl[j];
-    a.occ[j] = keep ? 1 : 0;
-    if (keep && a.last_cand) { const int c = a.last_cand[i]; if (c >= 0 && c < a.n_cand) a.skip[c] = 1; }
-  }
-  if (mine) atomicAdd(&s_nmatch, mine);
-  asd_syncthreads();
-  if (t == 0) {
-    float T[16];
-    if (s_nmatch >= 3) {   // asd_pose7_to_tcw
-      const double* p = a.io1;
-      const double x = p[0], y = p[1], z = p[2], w = p[3];
-      const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-      const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
-      const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
-      for (int i = 0; i < 3; ++i) {
-        for (int j = 0; j < 3; ++j) T[i * 4 + j] = (float)R[i * 3 + j];
-        T[i * 4 + 3] = (float)p[4 + i];
-      }
-      T[12] = T[13] = T[14] = 0.f;
-      T[15] = 1.f;
-    } else {
-      for (int i = 0; i < 16; ++i) T[i] = a.T_pred[i];
-    }
-    for (int i = 0; i < 16; ++i) a.T1[i] = T[i];
-    for (int i = 0; i < 3; ++i) {  // mOw = -mRcw.t()*mtcw (Frame.cc:157): transposed gemm accumulates in double
-      double sum = 0;
-      for (int k = 0; k < 3; ++k) sum += (double)T[k * 4 + i] * (double)T[k * 4 + 3];
-      a.T1[16 + i] = (float)(-1.0 * sum);
-    }
-  }
-}
-
+// (k_between's body lives in ctx.h: asd_between_body -- it runs as the tail of the motion-model stage's k_pose_opt)
 // ---- host helpers -------------------------------------------------------------------------
 inline void three_maxima(const int* cnt, int& ind1, int& ind2, int& ind3) {  // ORBmatcher.cc:1584-1625
   int max1 = 0, max2 = 0, max3 = 0;
@@ -2411,11 +2350,20 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   const size_t o_obs1 = A.last_obs_positive ? up.add(A.last_obs_positive, nl) : 0, o_obs2 = A.cand_obs_positive ? up.add(A.cand_obs_positive, ncand) : 0;
   const size_t o_has = up.add(A.has_mp, nl), o_Xw = up.add(A.Xw_last, (size_t)nl * 12), o_rows1 = up.add(A.last_rows, (size_t)nl * 4);
   const size_t o_lc = A.last_cand ? up.add(A.last_cand, (size_t)nl * 4) : 0, o_crows = up.add(A.cand_rows, (size_t)ncand * 4);
+  const size_t o_btw = up.reserve(sizeof(AsdBetweenArgs));   // (filled below, before the launch whose tail blocks copy the block to the device)
   const size_t o_out1 = down.reserve(((size_t)nc + 16) * sizeof(int)), o_res1 = down.reserve(io_bytes);
   const size_t o_out2 = down.reserve(((size_t)nc + 16) * sizeof(int)), o_res2 = down.reserve(io_bytes);
   const bool has_obs1 = A.last_obs_positive != nullptr, has_obs2 = A.cand_obs_positive != nullptr, has_lc = A.last_cand != nullptr;
   const std::array<double, 4> Kd = {(double)A.K[0], (double)A.K[1], (double)A.K[2], (double)A.K[3]};
 
+  {
+    AsdBetweenArgs b{};
+    b.n_cur = nc; b.n_last = nl; b.n_cand = ncand;
+    b.match1 = down.dev<int>(o_out1); b.io1 = d_io1; b.Xw_last = up.dev<float>(o_Xw); b.last_cand = has_lc ? up.dev<int>(o_lc) : nullptr;
+    memcpy(b.T_pred, A.Tcw, sizeof b.T_pred);
+    b.occ = d_occ; b.cur_Xw = d_curXw; b.skip = d_skip; b.T1 = d_T1;
+    memcpy(up.host<char>(o_btw), &b, sizeof b);
+  }
   // ---- motion-model stage
   {
     ProjectArgs pa{};
@@ -2467,19 +2415,11 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   if ((rc = search_resolve(std::integral_constant<int, 0>{}, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr,
                            has_obs1 ? up.dev<uint8_t>(o_obs1) : nullptr, L->d_kp, A.check_orientation, 0.f, down.dev<int>(o_out1), down.host<int>(o_out1))) != ASD_OK)
     return rc;
+  // ---- ... and what happens between the stages, as the tail of its PoseOptimization kernel (the workgroup that has just written the
+  // flags and the pose: no launch, no second read of them)
   if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                               d_io1)) != ASD_OK)
+                               d_io1, up.dev<AsdBetweenArgs>(o_btw))) != ASD_OK)
     return rc;
-  // ---- between the stages
-  {
-    BetweenArgs b{};
-    b.n_cur = nc; b.n_last = nl; b.n_cand = ncand;
-    b.match1 = down.dev<int>(o_out1); b.io1 = d_io1; b.Xw_last = up.dev<float>(o_Xw); b.last_cand = has_lc ? up.dev<int>(o_lc) : nullptr;
-    memcpy(b.T_pred, A.Tcw, sizeof b.T_pred);
-    b.occ = d_occ; b.cur_Xw = d_curXw; b.skip = d_skip; b.T1 = d_T1;
-    hipLaunchKernelGGL(k_between, dim3(1), dim3(1024), 0, st, b);
-    ASD_HIP_CHECK(ctx, hipGetLastError());
-  }
   // ---- local-map stage
   {
     FrustumArgs fa{};
