@@ -125,6 +125,10 @@ class AsdHip:
     def last_error(self):
         return self.lib.asd_last_error(self.ctx).decode()
 
+    def calibration_note(self):
+        self.lib.asd_calibration_note.restype = C.c_char_p
+        return self.lib.asd_calibration_note(self.ctx).decode()
+
     # ---- tables
     def scale_tables(self):
         n = self.n_levels
@@ -153,6 +157,11 @@ class AsdHip:
     def device_alloc(self, nbytes):
         p = C.c_void_p()
         self._chk(self.lib.asd_device_alloc(self.ctx, C.c_uint64(nbytes), C.byref(p)))
+        return p
+
+    def host_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.asd_host_alloc(self.ctx, C.c_uint64(nbytes), C.byref(p)))
         return p
 
     def device_free(self, p):

@@ -1669,9 +1669,10 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
 
 static int asdnet_calibrate(asd_ctx* ctx, const float* const conv_w[7], const float* const bn_mean[7], const float* const bn_var[7], float eps) {
   ctx->calib_note.clear();
+  ctx->net_pieces = ctx->net_pieces_req;   // every load starts from the form the context was created with: a fall-back is not sticky
   if (ctx->net_pieces != 2 || !(ctx->net_split & 31)) return ASD_OK;   // only the fp16 form has a range
   if (const char* e = getenv("ASD_ASDNET_CALIBRATE")) if (atoi(e) == 0) return ASD_OK;   // tests of the run-time flag switch the guard at load off
-  constexpr int N = 64;
+  const int N = std::min(64, ctx->cfg.max_patches);   // (a context sized for fewer patches than the calibration set calibrates on what fits)
   constexpr float kCalibLimit = 2048.f;
   std::vector<uint8_t> pat((size_t)N * 1024);
   uint32_t rng = 0x9e3779b9u;
@@ -1721,12 +1722,11 @@ static int asdnet_calibrate(asd_ctx* ctx, const float* const conv_w[7], const fl
   uint8_t* d_pat = nullptr;
   unsigned* d_max = nullptr;
   float* d_out = nullptr;
-  ASD_HIP_CHECK(ctx, hipMalloc(&d_pat, pat.size()));
-  ASD_HIP_CHECK(ctx, hipMalloc(&d_max, 8 * sizeof(unsigned)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&d_out, (size_t)N * 128 * sizeof(float)));
   int rc = ASD_OK;
   unsigned hmax[8] = {};
   do {
+    if (hipMalloc(&d_pat, pat.size()) != hipSuccess || hipMalloc(&d_max, 8 * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc(&d_out, (size_t)N * 128 * sizeof(float)) != hipSuccess) { rc = ASD_ERR_HIP; break; }   // (whatever was allocated is freed below)
     if (hipMemcpy(d_pat, pat.data(), pat.size(), hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_max, 0, 8 * sizeof(unsigned)) != hipSuccess) { rc = ASD_ERR_HIP; break; }
     ctx->d_calib = d_max;
     rc = asdnet_forward_device(ctx, d_pat, N, d_out, ctx->stream, nullptr);
@@ -1734,7 +1734,9 @@ static int asdnet_calibrate(asd_ctx* ctx, const float* const conv_w[7], const fl
     if (rc != ASD_OK) break;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(hmax, d_max, sizeof hmax, hipMemcpyDeviceToHost) != hipSuccess) rc = ASD_ERR_HIP;
   } while (0);
-  (void)hipFree(d_pat); (void)hipFree(d_max); (void)hipFree(d_out);
+  if (d_pat) (void)hipFree(d_pat);
+  if (d_max) (void)hipFree(d_max);
+  if (d_out) (void)hipFree(d_out);
   if (rc != ASD_OK) { ctx->set_error("asd_load_weights: the range calibration pass failed"); return rc; }
   float worst = max1;
   int worst_layer = 1;
@@ -1749,8 +1751,7 @@ static int asdnet_calibrate(asd_ctx* ctx, const float* const conv_w[7], const fl
     char buf[256];
     snprintf(buf, sizeof buf, "asd_load_weights: calibration found |activation| = %g behind conv%d (limit %g for the two-piece fp16 form): this context uses the three-piece bf16 form (asd_asdnet_pieces = 3)",
              (double)worst, worst_layer, (double)kCalibLimit);
-    ctx->calib_note = buf;
-    ctx->set_error("%s", buf);
+    ctx->calib_note = buf;   // a note, not an error: asd_calibration_note() hands it out, asd_last_error stays as it was
   }
   return ASD_OK;
 }

@@ -2364,7 +2364,21 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     int n_free_max = 0;
     for (int p = 0; p < P; ++p) n_free_max += !pr->fixed[p];
     static const bool struct_host = getenv("ASD_BA_STRUCT") && !strcmp(getenv("ASD_BA_STRUCT"), "host");
-    const bool struct_dev = !struct_host && E > 0 && P <= kStructMaxP && n_free_max <= kStructMaxFree;
+    // a landmark observed twice by one pose (nothing forbids it, the host loop and the general branch of k_ba_struct_pairs handle it)
+    // has more pairs than the device tables are sized for -- E (F + 1) / 2 assumes at most one edge per (landmark, free pose): such a
+    // problem takes the host-built structure instead of writing past the pair list
+    bool dup_edges = false;
+    if (round_idx == 0 && !struct_host && E > 0 && P <= kStructMaxP && n_free_max <= kStructMaxFree) {
+      const size_t words = ((size_t)P + 63) / 64;
+      std::vector<uint64_t> seen((size_t)L * words, 0);
+      for (int e = 0; e < E && !dup_edges; ++e) {
+        uint64_t& w = seen[(size_t)pr->e_point[e] * words + (size_t)pr->e_pose[e] / 64];
+        const uint64_t bit = 1ull << (pr->e_pose[e] % 64);
+        dup_edges = (w & bit) != 0;
+        w |= bit;
+      }
+    }
+    const bool struct_dev = !struct_host && !dup_edges && E > 0 && P <= kStructMaxP && n_free_max <= kStructMaxFree;
     if (round_idx == 0 && struct_dev) {
       // ---- active structure, on the device (k_ba_struct_*): the tables are carved out of one block sized by upper bounds
       const int nblk_max = n_free_max * (n_free_max + 1) / 2;
@@ -2581,7 +2595,10 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     int& predicted = s->lm_blocks[round_idx];
     int chunk = predicted > 0 ? predicted : iterations;
     int done = 0;
-    for (int guard = 0; guard < 64 && iterations > 0; ++guard) {
+    // a round takes at most `iterations` iterations of at most ten trials each (levenberg.cpp:_maxTrialsAfterFailure): that, not a
+    // fixed number of chunks, bounds the loop -- a slowly converging problem with many iterations is not a numeric failure
+    const int max_trials = iterations * 10 + 2;
+    while (iterations > 0 && n_trials < max_trials) {
       for (int b = 0; b < chunk; ++b) if ((r2 = enqueue_block()) != ASD_OK) return r2;
       n_trials += chunk;
       // activeRobustChi2() from the stored edge errors behind every chunk: if the round ended inside it, its report is already there

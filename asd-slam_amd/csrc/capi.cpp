@@ -122,6 +122,7 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
     else if (!strcmp(e, "bf16x3")) c->net_pieces = 3;
     else if (strcmp(e, "split")) fprintf(stderr, "libasdhip: ASD_ASDNET_MATH=%s not understood (f32 | split | f16x2 | bf16x3); using f16x2\n", e);
   }
+  c->net_pieces_req = c->net_pieces;
   if (const char* e = getenv("ASD_ASDNET_SPLIT_LAYERS")) c->net_split = (int)strtol(e, nullptr, 0) & 0x3f;
   // tracking kernels (small, latency critical) outrank the pipelined extractor's stream
   int prio_least = 0, prio_greatest = 0;
@@ -251,6 +252,7 @@ int asd_last_stage_ms(const asd_ctx* ctx, const char* stage, float* ms) {
 
 int32_t asd_asdnet_split_mask(const asd_ctx* ctx) { return ctx ? (ctx->net_split & 0x3f) : 0; }
 int32_t asd_asdnet_pieces(const asd_ctx* ctx) { return ctx ? ctx->net_pieces : 0; }
+const char* asd_calibration_note(const asd_ctx* ctx) { return ctx ? ctx->calib_note.c_str() : ""; }
 
 int asd_profile_enable(asd_ctx* ctx, int32_t on) {
   if (!ctx) return ASD_ERR_INVALID;
@@ -310,6 +312,17 @@ int asd_device_alloc(asd_ctx* ctx, uint64_t bytes, void** dptr) {
 int asd_device_free(asd_ctx* ctx, void* dptr) {
   if (!ctx) return ASD_ERR_INVALID;
   ASD_HIP_CHECK(ctx, hipFree(dptr));
+  return ASD_OK;
+}
+int asd_host_alloc(asd_ctx* ctx, uint64_t bytes, void** hptr) {
+  if (!ctx || !hptr) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  ASD_HIP_CHECK(ctx, hipHostMalloc(hptr, bytes));
+  return ASD_OK;
+}
+int asd_host_free(asd_ctx* ctx, void* hptr) {
+  if (!ctx) return ASD_ERR_INVALID;
+  ASD_HIP_CHECK(ctx, hipHostFree(hptr));
   return ASD_OK;
 }
 int asd_memcpy_h2d(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes) {

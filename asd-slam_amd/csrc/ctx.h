@@ -222,6 +222,7 @@ struct asd_ctx {
   bool match_replay_host = false;  // ASD_MATCH_REPLAY=host (read at asd_ctx_create): matcher claim replay on the host
   void* d_wx2[7] = {};          // layers 1..5 split into two fp16 terms of (weight * wx2_scale[l]) (ASD_ASDNET_MATH=f16x2)
   float wx2_scale[7] = {1, 1, 1, 1, 1, 1, 1};
+  int net_pieces_req = 2;       // the form asked for at asd_ctx_create (ASD_ASDNET_MATH); asd_load_weights starts from it every time
   int net_pieces = 2;           // 3 = bf16x3 (six products, exact operands), 2 = fp16x2 (three products, 22-bit operands)
   int net_split = 1;            // ASD_ASDNET_MATH: 1 = split-bf16 kernels where a layer has one, 0 = f32 MFMA everywhere
   float* d_act[2] = {};         // ping-pong NHWC activations

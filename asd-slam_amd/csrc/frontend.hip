@@ -102,6 +102,24 @@ __device__ inline const LevelDev& find_level(const PyrDev& P, int tile, int& loc
 // ---------------------------------------------------------------- E2a: FAST-9/16 score map
 // score = (max over the 16 arcs of 9 contiguous ring pixels of min |v - p|, one-sided) - 1,
 // exactly cornerScore<16> for a pixel that passes the segment test; 0 if score < min_th.
+// Level 0 of the pyramid = the input image, copied row by row into the pitched level buffer by a kernel: the source is device memory
+// or PAGE-LOCKED host memory read over PCIe (467 KB per KITTI frame).  hipMemcpy2DAsync from host memory made the front half's stream wait
+// milliseconds per frame (round 4: 347 frames/s against 1187 with the frames resident), and a copy command costs this stream more than a
+// launch anyway.  A thread moves four destination bytes (the level pitch is a multiple of 64, so they are aligned); the source row may
+// start anywhere: two aligned dwords around it, funnel-shifted -- never a byte load over PCIe, never a read beyond the buffer's last dword.
+__global__ __launch_bounds__(256) void k_copy_image(const uint8_t* __restrict__ src, int stride, int width, int height, uint8_t* __restrict__ dst, int pitch) {
+  const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+  if (x4 >= width || y >= height) return;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(src) + (size_t)y * stride + x4;
+  const uintptr_t last = (reinterpret_cast<uintptr_t>(src) + (size_t)(height - 1) * stride + width - 1) & ~(uintptr_t)3;   // the last dword that holds image bytes
+  const uintptr_t a0 = a & ~(uintptr_t)3;
+  const unsigned sh = (unsigned)(a & 3) * 8;
+  const uint32_t w0 = *reinterpret_cast<const uint32_t*>(a0);
+  const uint32_t w1 = (sh && a0 + 4 <= last) ? *reinterpret_cast<const uint32_t*>(a0 + 4) : 0u;
+  const uint32_t v = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+  *reinterpret_cast<uint32_t*>(dst + (size_t)y * pitch + x4) = v;   // (bytes beyond `width` inside the pitch are never read as image)
+}
+
 __global__ __launch_bounds__(256) void k_fast_score(PyrDev P, const uint8_t* __restrict__ pyr,
                                                     uint8_t* __restrict__ score, int min_th) {
   int local;
@@ -674,8 +692,22 @@ static int extract_front(asd_ctx* ctx, FrontendState* fe, const ExtractJob& J, E
   const auto t_start = now();
   ASD_HIP_CHECK(ctx, hipEventRecord(S.ev_begin, st));
   // E1 pyramid
-  ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, J.image, stride, width, height,
-                                      J.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  {
+    // device memory and page-locked host memory go through the copy kernel; pageable host memory (asd_extract with an ordinary buffer)
+    // needs the runtime's staging copy
+    bool by_kernel = J.on_device;
+    if (!by_kernel) {
+      hipPointerAttribute_t at{};
+      by_kernel = hipPointerGetAttributes(&at, J.image) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+      if (!by_kernel) (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not ours)
+    }
+    if (by_kernel) {
+      hipLaunchKernelGGL(k_copy_image, dim3((width + 1023) / 1024, height), dim3(256), 0, st, J.image, stride, width, height, fe->d_pyr + P.lv[0].off, P.lv[0].pitch);
+      ASD_HIP_CHECK(ctx, hipGetLastError());
+    } else {
+      ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, J.image, stride, width, height, hipMemcpyHostToDevice, st));
+    }
+  }
   for (int l = 1; l < nl; ++l) {
     const LevelDev &Sl = P.lv[l - 1], &D = P.lv[l];
     hipLaunchKernelGGL(k_resize, dim3((D.w + 255) / 256, (D.h + 3) / 4), dim3(256), 0, st, fe->d_pyr + Sl.off, Sl.w, Sl.h,

@@ -1350,6 +1350,8 @@ struct ChainHook {
   // enqueue the chain's kernels: match table, the uploaded tables, where the results go (all device pointers)
   std::function<int(const int* d_match, void* const* d_tab, void* d_result)> enqueue;
   const void* h_result = nullptr;     // out: the chain's results on the host after the call
+  bool kp_flags = false;              // out: the form pose_chain_enqueue gave the flags in that block (per keypoint + edge count, or per edge) --
+                                      // carried with the chain: the context-wide pose_chain_kp_flags belongs to whichever chain was enqueued last
 };
 
 template <int KIND>
@@ -1492,6 +1494,7 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     if (chain) {
       if ((rc = chain->enqueue(d_out, d_tab, zero_copy ? down.host<void>(o_res) : down.dev<void>(o_res))) != ASD_OK) return rc;
       chain->h_result = down.host<void>(o_res);
+      chain->kp_flags = ctx->pose_chain_kp_flags;
     }
     if (!zero_copy) ASD_HIP_CHECK(ctx, down.download(st));
     // the completion waits for THIS point of the stream, not for the stream: a split-phase caller enqueues the next frame's grid
@@ -2002,9 +2005,9 @@ namespace {
 // after the chain: outlier flags per KEYPOINT from the per-edge bytes, or the whole PoseOptimization through the separate
 // entry point when the matches were replayed on the host (ASD_MATCH_REPLAY=host, very large inputs)
 int finish_pose_chain(asd_ctx* ctx, const AsdFrameSlot& C, const std::function<const float*(int)>& point_of, bool chained, const double* h_io,
-                      const double* Kd, double* pose7, uint8_t* outlier, int32_t* n_inliers) {
+                      const double* Kd, double* pose7, uint8_t* outlier, int32_t* n_inliers, bool kp_flags) {
   const int n_cur = C.n;
-  if (chained && ctx->pose_chain_kp_flags) {
+  if (chained && kp_flags) {
     // the gather form of k_pose_opt hands the flags over per keypoint with the edge count behind them: no walk over the keypoints
     const int ne = (int)(h_io[8 + (n_cur + 7) / 8] + 0.5);
     memcpy(outlier, h_io + 8, (size_t)n_cur);
@@ -2089,7 +2092,7 @@ int track_motion_model_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
   auto fin = [=]() -> int {
     if (search_done) { const int r = search_done(); if (r != ASD_OK) return r; }
     return finish_pose_chain(ctx, *C, [=](int j) -> const float* { return match_cur[j] >= 0 ? Xw + 3 * (size_t)match_cur[j] : nullptr; }, chained,
-                             static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+                             static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers, chain->kp_flags);
   };
   if (defer && search_done) { *defer = fin; return ASD_OK; }   // (a search that finished on the host is complete already)
   return fin();
@@ -2125,13 +2128,13 @@ int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uin
       if (r != ASD_OK) return r;
       const uint8_t* oc = occ->data();
       return finish_pose_chain(ctx, *F, [=](int j) -> const float* { return (oc[j] || match_cur[j] >= 0) ? reinterpret_cast<const float*>(oc) : nullptr; },
-                               true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+                               true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers, chain->kp_flags);
     };
     return ASD_OK;
   }
   return finish_pose_chain(ctx, *F, [&](int j) -> const float* {
     return occupied[j] ? cur_Xw + 3 * (size_t)j : (match_cur[j] >= 0 ? mp_Xw + 3 * (size_t)match_cur[j] : nullptr); }, chained,
-    static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+    static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers, chain->kp_flags);
 }
 
 // Tracking::SearchLocalPoints (Tracking.cc:803-851: isInFrustum for every local map point, then SearchByProjection) +
@@ -2217,7 +2220,7 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
     const uint8_t* oc = occ->data();
     // chained: finish_pose_chain only asks which keypoints carry an edge (the positions went to the device in the upload block)
     return finish_pose_chain(ctx, *F, [=](int j) -> const float* { return (oc[j] || match_cur[j] >= 0) ? reinterpret_cast<const float*>(oc) : nullptr; },
-                             true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers);
+                             true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers, chain->kp_flags);
   };
   if (defer && search_done) { *defer = fin; return ASD_OK; }
   return fin();

@@ -45,6 +45,7 @@ struct asd_track_handle {
   // (asd_prep_async) beside the stages instead of behind them.  Needs three frame slots (the next frame's grid is written while the
   // motion-model stage may still read the last frame's) and two alternating bank regions.
   bool chain = true;
+  int frames_on_host = 0;   // the frame pointers are (pinned) host memory: asd_extract_submit(device_resident = 0), the image crosses PCIe per frame
   int bank_base = 0;        // first bank row of the map the prepared frame is tracked against
   std::vector<int32_t> last_cand, cand_rows;
   asd_track_frame_args fa;
@@ -114,6 +115,27 @@ void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on
 void asd_track_set_async_ba(asd_track_handle* h, int32_t on) { if (h) h->async_ba = on != 0; }
 void asd_track_set_split(asd_track_handle* h, int32_t on) { if (h) h->split = on != 0; }
 void asd_track_set_chain(asd_track_handle* h, int32_t on) { if (h) h->chain = on != 0; }
+// hands every read-ahead submission of this handle back to the library (another handle of the same context can then start)
+int asd_track_drain(asd_track_handle* h) {
+  if (!h) return ASD_ERR_INVALID;
+  int rc = ASD_OK;
+  while (!h->pending.empty()) {
+    const asd_keypoint* k; const float* d; int32_t n;
+    const int r = asd_extract_wait_view(h->ctx, &k, &d, &n);
+    if (r != ASD_OK) rc = r;
+    h->pending.pop_front();
+  }
+  h->prep_t = -1;
+  h->have_last = false;
+  return rc;
+}
+void asd_track_set_frames_on_host(asd_track_handle* h, int32_t on) { if (h) h->frames_on_host = on != 0; }
+void asd_track_get_times(const asd_track_handle* h, double* ba_ms, double* extract_wait_ms, int64_t* steps) {
+  if (!h) return;
+  if (ba_ms) *ba_ms = h->ba_ms;
+  if (extract_wait_ms) *extract_wait_ms = h->wait_ms;
+  if (steps) *steps = h->steps;
+}
 void asd_track_set_drift(asd_track_handle* h, float cx, float cy, float z, float dx, float dy) {
   if (h) { h->drift_cx = cx; h->drift_cy = cy; h->drift_z = z; h->drift_dx = dx; h->drift_dy = dy; }
 }
@@ -179,7 +201,7 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
       h->pending.pop_front();
     }
-    if ((rc = asd_extract_device(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
+    if ((rc = (h->frames_on_host ? asd_extract : asd_extract_device)(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
     kps = h->kps.data();
   }
   const bool chain = h->fused && h->split && h->chain;
@@ -198,7 +220,7 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       }
     }
     for (size_t i = h->pending.size(); i < next.size(); ++i) {
-      if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
+      if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], h->frames_on_host ? 0 : 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
       h->pending.push_back(next[i]);
     }
   }
@@ -491,7 +513,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
       h->pending.pop_front();
     }
-    if ((rc = asd_extract_device(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
+    if ((rc = (h->frames_on_host ? asd_extract : asd_extract_device)(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
     kps = h->kps.data();
   }
   // ---- Frame::AssignFeaturesToGrid + adopt the device-resident descriptors
@@ -512,7 +534,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       }
     }
     for (size_t i = h->pending.size(); i < next.size(); ++i) {
-      if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
+      if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], h->frames_on_host ? 0 : 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
       h->pending.push_back(next[i]);
     }
   }

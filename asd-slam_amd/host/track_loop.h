@@ -31,6 +31,14 @@ void asd_track_set_split(asd_track_handle* h, int32_t on);
 /* 1 (default, with fused + split): both stages as one submission (asd_track_frame), the next frame constructed on the context's second
  * stream beside them (asd_prep_async); 0 = two submissions with the host in between */
 void asd_track_set_chain(asd_track_handle* h, int32_t on);
+/* 1 = the frame pointers given to asd_track_create are page-locked HOST memory: every frame's image goes host -> device inside the step
+ * (asd_extract_submit(device_resident = 0)), as kitti.cc:116-155 hands images over; 0 (default) = frames resident in HBM */
+void asd_track_set_frames_on_host(asd_track_handle* h, int32_t on);
+/* waits for every read-ahead extraction this handle has outstanding and forgets its last frame: another handle on the same context may
+ * then run (the next asd_track_run of this one starts like a first frame) */
+int asd_track_drain(asd_track_handle* h);
+/* accumulated since asd_track_create: wall time inside LocalBA, time blocked on the extractor (ms), steps run */
+void asd_track_get_times(const asd_track_handle* h, double* ba_ms, double* extract_wait_ms, int64_t* steps);
 /* where the stand-in map points of frame t land in frame t+1: u' = (u - cx) z + cx - dx z, v' = (v - cy) z + cy - dy z.  Default = the
  * synthetic stream of synth.scene_frame (cx 620.5, cy 188, z 1.003, dx 3, dy 0.2); a real sequence uses z = 1, dx = dy = 0. */
 void asd_track_set_drift(asd_track_handle* h, float cx, float cy, float z, float dx, float dy);

@@ -581,11 +581,18 @@ int32_t asd_asdnet_split_mask(const asd_ctx* ctx);
  *      libtorch path (ORBextractor.cc:1127-1132) has no such failure mode, so it is an error here, never a silent NaN.
  *   3  ("bf16x3")  exact sum of three bf16 terms, six products; no range restriction; 1.35x the ASDNet time of the default. */
 int32_t asd_asdnet_pieces(const asd_ctx* ctx);
+/* what the calibration pass of the last asd_load_weights found ("" = nothing to report; non-empty when it switched the context to
+ * the three-piece form).  A note on a successful call: asd_last_error is not touched by it. */
+const char* asd_calibration_note(const asd_ctx* ctx);
 /* Raw handles for harnesses that keep inputs resident (bench.py): the ctx stream
  * (hipStream_t) and device scratch. */
 void* asd_ctx_stream(asd_ctx* ctx);
 int asd_device_alloc(asd_ctx* ctx, uint64_t bytes, void** dptr);
 int asd_device_free(asd_ctx* ctx, void* dptr);
+/* page-locked host memory (an image buffer handed to asd_extract_submit(device_resident = 0) from here is copied by the front
+ * half's stream without a staging pass) */
+int asd_host_alloc(asd_ctx* ctx, uint64_t bytes, void** hptr);
+int asd_host_free(asd_ctx* ctx, void* hptr);
 int asd_memcpy_h2d(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int asd_memcpy_d2h(asd_ctx* ctx, void* dst, const void* src, uint64_t bytes);
 int asd_sync(asd_ctx* ctx);

@@ -260,9 +260,19 @@ def test_f16x2_range_is_an_error_not_a_nan(pkg, synth, monkeypatch):
         assert ctx.asdnet_pieces() == 2
         ctx.load_weights(layers)
         assert ctx.asdnet_pieces() == 3                      # the calibration fell back ...
-        assert "calibration" in ctx.last_error()             # ... and says so
+        assert "calibration" in ctx.calibration_note()       # ... and says so (a note: the call succeeded, asd_last_error is untouched)
+        assert "calibration" not in ctx.last_error()
         assert np.isfinite(ctx.describe(patches)).all()
-        ctx.load_weights(synth.asdnet_weights(0))            # ordinary weights: a context that fell back stays on bf16x3, still correct
+        ctx.load_weights(synth.asdnet_weights(0))            # ordinary weights again: the fall-back is not sticky
+        assert ctx.asdnet_pieces() == 2 and ctx.calibration_note() == ""
+        assert np.isfinite(ctx.describe(patches)).all()
+    finally:
+        ctx.close()
+    # a context sized for fewer patches than the calibration batch still loads (calibrates on what fits)
+    ctx = pkg.AsdHip(n_features=20, max_width=640, max_height=240, max_patches=24)
+    try:
+        ctx.load_weights(synth.asdnet_weights(0))
+        assert ctx.asdnet_pieces() == 2
         assert np.isfinite(ctx.describe(patches)).all()
     finally:
         ctx.close()

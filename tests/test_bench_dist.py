@@ -33,6 +33,10 @@ def test_gpus_flag_launches_its_own_ranks():
     assert len(j["tickets"]) == 2 and all(len(r) > 0 for r in j["tickets"])
     # longest first: KITTI 02 (4661 frames), 00 (4541), 08 (4071) lead the queue
     assert j["queue"][:3] == ["02", "00", "08"]
+    # every rank pinned itself (before any HIP call) to its own CPUs: the two sets are disjoint and non-empty
+    a0, a1 = (set(a) for a in j["affinity"])
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert a0 and a1 and not (a0 & a1), (a0, a1)
 
 
 def test_world_size_mismatch_is_refused():
