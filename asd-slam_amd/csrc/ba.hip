@@ -230,6 +230,12 @@ struct PoseOptArgs {
   double pose0[7];      // initial pose (by value: no read of host memory on the kernel's critical path)
   const double* pose0_dev;  // non-null (asd_track_frame: the stage behind another PoseOptimization): the initial pose is read from here
   double* io_dev;           // non-null: the result block is written here as well (device memory, for the kernels of the next stage)
+  // asd_track_frame launches this kernel EARLY on a stream of its own, so that it is resident -- it needs most of a CU, and beside the
+  // extractor's ASDNet workgroups it waited 40-55 us for one (device-clock stamps) -- when the claim replay in front of it
+  // finishes: it then waits for *wait_flag to reach wait_value (set by k_resolve2 behind its last store) instead of for stream order.
+  // The wait is bounded (kPoseWaitPolls): a flag that never comes ends the kernel with io[7] = -1 instead of hanging the device.
+  const unsigned* wait_flag;
+  unsigned wait_value;
   const AsdBetweenArgs* between;   // device memory or null.  asd_track_frame, motion-model stage: the kernel ends with the work between the
                                    // two stages (needs io_dev).  A pointer, not a member: a larger argument block costs the kernel a scratch copy
   double isg_tab[16];   // MODE 2: the distinct information values ...
@@ -243,6 +249,7 @@ struct PoseOptArgs {
 #define ASD_POSE_THREADS 512
 #endif
 constexpr int kPoseThreads = ASD_POSE_THREADS, kPoseWaves = kPoseThreads / 64;
+constexpr int kPoseWaitPolls = 200000;   // x (one L2 round trip + s_sleep 32 ~ 1 us): ~0.2 s, then the kernel gives up
 struct PoseShared {
   Pose7 T, T0, Tbak, Teval;
   double H[36], b[6], x[6];
@@ -506,6 +513,27 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
   // no private copy of the argument block: a copy that is indexed at run time (pose0[t], isg_tab[t]) lives in scratch memory, and
   // every a.fx / a.n of the passes then is a scratch load
   const PoseOptArgs& a = a_in;
+  if (a.wait_flag) {   // resident ahead of its inputs: one lane polls, everybody acquires
+    __shared__ int wait_ok;
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (int i = 0; i < kPoseWaitPolls; ++i) {
+        if ((int)(__hip_atomic_load(a.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) >= 0) { ok = 1; break; }
+        __builtin_amdgcn_s_sleep(32);
+      }
+      wait_ok = ok;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    if (!wait_ok) {   // the producer never signalled: report, do not touch anything else
+      if (threadIdx.x == 0) { a.io[7] = -1.0; if (a.io_dev) a.io_dev[7] = -1.0; }
+      return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz, device-wide: comparable with other kernels' stamps (ASD_TIMING)
   int ne = a.n;   // edge count (fused chains: made on the device below, a.n is then only the capacity)
   constexpr int kGatherChunks = 9;   // 150 KB / 35 B per edge: at most 4388 keypoints reach the LDS form
   __shared__ int g_cnt[kGatherChunks * kPoseWaves + 1];
@@ -832,7 +860,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     const unsigned long long* k8 = reinterpret_cast<const unsigned long long*>(kpf);
     const int nw = (a.g_ncur + 7) / 8;
     for (int i = t; i < nw; i += kPoseThreads) og8[i] = k8[i];
-    if (t == 0) a.io[8 + nw] = (double)ne;
+    if (t == 0) { a.io[8 + nw] = (double)ne; a.io[8 + nw + 1] = (double)(rt_start & 0xffffffffull); a.io[8 + nw + 2] = (double)(__builtin_amdgcn_s_memrealtime() & 0xffffffffull); }
     if (a.io_dev) {
       unsigned long long* od8 = reinterpret_cast<unsigned long long*>(a.io_dev + 8);
       for (int i = t; i < nw; i += kPoseThreads) od8[i] = k8[i];
@@ -2100,11 +2128,11 @@ void ba_free(asd_ctx* ctx) {
 // (pose, n_bad, outlier byte per edge in keypoint order) are copied to *h_io; the caller synchronises and unpacks them.
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
-                       const AsdBetweenArgs* between) {
+                       const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value) {
   // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
   // inside the caller's one result block: no copy is enqueued here
   BaState* s = ba_state(ctx);
-  hipStream_t st = ctx->stream;
+  hipStream_t st = st_early ? st_early : ctx->stream;
   int rc;
   const size_t idx_off = (size_t)n_cur * 48;
   if ((rc = s->po_Xw.ensure(ctx, idx_off + ((size_t)n_cur + 63) / 64 * 64 + 64)) || (rc = s->po_err.ensure(ctx, (size_t)n_cur * 64)) ||
@@ -2130,6 +2158,8 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   if (pose7) memcpy(a.pose0, pose7, 56);
   a.pose0_dev = d_pose0; a.io_dev = d_io_dev;
   a.between = between;
+  a.wait_flag = wait_flag; a.wait_value = wait_value;
+  if (wait_flag && mode != 2) { ctx->set_error("pose chain: the early launch needs the LDS form of the solver"); return ASD_ERR_CAPACITY; }
   if ((d_pose0 || d_io_dev) && mode != 2) { ctx->set_error("pose chain: the device-side hand-over needs the LDS form of the solver (frame too large)"); return ASD_ERR_CAPACITY; }
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
   a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;

@@ -197,6 +197,10 @@ struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
   hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
+  hipStream_t stream_solve = nullptr; // asd_track_frame: the PoseOptimization kernels, launched ahead of their inputs (they wait on a device flag)
+  hipEvent_t ev_solve[2] = {nullptr, nullptr};
+  unsigned* d_chain_flags = nullptr;  // [2] tickets the claim replays of the two stages publish
+  unsigned chain_seq = 0;
   hipStream_t stream_prep = nullptr; // asd_prep_async: frame construction (grid / descriptor / bank copies) beside the stages in flight
   hipEvent_t ev_prep = nullptr;
   bool prep_on = false;
@@ -327,10 +331,11 @@ void bow_free(asd_ctx* ctx);
 // between (optional, with d_io_dev; DEVICE memory): the work between the two tracking stages as the kernel's tail (asd_between_body)
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
-                       double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr);
+                       double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, hipStream_t st_early = nullptr,
+                       const unsigned* wait_flag = nullptr, unsigned wait_value = 0);
 // true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
 inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }
-inline size_t pose_chain_io_bytes(int n_cur) { return 64 + ((size_t)n_cur + 7) / 8 * 8 + 64; }   // pose[7], n_bad, flags (8-B words), edge count
+inline size_t pose_chain_io_bytes(int n_cur) { return 64 + ((size_t)n_cur + 7) / 8 * 8 + 64; }   // (+ two 100 MHz stamps behind the edge count: kernel entry, exit)   // pose[7], n_bad, flags (8-B words), edge count
 // capi.cpp
 void asd_compute_quotas(int nfeatures, float scaleFactor, int nl, int* out);
 

@@ -729,6 +729,8 @@ struct Resolve2Args {
   int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations, [3..6] stamps
   int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches
   int stage_cap;              // list entries [0, stage_cap) are copied into LDS (2 B each, KIND 1: 6 B) for the walks beyond the heads
+  unsigned* done_flag;        // null, or a ticket word: set to done_value behind the kernel's last store (a kernel resident on another
+  unsigned done_value;        // stream waits for it instead of for stream order: k_pose_opt, asd_track_frame)
 };
 __host__ __device__ inline size_t resolve2_fixed_lds(int kind, int n_cur) {   // claim tables + angle table (KIND 0) / octave table (KIND 1)
   return (size_t)n_cur * 8 + (kind == 0 ? (size_t)n_cur * 4 : ((size_t)n_cur + 15) / 16 * 16);
@@ -752,10 +754,23 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
   const int t = threadIdx.x;
   const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
   const int total = *a.total;
+  // every store of this workgroup is complete and written back before the ticket moves: waves drain their stores, barrier, one lane
+  // releases at agent scope and stores the ticket (MI355X_MICROARCH.md, "Valid forms": producer)
+  auto publish = [&]() {
+    if (!a.done_flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   if (total > a.cap || total == 0) {   // truncated lists (the host grows the buffers and searches again) / nothing in any window:
     // the match table is still written (no match anywhere) -- a fused chain behind this kernel gathers its edges from it
     for (int j = t; j < a.n_cur; j += NT) OUT(j, -1);
     if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
+    publish();
     return;
   }
   // the thread's queries first (their loads are then in flight under the LDS fills below): list length and start, the heads
@@ -938,7 +953,8 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
   if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, total); CNT(2, it + 1);
     // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs, the first iteration -- in units of 10 ns
     CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
-    for (int i = 7; i < 11; ++i) CNT(i, 0); }
+    CNT(7, 0); CNT(8, 0); CNT(9, (int)(ts0 & 0x7fffffffull)); CNT(10, (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffull)); }
+  publish();
 }
 #undef OUT
 #undef CNT
@@ -2367,6 +2383,26 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     b.occ = d_occ; b.cur_Xw = d_curXw; b.skip = d_skip; b.T1 = d_T1;
     memcpy(up.host<char>(o_btw), &b, sizeof b);
   }
+  // The two PoseOptimization kernels go FIRST, onto a stream of their own: each needs most of a CU (512 threads x 221 registers, 70 KB of
+  // LDS) and, launched in stream order, waited 40-55 us for one beside the extractor's ASDNet workgroups (device-clock stamps).  Launched
+  // ahead, the first is resident and waiting on the claim replay's ticket long before the replay is through, the second queues behind it
+  // and gets its CU while the local-map search runs.  Order between the streams: the tickets (k_resolve2 -> k_pose_opt) one way, an
+  // event per solver kernel the other (the main stream waits for it before k_frustum_queries / before the chain's end is recorded).
+  static const bool early = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return !(e && atoi(e) == 0); }();
+  unsigned seq = 0;
+  unsigned* flags = nullptr;
+  if (early) {
+    if (!ctx->stream_solve) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_solve, hipStreamNonBlocking, hi));
+      for (hipEvent_t& e : ctx->ev_solve) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_chain_flags, 256));
+      ASD_HIP_CHECK(ctx, hipMemset(ctx->d_chain_flags, 0, 256));
+    }
+    seq = ++ctx->chain_seq;
+    flags = ctx->d_chain_flags;
+  }
   // ---- motion-model stage
   {
     ProjectArgs pa{};
@@ -2393,7 +2429,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     return hipGetLastError();
   };
   auto search_resolve = [&](auto kind_tag, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in,
-                            const uint8_t* d_obs, const float4* kp_last, int check_ori, float nn_ratio, int* d_out, int* h_out) -> int {
+                            const uint8_t* d_obs, const float4* kp_last, int check_ori, float nn_ratio, int* d_out, int* h_out, unsigned* done_flag) -> int {
     constexpr int KIND = decltype(kind_tag)::value;
     GridDev G{C->d_kp, C->d_cell_start, C->d_cell_items, C->min_x, C->min_y, C->inv_w, C->inv_h};
     SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top};
@@ -2408,6 +2444,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     a.kp_cur = C->d_kp; a.kp_last = kp_last;
     a.check_ori = check_ori; a.nn_ratio = nn_ratio;
     a.match_cur = d_out; a.n_matches = d_out + nc; a.mirror = h_out;
+    a.done_flag = done_flag; a.done_value = seq;
     const size_t fixed = resolve_lds_bytes(KIND, nc, nq), per = KIND == 1 ? 6 : 2;
     a.stage_cap = (int)std::min<size_t>(((size_t)m->last_total[KIND] * 5 / 4 + 1023) / 1024 * 1024, ((size_t)96 * 1024 - fixed) / per / 8 * 8);
     const size_t lds = fixed + (size_t)a.stage_cap * per;
@@ -2416,12 +2453,25 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     return ASD_OK;
   };
   if ((rc = search_resolve(std::integral_constant<int, 0>{}, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr,
-                           has_obs1 ? up.dev<uint8_t>(o_obs1) : nullptr, L->d_kp, A.check_orientation, 0.f, down.dev<int>(o_out1), down.host<int>(o_out1))) != ASD_OK)
+                           has_obs1 ? up.dev<uint8_t>(o_obs1) : nullptr, L->d_kp, A.check_orientation, 0.f, down.dev<int>(o_out1), down.host<int>(o_out1), flags)) != ASD_OK)
     return rc;
+  // (the solver kernels are enqueued here, behind the motion-model stage's search and replay in HOST order: those start at once, and
+  // the solvers still have the whole search + replay to find their CU in)
+  if (early) {
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
+                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), ctx->stream_solve, flags, seq)) != ASD_OK)
+      return rc;
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_solve[0], ctx->stream_solve));
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
+                                 ctx->stream_solve, flags + 32, seq)) != ASD_OK)
+      return rc;
+    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_solve[1], ctx->stream_solve));
+  }
   // ---- ... and what happens between the stages, as the tail of its PoseOptimization kernel (the workgroup that has just written the
   // flags and the pose: no launch, no second read of them)
-  if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                               d_io1, up.dev<AsdBetweenArgs>(o_btw))) != ASD_OK)
+  if (early) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[0], 0));
+  else if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
+                                    d_io1, up.dev<AsdBetweenArgs>(o_btw))) != ASD_OK)
     return rc;
   // ---- local-map stage
   {
@@ -2438,9 +2488,10 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     ASD_HIP_CHECK(ctx, hipGetLastError());
   }
   if ((rc = search_resolve(std::integral_constant<int, 1>{}, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, has_obs2 ? up.dev<uint8_t>(o_obs2) : nullptr,
-                           nullptr, 0, A.nn_ratio, down.dev<int>(o_out2), down.host<int>(o_out2))) != ASD_OK)
+                           nullptr, 0, A.nn_ratio, down.dev<int>(o_out2), down.host<int>(o_out2), flags ? flags + 32 : nullptr)) != ASD_OK)
     return rc;
-  if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr)) != ASD_OK)
+  if (early) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[1], 0));
+  else if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr)) != ASD_OK)
     return rc;
   if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
   ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st));
@@ -2464,6 +2515,10 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       memcpy(pose, ne < 3 ? p_start : h_io, 56);   // Optimizer.cc:323-324: fewer than 3 correspondences leave the pose alone
       *n_inl = ne < 3 ? 0 : ne - (int)(h_io[7] + 0.5);
     };
+    if (ctx->down.host<double>(o_res1)[7] < 0 || ctx->down.host<double>(o_res2)[7] < 0) {
+      ctx->set_error("asd_track_frame: a PoseOptimization kernel launched ahead of its inputs never received the claim replay's ticket");
+      return ASD_ERR_HIP;
+    }
     unpack(h1, ctx->down.host<double>(o_res1), p_in.data(), O.match1, O.n_matches1, O.outlier1, O.pose1, O.n_inliers1);
     double p1[7];
     memcpy(p1, O.pose1, 56);
@@ -2471,13 +2526,27 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     ctx->ms_match = 0.f;
     static const bool timing = getenv("ASD_TIMING") != nullptr;
     if (timing) {   // k_resolve2's own stamps (10 ns units), averaged over 200 frames
-      static double acc[2][5]; static long calls;
+      static double acc[2][5], tl[8]; static long calls;
       const int* hh[2] = {h1, h2};
       for (int k = 0; k < 2; ++k) { acc[k][0] += hh[k][nc + 2]; for (int i = 0; i < 4; ++i) acc[k][1 + i] += 0.01 * hh[k][nc + 3 + i]; }
-      if (++calls % 200 == 0)
+      // the chain on the device's own 100 MHz clock: resolve 1 [start, end], pose 1 [start, end], resolve 2, pose 2
+      const double* io[2] = {ctx->down.host<double>(o_res1), ctx->down.host<double>(o_res2)};
+      const int nw = (nc + 7) / 8;
+      double st[8];
+      for (int k = 0; k < 2; ++k) {
+        st[4 * k] = hh[k][nc + 9]; st[4 * k + 1] = hh[k][nc + 10];
+        st[4 * k + 2] = (double)((long long)io[k][8 + nw + 1] & 0x7fffffff); st[4 * k + 3] = (double)((long long)io[k][8 + nw + 2] & 0x7fffffff);
+      }
+      auto d = [](double a, double b) { double x = b - a; if (x < 0) x += 2147483648.0; return 0.01 * x; };
+      tl[0] += d(st[0], st[1]); tl[1] += d(st[1], st[2]); tl[2] += d(st[2], st[3]); tl[3] += d(st[3], st[4]);
+      tl[4] += d(st[4], st[5]); tl[5] += d(st[5], st[6]); tl[6] += d(st[6], st[7]); tl[7] += d(st[0], st[7]);
+      if (++calls % 200 == 0) {
         for (int k = 0; k < 2; ++k)
           fprintf(stderr, "[track_frame resolve kind %d] %.1f iterations, %d candidates; staging %.1f us, iterations %.1f us (the first %.1f), outputs %.1f us\n", k,
                   acc[k][0] / calls, hh[k][nc + 1], acc[k][1] / calls, acc[k][2] / calls, acc[k][4] / calls, acc[k][3] / calls);
+        fprintf(stderr, "[track_frame device clock] resolve1 %.1f | -> pose1 %.1f | pose1 %.1f | -> (frustum, search) resolve2 %.1f | resolve2 %.1f | -> pose2 %.1f | pose2 %.1f | resolve1 start -> pose2 end %.1f us\n",
+                tl[0] / calls, tl[1] / calls, tl[2] / calls, tl[3] / calls, tl[4] / calls, tl[5] / calls, tl[6] / calls, tl[7] / calls);
+      }
     }
     return ASD_OK;
   };

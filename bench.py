@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 KF_INTERVAL = 15
-LOOKAHEAD = int(os.environ.get("ASD_BENCH_LOOKAHEAD", "2"))          # frames of read-ahead for the pipelined extractor (asd_extract_submit queue)
+LOOKAHEAD = int(os.environ.get("ASD_BENCH_LOOKAHEAD", "3"))          # frames of read-ahead for the pipelined extractor (asd_extract_submit queue)
 N_FRAMES = 30          # distinct synthetic frames kept resident in HBM, cycled
 PRIME_FRAMES = 30      # untimed frames before the timed region at least (allocations on first use, streams, clocks): warm-up + priming
 BOUNDS = (0.0, 1241.0, 0.0, 376.0)

@@ -18,13 +18,16 @@ def short(n):
 
 for r in rows:
     r["s"], r["e"], r["n"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])
-q = [r for r in rows if r["n"].startswith("k_pose_opt")][0]["Queue_Id"]
-tr = sorted([r for r in rows if r["Queue_Id"] == q], key=lambda r: r["s"])
+# round 4: the PoseOptimization kernels run on a stream of their own (launched ahead, waiting on a device flag): the tracking chain is
+# the search queue plus the solver queue; a solver kernel's span starts when it became resident, not when its inputs were ready
+q = [r for r in rows if r["n"].startswith("k_window_search")][0]["Queue_Id"]
+qs = {q, [r for r in rows if r["n"].startswith("k_pose_opt")][0]["Queue_Id"]}
+tr = sorted([r for r in rows if r["Queue_Id"] in qs], key=lambda r: r["s"])
 starts = [i for i, r in enumerate(tr) if r["n"].startswith("k_window_search")]
 frames = starts[0::2]                      # two searches per frame (frame-to-frame, local map)
 i0, i1 = frames[-8], frames[-7]
 t0, prev = tr[i0]["s"], None
-print(f"tracking stream = queue {q}; one frame ({(tr[i1]['s'] - t0) / 1e3:.1f} us):")
+print(f"tracking chain = queues {sorted(qs)}; one frame ({(tr[i1]['s'] - t0) / 1e3:.1f} us):")
 for r in tr[i0:i1]:
     gap = (r["s"] - prev) / 1e3 if prev else 0.0
     print(f'{(r["s"] - t0) / 1e3:9.1f} us  gap {gap:7.1f}  dur {(r["e"] - r["s"]) / 1e3:7.1f}  {r["n"]}')
@@ -61,3 +64,20 @@ if ba:
             b = [r["e"] - r["s"] for _, _, _, (x, y) in without for r in tr[x:y] if r["n"] == nm]
             if a and b:
                 print(f"   {nm:36s} beside BA {sum(a) / len(a) / 1e3:7.1f} us x{len(a) / len(with_ba):.1f}   alone {sum(b) / len(b) / 1e3:7.1f} us x{len(b) / len(without):.1f}")
+
+# dispatch waits: time between the end of the previous kernel of the same queue and the start of the big single-workgroup kernels
+# (they need most of a CU; beside the extractor's ASDNet workgroups that takes a while)
+def med(v):
+    return sorted(v)[len(v) // 2] if v else float("nan")
+byq = {}
+for r in sorted(rows, key=lambda r: r["s"]):
+    byq.setdefault(r["Queue_Id"], []).append(r)
+for name in ("k_ba_solve_lds", "k_ba_schur", "k_ba_step", "k_ba_linearize", "k_resolve2", "k_window_search"):
+    gaps, durs = [], []
+    for qq, lst in byq.items():
+        for a, b in zip(lst[:-1], lst[1:]):
+            if b["n"].startswith(name):
+                gaps.append((b["s"] - a["e"]) / 1e3)
+                durs.append((b["e"] - b["s"]) / 1e3)
+    if gaps:
+        print(f"   {name:18s} x{len(gaps):5d}: gap in front (median / mean) {med(gaps):6.1f} / {sum(gaps) / len(gaps):6.1f} us, duration median {med(durs):6.1f} us")
