@@ -52,6 +52,15 @@ def make_fv(node_of_kp):
     return fv, (ids, start, idx)
 
 
+class asd_kf_neighbor(C.Structure):
+    _fields_ = [("slot", C.c_int32), ("has_mp", C.c_void_p), ("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float),
+                ("Tcw", C.c_float * 16), ("K", C.c_float * 4)]
+
+
+class asd_fuse_call(C.Structure):
+    _fields_ = [("slot_kf", C.c_int32), ("first", C.c_int32), ("n", C.c_int32), ("Tcw", C.c_float * 16), ("K", C.c_float * 4)]
+
+
 class asd_track_frame_args(C.Structure):
     _fields_ = [("slot_cur", C.c_int32), ("slot_last", C.c_int32), ("has_mp", C.c_void_p), ("Xw_last", C.c_void_p), ("last_rows", C.c_void_p),
                 ("last_cand", C.c_void_p), ("last_obs_positive", C.c_void_p), ("Tcw", C.c_void_p), ("th", C.c_float), ("check_orientation", C.c_int32),
@@ -510,6 +519,48 @@ class AsdHip:
         bd = np.empty(n, np.float32)
         self._chk(self.lib.asd_fuse_search(self.ctx, slot_kf, n, _p(valid), _p(Xw), _p(normal), _p(min_dist), _p(max_dist),
                                            _p(desc), _p(Tcw), _p(K), C.c_float(th), _p(bi), _p(bd)))
+        return bi, bd
+
+    # ---- the per-keyframe stage, batched
+    def frame_set_bow(self, slot, nodes):
+        fv, keep = make_fv(nodes)
+        self._chk(self.lib.asd_frame_set_bow(self.ctx, slot, C.byref(fv)))
+
+    def create_map_points_batch(self, slot_cur, n_cur, has_cur, Tcw_cur, K_cur, neighbours):
+        """neighbours: list of dict(slot, has_mp, F12, ex, ey, Tcw, K) -> matches [nb][n_cur], n_matches [nb], x3D [nb][n_cur][3], ok [nb][n_cur]"""
+        nb = (asd_kf_neighbor * len(neighbours))()
+        keep = []
+        for b, d in enumerate(neighbours):
+            h = _c(d["has_mp"], np.uint8); keep.append(h)
+            nb[b].slot, nb[b].has_mp = d["slot"], h.ctypes.data
+            nb[b].F12 = (C.c_float * 9)(*[float(v) for v in np.asarray(d["F12"], np.float32).ravel()])
+            nb[b].ex, nb[b].ey = float(d["ex"]), float(d["ey"])
+            nb[b].Tcw = (C.c_float * 16)(*[float(v) for v in np.asarray(d["Tcw"], np.float32).ravel()])
+            nb[b].K = (C.c_float * 4)(*[float(v) for v in np.asarray(d["K"], np.float32).ravel()])
+        has_cur, Tcw_cur, K_cur = _c(has_cur, np.uint8), _c(Tcw_cur, np.float32), _c(K_cur, np.float32)
+        B = len(neighbours)
+        m = np.empty((B, n_cur), np.int32); nm = np.zeros(B, np.int32)
+        x = np.empty((B, n_cur, 3), np.float32); ok = np.empty((B, n_cur), np.uint8)
+        self._chk(self.lib.asd_create_map_points_batch(self.ctx, slot_cur, _p(has_cur), _p(Tcw_cur), _p(K_cur), B, nb, _p(m), _p(nm), _p(x), _p(ok)))
+        return m, nm, x, ok
+
+    def fuse_search_batch(self, calls, valid, Xw, normal, min_dist, max_dist, desc, th=3.0):
+        """calls: list of dict(slot_kf, first, n, Tcw, K) over the shared map-point tables -> best_idx, best_dist [n_total];
+        desc: float [n][128] descriptors or int32 rows of the descriptor bank"""
+        cs = (asd_fuse_call * len(calls))()
+        for c, d in enumerate(calls):
+            cs[c].slot_kf, cs[c].first, cs[c].n = d["slot_kf"], d["first"], d["n"]
+            cs[c].Tcw = (C.c_float * 16)(*[float(v) for v in np.asarray(d["Tcw"], np.float32).ravel()])
+            cs[c].K = (C.c_float * 4)(*[float(v) for v in np.asarray(d["K"], np.float32).ravel()])
+        valid, Xw, normal = _c(valid, np.uint8), _c(Xw, np.float32), _c(normal, np.float32)
+        min_dist, max_dist = _c(min_dist, np.float32), _c(max_dist, np.float32)
+        d = np.asarray(desc)
+        rows = d.dtype.kind in "iu"
+        d = _c(d, np.int32 if rows else np.float32)
+        n = len(valid)
+        bi, bd = np.empty(n, np.int32), np.empty(n, np.float32)
+        self._chk(self.lib.asd_fuse_search_batch(self.ctx, len(calls), cs, n, _p(valid), _p(Xw), _p(normal), _p(min_dist), _p(max_dist),
+                                                 _p(None if rows else d), _p(d if rows else None), C.c_float(th), _p(bi), _p(bd)))
         return bi, bd
 
     def triangulate_pairs(self, slot1, slot2, idx1, idx2, Tcw1, Tcw2, K1, K2):

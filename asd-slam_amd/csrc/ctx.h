@@ -189,6 +189,9 @@ struct AsdFrameSlot {
   float4* d_kp = nullptr;
   int32_t* d_cell_start = nullptr;
   int32_t* d_cell_items = nullptr;
+  // DBoW2::FeatureVector of a keyframe (asd_frame_set_bow): node ids ascending, CSR over keypoint indices, node id per keypoint (-1 none)
+  int32_t* d_fv = nullptr;       // one block: node_id [n] | start [n + 1] | idx [n] | kp_node [n] (capacity max_patches each)
+  int32_t fv_nodes = 0;
   char* h_stage = nullptr;
   hipEvent_t ev_staged = nullptr;  // recorded behind the slot's H2D copies: h_stage may be rewritten once it has completed
 };

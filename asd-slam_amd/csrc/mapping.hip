@@ -118,15 +118,11 @@ __device__ Row4 svd4_last_vt(Row4 A0, Row4 A1, Row4 A2, Row4 A3) {
   return V3;
 }
 
-__global__ __launch_bounds__(64) void k_triangulate(TriParams P, const float4* __restrict__ kp1, const float4* __restrict__ kp2,
-                                                   const int* __restrict__ idx1, const int* __restrict__ idx2, int n,
-                                                   float* __restrict__ x3d_out, unsigned char* __restrict__ ok_out) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= n) return;
-  const float4 a = kp1[idx1[i]], b = kp2[idx2[i]];
+// the per-match body of LocalMapping::CreateNewMapPoints (LocalMapping.cc:386-519) for one pair of keypoints
+__device__ __forceinline__ void triangulate_one(const TriParams& P, const float4 a, const float4 b, float (&X)[3], unsigned char& ok_out) {
   const int o1 = __float_as_int(a.z), o2 = __float_as_int(b.z);
   unsigned char ok = 0;
-  float X[3] = {0.f, 0.f, 0.f};
+  X[0] = X[1] = X[2] = 0.f;
   do {
     const float xn1[3] = {(a.x - P.cx1) * P.ifx1, (a.y - P.cy1) * P.ify1, 1.0f};
     const float xn2[3] = {(b.x - P.cx2) * P.ifx2, (b.y - P.cy2) * P.ify2, 1.0f};
@@ -182,10 +178,119 @@ __global__ __launch_bounds__(64) void k_triangulate(TriParams P, const float4* _
     if (ratioDist * P.ratio_factor < ratioOctave || ratioDist > ratioOctave * P.ratio_factor) break;
     ok = 1;
   } while (false);
+  ok_out = ok;
+}
+
+__global__ __launch_bounds__(64) void k_triangulate(TriParams P, const float4* __restrict__ kp1, const float4* __restrict__ kp2,
+                                                   const int* __restrict__ idx1, const int* __restrict__ idx2, int n,
+                                                   float* __restrict__ x3d_out, unsigned char* __restrict__ ok_out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  float X[3];
+  unsigned char ok;
+  triangulate_one(P, kp1[idx1[i]], kp2[idx2[i]], X, ok);
   ok_out[i] = ok;
   x3d_out[3 * i + 0] = ok ? X[0] : 0.f;
   x3d_out[3 * i + 1] = ok ? X[1] : 0.f;
   x3d_out[3 * i + 2] = ok ? X[2] : 0.f;
+}
+
+// ---- the batched per-keyframe stage (asd_create_map_points_batch): every neighbour of the current keyframe in one launch each ----
+struct NbDev {
+  const float4* kp; const float* desc; const int* fv; const uint8_t* has;   // fv block: node_id [cap] | start [cap + 1] | idx [cap] | kp_node [cap]
+  int n, n_nodes, cap;
+  float F12[9], ex, ey;
+};
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:669-822, bOnlyStereo = false, no orientation check) for keypoint i of the current
+// keyframe against neighbour b: one wave.  The keypoint's vocabulary node is looked up in the neighbour's FeatureVector (node ids
+// ascending: the std::map walk of :694-701 meets equal ids exactly once), its members are the candidates; a lane takes a candidate --
+// map point already there: skip (:729), DescriptorDistance in the reference's summation order, d > TH_LOW or d > bestDist: skip (:737),
+// too close to the epipole (:745-750), CheckDistEpipolarLine (:136-153) -- and the wave keeps the smallest distance, the LATEST such
+// candidate among equals (`d > bestDist` lets an equal distance through, so a later candidate of equal distance replaces an earlier one).
+constexpr float kTriThLow = 0.5f;   // TH_LOW
+__global__ __launch_bounds__(256) void k_tri_match_batch(const float4* __restrict__ kp_cur, const float* __restrict__ desc_cur, const int* __restrict__ kp_node_cur,
+                                                        const uint8_t* __restrict__ has_cur, int n_cur, const NbDev* __restrict__ nbs,
+                                                        const float* __restrict__ scale, const float* __restrict__ sigma2, int* __restrict__ matches) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= n_cur) return;
+  int result = -1;
+  const int node = kp_node_cur[i];
+  if (!has_cur[i] && node >= 0) {
+    const NbDev N = nbs[b];
+    const int* node_id = N.fv;
+    const int* start = N.fv + N.cap;
+    const int* idx = N.fv + 2 * N.cap + 1;
+    int pos = -1;
+    for (int base = 0; base < N.n_nodes && pos < 0; base += 64) {
+      const bool hit = base + lane < N.n_nodes && node_id[base + lane] == node;
+      const unsigned long long m = __ballot(hit);
+      if (m) pos = base + (__ffsll((long long)m) - 1);
+    }
+    if (pos >= 0) {
+      const int cb = start[pos], ce = start[pos + 1];
+      const float4 k1 = kp_cur[i];
+      const float la = k1.x * N.F12[0] + k1.y * N.F12[3] + N.F12[6];
+      const float lb = k1.x * N.F12[1] + k1.y * N.F12[4] + N.F12[7];
+      const float lc = k1.x * N.F12[2] + k1.y * N.F12[5] + N.F12[8];
+      const float den = la * la + lb * lb;
+      const float4* qa = reinterpret_cast<const float4*>(desc_cur + (size_t)i * 128);
+      unsigned long long best = ~0ull;
+      for (int t0 = cb; t0 < ce; t0 += 64) {
+        const int t = t0 + lane;
+        unsigned long long key = ~0ull;
+        if (t < ce) {
+          const int i2 = idx[t];
+          if (!N.has[i2]) {
+            const float4* qb = reinterpret_cast<const float4*>(N.desc + (size_t)i2 * 128);
+            float sqd = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+              const float4 x = qa[k], y = qb[k];
+              float d;
+              d = x.x - y.x; sqd = sqd + d * d;
+              d = x.y - y.y; sqd = sqd + d * d;
+              d = x.z - y.z; sqd = sqd + d * d;
+              d = x.w - y.w; sqd = sqd + d * d;
+            }
+            bool ok = !(sqd > kTriThLow);
+            const float4 k2 = N.kp[i2];
+            const int o2 = __float_as_int(k2.z);
+            const float dex = N.ex - k2.x, dey = N.ey - k2.y;
+            if (dex * dex + dey * dey < 100 * scale[o2]) ok = false;
+            const float num = la * k2.x + lb * k2.y + lc;
+            if (den == 0) ok = false;
+            const float dsqr = num * num / den;
+            if (!((double)dsqr < 3.84 * (double)sigma2[o2])) ok = false;
+            // smallest distance, among equals the latest candidate: key = distance bits (non-negative: ordered like the value) | ~t
+            if (ok) key = ((unsigned long long)__float_as_uint(sqd) << 32) | (unsigned long long)(0xffffffffu - (unsigned)t);
+          }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned long long o = __shfl_xor(key, off);
+          key = o < key ? o : key;
+        }
+        best = key < best ? key : best;
+      }
+      if (best != ~0ull) result = idx[0xffffffffu - (unsigned)(best & 0xffffffffull)];
+    }
+  }
+  if (lane == 0) matches[(size_t)b * n_cur + i] = result;
+}
+// the triangulation body for every match of every neighbour: one lane per (neighbour, keypoint of the current keyframe)
+__global__ __launch_bounds__(64) void k_triangulate_batch(const TriParams* __restrict__ P, const float4* __restrict__ kp_cur, const NbDev* __restrict__ nbs,
+                                                         const int* __restrict__ matches, int n_cur, float* __restrict__ x3d, unsigned char* __restrict__ ok_out) {
+  const int i = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (i >= n_cur) return;
+  const size_t o = (size_t)b * n_cur + i;
+  const int j = matches[o];
+  float X[3] = {0.f, 0.f, 0.f};
+  unsigned char ok = 0;
+  if (j >= 0) triangulate_one(P[b], kp_cur[i], nbs[b].kp[j], X, ok);
+  ok_out[o] = ok;
+  x3d[3 * o + 0] = ok ? X[0] : 0.f;
+  x3d[3 * o + 1] = ok ? X[1] : 0.f;
+  x3d[3 * o + 2] = ok ? X[2] : 0.f;
 }
 
 __global__ void k_svd4(const float* __restrict__ A, int n, float* __restrict__ v_out) {
@@ -305,6 +410,101 @@ int asd_triangulate_pairs(asd_ctx* ctx, int32_t slot1, int32_t slot2, int32_t n_
 }
 
 // right singular vector of the smallest singular value of n row-major 4x4 matrices (vt.row(3) of cv::SVD::compute)
+int asd_frame_set_bow(asd_ctx* ctx, int32_t slot, const asd_feature_vector* fv) {
+  if (!ctx || slot < 0 || slot >= ASD_MAX_FRAMES || !fv || fv->n_nodes < 0 || (fv->n_nodes > 0 && (!fv->node_id || !fv->start || !fv->idx))) return ASD_ERR_INVALID;
+  AsdFrameSlot& F = ctx->frames[slot];
+  if (!F.d_kp) { ctx->set_error("asd_frame_set_bow: frame slot %d not set", slot); return ASD_ERR_INVALID; }
+  const int cap = ctx->cfg.max_patches, nn = fv->n_nodes;
+  if (nn > cap || (nn > 0 && fv->start[nn] > F.n)) { ctx->set_error("asd_frame_set_bow: %d nodes / %d entries for a frame of %d keypoints", nn, nn ? fv->start[nn] : 0, F.n); return ASD_ERR_INVALID; }
+  (void)hipSetDevice(ctx->cfg.device);
+  if (!F.d_fv) ASD_HIP_CHECK(ctx, hipMalloc(&F.d_fv, ((size_t)4 * cap + 8) * sizeof(int)));
+  std::vector<int> blk((size_t)4 * cap + 8, -1);
+  int* node_id = blk.data(); int* start = node_id + cap; int* idx = start + cap + 1; int* kp_node = idx + cap;
+  for (int k = 0; k < nn; ++k) {
+    if (k > 0 && fv->node_id[k] <= fv->node_id[k - 1]) { ctx->set_error("asd_frame_set_bow: node ids must ascend"); return ASD_ERR_INVALID; }
+    node_id[k] = fv->node_id[k];
+    start[k] = fv->start[k];
+    for (int t = fv->start[k]; t < fv->start[k + 1]; ++t) {
+      const int i = fv->idx[t];
+      if (i < 0 || i >= F.n) { ctx->set_error("asd_frame_set_bow: keypoint index %d out of range", i); return ASD_ERR_INVALID; }
+      idx[t] = i;
+      kp_node[i] = fv->node_id[k];
+    }
+  }
+  start[nn] = nn ? fv->start[nn] : 0;
+  ASD_HIP_CHECK(ctx, hipMemcpyAsync(F.d_fv, blk.data(), blk.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  F.fv_nodes = nn;
+  return ASD_OK;
+}
+
+int asd_create_map_points_batch(asd_ctx* ctx, int32_t slot_cur, const uint8_t* has_mp_cur, const float* Tcw_cur, const float* K_cur, int32_t n_nb,
+                                const asd_kf_neighbor* nb, int32_t* matches12, int32_t* n_matches, float* x3D, uint8_t* ok) {
+  if (!ctx || slot_cur < 0 || slot_cur >= ASD_MAX_FRAMES || !has_mp_cur || !Tcw_cur || !K_cur || n_nb < 0 ||
+      (n_nb > 0 && (!nb || !matches12 || !n_matches || !x3D || !ok)))
+    return ASD_ERR_INVALID;
+  if (asd_track_busy(ctx, "asd_create_map_points_batch")) return ASD_ERR_INVALID;
+  const AsdFrameSlot& C = ctx->frames[slot_cur];
+  if (!C.d_kp || !C.d_fv) { ctx->set_error("asd_create_map_points_batch: slot %d needs asd_frame_set and asd_frame_set_bow", slot_cur); return ASD_ERR_INVALID; }
+  if (n_nb == 0 || C.n == 0) return ASD_OK;
+  (void)hipSetDevice(ctx->cfg.device);
+  const int nc = C.n, cap = ctx->cfg.max_patches;
+  size_t has_bytes = AsdDevBuf::padded(nc);
+  for (int b = 0; b < n_nb; ++b) {
+    if (nb[b].slot < 0 || nb[b].slot >= ASD_MAX_FRAMES || !nb[b].has_mp) return ASD_ERR_INVALID;
+    const AsdFrameSlot& N = ctx->frames[nb[b].slot];
+    if (!N.d_kp || !N.d_fv) { ctx->set_error("asd_create_map_points_batch: neighbour slot %d needs asd_frame_set and asd_frame_set_bow", nb[b].slot); return ASD_ERR_INVALID; }
+    has_bytes += AsdDevBuf::padded(N.n);
+  }
+  // one upload block (flags of every keyframe, the neighbours' records, the triangulation parameters, the level tables), one result block
+  hipStream_t st = ctx->stream;
+  AsdXfer &up = ctx->up, &down = ctx->down;
+  ASD_HIP_CHECK(ctx, up.begin(st, has_bytes + (size_t)n_nb * (sizeof(NbDev) + sizeof(TriParams) + 512) + 4096));
+  ASD_HIP_CHECK(ctx, down.begin(st, (size_t)n_nb * nc * (4 + 12 + 1) + 4096));
+  const size_t o_hc = up.add(has_mp_cur, nc);
+  std::vector<NbDev> nd(n_nb);
+  std::vector<TriParams> tp(n_nb);
+  for (int b = 0; b < n_nb; ++b) {
+    const AsdFrameSlot& N = ctx->frames[nb[b].slot];
+    const size_t o = up.add(nb[b].has_mp, N.n);
+    nd[b] = NbDev{N.d_kp, N.d_desc, N.d_fv, up.dev<uint8_t>(o), N.n, N.fv_nodes, cap, {}, nb[b].ex, nb[b].ey};
+    memcpy(nd[b].F12, nb[b].F12, sizeof nd[b].F12);
+    TriParams& P = tp[b];
+    memcpy(P.T1, Tcw_cur, sizeof P.T1);
+    memcpy(P.T2, nb[b].Tcw, sizeof P.T2);
+    camera_centre(Tcw_cur, P.Rwc1, P.Ow1);
+    camera_centre(nb[b].Tcw, P.Rwc2, P.Ow2);
+    const float* K1 = K_cur; const float* K2 = nb[b].K;
+    P.fx1 = K1[0]; P.fy1 = K1[1]; P.cx1 = K1[2]; P.cy1 = K1[3]; P.ifx1 = 1.0f / K1[0]; P.ify1 = 1.0f / K1[1];
+    P.fx2 = K2[0]; P.fy2 = K2[1]; P.cx2 = K2[2]; P.cy2 = K2[3]; P.ifx2 = 1.0f / K2[0]; P.ify2 = 1.0f / K2[1];
+    P.ratio_factor = 1.5f * ctx->cfg.scale_factor;
+    for (int l = 0; l < ASD_MAX_LEVELS; ++l) { P.sf[l] = ctx->scale[l]; P.sigma2[l] = ctx->sigma2[l]; }
+  }
+  const size_t o_nb = up.add(nd.data(), nd.size() * sizeof(NbDev)), o_tp = up.add(tp.data(), tp.size() * sizeof(TriParams));
+  float lv[2 * ASD_MAX_LEVELS];
+  for (int l = 0; l < ASD_MAX_LEVELS; ++l) { lv[l] = ctx->scale[l]; lv[ASD_MAX_LEVELS + l] = ctx->sigma2[l]; }
+  const size_t o_lv = up.add(lv, sizeof lv);
+  const size_t o_m = down.reserve((size_t)n_nb * nc * 4), o_x = down.reserve((size_t)n_nb * nc * 12), o_ok = down.reserve((size_t)n_nb * nc);
+  ASD_HIP_CHECK(ctx, up.upload(st));
+  const int* fvc = C.d_fv;
+  hipLaunchKernelGGL(k_tri_match_batch, dim3((nc + 3) / 4, n_nb), dim3(256), 0, st, C.d_kp, C.d_desc, fvc + 3 * (size_t)cap + 1, up.dev<uint8_t>(o_hc), nc,
+                     up.dev<NbDev>(o_nb), up.dev<float>(o_lv), up.dev<float>(o_lv) + ASD_MAX_LEVELS, down.dev<int>(o_m));
+  hipLaunchKernelGGL(k_triangulate_batch, dim3((nc + 63) / 64, n_nb), dim3(64), 0, st, up.dev<TriParams>(o_tp), C.d_kp, up.dev<NbDev>(o_nb), down.dev<int>(o_m), nc,
+                     down.dev<float>(o_x), down.dev<unsigned char>(o_ok));
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  ASD_HIP_CHECK(ctx, down.download(st));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  memcpy(matches12, down.host<int>(o_m), (size_t)n_nb * nc * 4);
+  memcpy(x3D, down.host<float>(o_x), (size_t)n_nb * nc * 12);
+  memcpy(ok, down.host<unsigned char>(o_ok), (size_t)n_nb * nc);
+  for (int b = 0; b < n_nb; ++b) {
+    int c = 0;
+    for (int i = 0; i < nc; ++i) c += matches12[(size_t)b * nc + i] >= 0;
+    n_matches[b] = c;
+  }
+  return ASD_OK;
+}
+
 int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v) {
   if (!ctx || n < 0 || (n > 0 && (!A || !v))) return ASD_ERR_INVALID;
   if (n == 0) return ASD_OK;

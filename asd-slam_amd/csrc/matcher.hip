@@ -1583,6 +1583,8 @@ hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t byte
 void matcher_free(asd_ctx* ctx) {
   for (auto& f : ctx->frames) {
     if (f.d_desc) (void)hipFree(f.d_desc);
+    if (f.d_fv) (void)hipFree(f.d_fv);
+    f.d_fv = nullptr;
     if (f.d_kp) (void)hipFree(f.d_kp);   // one block: keypoints, cell offsets, cell items
     if (f.h_stage) (void)hipHostFree(f.h_stage);
     if (f.ev_staged) (void)hipEventDestroy(f.ev_staged);
@@ -2642,6 +2644,192 @@ int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* 
     }
     if (best <= TH_LOW) { best_idx[i] = bi; best_dist[i] = best; }
   }
+  return ASD_OK;
+}
+
+// ---- asd_fuse_search_batch: every (keyframe, map point list) pair of SearchInNeighbors in one launch ------------------------------
+// One wave per candidate map point.  The gates of ORBmatcher::Fuse (ORBmatcher.cc:850-895) are evaluated by the wave (uniformly: every
+// lane the same f32 / f64 operations asd_fuse_search's host loop performs, -ffp-contract=off; the predicted level from the thresholds the
+// host derived from its own logf), the window is walked in KeyFrame::GetFeaturesInArea order (no level filter), a lane takes a
+// candidate -- level gate (:905-906), 5.99 chi2 gate (:909-916), DescriptorDistance in the reference's summation order -- and the wave
+// keeps the smallest distance, the FIRST such candidate among equals (`dist < bestDist`, :927).
+struct FuseCallDev {
+  GridDev G;
+  const float* desc;         // the keyframe's descriptors
+  float T[16], Ow[3], K[4];
+  float min_x, max_x, min_y, max_y;
+  int first, n;
+};
+struct FuseBatchArgs {
+  const FuseCallDev* calls; const int* call_of;   // [n_total]
+  int n_total, n_levels;
+  const uint8_t* valid; const float* Xw; const float* normal; const float* min_dist; const float* max_dist; const float* desc;
+  const int* desc_rows;      // null: desc is [n_total][128]; else desc = the descriptor bank and desc_rows[i] the map point's row
+  float th, level_thr[ASD_MAX_LEVELS], scale[ASD_MAX_LEVELS], inv_sigma2[ASD_MAX_LEVELS];
+  int* best_idx; float* best_dist;
+};
+__global__ __launch_bounds__(256) void k_fuse_batch(FuseBatchArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= a.n_total) return;
+  int out_idx = -1;
+  float out_dist = 256.f;
+  do {
+    if (!a.valid[i]) break;
+    const FuseCallDev& Cc = a.calls[a.call_of[i]];
+    const float* P = a.Xw + 3 * (size_t)i;
+    float Pc[3];
+    for (int r = 0; r < 3; ++r) {
+      const float t0 = Cc.T[r * 4 + 0] * P[0] + Cc.T[r * 4 + 1] * P[1] + Cc.T[r * 4 + 2] * P[2];
+      Pc[r] = (float)((double)t0 + (double)Cc.T[r * 4 + 3]);
+    }
+    if (Pc[2] < 0.0f) break;
+    const float invz = 1 / Pc[2];
+    const float u = Cc.K[0] * (Pc[0] * invz) + Cc.K[2], v = Cc.K[1] * (Pc[1] * invz) + Cc.K[3];
+    if (!(u >= Cc.min_x && u < Cc.max_x && v >= Cc.min_y && v < Cc.max_y)) break;  // KeyFrame::IsInImage
+    const float maxD = 1.2f * a.max_dist[i], minD = 0.8f * a.min_dist[i];
+    const float PO[3] = {P[0] - Cc.Ow[0], P[1] - Cc.Ow[1], P[2] - Cc.Ow[2]};
+    const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
+    const float dist3D = (float)sqrt(nn);
+    if (dist3D < minD || dist3D > maxD) break;
+    const float* Pn = a.normal + 3 * (size_t)i;
+    const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+    if (dot < 0.5 * dist3D) break;
+    const float ratio = a.max_dist[i] / dist3D;
+    int lvl = 0;
+    for (int k = 1; k < a.n_levels; ++k) lvl += ratio >= a.level_thr[k];
+    const float r = a.th * a.scale[lvl];
+    const GridDev& G = Cc.G;
+    const int nMinCellX = max(0, (int)floorf((u - G.min_x - r) * G.inv_w));
+    const int nMaxCellX = min(ASD_GRID_COLS - 1, (int)ceilf((u - G.min_x + r) * G.inv_w));
+    const int nMinCellY = max(0, (int)floorf((v - G.min_y - r) * G.inv_h));
+    const int nMaxCellY = min(ASD_GRID_ROWS - 1, (int)ceilf((v - G.min_y + r) * G.inv_h));
+    if (nMinCellX >= ASD_GRID_COLS || nMaxCellX < 0 || nMinCellY >= ASD_GRID_ROWS || nMaxCellY < 0) break;
+    const float4* qa = reinterpret_cast<const float4*>(a.desc + (size_t)(a.desc_rows ? a.desc_rows[i] : i) * 128);
+    unsigned long long best = ~0ull;
+    int pos = 0;   // position in GetFeaturesInArea order (ties: the first wins)
+    for (int ix = nMinCellX; ix <= nMaxCellX; ++ix) {
+      const int b = G.cell_start[ix * ASD_GRID_ROWS + nMinCellY], e = G.cell_start[ix * ASD_GRID_ROWS + nMaxCellY + 1];
+      for (int base = b; base < e; base += 64) {
+        const int it = base + lane;
+        bool in = false;
+        int idx = 0;
+        float4 kp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < e) {
+          idx = G.cell_items[it];
+          kp = G.kp[idx];
+          const float dx = kp.x - u, dy = kp.y - v;
+          in = fabsf(dx) < r && fabsf(dy) < r;
+        }
+        const unsigned long long m = __ballot(in);
+        unsigned long long key = ~0ull;
+        if (in) {
+          const int p = pos + __popcll(m & ((1ull << lane) - 1));
+          const int oct = __float_as_int(kp.z);
+          bool ok = !(oct < lvl - 1 || oct > lvl);
+          const float ex = u - kp.x, ey = v - kp.y;
+          const float e2 = ex * ex + ey * ey;
+          if ((double)(e2 * a.inv_sigma2[oct]) > 5.99) ok = false;
+          if (ok) {
+            const float4* qb = reinterpret_cast<const float4*>(Cc.desc + (size_t)idx * 128);
+            float sqd = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+              const float4 x = qa[k], y = qb[k];
+              float d;
+              d = x.x - y.x; sqd = sqd + d * d;
+              d = x.y - y.y; sqd = sqd + d * d;
+              d = x.z - y.z; sqd = sqd + d * d;
+              d = x.w - y.w; sqd = sqd + d * d;
+            }
+            if (sqd < 256.f) key = ((unsigned long long)__float_as_uint(sqd) << 32) | ((unsigned long long)(unsigned)p << 16) | (unsigned)idx;
+          }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+          const unsigned long long o = __shfl_xor(key, off);
+          key = o < key ? o : key;
+        }
+        best = key < best ? key : best;
+        pos += __popcll(m);
+      }
+    }
+    if (best != ~0ull) {
+      const float d = __uint_as_float((unsigned)(best >> 32));
+      if (d <= TH_LOW) { out_idx = (int)(best & 0xffffu); out_dist = d; }
+    }
+  } while (false);
+  if (lane == 0) { a.best_idx[i] = out_idx; a.best_dist[i] = out_dist; }
+}
+
+int asd_fuse_search_batch(asd_ctx* ctx, int32_t n_calls, const asd_fuse_call* calls, int32_t n_total, const uint8_t* valid, const float* Xw,
+                          const float* normal, const float* min_dist, const float* max_dist, const float* desc, const int32_t* desc_rows, float th,
+                          int32_t* best_idx, float* best_dist) {
+  if (!ctx || n_calls < 0 || n_total < 0 || (n_calls > 0 && !calls) ||
+      (n_total > 0 && (!valid || !Xw || !normal || !min_dist || !max_dist || (!desc && !desc_rows) || !best_idx || !best_dist)))
+    return ASD_ERR_INVALID;
+  if (asd_track_busy(ctx, "asd_fuse_search_batch")) return ASD_ERR_INVALID;
+  for (int i = 0; i < n_total; ++i) { best_idx[i] = -1; best_dist[i] = 256.f; }
+  if (n_calls == 0 || n_total == 0) return ASD_OK;
+  (void)hipSetDevice(ctx->cfg.device);
+  std::vector<FuseCallDev> cd(n_calls);
+  std::vector<int> call_of(n_total, -1);
+  for (int c = 0; c < n_calls; ++c) {
+    const asd_fuse_call& A = calls[c];
+    AsdFrameSlot* KF = slot_of(ctx, A.slot_kf);
+    if (!KF || !KF->d_kp || A.first < 0 || A.n < 0 || A.first + A.n > n_total) { ctx->set_error("asd_fuse_search_batch: call %d: slot %d / rows [%d, %d) of %d", c, A.slot_kf, A.first, A.first + A.n, n_total); return ASD_ERR_INVALID; }
+    if (KF->n >= 65536) { ctx->set_error("asd_fuse_search_batch: keyframe of %d keypoints", KF->n); return ASD_ERR_CAPACITY; }
+    FuseCallDev& D = cd[c];
+    D.G = GridDev{KF->d_kp, KF->d_cell_start, KF->d_cell_items, KF->min_x, KF->min_y, KF->inv_w, KF->inv_h};
+    D.desc = KF->d_desc;
+    memcpy(D.T, A.Tcw, sizeof D.T);
+    for (int i = 0; i < 3; ++i) {  // KeyFrame::SetPose: Ow = -Rwc*tcw with Rwc materialised (gemm small-matrix path, f32 sums) -- as asd_fuse_search
+      const float t0 = A.Tcw[0 * 4 + i] * A.Tcw[3] + A.Tcw[1 * 4 + i] * A.Tcw[7] + A.Tcw[2 * 4 + i] * A.Tcw[11];
+      D.Ow[i] = (float)((double)t0 * -1.0);
+    }
+    memcpy(D.K, A.K, sizeof D.K);
+    D.min_x = KF->min_x; D.max_x = KF->max_x; D.min_y = KF->min_y; D.max_y = KF->max_y;
+    D.first = A.first; D.n = A.n;
+    for (int i = A.first; i < A.first + A.n; ++i) {
+      if (call_of[i] >= 0) { ctx->set_error("asd_fuse_search_batch: rows of calls %d and %d overlap", call_of[i], c); return ASD_ERR_INVALID; }
+      call_of[i] = c;
+    }
+  }
+  std::vector<uint8_t> val(valid, valid + n_total);
+  for (int i = 0; i < n_total; ++i) if (call_of[i] < 0) { val[i] = 0; call_of[i] = 0; }   // rows no call covers: nothing to search
+  MatcherState* mst = mstate(ctx);
+  if (!desc)
+    for (int i = 0; i < n_total; ++i)
+      if (val[i] && (desc_rows[i] < 0 || desc_rows[i] >= mst->bank_cap)) { ctx->set_error("asd_fuse_search_batch: bank row %d out of range", desc_rows[i]); return ASD_ERR_INVALID; }
+  hipStream_t st = ctx->stream;
+  AsdXfer &up = ctx->up, &down = ctx->down;
+  ASD_HIP_CHECK(ctx, up.begin(st, (size_t)n_total * (1 + 12 + 12 + 4 + 4 + 512 + 4) + (size_t)n_calls * sizeof(FuseCallDev) + 16 * 256));
+  ASD_HIP_CHECK(ctx, down.begin(st, (size_t)n_total * 8 + 1024));
+  FuseBatchArgs a{};
+  a.calls = up.dev<FuseCallDev>(up.add(cd.data(), cd.size() * sizeof(FuseCallDev)));
+  a.call_of = up.dev<int>(up.add(call_of.data(), (size_t)n_total * 4));
+  a.n_total = n_total; a.n_levels = ctx->cfg.n_levels;
+  a.valid = up.dev<uint8_t>(up.add(val.data(), n_total));
+  a.Xw = up.dev<float>(up.add(Xw, (size_t)n_total * 12));
+  a.normal = up.dev<float>(up.add(normal, (size_t)n_total * 12));
+  a.min_dist = up.dev<float>(up.add(min_dist, (size_t)n_total * 4));
+  a.max_dist = up.dev<float>(up.add(max_dist, (size_t)n_total * 4));
+  if (desc) { a.desc = up.dev<float>(up.add(desc, (size_t)n_total * 512)); a.desc_rows = nullptr; }
+  else { a.desc = mst->d_bank; a.desc_rows = up.dev<int>(up.add(desc_rows, (size_t)n_total * 4)); }
+  a.th = th;
+  for (int l = 0; l < ASD_MAX_LEVELS; ++l) {
+    a.level_thr[l] = ctx->level_thr[l];
+    a.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f;
+    a.inv_sigma2[l] = l < ctx->cfg.n_levels ? ctx->inv_sigma2[l] : 0.f;
+  }
+  const size_t o_i = down.reserve((size_t)n_total * 4), o_d = down.reserve((size_t)n_total * 4);
+  a.best_idx = down.dev<int>(o_i); a.best_dist = down.dev<float>(o_d);
+  ASD_HIP_CHECK(ctx, up.upload(st));
+  hipLaunchKernelGGL(k_fuse_batch, dim3((n_total + 3) / 4), dim3(256), 0, st, a);
+  ASD_HIP_CHECK(ctx, hipGetLastError());
+  ASD_HIP_CHECK(ctx, down.download(st));
+  ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  memcpy(best_idx, down.host<int>(o_i), (size_t)n_total * 4);
+  memcpy(best_dist, down.host<float>(o_d), (size_t)n_total * 4);
   return ASD_OK;
 }
 

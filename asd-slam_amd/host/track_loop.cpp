@@ -45,6 +45,12 @@ struct asd_track_handle {
   // (asd_prep_async) beside the stages instead of behind them.  Needs three frame slots (the next frame's grid is written while the
   // motion-model stage may still read the last frame's) and two alternating bank regions.
   bool chain = true;
+  const asd_do_mapping_inputs* dm = nullptr;   // the batched per-keyframe stage in front of LocalBA (asd_track_set_do_mapping)
+  std::vector<int32_t> dm_matches, dm_nmatch, dm_best, dm_distinct;
+  std::vector<float> dm_x3d, dm_bdist;
+  std::vector<uint8_t> dm_ok;
+  double dm_ms = 0.0;
+  long dm_calls = 0;
   int frames_on_host = 0;   // the frame pointers are (pinned) host memory: asd_extract_submit(device_resident = 0), the image crosses PCIe per frame
   int bank_base = 0;        // first bank row of the map the prepared frame is tracked against
   std::vector<int32_t> last_cand, cand_rows;
@@ -130,6 +136,20 @@ int asd_track_drain(asd_track_handle* h) {
   return rc;
 }
 void asd_track_set_frames_on_host(asd_track_handle* h, int32_t on) { if (h) h->frames_on_host = on != 0; }
+void asd_track_set_do_mapping(asd_track_handle* h, const asd_do_mapping_inputs* in, int32_t n_cur) {
+  if (!h) return;
+  h->dm = in;
+  if (!in) return;
+  h->dm_matches.assign((size_t)in->n_nb * n_cur, -1); h->dm_nmatch.assign(std::max(in->n_nb, 1), 0);
+  h->dm_x3d.assign((size_t)in->n_nb * n_cur * 3, 0.f); h->dm_ok.assign((size_t)in->n_nb * n_cur, 0);
+  h->dm_best.assign(std::max(in->n_fuse_total, 1), -1); h->dm_bdist.assign(std::max(in->n_fuse_total, 1), 0.f);
+  h->dm_distinct.assign(std::max(in->n_sets, 1), 0);
+}
+void asd_track_get_do_mapping_times(const asd_track_handle* h, double* ms, int64_t* calls) {
+  if (!h) return;
+  if (ms) *ms = h->dm_ms;
+  if (calls) *calls = h->dm_calls;
+}
 void asd_track_get_times(const asd_track_handle* h, double* ba_ms, double* extract_wait_ms, int64_t* steps) {
   if (!h) return;
   if (ba_ms) *ba_ms = h->ba_ms;
@@ -689,10 +709,30 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
 // LocalBA at a keyframe: in line (the reference's order) or on the optional lane (collected later).  The problem of keyframe number
 // t / kf_interval = the nominal problem with every observation displaced by a deterministic +-0.1 px (bench.py,
 // ba_problem_for_keyframe: same integer hash, same double arithmetic): a real map changes between keyframes.
+// LocalMapping::DoMapping in front of its LocalBundleAdjustment call (LocalMapping.cc:66-88): new map points against the covisible
+// keyframes, fusion with the neighbours, distinctive descriptors of the touched points -- three batched submissions
+static int do_mapping_stage(asd_track_handle* h) {
+  const asd_do_mapping_inputs& D = *h->dm;
+  asd_ctx* ctx = h->ctx;
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  if (D.n_nb > 0 && (rc = asd_create_map_points_batch(ctx, D.slot_cur, D.has_mp_cur, D.Tcw_cur, D.K_cur, D.n_nb, D.nb, h->dm_matches.data(), h->dm_nmatch.data(),
+                                                      h->dm_x3d.data(), h->dm_ok.data())) != ASD_OK)
+    return rc;
+  if (D.n_fuse_calls > 0 && (rc = asd_fuse_search_batch(ctx, D.n_fuse_calls, D.fuse_calls, D.n_fuse_total, D.valid, D.Xw, D.normal, D.min_dist, D.max_dist, nullptr,
+                                                        D.desc_rows, D.th, h->dm_best.data(), h->dm_bdist.data())) != ASD_OK)
+    return rc;
+  if (D.n_sets > 0 && (rc = asd_distinctive_descriptor_batch(ctx, D.n_sets, D.set_start, D.set_desc, h->dm_distinct.data())) != ASD_OK) return rc;
+  h->dm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ++h->dm_calls;
+  return ASD_OK;
+}
+
 static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
   asd_ctx* ctx = h->ctx;
   int rc;
   if ((rc = collect_ba(h, nullptr, -1)) != ASD_OK) return rc;   // the previous keyframe's run (its buffers are reused below)
+  if (h->dm && !h->async_ba && (rc = do_mapping_stage(h)) != ASD_OK) return rc;   // (in line only: with the lane a tracking stage is outstanding here)
   const asd_ba_problem& B = h->ba;
   h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
   h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);

@@ -42,6 +42,22 @@ void asd_track_get_times(const asd_track_handle* h, double* ba_ms, double* extra
 /* where the stand-in map points of frame t land in frame t+1: u' = (u - cx) z + cx - dx z, v' = (v - cy) z + cy - dy z.  Default = the
  * synthetic stream of synth.scene_frame (cx 620.5, cy 188, z 1.003, dx 3, dy 0.2); a real sequence uses z = 1, dx = dy = 0. */
 void asd_track_set_drift(asd_track_handle* h, float cx, float cy, float z, float dx, float dy);
+/* LocalMapping::DoMapping's per-keyframe work in front of LocalBundleAdjustment (LocalMapping.cc:59-113: CreateNewMapPoints :299-545,
+ * SearchInNeighbors :557-636, ComputeDistinctiveDescriptors of the touched points, MapPoint.cc:271-338) as the three batched submissions of
+ * the library -- run at every keyframe, before asd_local_ba, when set (NULL = off, the default: the metric is tracking + LocalBA).  All
+ * arrays are the caller's and must outlive the handle: a stand-in neighbourhood (current keyframe + its covisible keyframes resident in
+ * frame slots, their FeatureVectors set) like the nominal LocalBA problem is a stand-in map. */
+typedef struct asd_do_mapping_inputs {
+  int32_t slot_cur; const uint8_t* has_mp_cur; const float* Tcw_cur; const float* K_cur;
+  int32_t n_nb; const asd_kf_neighbor* nb;
+  int32_t n_fuse_calls; const asd_fuse_call* fuse_calls;
+  int32_t n_fuse_total; const uint8_t* valid; const float* Xw; const float* normal; const float* min_dist; const float* max_dist;
+  const int32_t* desc_rows; float th;
+  int32_t n_sets; const int32_t* set_start; const float* set_desc;
+} asd_do_mapping_inputs;
+void asd_track_set_do_mapping(asd_track_handle* h, const asd_do_mapping_inputs* in, int32_t n_cur /* keypoints of slot_cur */);
+/* accumulated wall time inside that stage (ms) and the number of times it ran */
+void asd_track_get_do_mapping_times(const asd_track_handle* h, double* ms, int64_t* calls);
 /* n frames t0 .. t0+n-1; frames after the last one are read ahead only when the replay continues (prefetch_beyond) */
 int asd_track_run(asd_track_handle* h, int32_t t0, int32_t n, int32_t prefetch_beyond, asd_track_stats* stats);
 

@@ -373,6 +373,73 @@ class asd_track_stats(__import__("ctypes").Structure):
                 ("has_inliers", __import__("ctypes").c_int32), ("has_ba", __import__("ctypes").c_int32)]
 
 
+class asd_do_mapping_inputs(__import__("ctypes").Structure):
+    _C = __import__("ctypes")
+    _fields_ = [("slot_cur", _C.c_int32), ("has_mp_cur", _C.c_void_p), ("Tcw_cur", _C.c_void_p), ("K_cur", _C.c_void_p),
+                ("n_nb", _C.c_int32), ("nb", _C.c_void_p), ("n_fuse_calls", _C.c_int32), ("fuse_calls", _C.c_void_p),
+                ("n_fuse_total", _C.c_int32), ("valid", _C.c_void_p), ("Xw", _C.c_void_p), ("normal", _C.c_void_p), ("min_dist", _C.c_void_p),
+                ("max_dist", _C.c_void_p), ("desc_rows", _C.c_void_p), ("th", _C.c_float),
+                ("n_sets", _C.c_int32), ("set_start", _C.c_void_p), ("set_desc", _C.c_void_p)]
+
+
+def build_do_mapping_inputs(pkg, hip, n_nb=20, n_kp=2000, slot0=8, bank_row0=20000):
+    """Stand-in keyframe neighbourhood for the per-keyframe stage in front of LocalBA (LocalMapping::DoMapping, LocalMapping.cc:59-113):
+    a current keyframe and nn = 20 covisible keyframes observing the same points (LocalMapping.cc:303-307), resident in frame slots
+    slot0 .. slot0 + 20 with their FeatureVectors; Fuse candidates = 1200 points into each neighbour + 2400 into the current keyframe
+    (SearchInNeighbors, :557-636), descriptors in the bank; 600 touched map points for ComputeDistinctiveDescriptors.  Returns the
+    struct and everything that must stay alive."""
+    import ctypes as C
+    from tests.test_mapping import K_KITTI, _kf_with_neighbours
+    from tests.test_matcher import SCALES, backproject, perturbed_descriptors
+    capi = pkg.capi
+    kc, dc, Tc, nodes_c, has_c, nbs = _kf_with_neighbours(n_kp, n_nb, 77)
+    hip.frame_set(slot0, kc, dc, BOUNDS); hip.frame_set_bow(slot0, nodes_c)
+    keep = [np.ascontiguousarray(has_c, np.uint8), np.ascontiguousarray(Tc, np.float32), np.ascontiguousarray(K_KITTI, np.float32)]
+    nb = (capi.asd_kf_neighbor * n_nb)()
+    for b, d in enumerate(nbs):
+        hip.frame_set(slot0 + 1 + b, d["kps"], d["desc"], BOUNDS); hip.frame_set_bow(slot0 + 1 + b, d["nodes"])
+        h = np.ascontiguousarray(d["has"], np.uint8); keep.append(h)
+        nb[b].slot, nb[b].has_mp = slot0 + 1 + b, h.ctypes.data
+        nb[b].F12 = (C.c_float * 9)(*[float(v) for v in np.asarray(d["F12"], np.float32).ravel()])
+        nb[b].ex, nb[b].ey = float(d["ex"]), float(d["ey"])
+        nb[b].Tcw = (C.c_float * 16)(*[float(v) for v in np.asarray(d["T"], np.float32).ravel()])
+        nb[b].K = (C.c_float * 4)(*[float(v) for v in K_KITTI])
+    rng = np.random.default_rng(5)
+    calls = (capi.asd_fuse_call * (n_nb + 1))()
+    tabs, first = [], 0
+    for c in range(n_nb + 1):
+        kk, dd, Tk = (nbs[c]["kps"], nbs[c]["desc"], nbs[c]["T"]) if c < n_nb else (kc, dc, Tc)
+        n_mp = 1200 if c < n_nb else 2400
+        src = rng.integers(0, n_kp, n_mp)
+        uv = np.stack([kk["x"][src], kk["y"][src]], 1) + rng.uniform(-1.5, 1.5, (n_mp, 2)).astype(np.float32)
+        X = backproject(Tk, K_KITTI, uv, rng.uniform(3, 60, n_mp))
+        O = -(Tk[:3, :3].astype(np.float64).T @ Tk[:3, 3].astype(np.float64))
+        nv = X.astype(np.float64) - O
+        dv = np.linalg.norm(nv, axis=1)
+        mx = (dv * SCALES[kk["octave"][src]]).astype(np.float32)
+        tabs.append((np.ones(n_mp, np.uint8), X, (nv / dv[:, None]).astype(np.float32), (mx / np.float32(SCALES[7])).astype(np.float32), mx,
+                     perturbed_descriptors(dd[src], 0.04, 800 + c)))
+        calls[c].slot_kf, calls[c].first, calls[c].n = (slot0 + 1 + c if c < n_nb else slot0), first, n_mp
+        calls[c].Tcw = (C.c_float * 16)(*[float(v) for v in np.asarray(Tk, np.float32).ravel()])
+        calls[c].K = (C.c_float * 4)(*[float(v) for v in K_KITTI])
+        first += n_mp
+    cat = [np.ascontiguousarray(np.concatenate([t[k] for t in tabs])) for k in range(6)]
+    hip.bank_put(bank_row0, cat[5])
+    rows = np.arange(bank_row0, bank_row0 + first, dtype=np.int32)
+    sizes = np.random.default_rng(9).integers(2, 16, 600)
+    set_start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    set_desc = np.ascontiguousarray(np.concatenate([perturbed_descriptors(np.repeat(dc[k:k + 1], n, 0), 0.05, 100 + k) for k, n in enumerate(sizes)]), np.float32)
+    keep += [nb, calls, rows, set_start, set_desc] + cat[:5]
+    D = asd_do_mapping_inputs()
+    D.slot_cur, D.has_mp_cur, D.Tcw_cur, D.K_cur = slot0, keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data
+    D.n_nb, D.nb = n_nb, C.addressof(nb)
+    D.n_fuse_calls, D.fuse_calls, D.n_fuse_total = n_nb + 1, C.addressof(calls), first
+    D.valid, D.Xw, D.normal, D.min_dist, D.max_dist = (cat[k].ctypes.data for k in range(5))
+    D.desc_rows, D.th = rows.ctypes.data, 3.0
+    D.n_sets, D.set_start, D.set_desc = 600, set_start.ctypes.data, set_desc.ctypes.data
+    return D, keep, n_kp
+
+
 class NativeHost:
     """The same tracking step as track_step(), run by C++ host code (asd-slam_amd/host/track_loop.cpp -> libasdtrack.so)
     over the C ABI: the reference's host side is C++, the Python loop costs ~0.25 ms of a ~2 ms step."""
@@ -870,6 +937,7 @@ def main():
                     help="variant: LocalBA on the library's lane (asd_local_ba_submit / _wait) beside the next frames, which then track against the "
                          "pre-BA map -- not the reference's order (Tracking.cc:797 -> LocalMapping.cc:89 runs it in line, the default here)")
     ap.add_argument("--sync-ba", action="store_true", help="(default since round 3, kept for old command lines) LocalBA in line with tracking")
+    ap.add_argument("--no-do-mapping-variant", action="store_true", help="skip the extra pass with the batched per-keyframe stage in front of LocalBA (N = 1 only)")
     ap.add_argument("--no-h2d-variant", action="store_true", help="skip the extra pass with the frames handed over in page-locked host memory (N = 1 only)")
     ap.add_argument("--no-lane-variant", action="store_true", help="skip the extra untimed-for-the-headline pass that measures the lane variant (N = 1 only)")
     ap.add_argument("--no-fuse", action="store_true", help="matcher and PoseOptimization as separate calls (two host round trips per stage)")
@@ -982,6 +1050,8 @@ def main():
                                 "of the run; frames t+1.. are tracked against the map as it was BEFORE that LocalBA -- not the reference's "
                                 "order, so poses on a real sequence differ from the reference's; optional entry point, never the headline"}
         be.async_ba = False
+        if be.native is not None:
+            be.native.lib.asd_track_set_async_ba(be.native.h, 0)
 
     # per-kernel device time of the dominant kernel (ASDNet conv2, f32 MFMA), hipEvents on the ctx stream
     layer_names = ["norm+conv1", "conv2", "conv3", "conv4", "conv5", "conv6", "conv7(fc)", "l2norm"]
@@ -1017,6 +1087,36 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS
         roof_kernel = "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)"
         roof_extra = {}
+    # The per-keyframe stage of LocalMapping::DoMapping in front of LocalBA (CreateNewMapPoints against 20 neighbours, SearchInNeighbors'
+    # Fuse calls, distinctive descriptors) as the library's three batched submissions at every keyframe: reference order
+    # (LocalMapping.cc:59-113).  An extra key: the metric -- and `value` -- is tracking + LocalBA.
+    do_mapping_variant = None
+    if world == 1 and be.native is not None and not args.no_do_mapping_variant:
+        import ctypes as C
+        D, dm_keep, dm_n = build_do_mapping_inputs(pkg, be.hip)
+        be.native.lib.asd_track_set_do_mapping(be.native.h, C.byref(D), dm_n)
+        tl = prime + args.warmup + 2 * args.steps + 4 * KF_INTERVAL
+        while kf_in(tl + KF_INTERVAL, args.steps) < want_kf:
+            tl += 1
+        run_steps(be, wl, tl, KF_INTERVAL, None, prefetch_beyond=True)
+        be.hip.sync(); device_sync(device)
+        ms0, calls0 = C.c_double(), C.c_int64()
+        be.native.lib.asd_track_get_do_mapping_times(be.native.h, C.byref(ms0), C.byref(calls0))
+        d0 = time.perf_counter()
+        run_steps(be, wl, tl + KF_INTERVAL, args.steps, None, prefetch_beyond=True)
+        be.hip.sync(); device_sync(device)
+        ddt = time.perf_counter() - d0
+        ms1, calls1 = C.c_double(), C.c_int64()
+        be.native.lib.asd_track_get_do_mapping_times(be.native.h, C.byref(ms1), C.byref(calls1))
+        be.native.lib.asd_track_set_do_mapping(be.native.h, None, 0)
+        nkf = max(1, calls1.value - calls0.value)
+        do_mapping_variant = {"value": args.steps / ddt, "unit": "frames/s", "ms_per_step": 1e3 * ddt / args.steps, "steps": args.steps,
+                              "keyframes": int(calls1.value - calls0.value), "ms_per_keyframe_stage": (ms1.value - ms0.value) / nkf,
+                              "what": "the headline chain with LocalMapping::DoMapping's per-keyframe work in front of LocalBA at every keyframe (reference "
+                                      "order, LocalMapping.cc:59-113): asd_create_map_points_batch (20 neighbours x 2000 keypoints), asd_fuse_search_batch "
+                                      "(21 calls, 26400 candidate points, descriptors by bank row), asd_distinctive_descriptor_batch (600 points) on a "
+                                      "stand-in neighbourhood"}
+
     # The same K frames with every image handed over in page-locked HOST memory (asd_extract_submit(device_resident = 0): the front
     # half's stream copies it, 467 KB per frame over PCIe) -- how kitti.cc:116-155 hands images to the tracker.  An extra key: `value`
     # keeps its definition (inputs resident in HBM when the timed region starts).
@@ -1088,6 +1188,8 @@ def main():
             out["lane_variant"] = lane_variant
         if h2d_variant is not None:
             out["h2d_variant"] = h2d_variant
+        if do_mapping_variant is not None:
+            out["do_mapping_variant"] = do_mapping_variant
         if steady is not None:
             out["steady_state"] = steady
         if args.cpu_frames > 0 and world == 1:   # reported baseline: rank 0 at N = 1 only

@@ -158,7 +158,7 @@ int asd_get_raw_corners(asd_ctx* ctx, int32_t level, int32_t capacity, float* x,
 /* A frame slot keeps what the reference keeps in Frame: undistorted keypoints
  * (mvKeysUn), descriptors (mDescriptors) and the 64x48 grid (Frame.cc:123-138), all
  * resident in HBM.  Slots are small integers in [0, ASD_MAX_FRAMES). */
-#define ASD_MAX_FRAMES 8
+#define ASD_MAX_FRAMES 64   /* (round 4: a keyframe and its 20 + 5 x 20 covisible neighbours resident for the batched per-keyframe stage) */
 /* Replaces Frame::Frame(...) bookkeeping after ExtractORB: UndistortKeyPoints is the
  * identity for zero distortion (Frame.cc:298-304), image bounds (Frame.cc:351-357),
  * AssignFeaturesToGrid (Frame.cc:123-138).  desc may be NULL to adopt the descriptors of
@@ -478,6 +478,49 @@ int asd_fuse_search(asd_ctx* ctx, int32_t slot_kf, int32_t n_mp, const uint8_t* 
 int asd_triangulate_pairs(asd_ctx* ctx, int32_t slot1, int32_t slot2, int32_t n_pairs, const int32_t* idx1,
                           const int32_t* idx2, const float* Tcw1, const float* Tcw2, const float* K1,
                           const float* K2, float* x3D, uint8_t* ok, int32_t* n_ok);
+/* ---- the per-keyframe work in front of LocalBA, batched (LocalMapping::DoMapping, LocalMapping.cc:59-113) ----
+ * CreateNewMapPoints (:299-545) runs SearchForTriangulation + the per-match triangulation against nn = 20 covisible keyframes,
+ * SearchInNeighbors (:557-636) runs Fuse against 20 + second neighbours both ways: 40-100 matcher calls per keyframe, each a
+ * few hundred microseconds as a call of its own.  The batch entry points take all of them in ONE submission: one upload, one
+ * launch chain, one synchronisation.  What makes that legitimate: inside one call the searches do not feed each other --
+ * vbMatched2 is never set in SearchForTriangulation (ORBmatcher.cc:688, :729), Fuse's Replace / AddObservation side effects
+ * never enter the search (:938-956) -- and the only coupling BETWEEN the reference's consecutive calls is a filter the caller
+ * applies when it walks the results in the reference's order: a keypoint of the current keyframe that an earlier neighbour
+ * already gave a map point is skipped for later neighbours (pKF1->GetMapPoint(idx1), ORBmatcher.cc:703-707 after
+ * LocalMapping.cc:497-503), a map point an earlier Fuse replaced is bad for later ones (:840-846).  Every result equals the
+ * per-pair call's (asd_match_triangulate + asd_triangulate_pairs, asd_fuse_search) bit for bit. */
+
+/* The keyframe's DBoW2::FeatureVector resident beside its descriptors (slot must hold the frame): node ids ascending. */
+int asd_frame_set_bow(asd_ctx* ctx, int32_t slot, const asd_feature_vector* fv);
+
+typedef struct asd_kf_neighbor {
+  int32_t slot;              /* frame slot of the neighbour keyframe (asd_frame_set + asd_frame_set_bow done) */
+  const uint8_t* has_mp;     /* [n_keypoints of that slot] it already holds a map point there */
+  float F12[9];              /* fundamental matrix, current keyframe -> neighbour (LocalMapping.cc:547-555), row-major f32 */
+  float ex, ey;              /* epipole of the current camera in the neighbour's image (ORBmatcher.cc:675-683) */
+  float Tcw[16];             /* the neighbour's pose */
+  float K[4];                /* its intrinsics fx fy cx cy */
+} asd_kf_neighbor;
+/* SearchForTriangulation (check_orientation = false, as LocalMapping.cc:370 calls it) + the per-match triangulation body for
+ * every neighbour: matches12[b][i] = keypoint of neighbour b matched to keypoint i of the current keyframe or -1 (has_mp_cur
+ * as at entry: see above), x3D[b][i][3] / ok[b][i] as asd_triangulate_pairs returns them for that pair (0 where no match).
+ * Arrays are [n_nb][n_cur] row-major. */
+int asd_create_map_points_batch(asd_ctx* ctx, int32_t slot_cur, const uint8_t* has_mp_cur, const float* Tcw_cur, const float* K_cur,
+                                int32_t n_nb, const asd_kf_neighbor* nb, int32_t* matches12, int32_t* n_matches, float* x3D, uint8_t* ok);
+
+typedef struct asd_fuse_call {
+  int32_t slot_kf;           /* target keyframe */
+  int32_t first, n;          /* its candidate map points: rows [first, first + n) of the tables below */
+  float Tcw[16];
+  float K[4];
+} asd_fuse_call;
+/* asd_fuse_search for n_calls (keyframe, map point list) pairs over shared tables (valid, Xw, normal, min_dist, max_dist,
+ * and the map points' descriptors: desc [n_total][128], or desc == NULL and desc_rows [n_total] = rows of the descriptor bank --
+ * 4 bytes per point uploaded instead of 512); best_idx / best_dist [n_total] as asd_fuse_search returns them per call. */
+int asd_fuse_search_batch(asd_ctx* ctx, int32_t n_calls, const asd_fuse_call* calls, int32_t n_total, const uint8_t* valid, const float* Xw,
+                          const float* normal, const float* min_dist, const float* max_dist, const float* desc, const int32_t* desc_rows,
+                          float th, int32_t* best_idx, float* best_dist);
+
 /* vt.row(3) of cv::SVD::compute(A, w, u, vt, MODIFY_A|FULL_UV) for n row-major 4x4 f32 matrices
  * (the call at LocalMapping.cc:444); v is [n][4].  Exposed for the parity tests of the SVD itself. */
 int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v);

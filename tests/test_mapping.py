@@ -151,3 +151,112 @@ def test_triangulate_pairs_errors(hip):
         hip.triangulate_pairs(4, 5, [0, 10], [0, 1], T, T, K_KITTI, K_KITTI)   # index out of range
     x, ok, n = hip.triangulate_pairs(4, 5, np.zeros(0, np.int32), np.zeros(0, np.int32), T, T, K_KITTI, K_KITTI)
     assert n == 0 and len(ok) == 0
+
+
+# ------------------------------------------------------------------ the batched per-keyframe stage (round 4)
+def _kf_with_neighbours(n, n_nb, seed):
+    """a current keyframe + n_nb neighbours observing the same 3-D points from poses along a track: keypoints = projections + noise,
+    descriptors = perturbed copies, vocabulary nodes from the descriptors' signs (as tests/test_matcher.py's BoW tests)"""
+    from tests.test_matcher import _bow_nodes, perturbed_descriptors
+    rng = np.random.default_rng(seed)
+    Tc = pose_T((0.01, -0.02, 0.005), (0.1, -0.05, 0.3))
+    kc, dc = make_frame(n, seed + 1)
+    depth = rng.uniform(4, 35, n)
+    uv = np.stack([kc["x"], kc["y"]], 1).astype(np.float64)
+    Xc = np.stack([(uv[:, 0] - K_KITTI[2]) / K_KITTI[0] * depth, (uv[:, 1] - K_KITTI[3]) / K_KITTI[1] * depth, depth], 1)
+    Rc, tc = Tc[:3, :3].astype(np.float64), Tc[:3, 3].astype(np.float64)
+    X = (Xc - tc) @ Rc
+    out = []
+    for b in range(n_nb):
+        Tb = pose_T((0.012 + 0.002 * b, -0.03 - 0.004 * b, 0.001 * b), (0.1 - 0.6 - 0.25 * b, -0.02, 0.1 + 0.05 * b))
+        uv2, z2 = _project(Tb, K_KITTI, X)
+        kb = kc.copy()
+        kb["x"] = (uv2[:, 0] + rng.normal(0, 0.4, n)).astype(np.float32)
+        kb["y"] = (uv2[:, 1] + rng.normal(0, 0.4, n)).astype(np.float32)
+        vis = (z2 > 0.5) & (kb["x"] > 19) & (kb["x"] < 1221) & (kb["y"] > 19) & (kb["y"] < 356)
+        kb["x"][~vis] = rng.uniform(19, 1221, (~vis).sum()).astype(np.float32)
+        kb["y"][~vis] = rng.uniform(19, 356, (~vis).sum()).astype(np.float32)
+        perm = rng.permutation(n)
+        kb, db = kb[perm].copy(), perturbed_descriptors(dc[perm], 0.03, seed + 10 + b)
+        # F12 of (current, neighbour) as LocalMapping::ComputeF12 builds it (:547-555): K1^-T [t12]x R12 K2^-1
+        R1w, t1w, R2w, t2w = Rc, tc, Tb[:3, :3].astype(np.float64), Tb[:3, 3].astype(np.float64)
+        R12 = R1w @ R2w.T
+        t12 = -R1w @ R2w.T @ t2w + t1w
+        tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]])
+        Km = np.array([[K_KITTI[0], 0, K_KITTI[2]], [0, K_KITTI[1], K_KITTI[3]], [0, 0, 1]], np.float64)
+        F12 = (np.linalg.inv(Km).T @ tx @ R12 @ np.linalg.inv(Km)).astype(np.float32)
+        C2 = R2w @ (-(Rc.T @ tc)) + t2w          # the current camera's centre in the neighbour's frame -> epipole
+        ex, ey = np.float32(K_KITTI[0] * C2[0] / C2[2] + K_KITTI[2]), np.float32(K_KITTI[1] * C2[1] / C2[2] + K_KITTI[3])
+        out.append(dict(kps=kb, desc=db, T=Tb, F12=F12, ex=ex, ey=ey, nodes=_bow_nodes(db), has=(rng.uniform(size=n) < 0.25).astype(np.uint8)))
+    return kc, dc, Tc, _bow_nodes(dc), (rng.uniform(size=n) < 0.4).astype(np.uint8), out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_nb", [(2000, 6), (300, 20)])
+def test_create_map_points_batch_equals_the_per_pair_calls(hip, n, n_nb):
+    """asd_create_map_points_batch (every neighbour in one submission) against asd_match_triangulate + asd_triangulate_pairs per
+    neighbour: the same match ids, the same accept flags, the same coordinates bit for bit"""
+    kc, dc, Tc, nodes_c, has_c, nbs = _kf_with_neighbours(n, n_nb, 900 + n)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set_bow(0, nodes_c)
+    for b, d in enumerate(nbs):
+        hip.frame_set(1 + b, d["kps"], d["desc"], BOUNDS)
+        hip.frame_set_bow(1 + b, d["nodes"])
+    m, nm, x, ok = hip.create_map_points_batch(0, n, has_c, Tc, K_KITTI, [dict(slot=1 + b, has_mp=d["has"], F12=d["F12"], ex=d["ex"], ey=d["ey"], Tcw=d["T"], K=K_KITTI)
+                                                                      for b, d in enumerate(nbs)])
+    total_ok = 0
+    for b, d in enumerate(nbs):
+        em, en = hip.match_triangulate(0, 1 + b, n, nodes_c, d["nodes"], has_c, d["has"], d["F12"], d["ex"], d["ey"], False)
+        np.testing.assert_array_equal(m[b], em)
+        assert nm[b] == en
+        i1 = np.nonzero(em >= 0)[0].astype(np.int32)
+        ex_, eok, _ = hip.triangulate_pairs(0, 1 + b, i1, em[i1], Tc, d["T"], K_KITTI, K_KITTI)
+        np.testing.assert_array_equal(ok[b][i1], eok)
+        np.testing.assert_array_equal(x[b][i1], ex_)
+        assert not ok[b][em < 0].any() and not x[b][em < 0].any()
+        total_ok += int(eok.sum())
+    assert nm.sum() > 0.1 * n * n_nb * 0.3 and total_ok > 0
+
+
+@pytest.mark.gpu
+def test_fuse_search_batch_equals_the_per_call_search(hip, synth):
+    """asd_fuse_search_batch over several (keyframe, map point list) pairs against asd_fuse_search per pair"""
+    from tests.test_matcher import backproject, perturbed_descriptors
+    rng = np.random.default_rng(77)
+    K = np.array(synth.KITTI_K, np.float32)
+    calls, tabs, exp = [], [], []
+    first = 0
+    for c in range(7):
+        kc, dc = make_frame(2000 if c < 5 else 300, 500 + c)
+        T = pose_T((0.01 + 0.003 * c, -0.02, 0.005), (0.1 - 0.2 * c, -0.05, 0.3))
+        n_mp = [4000, 1500, 50, 900, 2500, 700, 1][c]
+        src = rng.integers(0, len(kc), n_mp)
+        uv = np.stack([kc["x"][src], kc["y"][src]], 1) + rng.uniform(-1.5, 1.5, (n_mp, 2)).astype(np.float32)
+        uv[: n_mp // 8] += 2500
+        Xw = backproject(T, K, uv, rng.uniform(3, 60, n_mp))
+        Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+        nrm = Xw.astype(np.float64) - Ow
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        nrm = (nrm + rng.normal(0, 0.4, nrm.shape)).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        dist = np.linalg.norm(Xw.astype(np.float64) - Ow, axis=1)
+        maxd = (dist * SCALES[kc["octave"][src]] * rng.uniform(0.9, 1.1, n_mp)).astype(np.float32)
+        mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+        desc = perturbed_descriptors(dc[src], 0.04, 600 + c)
+        valid = (rng.uniform(size=n_mp) < 0.9).astype(np.uint8)
+        hip.frame_set(10 + c, kc, dc, BOUNDS)
+        exp.append(hip.fuse_search(10 + c, valid, Xw, nrm, mind, maxd, desc, T, K, 3.0))
+        calls.append(dict(slot_kf=10 + c, first=first, n=n_mp, Tcw=T, K=K))
+        tabs.append((valid, Xw, nrm, mind, maxd, desc))
+        first += n_mp
+    cat = [np.concatenate([t[k] for t in tabs]) for k in range(6)]
+    bi, bd = hip.fuse_search_batch(calls, *cat, th=3.0)
+    for c, (ei, ed) in zip(calls, exp):
+        np.testing.assert_array_equal(bi[c["first"]: c["first"] + c["n"]], ei)
+        np.testing.assert_array_equal(bd[c["first"]: c["first"] + c["n"]], ed)
+    assert (bi >= 0).sum() > 2000
+    # the map points' descriptors as rows of the descriptor bank instead of 512-byte rows
+    hip.bank_put(1000, cat[5])
+    ri, rd = hip.fuse_search_batch(calls, *cat[:5], np.arange(1000, 1000 + len(cat[5]), dtype=np.int32), th=3.0)
+    np.testing.assert_array_equal(ri, bi)
+    np.testing.assert_array_equal(rd, bd)

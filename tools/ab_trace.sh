@@ -5,7 +5,7 @@ stats() {  # $1 = label, rest = env assignments
   lbl=$1; shift
   rm -rf $O/prof_$lbl
   env "$@" true
-  ( export "$@"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$lbl -o b -- python3 bench.py --cpu-frames 0 --no-lane-variant --no-h2d-variant --steps 150 --warmup 45 > $O/prof_$lbl.log 2>&1 )
+  ( export "$@"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$lbl -o b -- python3 bench.py --cpu-frames 0 --no-lane-variant --no-h2d-variant --no-do-mapping-variant --steps 150 --warmup 45 > $O/prof_$lbl.log 2>&1 )
   python3 - $O/prof_$lbl $lbl <<'PY'
 import csv,glob,sys,re,json
 d,lbl=sys.argv[1],sys.argv[2]

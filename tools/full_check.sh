@@ -9,6 +9,6 @@ python3 - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r4b/bench.json').read().strip().splitlines()[-1])
 print('value', d['value'], 'ms', d['ms_per_step'], 'frac', d['roofline']['frac'], 'asdnet_ms', d['roofline']['asdnet_forward_ms'])
-for k in ('steady_state','h2d_variant','lane_variant','cpu_baseline','cpu_baseline_500'):
+for k in ('steady_state','do_mapping_variant','h2d_variant','lane_variant','cpu_baseline','cpu_baseline_500'):
     v=d.get(k); print(k, {kk:vv for kk,vv in v.items() if kk not in ('what','sample')} if v else None)
 PY

@@ -14,7 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as graft  # noqa: E402
 from tests.test_matcher import BOUNDS, SCALES, _bow_nodes, _two_views, backproject, make_frame, perturbed_descriptors, pose_T  # noqa: E402
-from tests.test_mapping import K_KITTI, _two_keyframes  # noqa: E402
+from tests.test_mapping import K_KITTI, _kf_with_neighbours, _two_keyframes  # noqa: E402
 
 
 def timeit(f, reps):
@@ -122,6 +122,61 @@ def main():
     out["distinctive_descriptor_batch"] = dict(gpu_ms=timeit(lambda: hip.distinctive_descriptor_batch(start, alld), a.reps),
                                                cpu_ms=timeit(lambda: [orc.distinctive_descriptor(d) for d in sets], a.cpu_reps),
                                                note=f"600 map points, {int(sizes.sum())} observations, one call")
+    # ---- the per-keyframe stage in front of LocalBA, batched (round 4): LocalMapping::DoMapping's CreateNewMapPoints against nn = 20
+    # neighbours and SearchInNeighbors' Fuse calls (20 neighbours + the current keyframe's points fused into each, and their points into
+    # the current keyframe), each as ONE submission, against the same work as a sequence of per-pair calls
+    NB = 20
+    kcur, dcur, Tcur, nodes_c, has_c, nbs = _kf_with_neighbours(2000, NB, 77)
+    hip.frame_set(8, kcur, dcur, BOUNDS); hip.frame_set_bow(8, nodes_c)
+    for b, d in enumerate(nbs):
+        hip.frame_set(9 + b, d["kps"], d["desc"], BOUNDS); hip.frame_set_bow(9 + b, d["nodes"])
+    nb_args = [dict(slot=9 + b, has_mp=d["has"], F12=d["F12"], ex=d["ex"], ey=d["ey"], Tcw=d["T"], K=K_KITTI) for b, d in enumerate(nbs)]
+
+    def per_pair():
+        for b, d in enumerate(nbs):
+            em, _ = hip.match_triangulate(8, 9 + b, 2000, nodes_c, d["nodes"], has_c, d["has"], d["F12"], d["ex"], d["ey"], False)
+            i1 = np.nonzero(em >= 0)[0].astype(np.int32)
+            hip.triangulate_pairs(8, 9 + b, i1, em[i1], Tcur, d["T"], K_KITTI, K_KITTI)
+    mm, nm, _, okb = hip.create_map_points_batch(8, 2000, has_c, Tcur, K_KITTI, nb_args)
+    out["create_new_map_points_batch"] = dict(gpu_ms=timeit(lambda: hip.create_map_points_batch(8, 2000, has_c, Tcur, K_KITTI, nb_args), a.reps),
+                                              per_pair_calls_ms=timeit(per_pair, max(2, a.reps // 4)),
+                                              note=f"{NB} neighbours x 2000 keypoints: SearchForTriangulation + triangulation, {int(nm.sum())} matches, {int(okb.sum())} new points")
+    # Fuse: the current keyframe's ~1200 map points into each of the 20 neighbours, then ~2400 candidate points of the neighbours into it
+    rngf = np.random.default_rng(5)
+    calls, tabs, first = [], [], 0
+    for c in range(NB + 1):
+        slot = 9 + c if c < NB else 8
+        kk = nbs[c]["kps"] if c < NB else kcur
+        dd = nbs[c]["desc"] if c < NB else dcur
+        Tk = nbs[c]["T"] if c < NB else Tcur
+        n_mp_c = 1200 if c < NB else 2400
+        srcc = rngf.integers(0, 2000, n_mp_c)
+        uvc = np.stack([kk["x"][srcc], kk["y"][srcc]], 1) + rngf.uniform(-1.5, 1.5, (n_mp_c, 2)).astype(np.float32)
+        Xc = backproject(Tk, K, uvc, rngf.uniform(3, 60, n_mp_c))
+        Oc = -(Tk[:3, :3].astype(np.float64).T @ Tk[:3, 3].astype(np.float64))
+        nc_ = Xc.astype(np.float64) - Oc
+        dc_ = np.linalg.norm(nc_, axis=1)
+        nc_ = (nc_ / dc_[:, None]).astype(np.float32)
+        mx = (dc_ * SCALES[kk["octave"][srcc]]).astype(np.float32)
+        tabs.append((np.ones(n_mp_c, np.uint8), Xc, nc_, (mx / np.float32(SCALES[7])).astype(np.float32), mx, perturbed_descriptors(dd[srcc], 0.04, 800 + c)))
+        calls.append(dict(slot_kf=slot, first=first, n=n_mp_c, Tcw=Tk, K=K))
+        first += n_mp_c
+    cat = [np.concatenate([t[k] for t in tabs]) for k in range(6)]
+
+    def fuse_per_call():
+        for cdesc, t in zip(calls, tabs):
+            hip.fuse_search(cdesc["slot_kf"], *t, cdesc["Tcw"], K, 3.0)
+    bi, _ = hip.fuse_search_batch(calls, *cat, th=3.0)
+    out["search_in_neighbors_fuse_batch"] = dict(gpu_ms=timeit(lambda: hip.fuse_search_batch(calls, *cat, th=3.0), a.reps),
+                                                 per_call_ms=timeit(fuse_per_call, max(2, a.reps // 4)),
+                                                 note=f"{NB + 1} Fuse calls, {first} candidate map points, {int((bi >= 0).sum())} found")
+    hip.bank_put(0, cat[5])   # the map points' descriptors live in the bank (written when a point's descriptor changes, once per keyframe)
+    rows = np.arange(first, dtype=np.int32)
+    assert np.array_equal(hip.fuse_search_batch(calls, *cat[:5], rows, th=3.0)[0], bi)
+    out["search_in_neighbors_fuse_batch"]["gpu_bank_rows_ms"] = timeit(lambda: hip.fuse_search_batch(calls, *cat[:5], rows, th=3.0), a.reps)
+    out["per_keyframe_stage_batched_ms"] = (out["create_new_map_points_batch"]["gpu_ms"] + out["search_in_neighbors_fuse_batch"]["gpu_bank_rows_ms"] +
+                                            out["distinctive_descriptor_batch"]["gpu_ms"])
+
     # ---- ComputeStereoMatches: two extractor contexts, constant-disparity synthetic pair
     wide = pkg.synth.scene_frame(1, w=1241 + 96, h=376)
     left, right = np.ascontiguousarray(wide[:, 32:32 + 1241]), np.ascontiguousarray(wide[:, 44:44 + 1241])
@@ -142,9 +197,13 @@ def main():
                                cpu_ms=timeit(lambda: exl.stereo_match(exr, kl, dl, kr, dr, mb, mbf), a.cpu_reps),
                                note=f"{len(kl)} x {len(kr)} keypoints, {gn} stereo matches")
     SL.close(); SR.close()
-    for v in out.values():
-        v["gpu_ms"] = round(v["gpu_ms"], 4)
-        v["cpu_ms"] = round(v["cpu_ms"], 4)
+    for k, v in out.items():
+        if isinstance(v, dict):
+            for kk in list(v):
+                if kk.endswith("_ms"):
+                    v[kk] = round(v[kk], 4)
+        else:
+            out[k] = round(v, 4)
     print(json.dumps({"kf_ops": out, "cpu": "oracle restatement, 1 thread", "gpu": "MI355X, wall time per C-ABI call incl. H2D/D2H"}))
 
 
