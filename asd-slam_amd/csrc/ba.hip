@@ -2126,6 +2126,25 @@ void ba_free(asd_ctx* ctx) {
 // stream directly behind the kernels that made the matches -- k_pose_edges builds the edge records from the device-resident
 // match table, k_pose_opt reads their count from the device -- so the chain needs ONE synchronisation, at its end.  The results
 // (pose, n_bad, outlier byte per edge in keypoint order) are copied to *h_io; the caller synchronises and unpacks them.
+// Everything pose_chain_enqueue may have to ask the runtime for -- scratch buffers, the kernel's dynamic-LDS attribute -- done ahead of
+// time.  asd_track_frame calls it before its first launch: once a PoseOptimization kernel sits on the device waiting for its ticket,
+// the host must not enter a runtime call that could wait for the device (an allocation, a function attribute) before the kernel that
+// publishes the ticket has been launched.
+int pose_chain_reserve(asd_ctx* ctx, int n_cur) {
+  BaState* s = ba_state(ctx);
+  int rc;
+  const size_t idx_off = (size_t)n_cur * 48;
+  if ((rc = s->po_Xw.ensure(ctx, idx_off + ((size_t)n_cur + 63) / 64 * 64 + 64)) || (rc = s->po_err.ensure(ctx, (size_t)n_cur * 64)) ||
+      (rc = s->po_level.ensure(ctx, (size_t)2 * n_cur)) || (rc = s->pc_n.ensure(ctx, 16)))
+    return rc;
+  static AsdPerDeviceOnce attr_set;
+  if (attr_set.need(ctx->cfg.device)) {
+    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set.done(ctx->cfg.device);
+  }
+  return ASD_OK;
+}
+
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
                        const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value) {

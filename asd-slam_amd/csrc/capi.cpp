@@ -156,6 +156,7 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   mapping_free(ctx);
   bow_free(ctx);
   ctx->scratch.release();
+  ctx->stereo_scratch.release();
   ctx->up.release();
   ctx->down.release();
   if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
@@ -315,6 +316,13 @@ int asd_device_alloc(asd_ctx* ctx, uint64_t bytes, void** dptr) {
 int asd_device_free(asd_ctx* ctx, void* dptr) {
   if (!ctx) return ASD_ERR_INVALID;
   ASD_HIP_CHECK(ctx, hipFree(dptr));
+  return ASD_OK;
+}
+int asd_extract_keep_pyramid(asd_ctx* ctx, int32_t on) {
+  if (!ctx) return ASD_ERR_INVALID;
+  if (asd_extractor_busy(ctx, "asd_extract_keep_pyramid")) return ASD_ERR_INVALID;
+  ctx->keep_pyramid = on != 0;
+  if (!on) ctx->d_pyr_view = nullptr;
   return ASD_OK;
 }
 int asd_host_alloc(asd_ctx* ctx, uint64_t bytes, void** hptr) {

@@ -204,6 +204,7 @@ struct asd_ctx {
   hipEvent_t ev_solve[2] = {nullptr, nullptr};
   unsigned* d_chain_flags = nullptr;  // [2] tickets the claim replays of the two stages publish
   unsigned chain_seq = 0;
+  bool chain_early_off = false;       // the probe found the solver stream on the main stream's hardware queue: PoseOptimization stays in stream order
   hipStream_t stream_prep = nullptr; // asd_prep_async: frame construction (grid / descriptor / bank copies) beside the stages in flight
   hipEvent_t ev_prep = nullptr;
   bool prep_on = false;
@@ -244,6 +245,9 @@ struct asd_ctx {
   bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
   uint8_t* d_patches = nullptr; // [max_patches][1024]
   float* d_desc = nullptr;      // [max_patches][128] descriptors of the last asd_extract / asd_describe
+  bool keep_pyramid = false;    // asd_extract_keep_pyramid: every submission keeps a copy of its pyramid for asd_stereo_match
+  const uint8_t* d_pyr_view = nullptr;   // that copy of the submission waited for last (null: the shared pyramid of a synchronous extraction)
+  AsdDevBuf stereo_scratch;     // asd_stereo_match's own device buffers (it may run beside tracking stages that own `scratch`)
   float* d_desc_last = nullptr; // device descriptors asd_frame_set(desc == NULL) adopts: last asd_extract or last waited submission
   hipEvent_t ev_adopt = nullptr;  // behind the last adoption copy out of d_desc_last (see asd_frame_set / asd_extract_submit)
   bool adopt_pending = false;
@@ -336,6 +340,7 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
                        double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, hipStream_t st_early = nullptr,
                        const unsigned* wait_flag = nullptr, unsigned wait_value = 0);
+int pose_chain_reserve(asd_ctx* ctx, int n_cur);   // its allocations and kernel attributes, ahead of time (see the definition)
 // true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
 inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }
 inline size_t pose_chain_io_bytes(int n_cur) { return 64 + ((size_t)n_cur + 7) / 8 * 8 + 64; }   // (+ two 100 MHz stamps behind the edge count: kernel entry, exit)   // pose[7], n_bad, flags (8-B words), edge count

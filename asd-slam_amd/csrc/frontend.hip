@@ -418,6 +418,10 @@ struct ExtractSlot {
   int* h_range = nullptr;   // pinned, behind the angles: the forward's fp16x2 range flag (asdnet.hip, k_l2norm)
   hipEvent_t ev_begin = nullptr, ev_front = nullptr, ev_end = nullptr;
   bool owned = false;  // slot 0 aliases the ctx / FrontendState buffers
+  // asd_extract_keep_pyramid: the submission's own copy of its pyramid (Frame::ComputeStereoMatches reads the level images around
+  // the keypoints, Frame.cc:442-505, after both extractions -- by then the shared pyramid holds a later frame of the read-ahead)
+  uint8_t* d_pyr_keep = nullptr;
+  size_t pyr_keep_cap = 0;
 };
 
 struct FrontendState {
@@ -667,6 +671,7 @@ static void slot_free(ExtractSlot& S) {
   }
   for (hipEvent_t* e : {&S.ev_begin, &S.ev_front, &S.ev_end})
     if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+  if (S.d_pyr_keep) (void)hipFree(S.d_pyr_keep);
   S = ExtractSlot();
 }
 
@@ -714,6 +719,18 @@ static int extract_front(asd_ctx* ctx, FrontendState* fe, const ExtractJob& J, E
                        Sl.pitch, fe->d_pyr + D.off, D.w, D.h, D.pitch, fe->d_xofs + fe->tab_x_off[l],
                        fe->d_ialpha + 2 * fe->tab_x_off[l], fe->d_yofs + fe->tab_y_off[l],
                        fe->d_ibeta + 2 * fe->tab_y_off[l]);
+  }
+  if (ctx->keep_pyramid) {   // the submission's own copy (device to device, ~1.4 MB at KITTI size)
+    size_t bytes = 0;
+    for (int l = 0; l < nl; ++l) bytes = std::max(bytes, (size_t)P.lv[l].off + (size_t)P.lv[l].pitch * P.lv[l].h);
+    bytes = (bytes + 15) / 16 * 16;
+    if (S.pyr_keep_cap < fe->buf_bytes) {
+      if (S.d_pyr_keep) (void)hipFree(S.d_pyr_keep);
+      S.d_pyr_keep = nullptr; S.pyr_keep_cap = 0;
+      ASD_HIP_CHECK(ctx, hipMalloc(&S.d_pyr_keep, fe->buf_bytes));
+      S.pyr_keep_cap = fe->buf_bytes;
+    }
+    ASD_HIP_CHECK(ctx, asd_copy_rows(st, S.d_pyr_keep, fe->d_pyr, bytes));
   }
   // E2 FAST score, per-cell NMS, compaction
   const int ncells = (int)fe->h_cells.size();
@@ -838,6 +855,7 @@ static int extract_impl(asd_ctx* ctx, const uint8_t* image, bool image_on_device
   *n_out = n;
   ctx->last_n = n;
   ctx->d_desc_last = S.d_desc;
+  ctx->d_pyr_view = nullptr;   // the shared pyramid holds this frame
   if (n == 0) return ASD_OK;
   if ((rc = extract_back_enqueue(ctx, S, n, ctx->stream)) != ASD_OK) return rc;
   return extract_finish(ctx, S, n, kps, desc);
@@ -1081,6 +1099,7 @@ static AsyncJob* wait_oldest(asd_ctx* ctx, int* rc) {
   if (a->job.rc != ASD_OK) { *rc = a->job.rc; return nullptr; }
   ctx->last_n = a->job.n;
   ctx->d_desc_last = ax->slots[a->slot].d_desc;
+  ctx->d_pyr_view = ctx->keep_pyramid ? ax->slots[a->slot].d_pyr_keep : nullptr;
   *rc = ASD_OK;
   return a;
 }
@@ -1288,6 +1307,9 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
   asd_ctx* ctx = ctx_left;
   if (ctx_left->cfg.device != ctx_right->cfg.device) { ctx->set_error("asd_stereo_match: both contexts must live on the same device"); return ASD_ERR_INVALID; }
   FrontendState *fl = ctx_left->fe, *fr = ctx_right->fe;
+  // (the pipelined extractor's second worker has a front-half state of its own: whichever is configured holds the level geometry)
+  if (fl && fl->cfg_w == 0 && ctx_left->ax && ctx_left->ax->fe[1]) fl = ctx_left->ax->fe[1];
+  if (fr && fr->cfg_w == 0 && ctx_right->ax && ctx_right->ax->fe[1]) fr = ctx_right->ax->fe[1];
   if (!fl || !fr || fl->cfg_w == 0 || fl->cfg_w != fr->cfg_w || fl->cfg_h != fr->cfg_h) {
     ctx->set_error("asd_stereo_match: extract the left and the right image (same size) on the two contexts first");
     return ASD_ERR_INVALID;
@@ -1298,13 +1320,19 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
   for (int i = 0; i < N; ++i) { u_right[i] = -1.0f; depth[i] = -1.0f; }
   if (N == 0 || Nr == 0) return ASD_OK;
   if (!FL.d_kp || !FR.d_kp) { ctx->set_error("asd_stereo_match: frame slot not set"); return ASD_ERR_INVALID; }
-  // the SAD windows are read from both contexts' pyramids: those must still hold the images the two frame slots came from
-  if (asd_extractor_busy(ctx_left, "asd_stereo_match") || asd_extractor_busy(ctx_right, "asd_stereo_match")) {
+  // the SAD windows are read from both contexts' pyramids: those must still hold the images the two frame slots came from -- either
+  // the shared pyramids of two synchronous extractions (nothing submitted since), or the kept copies of the two submissions waited for
+  // last (asd_extract_keep_pyramid: valid like that submission's descriptors, for two further submissions)
+  const bool views = ctx_left->d_pyr_view && ctx_right->d_pyr_view;
+  if (!views && (asd_extractor_busy(ctx_left, "asd_stereo_match") || asd_extractor_busy(ctx_right, "asd_stereo_match"))) {
     if (ctx != ctx_right) ctx->set_error("%s", ctx_right->last_error());
     return ASD_ERR_INVALID;
   }
   (void)hipSetDevice(ctx->cfg.device);
-  hipStream_t st = ctx->stream;
+  // inside an asd_prep_async bracket (frame construction beside the tracking stages in flight) the call runs on the context's second
+  // stream; its device buffers are its own either way (the stages in flight own ctx->scratch)
+  hipStream_t st = asd_prep_stream(ctx);
+  AsdDevBuf& scratch = ctx->stereo_scratch;
   // row table (:370-387): right keypoint iR is a candidate for every row within 2 * scale[octave] of its y
   const int nRows = fl->pyr.lv[0].h;
   std::vector<int> row_start(nRows + 1, 0);
@@ -1322,20 +1350,20 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
     for (int iR = 0; iR < Nr; ++iR)
       for (int y = lo[iR]; y <= hi[iR]; ++y) row_items[cur[y]++] = iR;  // ascending iR inside a row, like push_back order
   }
-  hipError_t e = ctx->scratch.reserve(AsdDevBuf::padded(row_start.size() * sizeof(int)) + AsdDevBuf::padded(row_items.size() * sizeof(int)) +
-                                      3 * AsdDevBuf::padded((size_t)N * sizeof(float)));
-  int* d_rs = ctx->scratch.carve<int>(row_start.size());
-  int* d_ri = ctx->scratch.carve<int>(row_items.size());
-  int* d_sad = ctx->scratch.carve<int>(N);
-  float* d_u = ctx->scratch.carve<float>(N);
-  float* d_d = ctx->scratch.carve<float>(N);
+  hipError_t e = scratch.reserve(AsdDevBuf::padded(row_start.size() * sizeof(int)) + AsdDevBuf::padded(row_items.size() * sizeof(int)) +
+                                 3 * AsdDevBuf::padded((size_t)N * sizeof(float)));
+  int* d_rs = scratch.carve<int>(row_start.size());
+  int* d_ri = scratch.carve<int>(row_items.size());
+  int* d_sad = scratch.carve<int>(N);
+  float* d_u = scratch.carve<float>(N);
+  float* d_d = scratch.carve<float>(N);
   if (e == hipSuccess) e = hipMemcpyAsync(d_rs, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyAsync(d_ri, row_items.data(), row_items.size() * sizeof(int), hipMemcpyHostToDevice, st);
   std::vector<int> sad(N);
   if (e == hipSuccess) {
     StereoArgs a;
     a.P = fl->pyr;
-    a.pyr_l = fl->d_pyr; a.pyr_r = fr->d_pyr;
+    a.pyr_l = views ? ctx_left->d_pyr_view : fl->d_pyr; a.pyr_r = views ? ctx_right->d_pyr_view : fr->d_pyr;
     a.kp_l = FL.d_kp; a.kp_r = FR.d_kp;
     a.desc_l = FL.d_desc; a.desc_r = FR.d_desc;
     a.row_start = d_rs; a.row_items = d_ri;
@@ -1343,8 +1371,8 @@ extern "C" int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t s
     a.maxD = mbf / mb; a.mbf = mbf;
     for (int l = 0; l < ASD_MAX_LEVELS; ++l) { a.scale[l] = ctx->scale[l]; a.inv_scale[l] = ctx->inv_scale[l]; }
     a.u_right = d_u; a.depth = d_d; a.sad = d_sad;
-    // the right pyramid was written on ctx_right's stream: make sure it is complete
-    e = hipStreamSynchronize(ctx_right->stream);
+    // the right pyramid was written on ctx_right's stream: make sure it is complete (a kept copy is: its submission was waited for)
+    if (!views) e = hipStreamSynchronize(ctx_right->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(k_stereo_match, dim3((N + 3) / 4), dim3(256), 0, st, a);
       e = hipGetLastError();

@@ -1605,13 +1605,26 @@ void matcher_free(asd_ctx* ctx) {
 
 extern "C" {
 
+static int frame_set_impl(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const float* desc, int32_t n, float min_x,
+                          float max_x, float min_y, float max_y, asd_ctx* src);
 int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const float* desc, int32_t n, float min_x,
                   float max_x, float min_y, float max_y) {
+  return frame_set_impl(ctx, slot, kps, desc, n, min_x, max_x, min_y, max_y, ctx);
+}
+// the frame's descriptors adopted from ANOTHER context's last extraction (same device): the right image of a stereo pair is extracted by
+// its own context (the reference keeps two extractors) and matched inside the left one's
+int asd_frame_set_from_ctx(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, int32_t n, float min_x, float max_x, float min_y, float max_y,
+                           asd_ctx* src) {
+  if (!ctx || !src || src->cfg.device != ctx->cfg.device) return ASD_ERR_INVALID;
+  return frame_set_impl(ctx, slot, kps, nullptr, n, min_x, max_x, min_y, max_y, src);
+}
+static int frame_set_impl(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const float* desc, int32_t n, float min_x,
+                          float max_x, float min_y, float max_y, asd_ctx* src) {
   AsdFrameSlot* F = slot_of(ctx, slot);
   if (!F || n < 0 || (n > 0 && !kps) || !(max_x > min_x) || !(max_y > min_y)) return ASD_ERR_INVALID;
   if (n > ctx->cfg.max_patches) { ctx->set_error("frame has %d keypoints, capacity %d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
-  if (!desc && !ctx->d_desc_last) { ctx->set_error("desc == NULL: no extraction has completed on this context yet"); return ASD_ERR_INVALID; }
-  if (!desc && n != ctx->last_n) { ctx->set_error("desc == NULL adopts the last extract (%d keypoints), got n=%d", ctx->last_n, n); return ASD_ERR_INVALID; }
+  if (!desc && !src->d_desc_last) { ctx->set_error("desc == NULL: no extraction has completed on the source context yet"); return ASD_ERR_INVALID; }
+  if (!desc && n != src->last_n) { ctx->set_error("desc == NULL adopts the last extract (%d keypoints), got n=%d", src->last_n, n); return ASD_ERR_INVALID; }
   (void)hipSetDevice(ctx->cfg.device);
   const size_t cap = ctx->cfg.max_patches;
   if (!F->d_desc) {
@@ -1631,7 +1644,7 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   hipStream_t st = asd_prep_stream(ctx);
   if (n > 0) {
     if (desc) ASD_HIP_CHECK(ctx, hipMemcpyAsync(F->d_desc, desc, (size_t)n * 128 * sizeof(float), hipMemcpyHostToDevice, st));
-    else ASD_HIP_CHECK(ctx, copy_rows(st, F->d_desc, ctx->d_desc_last, (size_t)n * 128 * sizeof(float)));
+    else ASD_HIP_CHECK(ctx, copy_rows(st, F->d_desc, src->d_desc_last, (size_t)n * 128 * sizeof(float)));
   }
   F->n = n;
   F->min_x = min_x; F->max_x = max_x; F->min_y = min_y; F->max_y = max_y;
@@ -1676,10 +1689,10 @@ int asd_frame_set(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, const flo
   // out of (asd_extract_submit waits for it before the worker may reuse that buffer on its own streams).
   // desc != NULL: the caller's buffer is ordinary host memory and may be freed or rewritten as soon as we return.
   ASD_HIP_CHECK(ctx, hipEventRecord(F->ev_staged, st));
-  if (!desc && n > 0) {
-    if (!ctx->ev_adopt) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_adopt, hipEventDisableTiming));
-    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_adopt, st));
-    ctx->adopt_pending = true;
+  if (!desc && n > 0) {   // (the SOURCE context's extractor must not reuse that buffer before the copy has left it)
+    if (!src->ev_adopt) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&src->ev_adopt, hipEventDisableTiming));
+    ASD_HIP_CHECK(ctx, hipEventRecord(src->ev_adopt, st));
+    src->adopt_pending = true;
   } else {
     ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
   }
@@ -2323,6 +2336,22 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
 // back on the context's stream, no host decision and no upload in between (the host's turn-around between the two submissions was
 // 50-60 us of an 0.7 ms frame, plus a 130 KB upload of gathered tables).  Same kernels and the same arithmetic as the two calls:
 // tests/test_track_chain.py holds the results to the same bits.
+// A kernel that waits on the device for a ticket another stream's kernel publishes needs the two streams on DIFFERENT hardware queues:
+// HIP multiplexes its streams onto a few AQL queues (GPU_MAX_HW_QUEUES, 4 by default, per priority level) and orders the packets of
+// streams that share one with barrier bits -- the publisher would then wait for the waiter to END.  (Found the hard way: the solver
+// stream landed on the main stream's queue in a process that had created other streams first, and every frame ran into the waiter's
+// timeout.)  So each context checks ONCE, with two trivial kernels and a 3 ms bound, that a waiter on its solver stream really is
+// released by a publisher on its main stream; if not, the context keeps the PoseOptimization kernels in stream order.
+__global__ void k_probe_wait(const unsigned* flag, unsigned value, int polls, int* out) {
+  int ok = 0;
+  for (int i = 0; i < polls; ++i) {
+    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(32);
+  }
+  *out = ok;
+}
+__global__ void k_probe_set(unsigned* flag, unsigned value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 namespace {
 int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<int()>* defer) {
   AsdFrameSlot *C = slot_of(ctx, A.slot_cur), *L = slot_of(ctx, A.slot_last);
@@ -2393,15 +2422,47 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   static const bool early = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return !(e && atoi(e) == 0); }();
   unsigned seq = 0;
   unsigned* flags = nullptr;
-  if (early) {
-    if (!ctx->stream_solve) {
-      int lo = 0, hi = 0;
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_solve, hipStreamNonBlocking, hi));
-      for (hipEvent_t& e : ctx->ev_solve) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_chain_flags, 256));
-      ASD_HIP_CHECK(ctx, hipMemset(ctx->d_chain_flags, 0, 256));
+  {
+    // every runtime request of the chain that is not a launch happens HERE, before the first kernel goes out: with a solver kernel on
+    // the device waiting for its ticket, an allocation or a function attribute in front of the launch that publishes the ticket could
+    // wait for that very kernel
+    if ((rc = pose_chain_reserve(ctx, nc)) != ASD_OK) return rc;
+    static AsdPerDeviceOnce attrs;
+    if (attrs.need(ctx->cfg.device)) {
+      const void* ks[] = {reinterpret_cast<const void*>(k_resolve2<0, 2>), reinterpret_cast<const void*>(k_resolve2<0, 4>),
+                          reinterpret_cast<const void*>(k_resolve2<1, 2>), reinterpret_cast<const void*>(k_resolve2<1, 4>)};
+      for (const void* k : ks) ASD_HIP_CHECK(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attrs.done(ctx->cfg.device);
     }
+  }
+  if (early && !ctx->stream_solve && !ctx->chain_early_off) {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // At the HIGHEST priority like the main stream.  A priority level of its own would also be a queue pool of its own (no sharing with
+    // the main stream by construction) -- measured, round 4: with any stream of the context at the MIDDLE level and a solver kernel
+    // waiting on the device, the lowest-priority ASDNet stream slows from 0.59 to 0.81 ms per forward (988 frames/s against 1170;
+    // tools/ab_quick.sh); two levels only (highest / lowest) do not show it.  So: same level, and the probe below decides.
+    static const int solve_prio_sel = [] { const char* e = getenv("ASD_SOLVE_PRIO"); return e ? atoi(e) : 2; }();   // 0 lowest, 1 middle, 2 highest (A/B)
+    ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_solve, hipStreamNonBlocking, solve_prio_sel == 2 ? hi : solve_prio_sel == 0 ? lo : lo + (hi - lo) / 2));
+    for (hipEvent_t& e : ctx->ev_solve) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_chain_flags, 512));
+    ASD_HIP_CHECK(ctx, hipMemset(ctx->d_chain_flags, 0, 512));
+    // probe: waiter on the solver stream, publisher on the main stream (flag word 64, result word 96)
+    int probe = 0;
+    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, ctx->stream_solve, ctx->d_chain_flags + 64, 1u, 2000, reinterpret_cast<int*>(ctx->d_chain_flags + 96));
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, st, ctx->d_chain_flags + 64, 1u);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream_solve));
+    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    ASD_HIP_CHECK(ctx, hipMemcpy(&probe, ctx->d_chain_flags + 96, sizeof probe, hipMemcpyDeviceToHost));
+    if (!probe) {
+      ctx->chain_early_off = true;
+      static bool said = false;
+      if (!said) { said = true; fprintf(stderr, "libasdhip: the solver stream shares a hardware queue with the context's stream (GPU_MAX_HW_QUEUES): asd_track_frame keeps its PoseOptimization kernels in stream order\n"); }
+    }
+  }
+  const bool early_now = early && ctx->stream_solve && !ctx->chain_early_off;
+  if (early_now) {
     seq = ++ctx->chain_seq;
     flags = ctx->d_chain_flags;
   }
@@ -2420,13 +2481,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     hipLaunchKernelGGL(k_project_queries, dim3(pa.up.q_blocks + kUploadTailBlocks), dim3(256), 0, st, pa);
     ASD_HIP_CHECK(ctx, hipGetLastError());
   }
-  auto resolve_launch = [&](auto kern, const Resolve2Args& a, size_t lds) -> hipError_t {
-    static AsdPerDeviceOnce attr_set;
-    if (attr_set.need(ctx->cfg.device)) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      if (e != hipSuccess) return e;
-      attr_set.done(ctx->cfg.device);
-    }
+  auto resolve_launch = [&](auto kern, const Resolve2Args& a, size_t lds) -> hipError_t {   // (attributes: set above)
     hipLaunchKernelGGL(kern, dim3(1), dim3(kResolve2Threads), lds, st, a);
     return hipGetLastError();
   };
@@ -2459,7 +2514,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     return rc;
   // (the solver kernels are enqueued here, behind the motion-model stage's search and replay in HOST order: those start at once, and
   // the solvers still have the whole search + replay to find their CU in)
-  if (early) {
+  if (early_now) {
     if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
                                  d_io1, up.dev<AsdBetweenArgs>(o_btw), ctx->stream_solve, flags, seq)) != ASD_OK)
       return rc;
@@ -2471,7 +2526,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   }
   // ---- ... and what happens between the stages, as the tail of its PoseOptimization kernel (the workgroup that has just written the
   // flags and the pose: no launch, no second read of them)
-  if (early) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[0], 0));
+  if (early_now) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[0], 0));
   else if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
                                     d_io1, up.dev<AsdBetweenArgs>(o_btw))) != ASD_OK)
     return rc;
@@ -2492,7 +2547,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   if ((rc = search_resolve(std::integral_constant<int, 1>{}, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, has_obs2 ? up.dev<uint8_t>(o_obs2) : nullptr,
                            nullptr, 0, A.nn_ratio, down.dev<int>(o_out2), down.host<int>(o_out2), flags ? flags + 32 : nullptr)) != ASD_OK)
     return rc;
-  if (early) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[1], 0));
+  if (early_now) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[1], 0));
   else if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr)) != ASD_OK)
     return rc;
   if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
@@ -2518,7 +2573,9 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       *n_inl = ne < 3 ? 0 : ne - (int)(h_io[7] + 0.5);
     };
     if (ctx->down.host<double>(o_res1)[7] < 0 || ctx->down.host<double>(o_res2)[7] < 0) {
-      ctx->set_error("asd_track_frame: a PoseOptimization kernel launched ahead of its inputs never received the claim replay's ticket");
+      ctx->set_error("asd_track_frame: a PoseOptimization kernel launched ahead of its inputs never received the claim replay's ticket (stage 1: %g, stage 2: %g; "
+                     "replay counters %d / %d candidates, %d / %d iterations)", ctx->down.host<double>(o_res1)[7], ctx->down.host<double>(o_res2)[7], h1[nc + 1], h2[nc + 1],
+                     h1[nc + 2], h2[nc + 2]);
       return ASD_ERR_HIP;
     }
     unpack(h1, ctx->down.host<double>(o_res1), p_in.data(), O.match1, O.n_matches1, O.outlier1, O.pose1, O.n_inliers1);
@@ -3205,7 +3262,10 @@ int asd_prep_async(asd_ctx* ctx, int32_t on) {
     if (!ctx->stream_prep) {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, hi));
+      // highest priority, like the main stream (a middle level slows the ASDNet stream while a solver kernel waits on the device: see
+      // the solver stream's comment in track_frame_impl)
+      static const int prep_prio_sel = [] { const char* e = getenv("ASD_PREP_PRIO"); return e ? atoi(e) : 2; }();   // 0 lowest, 1 middle, 2 highest (A/B)
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, prep_prio_sel == 2 ? hi : prep_prio_sel == 0 ? lo : lo + (hi - lo) / 2));
       ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     }
     ctx->prep_on = true;

@@ -51,6 +51,14 @@ struct asd_track_handle {
   std::vector<uint8_t> dm_ok;
   double dm_ms = 0.0;
   long dm_calls = 0;
+  // stereo mode (asd_track_set_stereo)
+  asd_ctx* ctx_r = nullptr;
+  std::vector<const uint8_t*> d_frames_r;
+  float mb = 0.f, mbf = 0.f;
+  std::vector<float> u_right, depth_r;
+  std::vector<asd_keypoint> kps_r;
+  std::vector<float> desc_sync_r;
+  int32_t prep_stereo = -1;   // stereo matches of the prepared frame
   int frames_on_host = 0;   // the frame pointers are (pinned) host memory: asd_extract_submit(device_resident = 0), the image crosses PCIe per frame
   int bank_base = 0;        // first bank row of the map the prepared frame is tracked against
   std::vector<int32_t> last_cand, cand_rows;
@@ -129,6 +137,7 @@ int asd_track_drain(asd_track_handle* h) {
     const asd_keypoint* k; const float* d; int32_t n;
     const int r = asd_extract_wait_view(h->ctx, &k, &d, &n);
     if (r != ASD_OK) rc = r;
+    if (h->ctx_r) { const int r2 = asd_extract_wait_view(h->ctx_r, &k, &d, &n); if (r2 != ASD_OK) rc = r2; }
     h->pending.pop_front();
   }
   h->prep_t = -1;
@@ -136,6 +145,16 @@ int asd_track_drain(asd_track_handle* h) {
   return rc;
 }
 void asd_track_set_frames_on_host(asd_track_handle* h, int32_t on) { if (h) h->frames_on_host = on != 0; }
+int asd_track_set_stereo(asd_track_handle* h, asd_ctx* ctx_right, const void* const* d_frames_right, float mb, float mbf) {
+  if (!h || !ctx_right || !d_frames_right || !(mb > 0) || !(mbf > 0) || !h->pending.empty()) return ASD_ERR_INVALID;
+  int rc;
+  if ((rc = asd_extract_keep_pyramid(h->ctx, 1)) != ASD_OK || (rc = asd_extract_keep_pyramid(ctx_right, 1)) != ASD_OK) return rc;
+  h->ctx_r = ctx_right;
+  h->d_frames_r.clear();
+  for (size_t i = 0; i < h->d_frames.size(); ++i) h->d_frames_r.push_back(static_cast<const uint8_t*>(d_frames_right[i]));
+  h->mb = mb; h->mbf = mbf;
+  return ASD_OK;
+}
 void asd_track_set_do_mapping(asd_track_handle* h, const asd_do_mapping_inputs* in, int32_t n_cur) {
   if (!h) return;
   h->dm = in;
@@ -177,6 +196,7 @@ void asd_track_destroy(asd_track_handle* h) {
   while (!h->pending.empty()) {  // drain: the library still owns those submissions
     const asd_keypoint* k; const float* d; int32_t n;
     (void)asd_extract_wait_view(h->ctx, &k, &d, &n);
+    if (h->ctx_r) (void)asd_extract_wait_view(h->ctx_r, &k, &d, &n);
     h->pending.pop_front();
   }
   (void)collect_ba(h, nullptr, -1);
@@ -199,6 +219,7 @@ void asd_track_destroy(asd_track_handle* h) {
 // behind whatever stage is still in flight and reads none of its results.
 static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& next) {
   asd_ctx* ctx = h->ctx;
+  asd_ctx* ctxr = h->ctx_r;   // stereo mode: the right image's extractor, its queue in lockstep with the left one's
   const int nf = (int)h->d_frames.size();
   int rc;
   auto tp = std::chrono::steady_clock::now();
@@ -207,40 +228,58 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
     h->seg_ms[i] += std::chrono::duration<double, std::milli>(now - tp).count();
     tp = now;
   };
-  const asd_keypoint* kps = nullptr;
-  int32_t n = 0;
+  auto drop_pending = [&]() -> int {
+    while (!h->pending.empty()) {
+      const asd_keypoint* k; const float* d; int32_t nn;
+      int r = asd_extract_wait_view(ctx, &k, &d, &nn);
+      if (r == ASD_OK && ctxr) r = asd_extract_wait_view(ctxr, &k, &d, &nn);
+      if (r != ASD_OK) return r;
+      h->pending.pop_front();
+    }
+    return ASD_OK;
+  };
+  const asd_keypoint *kps = nullptr, *kps_r = nullptr;
+  int32_t n = 0, n_r = 0;
   if (!h->pending.empty() && h->pending.front() == t) {
     const float* d = nullptr;
     const auto w0 = std::chrono::steady_clock::now();
     if ((rc = asd_extract_wait_view(ctx, &kps, &d, &n)) != ASD_OK) return rc;
+    if (ctxr && (rc = asd_extract_wait_view(ctxr, &kps_r, &d, &n_r)) != ASD_OK) return rc;
     h->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
     h->pending.pop_front();
   } else {
-    while (!h->pending.empty()) {
-      const asd_keypoint* k; const float* d; int32_t nn;
-      if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
-      h->pending.pop_front();
-    }
+    if ((rc = drop_pending()) != ASD_OK) return rc;
     if ((rc = (h->frames_on_host ? asd_extract : asd_extract_device)(ctx, h->d_frames[t % nf], h->W, h->H, h->W, 0, h->kps.data(), h->desc_sync.data(), &n)) != ASD_OK) return rc;
     kps = h->kps.data();
+    if (ctxr) {
+      h->kps_r.resize(1 << 13); h->desc_sync_r.resize((size_t)(1 << 13) * 128);
+      if ((rc = asd_extract_device(ctxr, h->d_frames_r[t % nf], h->W, h->H, h->W, 0, h->kps_r.data(), h->desc_sync_r.data(), &n_r)) != ASD_OK) return rc;
+      kps_r = h->kps_r.data();
+    }
   }
   const bool chain = h->fused && h->split && h->chain;
   if (chain) h->slot = (h->slot + 1) % 3; else h->slot ^= 1;
   seg(7);
   if ((rc = asd_frame_set(ctx, h->slot, kps, nullptr, n, 0.f, (float)h->W, 0.f, (float)h->H)) != ASD_OK) return rc;
   seg(0);
+  if (ctxr) {
+    // Frame::ComputeStereoMatches (Frame.cc:360-535): the right frame in a slot of the left context (its descriptors device to device
+    // from the right extractor's buffer), then the association over both submissions' own pyramids
+    const int slot_r = 3 + h->slot;
+    if ((rc = asd_frame_set_from_ctx(ctx, slot_r, kps_r, n_r, 0.f, (float)h->W, 0.f, (float)h->H, ctxr)) != ASD_OK) return rc;
+    h->u_right.resize(std::max(n, 1)); h->depth_r.resize(std::max(n, 1));
+    int32_t nm = 0;
+    if ((rc = asd_stereo_match(ctx, ctxr, h->slot, slot_r, h->mb, h->mbf, h->u_right.data(), h->depth_r.data(), &nm)) != ASD_OK) return rc;
+    h->prep_stereo = nm;
+    seg(4);
+  }
   if (h->lookahead > 0) {
     bool same = h->pending.size() <= next.size();
     for (size_t i = 0; same && i < h->pending.size(); ++i) same = h->pending[i] == next[i];
-    if (!same) {
-      while (!h->pending.empty()) {
-        const asd_keypoint* k; const float* d; int32_t nn;
-        if ((rc = asd_extract_wait_view(ctx, &k, &d, &nn)) != ASD_OK) return rc;
-        h->pending.pop_front();
-      }
-    }
+    if (!same && (rc = drop_pending()) != ASD_OK) return rc;
     for (size_t i = h->pending.size(); i < next.size(); ++i) {
       if ((rc = asd_extract_submit(ctx, h->d_frames[next[i] % nf], h->frames_on_host ? 0 : 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
+      if (ctxr && (rc = asd_extract_submit(ctxr, h->d_frames_r[next[i] % nf], 1, h->W, h->H, h->W, 0)) != ASD_OK) return rc;
       h->pending.push_back(next[i]);
     }
   }
@@ -457,6 +496,7 @@ static int track_step_chain(asd_track_handle* h, int t, bool do_ba, const std::v
   h->prep_t = -1;
   memset(st, 0, sizeof *st);
   st->n_kp = n;
+  if (h->ctx_r) { st->stereo_matched = h->prep_stereo; st->has_stereo = 1; }
   const bool had_last = h->have_last;
   if (had_last) {
     h->m1.assign(n, -1); h->m2.assign(n, -1);

@@ -13,6 +13,7 @@ typedef struct asd_track_stats {
   int32_t n_kp, m1, m2, inliers;
   double ba_chi2;
   int32_t has_m1, has_m2, has_inliers, has_ba;
+  int32_t stereo_matched, has_stereo;   /* stereo mode: Frame::ComputeStereoMatches' surviving matches of the frame */
 } asd_track_stats;
 
 typedef struct asd_track_handle asd_track_handle;
@@ -34,6 +35,11 @@ void asd_track_set_chain(asd_track_handle* h, int32_t on);
 /* 1 = the frame pointers given to asd_track_create are page-locked HOST memory: every frame's image goes host -> device inside the step
  * (asd_extract_submit(device_resident = 0)), as kitti.cc:116-155 hands images over; 0 (default) = frames resident in HBM */
 void asd_track_set_frames_on_host(asd_track_handle* h, int32_t on);
+/* Stereo mode (BASELINE configs[3]): ctx_right = the right image's extractor context (same device, weights loaded), d_frames_right =
+ * the right images resident in HBM (as many as the left ones); every frame is extracted on both contexts (both read-ahead queues kept
+ * full), the right frame goes into a slot of the left context (asd_frame_set_from_ctx) and Frame::ComputeStereoMatches (Frame.cc:360-535)
+ * runs as asd_stereo_match during frame construction, before the left frame is tracked.  mb = baseline (m), mbf = baseline * fx. */
+int asd_track_set_stereo(asd_track_handle* h, asd_ctx* ctx_right, const void* const* d_frames_right, float mb, float mbf);
 /* waits for every read-ahead extraction this handle has outstanding and forgets its last frame: another handle on the same context may
  * then run (the next asd_track_run of this one starts like a first frame) */
 int asd_track_drain(asd_track_handle* h);

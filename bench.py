@@ -370,7 +370,8 @@ class asd_track_stats(__import__("ctypes").Structure):
     _fields_ = [("n_kp", __import__("ctypes").c_int32), ("m1", __import__("ctypes").c_int32), ("m2", __import__("ctypes").c_int32),
                 ("inliers", __import__("ctypes").c_int32), ("ba_chi2", __import__("ctypes").c_double),
                 ("has_m1", __import__("ctypes").c_int32), ("has_m2", __import__("ctypes").c_int32),
-                ("has_inliers", __import__("ctypes").c_int32), ("has_ba", __import__("ctypes").c_int32)]
+                ("has_inliers", __import__("ctypes").c_int32), ("has_ba", __import__("ctypes").c_int32),
+                ("stereo_matched", __import__("ctypes").c_int32), ("has_stereo", __import__("ctypes").c_int32)]
 
 
 class asd_do_mapping_inputs(__import__("ctypes").Structure):
@@ -444,7 +445,9 @@ class NativeHost:
     """The same tracking step as track_step(), run by C++ host code (asd-slam_amd/host/track_loop.cpp -> libasdtrack.so)
     over the C ABI: the reference's host side is C++, the Python loop costs ~0.25 ms of a ~2 ms step."""
 
-    def __init__(self, pkg, be, wl, pipeline, cam=None, frames_on_host=False):
+    def __init__(self, pkg, be, wl, pipeline, cam=None, frames_on_host=False, size=None, drift=None, stereo=None):
+        """size = (W, H) of the frames (default KITTI 00-02); drift = (cx, cy, z, dx, dy) of the stand-in map's motion (default: the mono stream's);
+        stereo = (right context, right frames resident in HBM, mb, mbf): BASELINE configs[3]"""
         import ctypes as C
         self.C = C
         path = os.path.join(ROOT, "asd-slam_amd", "libasdtrack.so")
@@ -463,6 +466,8 @@ class NativeHost:
                                         k[3].ctypes.data, k[4].ctypes.data, k[5].ctypes.data, k[6].ctypes.data,
                                         (C.c_double * 4)(*[float(x) for x in ba["K"]]), 5, 10)
         d_frames, W, H, K32 = (be.host_frames() if frames_on_host else be.d_frames), 1241, 376, wl.K32
+        if size is not None:
+            W, H = size
         if cam is not None:   # a sequence of another camera class (image size + intrinsics)
             d_frames, (W, H, K) = be.d_cam_frames[cam], KITTI_CAM[cam]
             K32 = np.array(K, np.float32)
@@ -480,6 +485,13 @@ class NativeHost:
         self.lib.asd_track_set_split(self.h, int(getattr(be, "split", True)))
         self.lib.asd_track_set_chain(self.h, int(getattr(be, "chain", True)))
         self.lib.asd_track_set_frames_on_host(self.h, int(frames_on_host))
+        if drift is not None:
+            self.lib.asd_track_set_drift(self.h, *[C.c_float(v) for v in drift])
+        if stereo is not None:
+            ctx_r, frames_r, mb, mbf = stereo
+            fr = (C.c_void_p * len(frames_r))(*[f.value for f in frames_r])
+            if self.lib.asd_track_set_stereo(self.h, ctx_r, fr, C.c_float(mb), C.c_float(mbf)) != 0:
+                raise RuntimeError("asd_track_set_stereo failed")
         self.be = be
 
     def times(self):
@@ -500,6 +512,8 @@ class NativeHost:
                 out[k] = int(getattr(st, k))
         if st.has_ba:
             out["ba_chi2"] = float(st.ba_chi2)
+        if st.has_stereo:
+            out["stereo_matched"] = int(st.stereo_matched)
         return out
 
     def close(self):
@@ -778,6 +792,18 @@ class StereoBackend:
         self.slot = 0
         self.native = None
         self.stereo_matched = 0
+        self.d_frames = self.dL   # (NativeHost: the left frames; the right ones go in through asd_track_set_stereo)
+        self.fused = True         # the stages as asd_track_motion_model / asd_track_local_points in the Python loop, asd_track_frame in the C++ one
+        self.async_ba = False
+        self.split = True
+        self.chain = True
+
+    def native_host(self, pkg, pipeline=True):
+        """the C++ host loop in stereo mode: both extractors read ahead, asd_stereo_match during frame construction"""
+        W, H, mb = EUROC["w"], EUROC["h"], EUROC["mb"]
+        nh = NativeHost(pkg, self, self.wl, pipeline=pipeline, size=(W, H), drift=(W / 2 + 16.0, H / 2.0, 1.003, 3.0, 0.2),
+                        stereo=(self.R.ctx, self.dR, mb, mb * EUROC["K"][0]))
+        return nh
 
     def image(self, t):
         return t % len(self.dL)
@@ -817,6 +843,12 @@ class StereoBackend:
     def match_points(self, cur, n_cur, fr, desc, sel, occ, th, ratio):
         return self.L.match_project_points_bank(cur, n_cur, fr[0], fr[1], fr[2], fr[3], self.rows[sel], occ, th, ratio)
 
+    def track_motion_model(self, cur, last, n_cur, has, Xw, T, K, th, pose0):
+        return self.L.track_motion_model(cur, last, n_cur, has, Xw, self.rows[:len(has)], T, K, th, pose0, True)
+
+    def track_local_points(self, cur, n_cur, Xw, normal, mind, maxd, sel, occ, cur_Xw, th, ratio, T, K, pose0):
+        return self.L.track_local_points(cur, n_cur, Xw, normal, mind, maxd, self.rows[sel], T, K, occ, cur_Xw, th, ratio, pose0)
+
     def pose7_to_tcw(self, pose):
         return self.L.pose7_to_tcw(pose)
 
@@ -828,6 +860,15 @@ class StereoBackend:
         self.R.close()
 
 
+def stereo_steps(be, wl, t0, n, last):
+    """n frames through the stereo backend: the C++ host (be.native) or the Python loop; per-frame stats carry stereo_matched"""
+    if be.native is not None:
+        return None, be.native.run(t0, n, True)
+    last, stats = run_steps_python(be, wl, t0, n, last)
+    stats["stereo_matched"] = int(be.stereo_matched)
+    return last, stats
+
+
 def run_euroc_stereo(args, pkg, dist, rank, world, device):
     """BASELINE configs[3] (secondary bench line): stereo association + the tracking chain + LocalBA at the EuRoC image size.
     What the reference would run in a stereo build and what it does not: the stereo optimiser edges
@@ -835,15 +876,22 @@ def run_euroc_stereo(args, pkg, dist, rank, world, device):
     empty vectors), so PoseOptimization / LocalBA run on monocular edges exactly as in the mono configs."""
     wl = EurocWorkload(pkg.synth, seed_offset=rank)
     be = StereoBackend(pkg, wl, device)
-    last, _ = run_steps_python(be, wl, 0, args.warmup, None)
+    if args.host == "cxx":
+        be.native = be.native_host(pkg, pipeline=not args.no_pipeline)
+    be.L.local_ba(wl.ba)                     # untimed: the solver's buffers come into being with the first run
+    warm = max(args.warmup, PRIME_FRAMES)
+    last, _ = stereo_steps(be, wl, 0, warm, None)
     be.L.sync(); be.R.sync(); device_sync(device); dist.barrier()
     t0 = time.perf_counter()
-    last, stats = run_steps_python(be, wl, args.warmup, args.steps, last)
+    last, stats = stereo_steps(be, wl, warm, args.steps, last)
     be.L.sync(); be.R.sync(); device_sync(device); dist.barrier()
     dt = time.perf_counter() - t0
     tmax = dist.max(dt)
     total = dist.sum(float(args.steps))
-    stats["stereo_matched"] = int(be.stereo_matched)
+    if be.native is not None:
+        be.native.lib.asd_track_drain(be.native.h)
+        be.native.close()
+        be.native = None
     be.close()
     if rank == 0:
         print(json.dumps({
@@ -856,7 +904,9 @@ def run_euroc_stereo(args, pkg, dist, rank, world, device):
                                    "frame through SearchByProjection(frame) + PoseOptimization + isInFrustum + SearchByProjection(map) + "
                                    "PoseOptimization, LocalBA every 15 frames",
                        "not_included": "stereo optimiser edges: dead code in the reference (Optimizer.cc:266-269, 521-528), mono edges only",
-                       "host": "Python loop (ctypes), sequential extraction (no read-ahead)", "kf_interval": KF_INTERVAL,
+                       "host": ("C++ host loop over the C ABI (libasdtrack, stereo mode): both extractors read ahead, asd_stereo_match during frame "
+                                "construction on the second stream, asd_track_frame per frame" if args.host == "cxx" else
+                                "Python loop (ctypes), sequential extraction (no read-ahead)"), "kf_interval": KF_INTERVAL,
                        "parallelism": f"replicas x{world}"},
             "last_step": stats}))
     dist.close()

@@ -532,6 +532,16 @@ int asd_svd4_null(asd_ctx* ctx, int32_t n, const float* A, float* v);
  * call this before the next extraction overwrites either pyramid.  u_right[N] / depth[N] = mvuRight / mvDepth (-1 =
  * no stereo match); *n_matched = matches that survive the 1.5 * 1.4 * median SAD filter (:517-531).
  * mb = baseline in metres, mbf = baseline * fx. */
+/* asd_frame_set(desc == NULL) with the descriptors of src's last extraction instead of ctx's own (both contexts on one device): the
+ * right frame of a stereo pair, extracted by its own context, put into a slot of the left one for asd_stereo_match. */
+int asd_frame_set_from_ctx(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, int32_t n, float min_x, float max_x, float min_y,
+                           float max_y, asd_ctx* src);
+/* With the pipelined extractor (asd_extract_submit / asd_extract_wait*) the shared pyramid of a context holds a LATER frame by the
+ * time both extractions of a stereo pair have been waited for: asd_extract_keep_pyramid(ctx, 1) makes every submission keep its own
+ * copy of its pyramid (one device-to-device copy in the front half), and asd_stereo_match then reads the copies of the submissions
+ * waited for last on the two contexts -- valid as long as their descriptors are (two further submissions).  Inside an
+ * asd_prep_async bracket of ctx_left the call runs on that context's second stream, beside tracking stages in flight. */
+int asd_extract_keep_pyramid(asd_ctx* ctx, int32_t on);
 int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t slot_left, int32_t slot_right, float mb, float mbf,
                      float* u_right, float* depth, int32_t* n_matched);
 

@@ -62,3 +62,32 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split):
     finally:
         cx.close()
     assert whole == ref[-1]
+
+
+@pytest.mark.gpu
+def test_cxx_stereo_host_equals_python_stereo_host(pkg):
+    """BASELINE configs[3] through the product's host path: libasdtrack in stereo mode (both extractors reading ahead, the right frame
+    adopted device to device, asd_stereo_match on the kept pyramids during frame construction, one submission per frame) against the
+    Python loop with sequential extractions: the same per-frame statistics, stereo matches included"""
+    bench = _bench()
+    wl = bench.EurocWorkload(pkg.synth)
+    n = bench.KF_INTERVAL + 3
+    py = bench.StereoBackend(pkg, wl, 0)
+    try:
+        last, ref = None, []
+        for t in range(n):
+            last, st = bench.stereo_steps(py, wl, t, 1, last)
+            ref.append(st)
+    finally:
+        py.close()
+    cx = bench.StereoBackend(pkg, wl, 0)
+    cx.native = cx.native_host(pkg)
+    try:
+        got = [cx.native.run(t, 1, True) for t in range(n)]
+        cx.native.lib.asd_track_drain(cx.native.h)
+        cx.native.close()
+        cx.native = None
+    finally:
+        cx.close()
+    assert got == ref
+    assert got[-1]["stereo_matched"] > 300 and got[-1]["m1"] > 300 and any("ba_chi2" in s for s in got)

@@ -1,10 +1,10 @@
 # the round-end checks in one gpurun call: GPU tests, smoke, default bench (gpurun_out/r4b)
 set -e
 O=gpurun_out/r4b; mkdir -p $O
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=5 > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -3 $O/tests.log
 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-python3 bench.py > $O/bench.json 2> $O/bench.err
+timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
 python3 - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r4b/bench.json').read().strip().splitlines()[-1])
