@@ -2419,7 +2419,11 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   // ahead, the first is resident and waiting on the claim replay's ticket long before the replay is through, the second queues behind it
   // and gets its CU while the local-map search runs.  Order between the streams: the tickets (k_resolve2 -> k_pose_opt) one way, an
   // event per solver kernel the other (the main stream waits for it before k_frustum_queries / before the chain's end is recorded).
-  static const bool early = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return !(e && atoi(e) == 0); }();
+  // OFF by default (ASD_CHAIN_EARLY=1 turns it on).  Measured, round 4 (tools/ab_early.sh, tools/ab_quick.sh): on the device's own clock
+  // the chain from the first replay to the second solver's end shrinks from 579 to 477 us per frame -- the two 40-55 us waits for a CU are
+  // gone -- but end to end the step is unchanged (1146-1231 frames/s with it, 1175-1201 without, box to box): the host's turn-around and
+  // the extractor take up the slack.  A kernel that waits on the device is not worth keeping in the default path for nothing.
+  static const bool early = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return e && atoi(e) != 0; }();
   unsigned seq = 0;
   unsigned* flags = nullptr;
   {
