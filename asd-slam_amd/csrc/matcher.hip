@@ -741,9 +741,11 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
 #define OUT(i, v) do { const int v_ = (v); a.match_cur[i] = v_; if (a.mirror) a.mirror[i] = v_; } while (0)
 #define CNT(i, v) do { const int v_ = (v); a.n_matches[i] = v_; if (a.mirror) a.mirror[a.n_cur + (i)] = v_; } while (0)
   constexpr int NT = kResolve2Threads;
+  __builtin_amdgcn_s_setprio(3);   // the tracking thread's critical path, on a CU it shares with ASDNet workgroups: issue its waves first
   extern __shared__ unsigned lds_c[];
   unsigned* claim0 = lds_c;
-  unsigned* claim[2] = {claim0, claim0 + a.n_cur};
+  // the two claim tables are lds_c[0 .. n_cur) and lds_c[n_cur .. 2 n_cur), always addressed as lds_c[offset + j]: a table POINTER picked
+  // per iteration loses its address space, and the compiler then reads the claims with flat loads (several times an LDS read's latency)
   float* ang = reinterpret_cast<float*>(claim0 + 2 * a.n_cur);                       // KIND 0: the current frame's keypoint angles
   uint8_t* octv = reinterpret_cast<uint8_t*>(claim0 + 2 * a.n_cur);                  // KIND 1: their octaves
   char* tail = reinterpret_cast<char*>(lds_c) + resolve2_fixed_lds(KIND, a.n_cur);
@@ -812,45 +814,80 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
   const int max_it = a.nq + 2;
   int it = 0, f_cur = 0;   // f_cur = it % 3
   unsigned long long ts_it0 = ts1;
+  // the claims an iteration starts from are read at the END of the one before, in the same LDS round trip as its "anything changed" flag
+  // (a dependent chain of LDS round trips is what an iteration costs beside ASDNet workgroups that keep the CU's LDS queues full)
+  constexpr int NCL = HD;   // (KIND 1 only)
+  unsigned cl[QPT][NCL];
+  auto load_claims = [&](int rdt) {
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      {
+#pragma unroll
+        for (int i = 0; i < NCL; ++i) cl[k][i] = (i < cnt[k]) ? lds_c[rdt + top_j(k, i)] : 0u;
+      }
+    }
+  };
+  if (KIND == 0) {   // every map point posts at the head of its list
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) if (curj[k] >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[curj[k]], (unsigned)(t + k * NT));
+  } else load_claims(0);
+  int ph_work = 0, ph_bar = 0;   // thread 0's view (10 ns units): loop top -> barrier, barrier -> verdict
   for (;; ++it) {
+    const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
     // read the claims of iteration it-1 (table it & 1, tag it), post this iteration's picks into the other table (tag it+1)
-    const unsigned* rd = claim[it & 1];
-    unsigned* wr = claim[(it + 1) & 1];
+    const int rd = (it & 1) ? a.n_cur : 0, wr = a.n_cur - rd;   // offsets into lds_c
     const unsigned tag_rd = (unsigned)(0xffff - it), tag_wr = (unsigned)(0xffff - (it + 1));
     auto held = [&](unsigned c, int q) { return (c >> 16) == tag_rd && (c & 0xffffu) < (unsigned)q; };   // an earlier map point holds it
     int changed = 0;
     if (KIND == 0) {
-      unsigned c0[QPT];
+      // Frame-to-frame search keeps the BEST candidate only, so a map point's position in its list only ever moves forward and a keypoint's
+      // holder only ever gets replaced by an earlier map point: the replay's fixed point is unique and any order of (post, look, step
+      // forward) reaches it.  ONE claim table then (lds_c[0 .. n_cur), plain map point indices, atomicMin, never cleared) and no barrier
+      // between looks: a round is kPolls looks at the own claim -- one LDS read and a compare for a map point that still holds its
+      // keypoint, a walk and a post for a displaced one -- and the rounds end with the first one in which nobody moved (the table was then
+      // static for a whole round and every map point has checked itself against it).  The Jacobi form this replaces paid two LDS round
+      // trips, a barrier and a re-post of all 2000 claims per link of the longest displacement chain (13 on the bench stream).
+      constexpr int kPolls = 4;
+      auto peek = [&](int j) { return __hip_atomic_load(&lds_c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+      for (int poll = 0; poll < kPolls; ++poll) {
+        unsigned holder[QPT];   // all looks of the thread in one round trip
 #pragma unroll
-      for (int k = 0; k < QPT; ++k) c0[k] = curj[k] >= 0 ? rd[curj[k]] : 0u;
+        for (int k = 0; k < QPT; ++k) holder[k] = curj[k] >= 0 ? peek(curj[k]) : 0xffffffffu;
 #pragma unroll
-      for (int k = 0; k < QPT; ++k) {
-        const int q = t + k * NT;
-        if (curj[k] >= 0 && held(c0[k], q)) {   // step forward, four entries per round trip
+        for (int k = 0; k < QPT; ++k) {
+          const int q = t + k * NT;
+          if (!(holder[k] < (unsigned)q)) continue;
+          // displaced: step forward, kStep entries per PAIR of LDS round trips (unconditional loads from clamped addresses, selected
+          // afterwards -- as conditional loads the compiler serialised them, one round trip per entry)
+          constexpr int kStep = 4;
           int j = -1;
-          while (j < 0 && ptr[k] + 1 < cnt[k]) {
-            int jj[4]; unsigned cc[4];
+          if (n_stage == total) {
+            while (j < 0 && ptr[k] + 1 < cnt[k]) {
+              int jj[kStep]; unsigned cc[kStep];
+              const int p0 = ptr[k] + 1, lastp = cnt[k] - 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) jj[i] = ptr[k] + 1 + i < cnt[k] ? (ptr[k] + 1 + i < kTop ? (int)top_j(k, min(ptr[k] + 1 + i, kTop - 1)) : list_j(k, ptr[k] + 1 + i)) : -1;
+              for (int i = 0; i < kStep; ++i) jj[i] = (int)sidx[qoff[k] + min(p0 + i, lastp)];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cc[i] = jj[i] >= 0 ? rd[jj[i]] : 0u;
-            int adv = 4;
+              for (int i = 0; i < kStep; ++i) cc[i] = peek(jj[i]);
+              int adv = min(kStep, lastp - p0 + 1);
 #pragma unroll
-            for (int i = 3; i >= 0; --i) if (jj[i] >= 0 && !held(cc[i], q)) { j = jj[i]; adv = i + 1; }
-            ptr[k] += adv;
+              for (int i = kStep - 1; i >= 0; --i) if (p0 + i <= lastp && !(cc[i] < (unsigned)q)) { j = jj[i]; adv = i + 1; }
+              ptr[k] += adv;
+            }
+          } else {   // lists longer than the LDS copy: entry by entry, global beyond it
+            while (j < 0 && ptr[k] + 1 < cnt[k]) {
+              const int cand = list_j(k, ++ptr[k]);
+              if (!(peek(cand) < (unsigned)q)) j = cand;
+            }
           }
           curj[k] = j;
+          changed = 1;
+          if (j >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[j], (unsigned)q);
         }
-        changed |= curj[k] != pick[k];
-        pick[k] = curj[k];
-        if (curj[k] >= 0 && (posmask >> k & 1)) atomicMin(&wr[curj[k]], (tag_wr << 16) | (unsigned)q);
       }
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) pick[k] = curj[k];
     } else {
-      unsigned cl[QPT][HD];
-#pragma unroll
-      for (int k = 0; k < QPT; ++k)
-#pragma unroll
-        for (int i = 0; i < HD; ++i) cl[k][i] = (i < cnt[k]) ? rd[top_j(k, i)] : 0u;
       int p[QPT], p2[QPT], i1[QPT], i2[QPT];
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
@@ -867,7 +904,7 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
         if (found < 2 && cnt[k] > HD) {   // the heads did not settle it: on through the list (LDS copy, global beyond it)
           for (int i = HD; i < cnt[k] && found < 2; ++i) {
             const int j = list_j(k, i);
-            if (held(rd[j], q)) continue;
+            if (held(lds_c[rd + j], q)) continue;
             if (found == 0) { p[k] = j; i1[k] = i; }
             else { p2[k] = j; i2[k] = i; }
             ++found;
@@ -877,7 +914,9 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
       // ORBmatcher.cc:106-112 (bestDist2 starts at 256, bestLevel2 at -1): distances and levels of the two survivors, all queries together
       float best[QPT], best2[QPT];
       int lvl[QPT], lvl2[QPT];
-      auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; return pos < n_stage ? sdist[pos] : a.dist[pos]; };
+      // (not `pos < n_stage ? sdist[pos] : a.dist[pos]`: the compiler turns that, and every plain if/else form of it, into ONE flat load
+      // through a selected pointer; the empty asm pins the LDS read in front of the branch)
+      auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; float d = sdist[min(pos, n_stage - 1)]; asm volatile("" : "+v"(d)); if (n_stage != total && pos >= n_stage) d = a.dist[pos]; return d; };
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
         best[k] = p[k] >= 0 ? dist_at(k, i1[k]) : 0.f;
@@ -892,7 +931,7 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
         if (pk >= 0 && (!(best[k] <= TH_HIGH) || (lvl[k] == lvl2[k] && best[k] > a.nn_ratio * best2[k]))) pk = -1;
         changed |= pk != pick[k];
         pick[k] = pk;
-        if (pk >= 0 && (posmask >> k & 1)) atomicMin(&wr[pk], (tag_wr << 16) | (unsigned)q);
+        if (pk >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[wr + pk], (tag_wr << 16) | (unsigned)q);
       }
     }
     // "did any pick change" with ONE barrier (__syncthreads_or is three and a cross-lane reduction): a changed pick sets this
@@ -900,9 +939,12 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
     if (changed) flag[f_cur] = 1;
     const int f_next = f_cur == 2 ? 0 : f_cur + 1;
     if (t == 0) flag[f_next] = 0;
+    const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
     asd_syncthreads();
-    const bool more = flag[f_cur] != 0 && it < max_it;
+    if (KIND == 1) load_claims(wr);       // the next iteration's claims ...
+    const bool more = flag[f_cur] != 0 && it < max_it;   // ... and this one's verdict: one round trip
     f_cur = f_next;
+    { const unsigned long long p2 = __builtin_amdgcn_s_memrealtime(); ph_work += (int)(p1 - p0); ph_bar += (int)(p2 - p1); }
     if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
     if (!more) break;
   }
@@ -953,7 +995,7 @@ __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
   if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, total); CNT(2, it + 1);
     // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs, the first iteration -- in units of 10 ns
     CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
-    CNT(7, 0); CNT(8, 0); CNT(9, (int)(ts0 & 0x7fffffffull)); CNT(10, (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffull)); }
+    CNT(7, ph_work); CNT(8, ph_bar); CNT(9, (int)(ts0 & 0x7fffffffull)); CNT(10, (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffull)); }
   publish();
 }
 #undef OUT
@@ -2605,8 +2647,8 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       tl[4] += d(st[4], st[5]); tl[5] += d(st[5], st[6]); tl[6] += d(st[6], st[7]); tl[7] += d(st[0], st[7]);
       if (++calls % 200 == 0) {
         for (int k = 0; k < 2; ++k)
-          fprintf(stderr, "[track_frame resolve kind %d] %.1f iterations, %d candidates; staging %.1f us, iterations %.1f us (the first %.1f), outputs %.1f us\n", k,
-                  acc[k][0] / calls, hh[k][nc + 1], acc[k][1] / calls, acc[k][2] / calls, acc[k][4] / calls, acc[k][3] / calls);
+          fprintf(stderr, "[track_frame resolve kind %d] %.1f iterations, %d candidates; staging %.1f us, iterations %.1f us (the first %.1f), outputs %.1f us; last frame: thread 0 work %.1f us, barrier + verdict %.1f us\n", k,
+                  acc[k][0] / calls, hh[k][nc + 1], acc[k][1] / calls, acc[k][2] / calls, acc[k][4] / calls, acc[k][3] / calls, 0.01 * hh[k][nc + 7], 0.01 * hh[k][nc + 8]);
         fprintf(stderr, "[track_frame device clock] resolve1 %.1f | -> pose1 %.1f | pose1 %.1f | -> (frustum, search) resolve2 %.1f | resolve2 %.1f | -> pose2 %.1f | pose2 %.1f | resolve1 start -> pose2 end %.1f us\n",
                 tl[0] / calls, tl[1] / calls, tl[2] / calls, tl[3] / calls, tl[4] / calls, tl[5] / calls, tl[6] / calls, tl[7] / calls);
       }
