@@ -1,13 +1,23 @@
-# One gpurun call that produces every artifact of profiles/r03_* (copy them from gpurun_out/r03p afterwards).
+# One gpurun call that produces every artifact of profiles/r04_* (copy them from gpurun_out/r04p afterwards).
 # Every step must succeed: a non-zero exit of the profiled process fails the script (round 2 tolerated an exit-time segfault here
 # with `|| echo`; its cause -- the CU-masked stream, profiles/r03_teardown_diagnostics.txt -- is gone).
 set -e
-O=gpurun_out/r03p; mkdir -p $O
+O=gpurun_out/r04p; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --cpu-frames 0 --no-lane-variant > $O/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --cpu-frames 0 --no-lane-variant --no-h2d-variant --no-do-mapping-variant > $O/bench_prof.log 2>&1
 test -s $O/prof/bench_kernel_stats.csv
 python3 tools/timeline.py $O/prof > $O/timeline.txt
+python3 tools/extractor_timeline.py $O/prof > $O/extractor_timeline.txt
+python3 tools/ba_segment.py $O/prof > $O/ba_segment.txt
+# the tracking chain on the device clock (stamps of the kernels themselves) and the replay's phases
+ASD_TIMING=1 python3 bench.py --cpu-frames 0 --no-lane-variant --no-h2d-variant --no-do-mapping-variant --steps 400 --warmup 60 2> $O/chain_clock.err > /dev/null
+grep -E "track_frame (resolve|device)" $O/chain_clock.err | tail -3 > $O/chain_clock.txt
+# BASELINE configs[3] (stereo) through the C++ host, the driver's K = 20 / W = 5 command, the per-keyframe stage
+python3 bench.py --workload euroc-stereo --steps 300 --warmup 45 > $O/bench_euroc_stereo.json 2> $O/bench_euroc_stereo.err
+python3 bench.py --steps 20 --warmup 5 --cpu-frames 0 > $O/bench_k20.json 2> $O/bench_k20.err
+python3 tools/kf_times.py --reps 12 > $O/kf_ops.json 2> $O/kf_ops.err
+python3 bench.py --sequences 11 --seq-scale 0.05 > $O/sequences_1gpu.json 2> $O/sequences_1gpu.err
 find $O/prof -name "*kernel_trace.csv" -delete
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 tools/time_asdnet.py 2000 3 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 tools/time_asdnet.py 2000 3 > /dev/null 2>&1
