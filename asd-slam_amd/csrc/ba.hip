@@ -38,6 +38,7 @@
 #include <condition_variable>
 
 #include "ctx.h"
+#include "resolve2.h"
 #include "se3.h"
 
 namespace {
@@ -236,6 +237,8 @@ struct PoseOptArgs {
   // The wait is bounded (kPoseWaitPolls): a flag that never comes ends the kernel with io[7] = -1 instead of hanging the device.
   const unsigned* wait_flag;
   unsigned wait_value;
+  unsigned* done_flag;             // null, or the kernel's own ticket: set to wait_value behind its last store (k_frustum_queries of the
+                                   // local-map stage waits for the motion-model stage's solver this way, asd_track_frame)
   const AsdBetweenArgs* between;   // device memory or null.  asd_track_frame, motion-model stage: the kernel ends with the work between the
                                    // two stages (needs io_dev).  A pointer, not a member: a larger argument block costs the kernel a scratch copy
   double isg_tab[16];   // MODE 2: the distinct information values ...
@@ -249,7 +252,7 @@ struct PoseOptArgs {
 #define ASD_POSE_THREADS 512
 #endif
 constexpr int kPoseThreads = ASD_POSE_THREADS, kPoseWaves = kPoseThreads / 64;
-constexpr int kPoseWaitPolls = 200000;   // x (one L2 round trip + s_sleep 32 ~ 1 us): ~0.2 s, then the kernel gives up
+constexpr int kPoseWaitPolls = kAsdTicketPolls;   // x (one L2 round trip + s_sleep 32 ~ 1 us): ~0.2 s, then the kernel gives up
 struct PoseShared {
   Pose7 T, T0, Tbak, Teval;
   double H[36], b[6], x[6];
@@ -509,20 +512,12 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
 // MODE (the EdgeStore form) is a template parameter, not a run-time switch: with a pointer that may be LDS or global the
 // compiler falls back to FLAT loads, whose latency dominated the edge loop.
 template <int MODE>
-__global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
-  // no private copy of the argument block: a copy that is indexed at run time (pose0[t], isg_tab[t]) lives in scratch memory, and
-  // every a.fx / a.n of the passes then is a scratch load
-  const PoseOptArgs& a = a_in;
+__device__ __forceinline__ void pose_opt_body(const PoseOptArgs& a) {
+  // (a = the kernel's argument block itself.  No private copy of it: a copy that is indexed at run time (pose0[t], isg_tab[t]) lives in
+  // scratch memory, and every a.fx / a.n of the passes then is a scratch load)
   if (a.wait_flag) {   // resident ahead of its inputs: one lane polls, everybody acquires
     __shared__ int wait_ok;
-    if (threadIdx.x == 0) {
-      int ok = 0;
-      for (int i = 0; i < kPoseWaitPolls; ++i) {
-        if ((int)(__hip_atomic_load(a.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait_value) >= 0) { ok = 1; break; }
-        __builtin_amdgcn_s_sleep(32);
-      }
-      wait_ok = ok;
-    }
+    if (threadIdx.x == 0) wait_ok = asd_ticket_wait(a.wait_flag, a.wait_value) ? 1 : 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asd_syncthreads();
@@ -534,6 +529,17 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz, device-wide: comparable with other kernels' stamps (ASD_TIMING)
+  // the kernel's own ticket, behind its last store (producer form of MI355X_MICROARCH.md: stores drained, barrier, release, store)
+  auto publish = [&]() __attribute__((always_inline)) {
+    if (!a.done_flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.done_flag, a.wait_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
   int ne = a.n;   // edge count (fused chains: made on the device below, a.n is then only the capacity)
   constexpr int kGatherChunks = 9;   // 150 KB / 35 B per edge: at most 4388 keypoints reach the LDS form
   __shared__ int g_cnt[kGatherChunks * kPoseWaves + 1];
@@ -577,6 +583,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       asd_syncthreads();
       asd_between_body(*a.between, threadIdx.x, kPoseThreads);
     }
+    publish();
     return;
   }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
@@ -871,6 +878,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       asd_syncthreads();
       asd_between_body(*a.between, t, kPoseThreads);
     }
+    publish();
     return;
   }
   // outlier flags to the (pinned host) io block, eight per 8-byte store
@@ -881,6 +889,33 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) {
       if (8 * i + k < ne) w |= (unsigned long long)outl[8 * i + k] << (8 * k);
     og8[i] = w;
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) { pose_opt_body<MODE>(a_in); }
+
+// The claim replay and PoseOptimization of a tracking stage as ONE workgroup (asd_track_frame): resolve2_body on the solver's 512 threads,
+// then the solver (gather form: its edges come from the match table the replay has just written).  Stand-alone, k_pose_opt needs most of a
+// CU -- 8 waves x 221 registers, 70 KB of LDS -- and waited 35-50 us per launch for one beside the extractor's ASDNet workgroups, which
+// take every slot a finished workgroup frees (device-clock stamps, profiles/r04_chain_device_clock.txt); here it inherits the replay's.
+template <int KIND, int QPT>
+__global__ __launch_bounds__(kPoseThreads) void k_resolve_pose(Resolve2Args r, PoseOptArgs a_in) {
+  if (a_in.wait_flag) {   // resident ahead of the search that makes its lists (its ticket: k_window_search's last workgroup): one lane polls
+    __shared__ int search_ok;
+    if (threadIdx.x == 0) search_ok = asd_ticket_wait(a_in.wait_flag, a_in.wait_value) ? 1 : 0;
+    asd_syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!search_ok) {   // report, touch nothing else (nothing is published: a kernel waiting for this one reports the same way)
+      if (threadIdx.x == 0) { a_in.io[7] = -1.0; if (a_in.io_dev) a_in.io_dev[7] = -1.0; }
+      return;
+    }
+  }
+  resolve2_body<KIND, QPT, kPoseThreads>(r);
+  // the match table is this workgroup's own stores: complete, then visible to all its waves (and no stale line in the vector L1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asd_syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  pose_opt_body<2>(a_in);
 }
 
 // ---------------------------------------------------------------- fused tracking chains: edges made on the device
@@ -2140,14 +2175,21 @@ int pose_chain_reserve(asd_ctx* ctx, int n_cur) {
   static AsdPerDeviceOnce attr_set;
   if (attr_set.need(ctx->cfg.device)) {
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    const void* ks[] = {reinterpret_cast<const void*>(k_resolve_pose<0, 4>), reinterpret_cast<const void*>(k_resolve_pose<0, 8>),
+                        reinterpret_cast<const void*>(k_resolve_pose<1, 4>), reinterpret_cast<const void*>(k_resolve_pose<1, 8>)};
+    for (const void* k : ks) ASD_HIP_CHECK(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set.done(ctx->cfg.device);
   }
   return ASD_OK;
 }
 
+bool pose_chain_fused_ok(const asd_ctx* ctx, int kind, int nq, int n_cur, size_t lds) {
+  return (kind == 0 || kind == 1) && nq >= 1 && nq <= 8 * kPoseThreads && pose_chain_lds_form(ctx, n_cur) && lds <= 150 * 1024;
+}
+
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
-                       const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value) {
+                       const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value, const AsdFusedReplay* fused, unsigned* done_flag) {
   // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
   // inside the caller's one result block: no copy is enqueued here
   BaState* s = ba_state(ctx);
@@ -2177,7 +2219,7 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   if (pose7) memcpy(a.pose0, pose7, 56);
   a.pose0_dev = d_pose0; a.io_dev = d_io_dev;
   a.between = between;
-  a.wait_flag = wait_flag; a.wait_value = wait_value;
+  a.wait_flag = wait_flag; a.wait_value = wait_value; a.done_flag = done_flag;
   if (wait_flag && mode != 2) { ctx->set_error("pose chain: the early launch needs the LDS form of the solver"); return ASD_ERR_CAPACITY; }
   if ((d_pose0 || d_io_dev) && mode != 2) { ctx->set_error("pose chain: the device-side hand-over needs the LDS form of the solver (frame too large)"); return ASD_ERR_CAPACITY; }
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
@@ -2189,7 +2231,19 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set.done(ctx->cfg.device);
   }
-  if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
+  if (fused) {
+    if (mode != 2 || !pose_chain_fused_ok(ctx, fused->kind, fused->nq, n_cur, fused->lds)) { ctx->set_error("pose chain: no fused replay + solver form for this frame"); return ASD_ERR_CAPACITY; }
+    const Resolve2Args& r = *static_cast<const Resolve2Args*>(fused->args);
+    const size_t lds = std::max(lds_compact, fused->lds);
+    const int qpt = fused->nq <= 4 * kPoseThreads ? 4 : 8;
+    if (fused->kind == 0) {
+      if (qpt == 4) hipLaunchKernelGGL((k_resolve_pose<0, 4>), dim3(1), dim3(kPoseThreads), lds, st, r, a);
+      else hipLaunchKernelGGL((k_resolve_pose<0, 8>), dim3(1), dim3(kPoseThreads), lds, st, r, a);
+    } else {
+      if (qpt == 4) hipLaunchKernelGGL((k_resolve_pose<1, 4>), dim3(1), dim3(kPoseThreads), lds, st, r, a);
+      else hipLaunchKernelGGL((k_resolve_pose<1, 8>), dim3(1), dim3(kPoseThreads), lds, st, r, a);
+    }
+  } else if (mode == 2) hipLaunchKernelGGL(k_pose_opt<2>, dim3(1), dim3(kPoseThreads), lds_compact, st, a);
   else hipLaunchKernelGGL(k_pose_opt<0>, dim3(1), dim3(kPoseThreads), 0, st, a);
   ASD_HIP_CHECK(ctx, hipGetLastError());
   ctx->pose_chain_kp_flags = mode == 2;   // the form of the flags in d_io: per keypoint + edge count (gather form), or per edge

@@ -70,6 +70,16 @@ hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t byte
 // flaky tests/test_bench_host.py).  Every barrier in the library is written through these two, and `make check-isa` checks that
 // every s_barrier in the device code has the wait directly in front of it.
 #if defined(__HIPCC__)
+// Consumer side of a ticket word (MI355X_MICROARCH.md, "Valid forms"): ONE lane polls with a bounded number of sleeps (~0.2 s), the caller
+// follows with a barrier and an agent-scope acquire fence.  false = the producer never signalled.
+constexpr int kAsdTicketPolls = 200000;
+__device__ inline bool asd_ticket_wait(const unsigned* flag, unsigned value) {
+  for (int i = 0; i < kAsdTicketPolls; ++i) {
+    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0) return true;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  return false;
+}
 #define asd_syncthreads() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 __device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __syncthreads_or(pred); }
 #endif
@@ -332,6 +342,11 @@ void matcher_free(asd_ctx* ctx);
 void ba_free(asd_ctx* ctx);
 void mapping_free(asd_ctx* ctx);
 void bow_free(asd_ctx* ctx);
+// The claim replay that makes d_src, to run in FRONT of the solver inside its workgroup (k_resolve_pose, ba.hip) instead of as a kernel of
+// its own: args = the Resolve2Args of resolve2.h (both translation units include it), kind 0 / 1, nq = its query count, lds = the
+// dynamic LDS the replay needs.  pose_chain_fused_ok says whether that form exists for (kind, nq, n_cur).
+struct AsdFusedReplay { const void* args; int kind; int nq; size_t lds; };
+bool pose_chain_fused_ok(const asd_ctx* ctx, int kind, int nq, int n_cur, size_t lds);
 // ba.hip: PoseOptimization enqueued behind device-resident matches (fused tracking chains; see the definition)
 // d_pose0 (optional): the start pose on the device (the previous stage's result block), pose7 is then ignored; d_io_dev (optional): a
 // second copy of the result block in device memory for the kernels of a following stage (asd_track_frame)
@@ -339,7 +354,8 @@ void bow_free(asd_ctx* ctx);
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
                        double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, hipStream_t st_early = nullptr,
-                       const unsigned* wait_flag = nullptr, unsigned wait_value = 0);
+                       const unsigned* wait_flag = nullptr, unsigned wait_value = 0, const AsdFusedReplay* fused = nullptr,
+                       unsigned* done_flag = nullptr);
 int pose_chain_reserve(asd_ctx* ctx, int n_cur);   // its allocations and kernel attributes, ahead of time (see the definition)
 // true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
 inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }

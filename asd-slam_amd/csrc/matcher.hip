@@ -25,11 +25,11 @@
 #include <memory>
 
 #include "ctx.h"
+#include "resolve2.h"
 
 namespace {
 
-constexpr float TH_HIGH = 1.5f, TH_LOW = 0.5f;  // ORBmatcher.cc:37-38
-constexpr int HISTO = ASD_HISTO_LENGTH;
+// (TH_HIGH, TH_LOW, HISTO, kTop: resolve2.h)
 constexpr int GC = ASD_GRID_COLS, GR = ASD_GRID_ROWS;
 
 // A window query = one GetFeaturesInArea call + the descriptor it is matched against.
@@ -60,11 +60,13 @@ struct GridDev {
 constexpr int kSearchWaves = ASD_SEARCH_WAVES;   // queries (waves) per workgroup
 constexpr int kSearchCols = 16;                  // fast path: windows of up to this many grid columns ...
 constexpr int kSearchList = 128;                 // ... and up to this many candidates per query
-constexpr int kTop = 4;                          // SORT: entries per query in the compact head table
 struct SortArgs {
   const uint8_t* occ;      // [n_cur] or null: keypoints that cannot be matched (occupied on entry)
   float th_cut;            // q_cnt counts the entries with distance <= th_cut (they are the list's head); +inf = all
   uint16_t* top_idx;       // [nq][kTop] keypoint (0xffff = no entry)
+  // null, or a ticket: every workgroup counts itself in done_ctr behind its last store, the last one resets the counter and sets
+  // *done_flag = done_value -- a kernel resident on another stream (k_resolve_pose, asd_track_frame) waits for that instead of stream order
+  unsigned* done_ctr; unsigned* done_flag; unsigned done_value;
 };
 template <bool SORT>
 __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
@@ -218,7 +220,22 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
     return;
   }
   // ---- SORT: the list in preference order + the compact head table
-  if (!live) return;
+  auto ticket = [&]() {   // (every wave of the workgroup comes here)
+    if (!S.done_flag) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      const unsigned prev = __hip_atomic_fetch_add(S.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev + 1 == gridDim.x) {
+        __hip_atomic_store(S.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(S.done_flag, S.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  if (!live) { ticket(); return; }
   const bool fits = off + cnt <= cap;   // (an overflowing search is run again by the host: nothing of it is read)
   int n_keep = 0, s_off = off;
   auto put = [&](int base, int rank, int idx, float d) {
@@ -286,6 +303,7 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
   }
   if (lane < kTop && lane >= (fits ? cnt : 0)) S.top_idx[(size_t)q * kTop + lane] = 0xffffu;
   if (lane == 0) { q_cnt[q] = n_keep; q_off[q] = cnt ? s_off : 0; }
+  ticket();
 }
 
 // Node-restricted search (BoW-guided matchers): query q is matched against the explicit candidate list
@@ -699,307 +717,11 @@ __global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {
 #undef OUT
 #undef CNT
 
-// ---- claim replay over SORTED lists (round 4; the default) -------------------------------------------------------------
-// Same recurrence, same fixed-point iteration, same claim tables as k_resolve above -- what changed is how a map point finds its
-// pick inside an iteration.  k_resolve keeps all ~12 k candidates in registers and lets every one of them bid for its query with a
-// 64-bit LDS atomicMin in EVERY iteration (24 candidates per thread, 13 iterations: 90 us on one workgroup).  k_window_search<true>
-// hands the lists over in preference order, so "the best candidate no earlier map point holds" is the first entry of the list whose
-// keypoint carries no such claim, and the second best (KIND 1) the next one.
-// KIND 0 (best only): "keypoint j is held against q" can only become true and never false again from one iteration to the next --
-// the smallest claimant of j finds everything in front of j in its list still held and j still free, so it picks j again -- hence a
-// map point's position in its list only ever advances.  A thread keeps (position, keypoint) of each of its queries; an iteration
-// reads that keypoint's claim, steps forward past held entries if it has to (each list entry is stepped over at most once in the
-// whole kernel: ~700 steps per frame instead of 12 k bids per iteration), posts the claim.
-// KIND 1 (best / second best with the ratio test): a pick can be withdrawn (the second best changing its level), so every iteration
-// walks from the head -- the four heads' keypoints are in registers, their claims come in one LDS round trip, and the distances /
-// levels of the two survivors in a second one for all of the thread's queries together.
-// The LDS round trips are what an iteration costs (the workgroup shares its CU with ASDNet workgroups that keep the LDS queues
-// full), so every phase issues its reads for all of the thread's queries before it uses any.
-struct Resolve2Args {
-  int nq, n_cur;
-  const int* q_off; const int* q_cnt; const int* idx; const float* dist;   // k_window_search<true>: sorted lists (q_cnt = the head that can be picked)
-  const uint16_t* top_idx;                                                  // [nq][kTop] the lists' heads (keypoints; 0xffff = none)
-  const int* total; int cap;
-  const uint8_t* obs_pos;     // [nq] or null
-  const float4* kp_cur;       // (x, y, octave bits, angle)
-  const float4* kp_last;      // KIND 0: query q = last-frame keypoint q
-  int check_ori;
-  float nn_ratio;
-  int* match_cur;             // out [n_cur]
-  int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations, [3..6] stamps
-  int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches
-  int stage_cap;              // list entries [0, stage_cap) are copied into LDS (2 B each, KIND 1: 6 B) for the walks beyond the heads
-  unsigned* done_flag;        // null, or a ticket word: set to done_value behind the kernel's last store (a kernel resident on another
-  unsigned done_value;        // stream waits for it instead of for stream order: k_pose_opt, asd_track_frame)
-};
-__host__ __device__ inline size_t resolve2_fixed_lds(int kind, int n_cur) {   // claim tables + angle table (KIND 0) / octave table (KIND 1)
-  return (size_t)n_cur * 8 + (kind == 0 ? (size_t)n_cur * 4 : ((size_t)n_cur + 15) / 16 * 16);
-}
-constexpr int kResolve2Threads = 1024;
+// (the claim replay over sorted lists -- Resolve2Args, resolve2_body -- lives in resolve2.h: ba.hip runs it inside k_resolve_pose)
 template <int KIND, int QPT>
 __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
-#define OUT(i, v) do { const int v_ = (v); a.match_cur[i] = v_; if (a.mirror) a.mirror[i] = v_; } while (0)
-#define CNT(i, v) do { const int v_ = (v); a.n_matches[i] = v_; if (a.mirror) a.mirror[a.n_cur + (i)] = v_; } while (0)
-  constexpr int NT = kResolve2Threads;
-  __builtin_amdgcn_s_setprio(3);   // the tracking thread's critical path, on a CU it shares with ASDNet workgroups: issue its waves first
-  extern __shared__ unsigned lds_c[];
-  unsigned* claim0 = lds_c;
-  // the two claim tables are lds_c[0 .. n_cur) and lds_c[n_cur .. 2 n_cur), always addressed as lds_c[offset + j]: a table POINTER picked
-  // per iteration loses its address space, and the compiler then reads the claims with flat loads (several times an LDS read's latency)
-  float* ang = reinterpret_cast<float*>(claim0 + 2 * a.n_cur);                       // KIND 0: the current frame's keypoint angles
-  uint8_t* octv = reinterpret_cast<uint8_t*>(claim0 + 2 * a.n_cur);                  // KIND 1: their octaves
-  char* tail = reinterpret_cast<char*>(lds_c) + resolve2_fixed_lds(KIND, a.n_cur);
-  float* sdist = reinterpret_cast<float*>(tail);                                     // KIND 1: [stage_cap]
-  uint16_t* sidx = reinterpret_cast<uint16_t*>(tail + (KIND == 1 ? (size_t)a.stage_cap * 4 : 0));   // [stage_cap]
-  __shared__ int n_written, hist[HISTO], n_removed, flag[3];
-  int* last = reinterpret_cast<int*>(tail + (size_t)a.stage_cap * (KIND == 1 ? 6 : 2));   // [n_cur] the last writer of every keypoint
-  const int t = threadIdx.x;
-  const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
-  const int total = *a.total;
-  // every store of this workgroup is complete and written back before the ticket moves: waves drain their stores, barrier, one lane
-  // releases at agent scope and stores the ticket (MI355X_MICROARCH.md, "Valid forms": producer)
-  auto publish = [&]() {
-    if (!a.done_flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
-  if (total > a.cap || total == 0) {   // truncated lists (the host grows the buffers and searches again) / nothing in any window:
-    // the match table is still written (no match anywhere) -- a fused chain behind this kernel gathers its edges from it
-    for (int j = t; j < a.n_cur; j += NT) OUT(j, -1);
-    if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
-    publish();
-    return;
-  }
-  // the thread's queries first (their loads are then in flight under the LDS fills below): list length and start, the heads
-  int cnt[QPT], pick[QPT], qoff[QPT];
-  constexpr int HD = KIND == 1 ? 2 : kTop;   // heads kept in registers (KIND 1: the lists are short and two settle nearly every query)
-  uint2 tj[QPT];                        // the heads' keypoints (16 bit each; KIND 1 uses .x only)
-  float ang_last[KIND == 0 ? QPT : 1];
-  unsigned posmask = 0;
-#pragma unroll
-  for (int k = 0; k < QPT; ++k) {
-    const int q = t + k * NT;
-    const bool v = q < a.nq;
-    const int qc = v ? q : 0;
-    cnt[k] = v ? a.q_cnt[qc] : 0;
-    qoff[k] = a.q_off[qc];
-    if (KIND == 1) tj[k] = make_uint2(*reinterpret_cast<const unsigned*>(a.top_idx + (size_t)qc * kTop), 0u);
-    else tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
-    if (KIND == 0) ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
-    if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
-    pick[k] = -1;
-  }
-  for (int j = t; j < 2 * a.n_cur; j += NT) claim0[j] = 0xffffffffu;
-  for (int j = t; j < a.n_cur; j += NT) last[j] = -1;
-  if (KIND == 0) { if (a.check_ori) for (int j = t; j < a.n_cur; j += NT) ang[j] = a.kp_cur[j].w; }
-  else for (int j = t; j < a.n_cur; j += NT) octv[j] = (uint8_t)(__float_as_int(a.kp_cur[j].z) & 0xff);
-  const int n_stage = min(total, a.stage_cap);
-  for (int i = t; i < n_stage; i += NT) { sidx[i] = (uint16_t)a.idx[i]; if (KIND == 1) sdist[i] = a.dist[i]; }
-  if (t == 0) { n_written = 0; n_removed = 0; flag[0] = 0; flag[1] = 0; flag[2] = 0; }
-  if (t < HISTO) hist[t] = 0;
-  auto top_j = [&](int k, int i) -> unsigned { return ((i < 2 ? tj[k].x : tj[k].y) >> (16 * (i & 1))) & 0xffffu; };
-  auto list_j = [&](int k, int i) -> int { const int pos = qoff[k] + i; return pos < n_stage ? (int)sidx[pos] : a.idx[pos]; };
-  int ptr[KIND == 0 ? QPT : 1], curj[KIND == 0 ? QPT : 1];   // KIND 0: position in the list and the keypoint there (-1: list exhausted)
-  if (KIND == 0) {
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) { ptr[k] = 0; curj[k] = cnt[k] > 0 ? (int)top_j(k, 0) : -1; }
-  }
-  asd_syncthreads();
-  const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
-  const int max_it = a.nq + 2;
-  int it = 0, f_cur = 0;   // f_cur = it % 3
-  unsigned long long ts_it0 = ts1;
-  // the claims an iteration starts from are read at the END of the one before, in the same LDS round trip as its "anything changed" flag
-  // (a dependent chain of LDS round trips is what an iteration costs beside ASDNet workgroups that keep the CU's LDS queues full)
-  constexpr int NCL = HD;   // (KIND 1 only)
-  unsigned cl[QPT][NCL];
-  auto load_claims = [&](int rdt) {
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      {
-#pragma unroll
-        for (int i = 0; i < NCL; ++i) cl[k][i] = (i < cnt[k]) ? lds_c[rdt + top_j(k, i)] : 0u;
-      }
-    }
-  };
-  if (KIND == 0) {   // every map point posts at the head of its list
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) if (curj[k] >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[curj[k]], (unsigned)(t + k * NT));
-  } else load_claims(0);
-  int ph_work = 0, ph_bar = 0;   // thread 0's view (10 ns units): loop top -> barrier, barrier -> verdict
-  for (;; ++it) {
-    const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
-    // read the claims of iteration it-1 (table it & 1, tag it), post this iteration's picks into the other table (tag it+1)
-    const int rd = (it & 1) ? a.n_cur : 0, wr = a.n_cur - rd;   // offsets into lds_c
-    const unsigned tag_rd = (unsigned)(0xffff - it), tag_wr = (unsigned)(0xffff - (it + 1));
-    auto held = [&](unsigned c, int q) { return (c >> 16) == tag_rd && (c & 0xffffu) < (unsigned)q; };   // an earlier map point holds it
-    int changed = 0;
-    if (KIND == 0) {
-      // Frame-to-frame search keeps the BEST candidate only, so a map point's position in its list only ever moves forward and a keypoint's
-      // holder only ever gets replaced by an earlier map point: the replay's fixed point is unique and any order of (post, look, step
-      // forward) reaches it.  ONE claim table then (lds_c[0 .. n_cur), plain map point indices, atomicMin, never cleared) and no barrier
-      // between looks: a round is kPolls looks at the own claim -- one LDS read and a compare for a map point that still holds its
-      // keypoint, a walk and a post for a displaced one -- and the rounds end with the first one in which nobody moved (the table was then
-      // static for a whole round and every map point has checked itself against it).  The Jacobi form this replaces paid two LDS round
-      // trips, a barrier and a re-post of all 2000 claims per link of the longest displacement chain (13 on the bench stream).
-      constexpr int kPolls = 4;
-      auto peek = [&](int j) { return __hip_atomic_load(&lds_c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-      for (int poll = 0; poll < kPolls; ++poll) {
-        unsigned holder[QPT];   // all looks of the thread in one round trip
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) holder[k] = curj[k] >= 0 ? peek(curj[k]) : 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-          const int q = t + k * NT;
-          if (!(holder[k] < (unsigned)q)) continue;
-          // displaced: step forward, kStep entries per PAIR of LDS round trips (unconditional loads from clamped addresses, selected
-          // afterwards -- as conditional loads the compiler serialised them, one round trip per entry)
-          constexpr int kStep = 4;
-          int j = -1;
-          if (n_stage == total) {
-            while (j < 0 && ptr[k] + 1 < cnt[k]) {
-              int jj[kStep]; unsigned cc[kStep];
-              const int p0 = ptr[k] + 1, lastp = cnt[k] - 1;
-#pragma unroll
-              for (int i = 0; i < kStep; ++i) jj[i] = (int)sidx[qoff[k] + min(p0 + i, lastp)];
-#pragma unroll
-              for (int i = 0; i < kStep; ++i) cc[i] = peek(jj[i]);
-              int adv = min(kStep, lastp - p0 + 1);
-#pragma unroll
-              for (int i = kStep - 1; i >= 0; --i) if (p0 + i <= lastp && !(cc[i] < (unsigned)q)) { j = jj[i]; adv = i + 1; }
-              ptr[k] += adv;
-            }
-          } else {   // lists longer than the LDS copy: entry by entry, global beyond it
-            while (j < 0 && ptr[k] + 1 < cnt[k]) {
-              const int cand = list_j(k, ++ptr[k]);
-              if (!(peek(cand) < (unsigned)q)) j = cand;
-            }
-          }
-          curj[k] = j;
-          changed = 1;
-          if (j >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[j], (unsigned)q);
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < QPT; ++k) pick[k] = curj[k];
-    } else {
-      int p[QPT], p2[QPT], i1[QPT], i2[QPT];
-#pragma unroll
-      for (int k = 0; k < QPT; ++k) {
-        const int q = t + k * NT;
-        int found = 0;
-        p[k] = -1; p2[k] = -1; i1[k] = 0; i2[k] = 0;
-#pragma unroll
-        for (int i = 0; i < HD; ++i) {
-          if (i >= cnt[k] || held(cl[k][i], q) || found >= 2) continue;
-          if (found == 0) { p[k] = (int)top_j(k, i); i1[k] = i; }
-          else { p2[k] = (int)top_j(k, i); i2[k] = i; }
-          ++found;
-        }
-        if (found < 2 && cnt[k] > HD) {   // the heads did not settle it: on through the list (LDS copy, global beyond it)
-          for (int i = HD; i < cnt[k] && found < 2; ++i) {
-            const int j = list_j(k, i);
-            if (held(lds_c[rd + j], q)) continue;
-            if (found == 0) { p[k] = j; i1[k] = i; }
-            else { p2[k] = j; i2[k] = i; }
-            ++found;
-          }
-        }
-      }
-      // ORBmatcher.cc:106-112 (bestDist2 starts at 256, bestLevel2 at -1): distances and levels of the two survivors, all queries together
-      float best[QPT], best2[QPT];
-      int lvl[QPT], lvl2[QPT];
-      // (not `pos < n_stage ? sdist[pos] : a.dist[pos]`: the compiler turns that, and every plain if/else form of it, into ONE flat load
-      // through a selected pointer; the empty asm pins the LDS read in front of the branch)
-      auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; float d = sdist[min(pos, n_stage - 1)]; asm volatile("" : "+v"(d)); if (n_stage != total && pos >= n_stage) d = a.dist[pos]; return d; };
-#pragma unroll
-      for (int k = 0; k < QPT; ++k) {
-        best[k] = p[k] >= 0 ? dist_at(k, i1[k]) : 0.f;
-        best2[k] = p2[k] >= 0 ? dist_at(k, i2[k]) : 256.f;
-        lvl[k] = p[k] >= 0 ? (int)octv[p[k]] : -1;
-        lvl2[k] = p2[k] >= 0 ? (int)octv[p2[k]] : -1;
-      }
-#pragma unroll
-      for (int k = 0; k < QPT; ++k) {
-        const int q = t + k * NT;
-        int pk = p[k];
-        if (pk >= 0 && (!(best[k] <= TH_HIGH) || (lvl[k] == lvl2[k] && best[k] > a.nn_ratio * best2[k]))) pk = -1;
-        changed |= pk != pick[k];
-        pick[k] = pk;
-        if (pk >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[wr + pk], (tag_wr << 16) | (unsigned)q);
-      }
-    }
-    // "did any pick change" with ONE barrier (__syncthreads_or is three and a cross-lane reduction): a changed pick sets this
-    // iteration's flag word, thread 0 clears the next one's -- last read two barriers ago
-    if (changed) flag[f_cur] = 1;
-    const int f_next = f_cur == 2 ? 0 : f_cur + 1;
-    if (t == 0) flag[f_next] = 0;
-    const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
-    asd_syncthreads();
-    if (KIND == 1) load_claims(wr);       // the next iteration's claims ...
-    const bool more = flag[f_cur] != 0 && it < max_it;   // ... and this one's verdict: one round trip
-    f_cur = f_next;
-    { const unsigned long long p2 = __builtin_amdgcn_s_memrealtime(); ph_work += (int)(p1 - p0); ph_bar += (int)(p2 - p1); }
-    if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
-    if (!more) break;
-  }
-  const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
-  // ---- outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
-  int mine = 0;
-  int bin[QPT];
-#pragma unroll
-  for (int k = 0; k < QPT; ++k) {
-    bin[k] = -1;
-    if (pick[k] < 0) continue;
-    atomicMax(&last[pick[k]], t + k * NT);
-    ++mine;
-    if (KIND == 0 && a.check_ori) {
-      float rot = ang_last[k] - ang[pick[k]];   // ORBmatcher.cc:1419-1425
-      if (rot < 0.0) rot += 360.0f;
-      int b = (int)roundf(rot * (1.0f / HISTO));
-      if (b == HISTO) b = 0;
-      bin[k] = b;
-      atomicAdd(&hist[b], 1);
-    }
-  }
-  if (mine) atomicAdd(&n_written, mine);
-  asd_syncthreads();
-  if (KIND == 0 && a.check_ori) {
-    // ComputeThreeMaxima (:1584-1625), by every thread for itself (thirty broadcast reads instead of a barrier around thread 0)
-    int hs[HISTO];
-#pragma unroll
-    for (int i = 0; i < HISTO; i++) hs[i] = hist[i];
-    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-#pragma unroll
-    for (int i = 0; i < HISTO; i++) {
-      const int s = hs[i];
-      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-      else if (s > max3) { max3 = s; ind3 = i; }
-    }
-    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
-    int removed = 0;
-#pragma unroll
-    for (int k = 0; k < QPT; ++k)   // every write in a discarded bin clears the keypoint and is subtracted (:1437-1450)
-      if (bin[k] >= 0 && bin[k] != ind1 && bin[k] != ind2 && bin[k] != ind3) { last[pick[k]] = -1; ++removed; }
-    if (removed) atomicAdd(&n_removed, removed);
-    asd_syncthreads();
-  }
-  for (int j = t; j < a.n_cur; j += NT) OUT(j, last[j]);
-  if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, total); CNT(2, it + 1);
-    // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs, the first iteration -- in units of 10 ns
-    CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
-    CNT(7, ph_work); CNT(8, ph_bar); CNT(9, (int)(ts0 & 0x7fffffffull)); CNT(10, (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffull)); }
-  publish();
+  resolve2_body<KIND, QPT, kResolve2Threads>(a);
 }
-#undef OUT
-#undef CNT
 
 // Frame::isInFrustum (Frame.cc:160-217) + MapPoint::PredictScale (MapPoint.cc:438-453) + the search window of
 // ORBmatcher::SearchByProjection(F, vpMapPoints, th) (:60-70), one thread per map point, straight into the query table of
@@ -1036,12 +758,25 @@ struct FrustumArgs {
   // min / max distance), candidates flagged in `skip` are in the frame already (Tracking.cc:811-823) and make no query, and every
   // candidate's position is also written to xw_out[q] for the edges of the pose solver behind the search
   const float* T_dev; const float* attr; const uint8_t* skip; float* xw_out;
+  // null, or the ticket of the kernel that writes T_dev / skip (the stage-1 solver of asd_track_frame, resident on another stream): every
+  // workgroup waits for it (bounded) before it reads them; a workgroup that never sees it makes no query and sets *wait_failed
+  const unsigned* wait_flag; unsigned wait_value; unsigned* wait_failed;
 };
 __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
   if (upload_tail_block(a.up)) return;
+  bool gate_ok = true;
+  if (a.wait_flag) {
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) ok_s = asd_ticket_wait(a.wait_flag, a.wait_value) ? 1 : 0;
+    asd_syncthreads();
+    gate_ok = ok_s != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!gate_ok && threadIdx.x == 0) *a.wait_failed = 1u;
+  }
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
+  if (!gate_ok) { a.queries[q] = Q; return; }
   if (a.attr) {   // bank form
     const int row = a.rows[q];
     const float4 A0 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row], A1 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row + 1];
@@ -2512,9 +2247,9 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     seq = ++ctx->chain_seq;
     flags = ctx->d_chain_flags;
   }
-  // ---- motion-model stage
+  // ---- motion-model stage: projection arguments (launched below)
+  ProjectArgs pa{};
   {
-    ProjectArgs pa{};
     pa.n = nl; pa.kp_last = L->d_kp;
     memcpy(pa.T, A.Tcw, sizeof pa.T);
     pa.fx = A.K[0]; pa.fy = A.K[1]; pa.cx = A.K[2]; pa.cy = A.K[3];
@@ -2524,21 +2259,14 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     pa.queries = up.dev<WinQuery>(o_q1);
     pa.up = UploadTail{reinterpret_cast<const uint4*>(up.h), reinterpret_cast<uint4*>(up.d), ((size_t)nl * sizeof(WinQuery) + 255) / 256 * 16, (up.used + 15) / 16,
                        (nl + 255) / 256};
-    hipLaunchKernelGGL(k_project_queries, dim3(pa.up.q_blocks + kUploadTailBlocks), dim3(256), 0, st, pa);
-    ASD_HIP_CHECK(ctx, hipGetLastError());
   }
   auto resolve_launch = [&](auto kern, const Resolve2Args& a, size_t lds) -> hipError_t {   // (attributes: set above)
     hipLaunchKernelGGL(kern, dim3(1), dim3(kResolve2Threads), lds, st, a);
     return hipGetLastError();
   };
-  auto search_resolve = [&](auto kind_tag, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in,
-                            const uint8_t* d_obs, const float4* kp_last, int check_ori, float nn_ratio, int* d_out, int* h_out, unsigned* done_flag) -> int {
-    constexpr int KIND = decltype(kind_tag)::value;
-    GridDev G{C->d_kp, C->d_cell_start, C->d_cell_items, C->min_x, C->min_y, C->inv_w, C->inv_h};
-    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top};
-    hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, d_q, nq, m->d_bank, C->d_desc, d_off, d_cnt,
-                       d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, sa);
-    ASD_HIP_CHECK(ctx, hipGetLastError());
+  // the replay's arguments of a stage (every pointer is known before anything is launched)
+  auto replay_args = [&](int KIND, int nq, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_obs, const float4* kp_last, int check_ori,
+                         float nn_ratio, int* d_out, int* h_out, size_t* lds_out) {
     Resolve2Args a{};
     a.nq = nq; a.n_cur = nc;
     a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.top_idx = d_top;
@@ -2547,57 +2275,88 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     a.kp_cur = C->d_kp; a.kp_last = kp_last;
     a.check_ori = check_ori; a.nn_ratio = nn_ratio;
     a.match_cur = d_out; a.n_matches = d_out + nc; a.mirror = h_out;
-    a.done_flag = done_flag; a.done_value = seq;
     const size_t fixed = resolve_lds_bytes(KIND, nc, nq), per = KIND == 1 ? 6 : 2;
     a.stage_cap = (int)std::min<size_t>(((size_t)m->last_total[KIND] * 5 / 4 + 1023) / 1024 * 1024, ((size_t)96 * 1024 - fixed) / per / 8 * 8);
-    const size_t lds = fixed + (size_t)a.stage_cap * per;
-    if (nq <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<KIND, 2>, a, lds));
-    else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<KIND, 4>, a, lds));
+    *lds_out = fixed + (size_t)a.stage_cap * per;
+    return a;
+  };
+  auto search = [&](int KIND, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in, unsigned* ticket) -> int {
+    GridDev G{C->d_kp, C->d_cell_start, C->d_cell_items, C->min_x, C->min_y, C->inv_w, C->inv_h};
+    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top, ticket ? ticket + 8 : nullptr, ticket, seq};
+    hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, d_q, nq, m->d_bank, C->d_desc, d_off, d_cnt,
+                       d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, sa);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
-  if ((rc = search_resolve(std::integral_constant<int, 0>{}, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr,
-                           has_obs1 ? up.dev<uint8_t>(o_obs1) : nullptr, L->d_kp, A.check_orientation, 0.f, down.dev<int>(o_out1), down.host<int>(o_out1), flags)) != ASD_OK)
-    return rc;
-  // (the solver kernels are enqueued here, behind the motion-model stage's search and replay in HOST order: those start at once, and
-  // the solvers still have the whole search + replay to find their CU in)
-  if (early_now) {
-    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), ctx->stream_solve, flags, seq)) != ASD_OK)
-      return rc;
-    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_solve[0], ctx->stream_solve));
-    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
-                                 ctx->stream_solve, flags + 32, seq)) != ASD_OK)
-      return rc;
-    ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_solve[1], ctx->stream_solve));
-  }
-  // ---- ... and what happens between the stages, as the tail of its PoseOptimization kernel (the workgroup that has just written the
-  // flags and the pose: no launch, no second read of them)
-  if (early_now) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[0], 0));
-  else if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                                    d_io1, up.dev<AsdBetweenArgs>(o_btw))) != ASD_OK)
-    return rc;
-  // ---- local-map stage
-  {
-    FrustumArgs fa{};
-    fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
-    fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
-    fa.min_x = C->min_x; fa.max_x = C->max_x; fa.min_y = C->min_y; fa.max_y = C->max_y;
-    fa.cos_limit = A.viewing_cos_limit; fa.th = A.th_local;
-    for (int l = 0; l < ASD_MAX_LEVELS; ++l) { fa.level_thr[l] = ctx->level_thr[l]; fa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f; }
-    fa.rows = up.dev<int>(o_crows); fa.queries = d_q2;
-    fa.up = UploadTail{nullptr, nullptr, 0, 0, (ncand + 255) / 256};
-    fa.T_dev = d_T1; fa.attr = m->d_attr; fa.skip = d_skip; fa.xw_out = d_cXw;
+  size_t lds1 = 0, lds2 = 0;
+  Resolve2Args ra1 = replay_args(0, nl, d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, has_obs1 ? up.dev<uint8_t>(o_obs1) : nullptr, L->d_kp, A.check_orientation, 0.f,
+                                 down.dev<int>(o_out1), down.host<int>(o_out1), &lds1);
+  Resolve2Args ra2 = replay_args(1, ncand, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, has_obs2 ? up.dev<uint8_t>(o_obs2) : nullptr, nullptr, 0, A.nn_ratio,
+                                 down.dev<int>(o_out2), down.host<int>(o_out2), &lds2);
+  // ASD_CHAIN_FUSED=0: the replay and the solver as two kernels (the form up to the middle of round 4)
+  static const bool fused_on = [] { const char* e = getenv("ASD_CHAIN_FUSED"); return !e || atoi(e) != 0; }();
+  const bool fuse_now = fused_on && pose_chain_fused_ok(ctx, 0, nl, nc, lds1) && pose_chain_fused_ok(ctx, 1, ncand, nc, lds2);
+  AsdFusedReplay fr1{&ra1, 0, nl, lds1}, fr2{&ra2, 1, ncand, lds2};
+  // Resident form (early_now, with the fused kernels): the two replay + solver kernels go onto the solver stream, the first BEFORE anything
+  // else -- it finds its CU while the projection and the first search run -- and every hand-over between the streams is a ticket word:
+  // search -> replay (k_window_search's last workgroup), stage-1 solver -> k_frustum_queries (behind the work between the stages), search
+  // -> second replay.  No event crosses the streams; the host waits for the solver stream's last kernel.
+  const bool resident = early_now && fuse_now;
+  hipStream_t st_end = st;
+  FrustumArgs fa{};
+  fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
+  fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
+  fa.min_x = C->min_x; fa.max_x = C->max_x; fa.min_y = C->min_y; fa.max_y = C->max_y;
+  fa.cos_limit = A.viewing_cos_limit; fa.th = A.th_local;
+  for (int l = 0; l < ASD_MAX_LEVELS; ++l) { fa.level_thr[l] = ctx->level_thr[l]; fa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f; }
+  fa.rows = up.dev<int>(o_crows); fa.queries = d_q2;
+  fa.up = UploadTail{nullptr, nullptr, 0, 0, (ncand + 255) / 256};
+  fa.T_dev = d_T1; fa.attr = m->d_attr; fa.skip = d_skip; fa.xw_out = d_cXw;
+  auto project = [&]() -> int {
+    hipLaunchKernelGGL(k_project_queries, dim3(pa.up.q_blocks + kUploadTailBlocks), dim3(256), 0, st, pa);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    return ASD_OK;
+  };
+  auto frustum = [&]() -> int {
     hipLaunchKernelGGL(k_frustum_queries, dim3((ncand + 255) / 256), dim3(256), 0, st, fa);
     ASD_HIP_CHECK(ctx, hipGetLastError());
+    return ASD_OK;
+  };
+  if (resident) {
+    // NOTE the stage-1 kernel reads the chain's upload block (Xw of the last frame, the work between the stages): the copy of that block to
+    // the device rides in k_project_queries, which the search -- and so the ticket this kernel waits for -- is ordered behind
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
+                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), ctx->stream_solve, flags, seq, &fr1, flags + 16)) != ASD_OK)
+      return rc;
+    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, flags)) != ASD_OK) return rc;
+    fa.wait_flag = flags + 16; fa.wait_value = seq; fa.wait_failed = flags + 24;
+    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
+                                 ctx->stream_solve, flags + 32, seq, &fr2)) != ASD_OK)
+      return rc;
+    st_end = ctx->stream_solve;
+  } else {
+    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, nullptr)) != ASD_OK) return rc;
+    if (!fuse_now) {
+      if (nl <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<0, 2>, ra1, lds1));
+      else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<0, 4>, ra1, lds1));
+    }
+    // ... what happens between the stages is the tail of the stage's PoseOptimization kernel (the workgroup that has just written the
+    // flags and the pose: no launch, no second read of them)
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
+                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), nullptr, nullptr, 0, fuse_now ? &fr1 : nullptr)) != ASD_OK)
+      return rc;
+    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, nullptr)) != ASD_OK) return rc;
+    if (!fuse_now) {
+      if (ncand <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<1, 2>, ra2, lds2));
+      else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<1, 4>, ra2, lds2));
+    }
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
+                                 nullptr, nullptr, 0, fuse_now ? &fr2 : nullptr)) != ASD_OK)
+      return rc;
   }
-  if ((rc = search_resolve(std::integral_constant<int, 1>{}, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, has_obs2 ? up.dev<uint8_t>(o_obs2) : nullptr,
-                           nullptr, 0, A.nn_ratio, down.dev<int>(o_out2), down.host<int>(o_out2), flags ? flags + 32 : nullptr)) != ASD_OK)
-    return rc;
-  if (early_now) ASD_HIP_CHECK(ctx, hipStreamWaitEvent(st, ctx->ev_solve[1], 0));
-  else if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr)) != ASD_OK)
-    return rc;
   if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st_end));
 
   asd_track_frame_args O = A;   // (only the output pointers are used below)
   std::array<double, 7> p_in;

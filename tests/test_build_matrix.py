@@ -15,6 +15,7 @@ CASES = [
     # asd_track_frame with its PoseOptimization kernels launched ahead on the solver stream (opt-in), the old bid-based claim replay, one
     # extraction worker
     ({"ASD_CHAIN_EARLY": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
+    ({"ASD_CHAIN_FUSED": "0"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_RESOLVE": "bids"}, ["tests/test_matcher.py", "tests/test_track_chain.py::test_track_motion_model_equals_separate_calls"]),
     ({"ASD_EXTRACT_WORKERS": "1"}, ["tests/test_bench_host.py", "tests/test_kitti_configs.py"]),
     ({"ASD_ASDNET_PERSIST": "1", "ASD_ASDNET_RESERVE": "1"}, ["tests/test_asdnet.py", "tests/test_frontend.py::test_extract_kitti_size_bit_exact"]),
