@@ -132,6 +132,7 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
     delete c;
     return ASD_ERR_NO_DEVICE;
   }
+  asd_register_stream(c, c->stream);
   int rc = asdnet_alloc(c);
   if (rc == ASD_OK) rc = frontend_alloc(c);
   if (rc != ASD_OK) {
@@ -166,8 +167,6 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   for (int set = 0; set < 2; ++set)
     for (int i = 0; i < 9; ++i) if (ctx->prof_ev[set][i]) (void)hipEventDestroy(ctx->prof_ev[set][i]);
-  if (ctx->stream_solve) { (void)hipStreamSynchronize(ctx->stream_solve); (void)hipStreamDestroy(ctx->stream_solve); }
-  for (hipEvent_t e : ctx->ev_solve) if (e) (void)hipEventDestroy(e);
   if (ctx->d_chain_flags) (void)hipFree(ctx->d_chain_flags);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   if (ctx->stream_prep) (void)hipStreamDestroy(ctx->stream_prep);

@@ -210,11 +210,13 @@ struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
   hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
-  hipStream_t stream_solve = nullptr; // asd_track_frame: the PoseOptimization kernels, launched ahead of their inputs (they wait on a device flag)
-  hipEvent_t ev_solve[2] = {nullptr, nullptr};
-  unsigned* d_chain_flags = nullptr;  // [2] tickets the claim replays of the two stages publish
+  unsigned* d_chain_flags = nullptr;  // [128] asd_track_frame, resident form: ticket words (search 1 at 0, stage-1 solver at 16, search 2 at 32), probe words (64, 96)
   unsigned chain_seq = 0;
-  bool chain_early_off = false;       // the probe found the solver stream on the main stream's hardware queue: PoseOptimization stays in stream order
+  // every stream this context's entry points or worker threads launch into (registered when created): the per-frame solver kernel of
+  // asd_track_frame sits on the device waiting for a ticket, so its stream must not share a hardware queue with any stream whose work that
+  // ticket depends on -- track_solver_setup probes them all (asd_register_stream / aux_streams)
+  std::vector<hipStream_t> aux_streams;
+  std::mutex aux_mu;
   hipStream_t stream_prep = nullptr; // asd_prep_async: frame construction (grid / descriptor / bank copies) beside the stages in flight
   hipEvent_t ev_prep = nullptr;
   bool prep_on = false;
@@ -356,6 +358,23 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
                        double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, hipStream_t st_early = nullptr,
                        const unsigned* wait_flag = nullptr, unsigned wait_value = 0, const AsdFusedReplay* fused = nullptr,
                        unsigned* done_flag = nullptr);
+// ---- the per-frame solver kernel of asd_track_frame (k_track_solver, ba.hip; see its comment)
+// everything below returns ASD_OK or an error; `usable` = false when the streams' hardware queues rule the resident form out
+struct AsdSolverStage {   // pose_chain_enqueue's inputs of one stage
+  const void* replay; size_t replay_lds;   // Resolve2Args (resolve2.h)
+  const int* d_src; const float4* d_kp; const float* d_tab; const uint8_t* d_hold; const float* d_own; const double* pose7; double* d_io;
+  const double* d_pose0; double* d_io_dev; const AsdBetweenArgs* between;
+};
+int track_solver_setup(asd_ctx* ctx, unsigned* flags, bool* usable);
+bool track_solver_fits(const asd_ctx* ctx, int n_last, int n_cand, int n_cur, size_t lds1, size_t lds2);
+int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, const double* K, const AsdSolverStage& s1, const AsdSolverStage& s2);   // fill the frame's block; launch unless resident
+int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags);   // next frame's kernel, a frame ahead
+int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags);             // host: until the frame's kernel has ended (relaunches one that gave up waiting)
+inline void asd_register_stream(asd_ctx* ctx, hipStream_t st) { std::lock_guard<std::mutex> g(ctx->aux_mu); ctx->aux_streams.push_back(st); }
+inline void asd_unregister_stream(asd_ctx* ctx, hipStream_t st) {
+  std::lock_guard<std::mutex> g(ctx->aux_mu);
+  for (size_t i = 0; i < ctx->aux_streams.size(); ++i) if (ctx->aux_streams[i] == st) { ctx->aux_streams.erase(ctx->aux_streams.begin() + i); break; }
+}
 int pose_chain_reserve(asd_ctx* ctx, int n_cur);   // its allocations and kernel attributes, ahead of time (see the definition)
 // true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
 inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }

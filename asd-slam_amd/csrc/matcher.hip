@@ -2115,18 +2115,10 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
 // tests/test_track_chain.py holds the results to the same bits.
 // A kernel that waits on the device for a ticket another stream's kernel publishes needs the two streams on DIFFERENT hardware queues:
 // HIP multiplexes its streams onto a few AQL queues (GPU_MAX_HW_QUEUES, 4 by default, per priority level) and orders the packets of
-// streams that share one with barrier bits -- the publisher would then wait for the waiter to END.  (Found the hard way: the solver
+// streams that share one with barrier bits -- the publisher would then wait for the waiter to END.  (Found the hard way: a solver
 // stream landed on the main stream's queue in a process that had created other streams first, and every frame ran into the waiter's
-// timeout.)  So each context checks ONCE, with two trivial kernels and a 3 ms bound, that a waiter on its solver stream really is
-// released by a publisher on its main stream; if not, the context keeps the PoseOptimization kernels in stream order.
-__global__ void k_probe_wait(const unsigned* flag, unsigned value, int polls, int* out) {
-  int ok = 0;
-  for (int i = 0; i < polls; ++i) {
-    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0) { ok = 1; break; }
-    __builtin_amdgcn_s_sleep(32);
-  }
-  *out = ok;
-}
+// timeout.)  track_solver_setup (ba.hip) probes every registered stream of the context against the solver streams before the resident
+// form is used.  k_probe_set is also the searches' ticket in that form (a one-lane kernel behind the search).
 __global__ void k_probe_set(unsigned* flag, unsigned value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 namespace {
@@ -2191,16 +2183,18 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     b.occ = d_occ; b.cur_Xw = d_curXw; b.skip = d_skip; b.T1 = d_T1;
     memcpy(up.host<char>(o_btw), &b, sizeof b);
   }
-  // The two PoseOptimization kernels go FIRST, onto a stream of their own: each needs most of a CU (512 threads x 221 registers, 70 KB of
-  // LDS) and, launched in stream order, waited 40-55 us for one beside the extractor's ASDNet workgroups (device-clock stamps).  Launched
-  // ahead, the first is resident and waiting on the claim replay's ticket long before the replay is through, the second queues behind it
-  // and gets its CU while the local-map search runs.  Order between the streams: the tickets (k_resolve2 -> k_pose_opt) one way, an
-  // event per solver kernel the other (the main stream waits for it before k_frustum_queries / before the chain's end is recorded).
-  // OFF by default (ASD_CHAIN_EARLY=1 turns it on).  Measured, round 4 (tools/ab_early.sh, tools/ab_quick.sh): on the device's own clock
-  // the chain from the first replay to the second solver's end shrinks from 579 to 477 us per frame -- the two 40-55 us waits for a CU are
-  // gone -- but end to end the step is unchanged (1146-1231 frames/s with it, 1175-1201 without, box to box): the host's turn-around and
-  // the extractor take up the slack.  A kernel that waits on the device is not worth keeping in the default path for nothing.
-  static const bool early = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return e && atoi(e) != 0; }();
+  // The replay + solver kernel needs most of a CU (512 threads x 213-221 registers, 70-110 KB of LDS) and, launched in stream order, waits
+  // 35-100 us for one beside the extractor's ASDNet workgroups, twice per frame (device-clock stamps, profiles/r04_chain_device_clock.txt).
+  // ASD_CHAIN_EARLY selects the RESIDENT form instead: one solver kernel per frame (k_track_solver, ba.hip) on a stream of its own, launched
+  // ahead of its frame (1: when the previous frame is submitted, 2: when it completes), waiting on the device for the searches' tickets.
+  // OFF by default.  Measured, round 4 (tools/ab_resident*.sh): on the device's own clock the chain from the first replay to the second
+  // solver's end shrinks from 500-540 to 445-480 us per frame -- the waits for a CU are gone -- but the ASDNet forward beside it slows from
+  // 0.59 to 0.67-0.97 ms depending on the variant (0.67: tickets from one-lane kernels, next frame's kernel launched at completion), the
+  // extractor becomes the side the tracking thread waits for (0.34-0.69 ms per step) and the step gets slower end to end: 820-1140
+  // frames/s against 1180-1230 in stream order on the same boxes.  The extractor (ASDNet 0.59 ms + 0.07 ms between forwards) and the
+  // tracking thread (0.64 ms + LocalBA's share) are within a few percent of each other: neither side alone moves the step.
+  static const int early_sel = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return e ? atoi(e) : 0; }();   // 1: next frame's kernel launched at submit, 2: at completion
+  static const bool early = early_sel != 0;
   unsigned seq = 0;
   unsigned* flags = nullptr;
   {
@@ -2216,35 +2210,13 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       attrs.done(ctx->cfg.device);
     }
   }
-  if (early && !ctx->stream_solve && !ctx->chain_early_off) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // At the HIGHEST priority like the main stream.  A priority level of its own would also be a queue pool of its own (no sharing with
-    // the main stream by construction) -- measured, round 4: with any stream of the context at the MIDDLE level and a solver kernel
-    // waiting on the device, the lowest-priority ASDNet stream slows from 0.59 to 0.81 ms per forward (988 frames/s against 1170;
-    // tools/ab_quick.sh); two levels only (highest / lowest) do not show it.  So: same level, and the probe below decides.
-    static const int solve_prio_sel = [] { const char* e = getenv("ASD_SOLVE_PRIO"); return e ? atoi(e) : 2; }();   // 0 lowest, 1 middle, 2 highest (A/B)
-    ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_solve, hipStreamNonBlocking, solve_prio_sel == 2 ? hi : solve_prio_sel == 0 ? lo : lo + (hi - lo) / 2));
-    for (hipEvent_t& e : ctx->ev_solve) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_chain_flags, 512));
-    ASD_HIP_CHECK(ctx, hipMemset(ctx->d_chain_flags, 0, 512));
-    // probe: waiter on the solver stream, publisher on the main stream (flag word 64, result word 96)
-    int probe = 0;
-    hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, ctx->stream_solve, ctx->d_chain_flags + 64, 1u, 2000, reinterpret_cast<int*>(ctx->d_chain_flags + 96));
-    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, st, ctx->d_chain_flags + 64, 1u);
-    ASD_HIP_CHECK(ctx, hipGetLastError());
-    ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream_solve));
-    ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    ASD_HIP_CHECK(ctx, hipMemcpy(&probe, ctx->d_chain_flags + 96, sizeof probe, hipMemcpyDeviceToHost));
-    if (!probe) {
-      ctx->chain_early_off = true;
-      static bool said = false;
-      if (!said) { said = true; fprintf(stderr, "libasdhip: the solver stream shares a hardware queue with the context's stream (GPU_MAX_HW_QUEUES): asd_track_frame keeps its PoseOptimization kernels in stream order\n"); }
+  bool early_now = false;
+  if (early) {
+    if (!ctx->d_chain_flags) {
+      ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_chain_flags, 512));
+      ASD_HIP_CHECK(ctx, hipMemset(ctx->d_chain_flags, 0, 512));
     }
-  }
-  const bool early_now = early && ctx->stream_solve && !ctx->chain_early_off;
-  if (early_now) {
-    seq = ++ctx->chain_seq;
+    if ((rc = track_solver_setup(ctx, ctx->d_chain_flags, &early_now)) != ASD_OK) return rc;
     flags = ctx->d_chain_flags;
   }
   // ---- motion-model stage: projection arguments (launched below)
@@ -2282,9 +2254,15 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   };
   auto search = [&](int KIND, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in, unsigned* ticket) -> int {
     GridDev G{C->d_kp, C->d_cell_start, C->d_cell_items, C->min_x, C->min_y, C->inv_w, C->inv_h};
-    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top, ticket ? ticket + 8 : nullptr, ticket, seq};
+    // The search's ticket is a one-lane kernel BEHIND it, not the search's own last workgroup (SortArgs::done_flag can do that): a ticket
+    // from inside needs an agent-scope release in each of the ~500 workgroups, and on this chip that is a write-back of the whole L2 of
+    // the workgroup's XCD -- 1000 of them per frame under the extractor's ASDNet layers, which are writing 260 MB per launch through
+    // those L2s, slowed the ASDNet forward from 0.60 to 0.72-0.97 ms (tools/ab_resident*.sh).  A kernel's end releases once.
+    static const bool ticket_inside = getenv("ASD_TICKET_INSIDE") != nullptr;   // A/B only
+    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top, ticket && ticket_inside ? ticket + 8 : nullptr, ticket && ticket_inside ? ticket : nullptr, seq};
     hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, d_q, nq, m->d_bank, C->d_desc, d_off, d_cnt,
                        d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, sa);
+    if (ticket && !ticket_inside) hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, st, ticket, seq);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
@@ -2301,8 +2279,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   // else -- it finds its CU while the projection and the first search run -- and every hand-over between the streams is a ticket word:
   // search -> replay (k_window_search's last workgroup), stage-1 solver -> k_frustum_queries (behind the work between the stages), search
   // -> second replay.  No event crosses the streams; the host waits for the solver stream's last kernel.
-  const bool resident = early_now && fuse_now;
-  hipStream_t st_end = st;
+  const bool resident = early_now && fuse_now && track_solver_fits(ctx, nl, ncand, nc, lds1, lds2);
   FrustumArgs fa{};
   fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
   fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
@@ -2323,18 +2300,17 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     return ASD_OK;
   };
   if (resident) {
-    // NOTE the stage-1 kernel reads the chain's upload block (Xw of the last frame, the work between the stages): the copy of that block to
-    // the device rides in k_project_queries, which the search -- and so the ticket this kernel waits for -- is ordered behind
-    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), ctx->stream_solve, flags, seq, &fr1, flags + 16)) != ASD_OK)
-      return rc;
+    seq = ++ctx->chain_seq;
+    // the frame's argument blocks first (the kernel reads them behind the first search's ticket), then -- unless the kernel launched a
+    // frame ago still sits there waiting -- the kernel; then the searches; then the NEXT frame's kernel
+    AsdSolverStage s1{&ra1, lds1, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, down.host<double>(o_res1), nullptr, d_io1,
+                      up.dev<AsdBetweenArgs>(o_btw)};
+    AsdSolverStage s2{&ra2, lds2, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, down.host<double>(o_res2), d_io1, nullptr, nullptr};
+    if ((rc = track_solver_submit(ctx, seq, flags, nc, Kd.data(), s1, s2)) != ASD_OK) return rc;
     if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, flags)) != ASD_OK) return rc;
     fa.wait_flag = flags + 16; fa.wait_value = seq; fa.wait_failed = flags + 24;
     if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
-    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
-                                 ctx->stream_solve, flags + 32, seq, &fr2)) != ASD_OK)
-      return rc;
-    st_end = ctx->stream_solve;
+    if (early_sel == 1 && (rc = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rc;
   } else {
     if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, nullptr)) != ASD_OK) return rc;
     if (!fuse_now) {
@@ -2356,12 +2332,17 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       return rc;
   }
   if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
-  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st_end));
+  ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev_chain, st));
 
   asd_track_frame_args O = A;   // (only the output pointers are used below)
   std::array<double, 7> p_in;
   memcpy(p_in.data(), A.pose7, 56);
   auto complete = [=]() -> int {
+    if (resident) {
+      int rw = track_solver_wait(ctx, seq, flags);
+      if (rw != ASD_OK) return rw;
+      if (early_sel == 2 && (rw = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rw;   // the next frame's kernel: ~100 us ahead of its first ticket
+    }
     ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_chain));
     const int *h1 = ctx->down.host<int>(o_out1), *h2 = ctx->down.host<int>(o_out2);
     m->last_total[0] = h1[nc + 1]; m->last_total[1] = h2[nc + 1];
@@ -3071,6 +3052,7 @@ int asd_prep_async(asd_ctx* ctx, int32_t on) {
       // the solver stream's comment in track_frame_impl)
       static const int prep_prio_sel = [] { const char* e = getenv("ASD_PREP_PRIO"); return e ? atoi(e) : 2; }();   // 0 lowest, 1 middle, 2 highest (A/B)
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, prep_prio_sel == 2 ? hi : prep_prio_sel == 0 ? lo : lo + (hi - lo) / 2));
+      asd_register_stream(ctx, ctx->stream_prep);
       ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     }
     ctx->prep_on = true;

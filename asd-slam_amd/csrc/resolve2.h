@@ -52,8 +52,9 @@ constexpr int kResolve2Threads = 1024;
 // The replay as a device function over NT threads of ONE workgroup (dynamic LDS from offset 0): k_resolve2 (matcher.hip) is it on 1024
 // threads; k_resolve_pose (ba.hip) runs it on PoseOptimization's 512 in front of the solver, in the same workgroup -- the solver then
 // needs no dispatch of its own (it waited 35-50 us for a CU beside the extractor's ASDNet workgroups, twice per frame).
-template <int KIND, int QPT, int NT>
-__device__ __forceinline__ void resolve2_body(const Resolve2Args& a) {
+// (A = const Resolve2Args in whatever address space the block lives: a kernel's argument segment, or constant memory)
+template <int KIND, int QPT, int NT, class A>
+__device__ __forceinline__ void resolve2_body(A& a) {
 #pragma clang fp contract(off)
 #define OUT(i, v) do { const int v_ = (v); a.match_cur[i] = v_; if (a.mirror) a.mirror[i] = v_; } while (0)
 #define CNT(i, v) do { const int v_ = (v); a.n_matches[i] = v_; if (a.mirror) a.mirror[a.n_cur + (i)] = v_; } while (0)

@@ -12,9 +12,10 @@ CASES = [
     ({"ASD_RESULT_COPY": "1", "ASD_UPLOAD_COPY": "1"}, ["tests/test_track_chain.py", "tests/test_matcher.py::test_host_and_device_replay_agree"]),
     ({"ASD_UPLOAD_SEPARATE": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_FRONT_PRIO_MID": "1"}, ["tests/test_bench_host.py"]),
-    # asd_track_frame with its PoseOptimization kernels launched ahead on the solver stream (opt-in), the old bid-based claim replay, one
-    # extraction worker
+    # asd_track_frame in its resident form (one solver kernel per frame launched ahead, tickets between the streams; opt-in), replay and
+    # solver as separate kernels, the old bid-based claim replay, one extraction worker
     ({"ASD_CHAIN_EARLY": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
+    ({"ASD_CHAIN_EARLY": "2"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_CHAIN_FUSED": "0"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_RESOLVE": "bids"}, ["tests/test_matcher.py", "tests/test_track_chain.py::test_track_motion_model_equals_separate_calls"]),
     ({"ASD_EXTRACT_WORKERS": "1"}, ["tests/test_bench_host.py", "tests/test_kitti_configs.py"]),
