@@ -237,6 +237,8 @@ struct PoseOptArgs {
   // The wait is bounded (kPoseWaitPolls): a flag that never comes ends the kernel with io[7] = -1 instead of hanging the device.
   const unsigned* wait_flag;
   unsigned wait_value;
+  double host_done;                // 0, or a marker the kernel stores at io[8 + nw + 3] behind everything else (system scope): the host polls it
+                                   // instead of waiting for an event queued behind a kernel that sits on the device (k_resolve_pose)
   unsigned* done_flag;             // null, or the kernel's own ticket: set to wait_value behind its last store (k_frustum_queries of the
                                    // local-map stage waits for the motion-model stage's solver this way, asd_track_frame)
   const AsdBetweenArgs* between;   // device memory or null.  asd_track_frame, motion-model stage: the kernel ends with the work between the
@@ -901,22 +903,33 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) { p
 // take every slot a finished workgroup frees (device-clock stamps, profiles/r04_chain_device_clock.txt); here it inherits the replay's.
 template <int KIND, int QPT>
 __global__ __launch_bounds__(kPoseThreads) void k_resolve_pose(Resolve2Args r, PoseOptArgs a_in) {
-  if (a_in.wait_flag) {   // resident ahead of the search that makes its lists (its ticket: k_window_search's last workgroup): one lane polls
-    __shared__ int search_ok;
+  __shared__ int search_ok;
+  auto search_ok_all = [&](const PoseOptArgs&) { return search_ok != 0; };
+  if (a_in.wait_flag) {   // resident ahead of the search that makes its lists (its ticket: a one-lane kernel behind the search): one lane polls
     if (threadIdx.x == 0) search_ok = asd_ticket_wait(a_in.wait_flag, a_in.wait_value) ? 1 : 0;
     asd_syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (!search_ok) {   // report, touch nothing else (nothing is published: a kernel waiting for this one reports the same way)
       if (threadIdx.x == 0) { a_in.io[7] = -1.0; if (a_in.io_dev) a_in.io_dev[7] = -1.0; }
-      return;
     }
   }
-  resolve2_body<KIND, QPT, kPoseThreads>(r);
-  // the match table is this workgroup's own stores: complete, then visible to all its waves (and no stale line in the vector L1)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asd_syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  pose_opt_body<2>(a_in);
+  if (!a_in.wait_flag || search_ok_all(a_in)) {
+    resolve2_body<KIND, QPT, kPoseThreads>(r);
+    // the match table is this workgroup's own stores: complete, then visible to all its waves (and no stale line in the vector L1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    pose_opt_body<2>(a_in);
+  }
+  if (a_in.host_done != 0.0) {   // "done" for a host that polls pinned memory: behind every store of the workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a_in.io + 8 + (a_in.g_ncur + 7) / 8 + 3, a_in.host_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---- asd_track_frame, resident form: ONE solver kernel per frame, launched a frame AHEAD --------------------------------------------
@@ -2349,6 +2362,8 @@ int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, 
   return track_solver_launch(ctx, S, seq, flags);
 }
 
+hipStream_t track_solver_stream(asd_ctx* ctx, int slot) { return ba_state(ctx)->solver.st[slot & 1]; }
+
 int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags) {
   BaState::Solver& S = ba_state(ctx)->solver;
   return track_solver_launch(ctx, S, seq_next, flags);
@@ -2427,7 +2442,7 @@ static PoseOptArgs pose_chain_args(asd_ctx* ctx, BaState* s, int n_cur, const in
 
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
-                       const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value, const AsdFusedReplay* fused, unsigned* done_flag) {
+                       const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value, const AsdFusedReplay* fused, unsigned* done_flag, double host_done) {
   // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
   // inside the caller's one result block: no copy is enqueued here
   BaState* s = ba_state(ctx);
@@ -2439,6 +2454,7 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
   const int mode = pose_chain_lds_form(ctx, n_cur) ? 2 : 0;
   PoseOptArgs a = pose_chain_args(ctx, s, n_cur, d_src, d_kp, d_tab, d_hold, d_own, pose7, K, d_io, d_pose0, d_io_dev, between, wait_flag, wait_value, done_flag);
   a.use_lds = mode;
+  a.host_done = fused ? host_done : 0.0;
   if (mode != 2) {   // larger than LDS: edge records through HBM
     a.g_src = nullptr; a.g_hold = nullptr; a.g_tab = nullptr; a.g_own = nullptr; a.g_kp = nullptr; a.g_ncur = 0;
     PoseEdgesArgs e{};

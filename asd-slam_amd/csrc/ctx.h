@@ -357,7 +357,7 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
                        double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, hipStream_t st_early = nullptr,
                        const unsigned* wait_flag = nullptr, unsigned wait_value = 0, const AsdFusedReplay* fused = nullptr,
-                       unsigned* done_flag = nullptr);
+                       unsigned* done_flag = nullptr, double host_done = 0.0);
 // ---- the per-frame solver kernel of asd_track_frame (k_track_solver, ba.hip; see its comment)
 // everything below returns ASD_OK or an error; `usable` = false when the streams' hardware queues rule the resident form out
 struct AsdSolverStage {   // pose_chain_enqueue's inputs of one stage
@@ -369,7 +369,8 @@ int track_solver_setup(asd_ctx* ctx, unsigned* flags, bool* usable);
 bool track_solver_fits(const asd_ctx* ctx, int n_last, int n_cand, int n_cur, size_t lds1, size_t lds2);
 int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, const double* K, const AsdSolverStage& s1, const AsdSolverStage& s2);   // fill the frame's block; launch unless resident
 int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags);   // next frame's kernel, a frame ahead
-int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags);             // host: until the frame's kernel has ended (relaunches one that gave up waiting)
+int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags);
+hipStream_t track_solver_stream(asd_ctx* ctx, int slot);   // (after track_solver_setup said usable)             // host: until the frame's kernel has ended (relaunches one that gave up waiting)
 inline void asd_register_stream(asd_ctx* ctx, hipStream_t st) { std::lock_guard<std::mutex> g(ctx->aux_mu); ctx->aux_streams.push_back(st); }
 inline void asd_unregister_stream(asd_ctx* ctx, hipStream_t st) {
   std::lock_guard<std::mutex> g(ctx->aux_mu);

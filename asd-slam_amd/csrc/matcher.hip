@@ -2193,7 +2193,8 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   // extractor becomes the side the tracking thread waits for (0.34-0.69 ms per step) and the step gets slower end to end: 820-1140
   // frames/s against 1180-1230 in stream order on the same boxes.  The extractor (ASDNet 0.59 ms + 0.07 ms between forwards) and the
   // tracking thread (0.64 ms + LocalBA's share) are within a few percent of each other: neither side alone moves the step.
-  static const int early_sel = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return e ? atoi(e) : 0; }();   // 1: next frame's kernel launched at submit, 2: at completion
+  static const int early_sel = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return e ? atoi(e) : 0; }();   // 1: next frame's kernel launched at submit, 2: at completion;
+                                                                                                            // 3: only the local-map stage's kernel resident, launched with its frame
   static const bool early = early_sel != 0;
   unsigned seq = 0;
   unsigned* flags = nullptr;
@@ -2279,7 +2280,8 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   // else -- it finds its CU while the projection and the first search run -- and every hand-over between the streams is a ticket word:
   // search -> replay (k_window_search's last workgroup), stage-1 solver -> k_frustum_queries (behind the work between the stages), search
   // -> second replay.  No event crosses the streams; the host waits for the solver stream's last kernel.
-  const bool resident = early_now && fuse_now && track_solver_fits(ctx, nl, ncand, nc, lds1, lds2);
+  const bool resident = early_now && early_sel != 3 && fuse_now && track_solver_fits(ctx, nl, ncand, nc, lds1, lds2);
+  const bool resident2 = early_now && early_sel == 3 && fuse_now;   // stage 2's replay + solver on a solver stream, waiting for its search's ticket
   FrustumArgs fa{};
   fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
   fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
@@ -2311,6 +2313,20 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     fa.wait_flag = flags + 16; fa.wait_value = seq; fa.wait_failed = flags + 24;
     if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
     if (early_sel == 1 && (rc = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rc;
+  } else if (resident2) {
+    // Stage 1 in stream order; stage 2's kernel goes onto a solver stream NOW and finds its CU while stage 1 runs (in stream order it waits
+    // 30-60 us for one behind its search); it waits there for the second search's ticket.  The host polls the kernel's "done" marker in the
+    // pinned result block: an event queued behind a waiting kernel would hold its queue's command-processor pipe.
+    seq = ++ctx->chain_seq;
+    hipStream_t sb = track_solver_stream(ctx, (int)seq);
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
+                                 sb, flags + 32, seq, &fr2, nullptr, (double)seq)) != ASD_OK)
+      return rc;
+    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, nullptr)) != ASD_OK) return rc;
+    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
+                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), nullptr, nullptr, 0, &fr1)) != ASD_OK)
+      return rc;
+    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
   } else {
     if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, nullptr)) != ASD_OK) return rc;
     if (!fuse_now) {
@@ -2342,6 +2358,17 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       int rw = track_solver_wait(ctx, seq, flags);
       if (rw != ASD_OK) return rw;
       if (early_sel == 2 && (rw = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rw;   // the next frame's kernel: ~100 us ahead of its first ticket
+    }
+    if (resident2) {   // the stage-2 kernel's marker, behind all of its stores
+      const double* mk = ctx->down.host<double>(o_res2) + 8 + (nc + 7) / 8 + 3;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (long spin = 0; __atomic_load_n(reinterpret_cast<const unsigned long long*>(mk), __ATOMIC_ACQUIRE) != (unsigned long long)__builtin_bit_cast(unsigned long long, (double)seq); ++spin) {
+        if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
+          ctx->set_error("asd_track_frame: the local-map stage's kernel did not finish within 5 s");
+          return ASD_ERR_HIP;
+        }
+        __builtin_ia32_pause();
+      }
     }
     ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_chain));
     const int *h1 = ctx->down.host<int>(o_out1), *h2 = ctx->down.host<int>(o_out2);
