@@ -2281,7 +2281,8 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   // search -> replay (k_window_search's last workgroup), stage-1 solver -> k_frustum_queries (behind the work between the stages), search
   // -> second replay.  No event crosses the streams; the host waits for the solver stream's last kernel.
   const bool resident = early_now && early_sel != 3 && fuse_now && track_solver_fits(ctx, nl, ncand, nc, lds1, lds2);
-  const bool resident2 = early_now && early_sel == 3 && fuse_now;   // stage 2's replay + solver on a solver stream, waiting for its search's ticket
+  const bool resident2 = early_now && early_sel == 3 && fuse_now;
+  static const bool poll_marker = [] { const char* e = getenv("ASD_CHAIN_POLL"); return e && atoi(e) != 0; }();   // stage 2's replay + solver on a solver stream, waiting for its search's ticket
   FrustumArgs fa{};
   fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
   fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
@@ -2343,8 +2344,10 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       if (ncand <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<1, 2>, ra2, lds2));
       else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<1, 4>, ra2, lds2));
     }
+    // (ASD_CHAIN_POLL=1, A/B: the host polls the last kernel's marker in the pinned result block in front of hipEventSynchronize)
+    if (poll_marker && fuse_now) seq = ++ctx->chain_seq;
     if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
-                                 nullptr, nullptr, 0, fuse_now ? &fr2 : nullptr)) != ASD_OK)
+                                 nullptr, nullptr, 0, fuse_now ? &fr2 : nullptr, nullptr, poll_marker && fuse_now ? (double)seq : 0.0)) != ASD_OK)
       return rc;
   }
   if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
@@ -2359,7 +2362,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       if (rw != ASD_OK) return rw;
       if (early_sel == 2 && (rw = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rw;   // the next frame's kernel: ~100 us ahead of its first ticket
     }
-    if (resident2) {   // the stage-2 kernel's marker, behind all of its stores
+    if (resident2 || (poll_marker && fuse_now && !resident)) {   // the stage-2 kernel's marker, behind all of its stores
       const double* mk = ctx->down.host<double>(o_res2) + 8 + (nc + 7) / 8 + 3;
       const auto t0 = std::chrono::steady_clock::now();
       for (long spin = 0; __atomic_load_n(reinterpret_cast<const unsigned long long*>(mk), __ATOMIC_ACQUIRE) != (unsigned long long)__builtin_bit_cast(unsigned long long, (double)seq); ++spin) {

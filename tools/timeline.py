@@ -21,7 +21,7 @@ for r in rows:
 # round 4: the PoseOptimization kernels run on a stream of their own (launched ahead, waiting on a device flag): the tracking chain is
 # the search queue plus the solver queue; a solver kernel's span starts when it became resident, not when its inputs were ready
 q = [r for r in rows if r["n"].startswith("k_window_search")][0]["Queue_Id"]
-qs = {q, [r for r in rows if r["n"].startswith("k_pose_opt")][0]["Queue_Id"]}
+qs = {q, [r for r in rows if r["n"].startswith(("k_resolve_pose", "k_pose_opt", "k_track_solver"))][0]["Queue_Id"]}   # (the solver stream of ASD_CHAIN_EARLY, if any)
 tr = sorted([r for r in rows if r["Queue_Id"] in qs], key=lambda r: r["s"])
 starts = [i for i, r in enumerate(tr) if r["n"].startswith("k_window_search")]
 frames = starts[0::2]                      # two searches per frame (frame-to-frame, local map)
@@ -72,7 +72,7 @@ def med(v):
 byq = {}
 for r in sorted(rows, key=lambda r: r["s"]):
     byq.setdefault(r["Queue_Id"], []).append(r)
-for name in ("k_ba_solve_lds", "k_ba_schur", "k_ba_step", "k_ba_linearize", "k_resolve2", "k_window_search"):
+for name in ("k_ba_solve_lds", "k_ba_schur", "k_ba_step", "k_ba_linearize", "k_resolve_pose", "k_resolve2", "k_window_search"):
     gaps, durs = [], []
     for qq, lst in byq.items():
         for a, b in zip(lst[:-1], lst[1:]):
