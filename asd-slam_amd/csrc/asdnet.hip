@@ -1596,12 +1596,27 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
 
 int asdnet_profile_collect_set(asd_ctx* ctx, int set);
 
+static int asdnet_forward_one(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag);
 int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag) {
   if (!ctx->weights_loaded) { ctx->set_error("asd_load_weights has not been called"); return ASD_ERR_NO_WEIGHTS; }
   if (n < 0 || n > ctx->cfg.max_patches) { ctx->set_error("n=%d exceeds max_patches=%d", n, ctx->cfg.max_patches); return ASD_ERR_CAPACITY; }
   if (n == 0) return ASD_OK;
   if (!st) st = ctx->stream;
   std::lock_guard<std::mutex> prof_lock(ctx->prof_mutex);  // prof_* state is shared with asd_profile_enable / _get
+  // ASD_ASDNET_SLICES=k (A/B): the forward as k forwards over n / k patches each, one after the other on the same stream -- k times as many
+  // kernel ends, i.e. moments at which CUs run empty and a waiting whole-CU workgroup of the tracking stream can be placed
+  static const int slices = [] { const char* e = getenv("ASD_ASDNET_SLICES"); return e ? std::max(1, atoi(e)) : 1; }();
+  if (slices > 1 && n >= 256 * slices && !ctx->prof_on && !ctx->d_calib) {
+    const int per = ((n + slices - 1) / slices + 31) / 32 * 32;
+    for (int o = 0; o < n; o += per) {
+      const int rc = asdnet_forward_one(ctx, d_patches + (size_t)o * 1024, std::min(per, n - o), d_desc + (size_t)o * 128, st, range_flag);
+      if (rc != ASD_OK) return rc;
+    }
+    return ASD_OK;
+  }
+  return asdnet_forward_one(ctx, d_patches, n, d_desc, st, range_flag);
+}
+static int asdnet_forward_one(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag) {
   float *a0 = ctx->d_act[0], *a1 = ctx->d_act[1];
   const int npad = (n + 31) / 32 * 32;
   const bool prof = ctx->prof_on;
