@@ -945,7 +945,7 @@ __global__ __launch_bounds__(kPoseThreads) void k_resolve_pose(Resolve2Args r, P
 struct AsdSolverBlock { Resolve2Args r1, r2; PoseOptArgs p1, p2; };
 constexpr int kSolverQ0 = 4, kSolverQ1 = 8;   // queries per thread of the two replays: up to 2048 last-frame points, 4096 local-map candidates
 #define ASD_CONST_AS __attribute__((address_space(4)))
-__global__ __launch_bounds__(kPoseThreads) void k_track_solver(const AsdSolverBlock* blk, const unsigned* flags, unsigned seq, int idle_polls, unsigned* expired, unsigned* done) {
+__global__ __launch_bounds__(kPoseThreads) void k_track_solver(const AsdSolverBlock* blk, const unsigned* flags, unsigned seq, int idle_polls, unsigned* expired, unsigned* done, const unsigned* claim) {
   __shared__ int go;
   if (threadIdx.x == 0) {
     int ok = 0;
@@ -953,6 +953,9 @@ __global__ __launch_bounds__(kPoseThreads) void k_track_solver(const AsdSolverBl
       if ((int)(__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) { ok = 1; break; }
       __builtin_amdgcn_s_sleep(32);
     }
+    // out of patience -- unless the host has claimed this kernel for its frame meanwhile (it writes the claim word before it looks at
+    // `expired`, so a kernel it counts on does not give up under it; the frame's first search is then on its way: the long bound)
+    if (!ok && __hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) ok = asd_ticket_wait(flags, seq) ? 1 : 0;
     go = ok;
     if (!ok) __hip_atomic_store(expired, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
@@ -2167,7 +2170,8 @@ struct BaState {
     hipStream_t st[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     void* h_blk[2] = {nullptr, nullptr};       // pinned AsdSolverBlock
-    unsigned* h_expired = nullptr;             // pinned [4]: [slot] the seq a kernel gave up waiting for, [2 + slot] the seq a kernel has finished
+    unsigned* h_expired = nullptr;             // pinned [8]: [slot] the seq a kernel gave up waiting for, [2 + slot] the seq a kernel has finished,
+                                               // [4] the seq whose k_frustum_queries gave up waiting for the stage-1 solver, [5 + slot] the host's claim
     unsigned armed[2] = {0, 0};                // seq the kernel launched last on the slot waits for (0 = none)
     size_t probed = 0;                         // number of registered streams at the last probe
     bool usable = false, created = false;
@@ -2299,8 +2303,8 @@ int track_solver_setup(asd_ctx* ctx, unsigned* flags, bool* usable) {
       ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming));
       ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_blk[i], sizeof(AsdSolverBlock), hipHostMallocDefault));
     }
-    ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&S.h_expired), 4 * sizeof(unsigned), hipHostMallocDefault));
-    for (int i = 0; i < 4; ++i) S.h_expired[i] = 0;
+    ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&S.h_expired), 8 * sizeof(unsigned), hipHostMallocDefault));
+    for (int i = 0; i < 8; ++i) S.h_expired[i] = 0;
     ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_track_solver), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSolverLds));
     S.created = true;
   } else {
@@ -2336,8 +2340,9 @@ int track_solver_setup(asd_ctx* ctx, unsigned* flags, bool* usable) {
 
 static int track_solver_launch(asd_ctx* ctx, BaState::Solver& S, unsigned seq, unsigned* flags) {
   const int slot = seq & 1;
-  hipLaunchKernelGGL(k_track_solver, dim3(1), dim3(kPoseThreads), kSolverLds, S.st[slot], static_cast<const AsdSolverBlock*>(S.h_blk[slot]), flags, seq, kSolverIdlePolls,
-                     S.h_expired + slot, S.h_expired + 2 + slot);
+  static const int idle_polls = [] { const char* e = getenv("ASD_SOLVER_IDLE_POLLS"); return e && atoi(e) > 0 ? atoi(e) : kSolverIdlePolls; }();   // (tests: a tiny bound makes every kernel launched ahead give up)
+  hipLaunchKernelGGL(k_track_solver, dim3(1), dim3(kPoseThreads), kSolverLds, S.st[slot], static_cast<const AsdSolverBlock*>(S.h_blk[slot]), flags, seq, idle_polls,
+                     S.h_expired + slot, S.h_expired + 2 + slot, S.h_expired + 5 + slot);
   ASD_HIP_CHECK(ctx, hipGetLastError());   // (nothing is queued behind it: see the kernel's last lines)
   S.armed[slot] = seq;
   return ASD_OK;
@@ -2357,12 +2362,15 @@ int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, 
   b->p2 = pose_chain_args(ctx, s, n_cur, s2.d_src, s2.d_kp, s2.d_tab, s2.d_hold, s2.d_own, s2.pose7, K, s2.d_io, s2.d_pose0, s2.d_io_dev, s2.between, nullptr, seq, nullptr);
   ctx->pose_chain_kp_flags = true;
   // (the block is complete before the frame's first search is launched: the caller launches it after this returns)
+  __atomic_store_n(S.h_expired + 5 + slot, seq, __ATOMIC_SEQ_CST);   // the claim: a kernel that reads it does not give up any more
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   if (S.armed[slot] == seq && __atomic_load_n(S.h_expired + slot, __ATOMIC_ACQUIRE) != seq) return ASD_OK;   // resident, waiting for this frame
   S.h_expired[slot] = 0;
   return track_solver_launch(ctx, S, seq, flags);
 }
 
 hipStream_t track_solver_stream(asd_ctx* ctx, int slot) { return ba_state(ctx)->solver.st[slot & 1]; }
+unsigned* track_solver_gate_word(asd_ctx* ctx) { return ba_state(ctx)->solver.h_expired + 4; }
 
 int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags) {
   BaState::Solver& S = ba_state(ctx)->solver;
@@ -2374,7 +2382,14 @@ int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags) {
   const int slot = seq & 1;
   const auto t0 = std::chrono::steady_clock::now();
   for (long spin = 0;; ++spin) {
-    if (__atomic_load_n(S.h_expired + 2 + slot, __ATOMIC_ACQUIRE) == seq) return ASD_OK;
+    if (__atomic_load_n(S.h_expired + 2 + slot, __ATOMIC_ACQUIRE) == seq) {
+      if (__atomic_load_n(S.h_expired + 4, __ATOMIC_ACQUIRE) == seq) {
+        ctx->set_error("asd_track_frame: k_frustum_queries gave up waiting for the motion-model stage's solver (a kernel launched ahead gave up as its frame "
+                       "arrived and the call was not finished for %d polls): the local-map stage searched nothing", kAsdTicketPolls);
+        return ASD_ERR_HIP;
+      }
+      return ASD_OK;
+    }
     if (__atomic_load_n(S.h_expired + slot, __ATOMIC_ACQUIRE) == seq) {
       // the kernel launched a frame ahead gave up just as the frame arrived (the host had still seen it waiting): the searches have
       // run, their tickets stand -- a fresh kernel goes straight through

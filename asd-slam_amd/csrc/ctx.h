@@ -370,7 +370,8 @@ bool track_solver_fits(const asd_ctx* ctx, int n_last, int n_cand, int n_cur, si
 int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, const double* K, const AsdSolverStage& s1, const AsdSolverStage& s2);   // fill the frame's block; launch unless resident
 int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags);   // next frame's kernel, a frame ahead
 int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags);
-hipStream_t track_solver_stream(asd_ctx* ctx, int slot);   // (after track_solver_setup said usable)             // host: until the frame's kernel has ended (relaunches one that gave up waiting)
+hipStream_t track_solver_stream(asd_ctx* ctx, int slot);
+unsigned* track_solver_gate_word(asd_ctx* ctx);      // pinned: k_frustum_queries stores the frame's seq there when its wait for the stage-1 solver runs out   // (after track_solver_setup said usable)             // host: until the frame's kernel has ended (relaunches one that gave up waiting)
 inline void asd_register_stream(asd_ctx* ctx, hipStream_t st) { std::lock_guard<std::mutex> g(ctx->aux_mu); ctx->aux_streams.push_back(st); }
 inline void asd_unregister_stream(asd_ctx* ctx, hipStream_t st) {
   std::lock_guard<std::mutex> g(ctx->aux_mu);

@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
     asd_syncthreads();
     gate_ok = ok_s != 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (!gate_ok && threadIdx.x == 0) *a.wait_failed = 1u;
+    if (!gate_ok && threadIdx.x == 0) __hip_atomic_store(a.wait_failed, a.wait_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= a.n) return;
@@ -2311,7 +2311,7 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     AsdSolverStage s2{&ra2, lds2, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, down.host<double>(o_res2), d_io1, nullptr, nullptr};
     if ((rc = track_solver_submit(ctx, seq, flags, nc, Kd.data(), s1, s2)) != ASD_OK) return rc;
     if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, flags)) != ASD_OK) return rc;
-    fa.wait_flag = flags + 16; fa.wait_value = seq; fa.wait_failed = flags + 24;
+    fa.wait_flag = flags + 16; fa.wait_value = seq; fa.wait_failed = track_solver_gate_word(ctx);
     if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
     if (early_sel == 1 && (rc = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rc;
   } else if (resident2) {

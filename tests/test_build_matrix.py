@@ -17,6 +17,9 @@ CASES = [
     ({"ASD_CHAIN_EARLY": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_CHAIN_EARLY": "2"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_CHAIN_EARLY": "3"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
+    # ... and with kernels launched ahead that give up after ~20 us: every frame finds its kernel gone and launches a fresh one
+    ({"ASD_CHAIN_EARLY": "1", "ASD_SOLVER_IDLE_POLLS": "20"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
+    ({"ASD_CHAIN_EARLY": "2", "ASD_SOLVER_IDLE_POLLS": "20"}, ["tests/test_bench_host.py"]),
     ({"ASD_CHAIN_FUSED": "0"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_RESOLVE": "bids"}, ["tests/test_matcher.py", "tests/test_track_chain.py::test_track_motion_model_equals_separate_calls"]),
     ({"ASD_EXTRACT_WORKERS": "1"}, ["tests/test_bench_host.py", "tests/test_kitti_configs.py"]),
