@@ -257,6 +257,10 @@ class AsdHip:
         self.lib.asd_extract_view_valid.restype = C.c_int32
         return bool(self.lib.asd_extract_view_valid(self.ctx, C.c_uint64(view_id)))
 
+    def extract_hold(self, on=True):
+        """asd_extract_hold: no further ASDNet forward of the read-ahead extractor is enqueued while on (a wait on a held submission ends it)"""
+        self._chk(self.lib.asd_extract_hold(self.ctx, int(on)))
+
     def profile_enable(self, on=True):
         self._chk(self.lib.asd_profile_enable(self.ctx, int(on)))
 

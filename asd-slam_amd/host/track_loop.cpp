@@ -797,7 +797,13 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
     h->ba_out = true;
     h->ba_step = h->steps;
   } else {
-    if ((rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
+    // ASD_BA_HOLD_EXTRACT=1 (A/B; off by default): the extractor stands back while LocalBA runs in line.  Measured, round 4 (tools/ab_hold.sh):
+    // LocalBA 2.67 ms instead of 2.73-2.92, but the tracking thread then waits longer for the extractor; 1104-1190 frames/s with, 1142-1167 without.
+    static const bool hold = [] { const char* e = getenv("ASD_BA_HOLD_EXTRACT"); return e && atoi(e) != 0; }();
+    if (hold) { (void)asd_extract_hold(ctx, 1); if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 1); }
+    rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r);
+    if (hold) { (void)asd_extract_hold(ctx, 0); if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 0); }
+    if (rc != ASD_OK) return rc;
     st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
   }
   h->ba_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b0).count();

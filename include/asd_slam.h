@@ -542,6 +542,11 @@ int asd_frame_set_from_ctx(asd_ctx* ctx, int32_t slot, const asd_keypoint* kps, 
  * waited for last on the two contexts -- valid as long as their descriptors are (two further submissions).  Inside an
  * asd_prep_async bracket of ctx_left the call runs on that context's second stream, beside tracking stages in flight. */
 int asd_extract_keep_pyramid(asd_ctx* ctx, int32_t on);
+/* Read-ahead extraction on hold: while on != 0 the extractor's workers enqueue no further ASDNet forward (front halves continue, forwards
+ * already enqueued finish).  For a caller that runs LocalMapping::DoMapping in line (Tracking.cc:797 -> LocalMapping.cc:59-113): the extractor
+ * is told to stand back for the length of asd_local_ba and makes the time up beside the tracking stages.  asd_extract_wait[_view] on a
+ * submission that is held ends the hold (it could not return otherwise). */
+int asd_extract_hold(asd_ctx* ctx, int32_t on);
 int asd_stereo_match(asd_ctx* ctx_left, asd_ctx* ctx_right, int32_t slot_left, int32_t slot_right, float mb, float mbf,
                      float* u_right, float* depth, int32_t* n_matched);
 

@@ -344,6 +344,35 @@ def test_view_lifetime_is_checkable(pkg, synth):
 
 
 @pytest.mark.gpu
+def test_extract_hold_delays_nothing_but_the_forward(pkg, synth):
+    """asd_extract_hold: a held submission completes once the hold is lifted -- and a wait on it lifts the hold itself -- with the same results"""
+    ctx = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    try:
+        ctx.load_weights(synth.asdnet_weights(0))
+        img = np.ascontiguousarray(synth.scene_frame(3)[:240, :640])
+        ref_k, ref_d = ctx.extract(img)
+        p = ctx.device_alloc(img.nbytes)
+        ctx.h2d(p, img)
+        ctx.extract_hold(True)                     # before any read-ahead extraction exists: nothing to hold, not an error
+        ctx.extract_submit(p, 640, 240, 640)
+        ctx.extract_hold(True)
+        ctx.extract_submit(p, 640, 240, 640)       # its forward may be held ...
+        ctx.extract_hold(False)
+        for _ in range(2):
+            k, d = ctx.extract_wait(view=True)
+            np.testing.assert_array_equal(k, ref_k)
+            np.testing.assert_array_equal(d, ref_d)
+        ctx.extract_hold(True)
+        ctx.extract_submit(p, 640, 240, 640)
+        k, d = ctx.extract_wait(view=True)         # ... and a wait on a held submission ends the hold
+        np.testing.assert_array_equal(k, ref_k)
+        np.testing.assert_array_equal(d, ref_d)
+        ctx.device_free(p)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_pipelined_extract_device_descriptors_adoptable(hip, oracle, synth):
     """asd_frame_set(desc=NULL) after asd_extract_wait adopts THAT frame's device descriptors even though the next
     frames' ASDNet passes are already running: checked through a matcher that reads the slot's descriptors"""
