@@ -34,6 +34,8 @@ find $O/prof_ba -name "*kernel_trace.csv" -delete
 for n in 64 256 2000; do echo "n=$n"; ASD_X3_PHASES=1 python3 tools/x3_clock.py $n 2>&1; done > $O/asdnet_phases.txt
 # issue rates of one wave / of waves sharing a SIMD (VALU, MFMA, both)
 (tools/ubench/valu_rate; tools/ubench/mix_rate) > $O/issue_rates.txt 2>&1
+# what a waiting workgroup costs a stream of ASDNet-shaped grids on another queue (binary: hipcc --offload-arch=gfx950 -O3 tools/ubench/spinner_beside.hip)
+tools/ubench/spinner_beside > $O/spinner_beside.txt 2>&1
 # PoseOptimization beside the extractor: one result over thousands of calls
 python3 tools/diag/pose_determinism.py 3000 beside > $O/pose_determinism.txt 2>&1
 python3 tools/diag/ba_determinism.py 600 >> $O/pose_determinism.txt 2>&1
