@@ -1113,7 +1113,8 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
 // ASD_RESOLVE=bids: round 2/3's k_resolve (every candidate bids in every iteration) instead of the sorted-list replay, for A/B runs
 bool resolve_by_bids() { static const bool b = [] { const char* e = getenv("ASD_RESOLVE"); return e && !strcmp(e, "bids"); }(); return b; }
 size_t resolve_lds_bytes(int kind, int n_cur, int nq) {
-  if (!resolve_by_bids()) return resolve2_fixed_lds(kind, n_cur) + (size_t)n_cur * 4;   // k_resolve2: the two claim tables, angle / octave table, last-writer table
+  if (!resolve_by_bids())   // k_resolve2: the two claim tables, angle / octave table, last-writer table, (local map) the compacted list of map points with candidates
+    return resolve2_fixed_lds(kind, n_cur) + (size_t)n_cur * 4 + (kind == 1 ? ((size_t)nq * 2 + 15) / 16 * 16 : 0);
   return (size_t)(kind == 1 ? 2 : 1) * nq * 8 + (size_t)n_cur * 2 * sizeof(int) + (size_t)(n_cur + 15) / 16 * 16;
 }
 // room for the tail of the candidate lists in LDS (k_resolve, ov_cap): what the previous search of this kind produced beyond `slots`

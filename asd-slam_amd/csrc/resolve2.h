@@ -98,18 +98,64 @@ __device__ __forceinline__ void resolve2_body(A& a) {
   uint2 tj[QPT];                        // the heads' keypoints (16 bit each; KIND 1 uses .x only)
   float ang_last[KIND == 0 ? QPT : 1];
   unsigned posmask = 0;
+  // KIND 1: most local-map candidates have nothing in their window (bench: 1000 lists for 4000 candidates) -- the replay runs over the
+  // COMPACTED list of map points that have one, in their original order (ballot + prefix over (slot, wave), as the solver's edge gather
+  // does): qid[] = the map point a thread's slot stands for, and the slots beyond n_act -- whole rounds of k, for every thread -- are
+  // skipped by the loops below instead of being executed under an empty mask (8 queries per thread on the solver's 512 threads).
+  int qid[QPT];
+  int ka = QPT;   // slots [0, ka) hold map points somewhere in the workgroup (wave-uniform)
+  if constexpr (KIND == 1) {
+    constexpr int NW = NT / 64;
+    unsigned short* act_s = reinterpret_cast<unsigned short*>(last + a.n_cur);   // [nq], behind the last-writer table (resolve_lds_bytes counts it)
+    __shared__ int wbase[QPT * NW + 1];
+    const int lane = t & 63, wave = t >> 6;
+    unsigned long long bal[QPT];
 #pragma unroll
-  for (int k = 0; k < QPT; ++k) {
-    const int q = t + k * NT;
-    const bool v = q < a.nq;
-    const int qc = v ? q : 0;
-    cnt[k] = v ? a.q_cnt[qc] : 0;
-    qoff[k] = a.q_off[qc];
-    if (KIND == 1) tj[k] = make_uint2(*reinterpret_cast<const unsigned*>(a.top_idx + (size_t)qc * kTop), 0u);
-    else tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
-    if (KIND == 0) ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
-    if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
-    pick[k] = -1;
+    for (int k = 0; k < QPT; ++k) {
+      const int q = t + k * NT;
+      const bool actv = q < a.nq && a.q_cnt[min(q, a.nq - 1)] > 0;
+      bal[k] = __ballot(actv);
+      if (lane == 0) wbase[k * NW + wave] = __popcll(bal[k]);
+    }
+    asd_syncthreads();
+    if (t == 0) {
+      int sum = 0;
+      for (int i = 0; i < QPT * NW; ++i) { const int v = wbase[i]; wbase[i] = sum; sum += v; }
+      wbase[QPT * NW] = sum;
+    }
+    asd_syncthreads();
+#pragma unroll
+    for (int k = 0; k < QPT; ++k)
+      if (bal[k] >> lane & 1) act_s[wbase[k * NW + wave] + __popcll(bal[k] & ((1ull << lane) - 1))] = (unsigned short)(t + k * NT);
+    asd_syncthreads();
+    const int n_act = wbase[QPT * NW];
+    ka = __builtin_amdgcn_readfirstlane((n_act + NT - 1) / NT);
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int slot = t + k * NT;
+      const bool v = slot < n_act;
+      const int q = v ? (int)act_s[slot] : 0;
+      qid[k] = q;
+      cnt[k] = v ? a.q_cnt[q] : 0;
+      qoff[k] = a.q_off[q];
+      tj[k] = make_uint2(*reinterpret_cast<const unsigned*>(a.top_idx + (size_t)q * kTop), 0u);
+      if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
+      pick[k] = -1;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+      const int q = t + k * NT;
+      const bool v = q < a.nq;
+      const int qc = v ? q : 0;
+      qid[k] = q;
+      cnt[k] = v ? a.q_cnt[qc] : 0;
+      qoff[k] = a.q_off[qc];
+      tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
+      ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
+      if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
+      pick[k] = -1;
+    }
   }
   for (int j = t; j < 2 * a.n_cur; j += NT) claim0[j] = 0xffffffffu;
   for (int j = t; j < a.n_cur; j += NT) last[j] = -1;
@@ -138,10 +184,9 @@ __device__ __forceinline__ void resolve2_body(A& a) {
   auto load_claims = [&](int rdt) {
 #pragma unroll
     for (int k = 0; k < QPT; ++k) {
-      {
+      if (k >= ka) break;
 #pragma unroll
-        for (int i = 0; i < NCL; ++i) cl[k][i] = (i < cnt[k]) ? lds_c[rdt + top_j(k, i)] : 0u;
-      }
+      for (int i = 0; i < NCL; ++i) cl[k][i] = (i < cnt[k]) ? lds_c[rdt + top_j(k, i)] : 0u;
     }
   };
   if (KIND == 0) {   // every map point posts at the head of its list
@@ -208,9 +253,10 @@ __device__ __forceinline__ void resolve2_body(A& a) {
       int p[QPT], p2[QPT], i1[QPT], i2[QPT];
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
-        const int q = t + k * NT;
-        int found = 0;
         p[k] = -1; p2[k] = -1; i1[k] = 0; i2[k] = 0;
+        if (k >= ka) continue;
+        const int q = qid[k];
+        int found = 0;
 #pragma unroll
         for (int i = 0; i < HD; ++i) {
           if (i >= cnt[k] || held(cl[k][i], q) || found >= 2) continue;
@@ -236,6 +282,7 @@ __device__ __forceinline__ void resolve2_body(A& a) {
       auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; float d = sdist[min(pos, n_stage - 1)]; asm volatile("" : "+v"(d)); if (n_stage != total && pos >= n_stage) d = a.dist[pos]; return d; };
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
+        if (k >= ka) break;
         best[k] = p[k] >= 0 ? dist_at(k, i1[k]) : 0.f;
         best2[k] = p2[k] >= 0 ? dist_at(k, i2[k]) : 256.f;
         lvl[k] = p[k] >= 0 ? (int)octv[p[k]] : -1;
@@ -243,7 +290,8 @@ __device__ __forceinline__ void resolve2_body(A& a) {
       }
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
-        const int q = t + k * NT;
+        if (k >= ka) break;
+        const int q = qid[k];
         int pk = p[k];
         if (pk >= 0 && (!(best[k] <= TH_HIGH) || (lvl[k] == lvl2[k] && best[k] > a.nn_ratio * best2[k]))) pk = -1;
         changed |= pk != pick[k];
@@ -273,7 +321,7 @@ __device__ __forceinline__ void resolve2_body(A& a) {
   for (int k = 0; k < QPT; ++k) {
     bin[k] = -1;
     if (pick[k] < 0) continue;
-    atomicMax(&last[pick[k]], t + k * NT);
+    atomicMax(&last[pick[k]], qid[k]);
     ++mine;
     if (KIND == 0 && a.check_ori) {
       float rot = ang_last[k] - ang[pick[k]];   // ORBmatcher.cc:1419-1425
