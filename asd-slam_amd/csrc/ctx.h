@@ -93,6 +93,18 @@ __device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgk
 // local-map stage.  The conversions are asd_pose7_to_tcw's and track_local_points_impl's expressions, operation for operation (the
 // caller compiles this with -ffp-contract=off semantics: every product below is rounded before it is added -- see the pragma), so the
 // stage behind sees the bits a host in between would have handed it.
+// A window query = one GetFeaturesInArea call + the descriptor it is matched against (k_window_search's input; matcher.hip)
+struct AsdWinQuery { float x, y, r; int min_level, max_level, qrow; };
+// Frame::isInFrustum + PredictScale + the search window for the local-map candidates of asd_track_frame (rows of the attribute bank): the
+// arguments of the per-candidate arithmetic, shared by k_frustum_queries (matcher.hip) and the tail of the stage-1 solver (asd_between_body),
+// which makes the queries itself when `n` > 0 -- a launch and its dispatch less between the stages
+struct AsdFrustumTail {
+  int n, n_levels, bfactor;
+  const int* rows; const float* attr;
+  float fx, fy, cx, cy, min_x, max_x, min_y, max_y, cos_limit, th;
+  float level_thr[ASD_MAX_LEVELS], scale[ASD_MAX_LEVELS];
+  AsdWinQuery* queries; float* xw_out;
+};
 struct AsdBetweenArgs {
   int n_cur, n_last, n_cand;
   const int* match1;        // [n_cur] last-frame keypoint or -1
@@ -104,8 +116,53 @@ struct AsdBetweenArgs {
   float* cur_Xw;            // out [n_cur][3]: that map point's position
   uint8_t* skip;            // out [n_cand]
   float* T1;                // out [19]: Tcw (row major 4x4), Ow
+  AsdFrustumTail fr;        // fr.n > 0: the local-map stage's queries are made here as well
 };
 #if defined(__HIPCC__)
+// one candidate of the bank form: the arithmetic of asd_frustum, operation for operation (f32 with the reference's two double accumulations;
+// no contraction; IEEE division and square root), the level from comparisons with thresholds the host derived from its own logf
+// (F = AsdFrustumTail, or k_frustum_queries' own argument block, which carries the same fields: no private copy of the level tables)
+template <class F>
+__device__ inline void asd_frustum_bank_point(const F& a, const float* T_dev, const uint8_t* skip, const int q) {
+#pragma clang fp contract(off)
+  AsdWinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
+  const int row = a.rows[q];
+  const float4 A0 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row], A1 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row + 1];
+  a.xw_out[3 * (size_t)q] = A0.x; a.xw_out[3 * (size_t)q + 1] = A0.y; a.xw_out[3 * (size_t)q + 2] = A0.z;
+  if (!skip[q]) {
+    float T[16], Ow[3];
+    for (int i = 0; i < 16; ++i) T[i] = T_dev[i];
+    for (int i = 0; i < 3; ++i) Ow[i] = T_dev[16 + i];
+    const float P[3] = {A0.x, A0.y, A0.z}, Pn[3] = {A0.w, A1.x, A1.y};
+    const float min_dist = A1.z, max_dist = A1.w;
+    float Pc[3];
+    for (int r = 0; r < 3; ++r) {
+      const float t0 = T[r * 4 + 0] * P[0] + T[r * 4 + 1] * P[1] + T[r * 4 + 2] * P[2];
+      Pc[r] = (float)((double)t0 + (double)T[r * 4 + 3]);
+    }
+    bool ok = !(Pc[2] < 0.0f);
+    const float invz = 1.0f / Pc[2];
+    const float u = a.fx * Pc[0] * invz + a.cx, v = a.fy * Pc[1] * invz + a.cy;
+    if (u < a.min_x || u > a.max_x || v < a.min_y || v > a.max_y) ok = false;
+    const float maxD = 1.2f * max_dist, minD = 0.8f * min_dist;
+    const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
+    const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
+    const float dist = (float)sqrt(nn);
+    if (dist < minD || dist > maxD) ok = false;
+    const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
+    const float vc = (float)(dot / dist);
+    if (vc < a.cos_limit) ok = false;
+    if (ok) {
+      const float ratio = max_dist / dist;
+      int lvl = 0;
+      for (int k = 1; k < a.n_levels; ++k) lvl += ratio >= a.level_thr[k];
+      float r = vc > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (ORBmatcher.cc:126-132)
+      if (a.bfactor) r *= a.th;
+      Q = AsdWinQuery{u, v, r * a.scale[lvl], lvl - 1, lvl, row};
+    }
+  }
+  a.queries[q] = Q;
+}
 // every thread of ONE workgroup (nt threads) calls this behind a barrier that follows the workgroup's stores to io1
 __device__ inline void asd_between_body(const AsdBetweenArgs& a_dev, const int t, const int nt) {
 #pragma clang fp contract(off)
@@ -150,6 +207,14 @@ __device__ inline void asd_between_body(const AsdBetweenArgs& a_dev, const int t
       for (int k = 0; k < 3; ++k) sum += (double)T[k * 4 + i] * (double)T[k * 4 + 3];
       a.T1[16 + i] = (float)(-1.0 * sum);
     }
+  }
+  if (a_dev.fr.n > 0) {   // the local-map stage's queries from the pose and the skip flags just written (this workgroup's own stores: complete,
+    // then visible to all its waves, no stale line in the vector L1).  The frustum arguments are read in place (device memory): a private
+    // copy of a block with run-time indexed arrays would live in scratch.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asd_syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (int q = t; q < a_dev.fr.n; q += nt) asd_frustum_bank_point(a_dev.fr, a.T1, a.skip, q);
   }
 }
 #endif

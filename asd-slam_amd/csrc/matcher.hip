@@ -33,7 +33,7 @@ namespace {
 constexpr int GC = ASD_GRID_COLS, GR = ASD_GRID_ROWS;
 
 // A window query = one GetFeaturesInArea call + the descriptor it is matched against.
-struct WinQuery { float x, y, r; int min_level, max_level, qrow; };
+using WinQuery = AsdWinQuery;   // (ctx.h: the solver's tail makes queries too)
 struct GridDev {
   const float4* kp;        // (x, y, octave as int bits, angle) per keypoint
   const int* cell_start;   // [64*48+1], cell = ix*48 + iy
@@ -777,43 +777,8 @@ __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
   if (q >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
   if (!gate_ok) { a.queries[q] = Q; return; }
-  if (a.attr) {   // bank form
-    const int row = a.rows[q];
-    const float4 A0 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row], A1 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row + 1];
-    a.xw_out[3 * (size_t)q] = A0.x; a.xw_out[3 * (size_t)q + 1] = A0.y; a.xw_out[3 * (size_t)q + 2] = A0.z;
-    if (!a.skip[q]) {
-      float T[16], Ow[3];
-      for (int i = 0; i < 16; ++i) T[i] = a.T_dev[i];
-      for (int i = 0; i < 3; ++i) Ow[i] = a.T_dev[16 + i];
-      const float P[3] = {A0.x, A0.y, A0.z}, Pn[3] = {A0.w, A1.x, A1.y};
-      const float min_dist = A1.z, max_dist = A1.w;
-      float Pc[3];
-      for (int r = 0; r < 3; ++r) {
-        const float t0 = T[r * 4 + 0] * P[0] + T[r * 4 + 1] * P[1] + T[r * 4 + 2] * P[2];
-        Pc[r] = (float)((double)t0 + (double)T[r * 4 + 3]);
-      }
-      bool ok = !(Pc[2] < 0.0f);
-      const float invz = 1.0f / Pc[2];
-      const float u = a.fx * Pc[0] * invz + a.cx, v = a.fy * Pc[1] * invz + a.cy;
-      if (u < a.min_x || u > a.max_x || v < a.min_y || v > a.max_y) ok = false;
-      const float maxD = 1.2f * max_dist, minD = 0.8f * min_dist;
-      const float PO[3] = {P[0] - Ow[0], P[1] - Ow[1], P[2] - Ow[2]};
-      const double nn = (double)PO[0] * PO[0] + (double)PO[1] * PO[1] + (double)PO[2] * PO[2];
-      const float dist = (float)sqrt(nn);
-      if (dist < minD || dist > maxD) ok = false;
-      const double dot = (double)PO[0] * Pn[0] + (double)PO[1] * Pn[1] + (double)PO[2] * Pn[2];
-      const float vc = (float)(dot / dist);
-      if (vc < a.cos_limit) ok = false;
-      if (ok) {
-        const float ratio = max_dist / dist;
-        int lvl = 0;
-        for (int k = 1; k < a.n_levels; ++k) lvl += ratio >= a.level_thr[k];
-        float r = vc > 0.998 ? 2.5f : 4.0f;  // RadiusByViewingCos (:126-132)
-        if (a.bfactor) r *= a.th;
-        Q = WinQuery{u, v, r * a.scale[lvl], lvl - 1, lvl, row};
-      }
-    }
-    a.queries[q] = Q;
+  if (a.attr) {   // bank form (asd_track_frame): the per-candidate arithmetic lives in ctx.h, shared with the stage-1 solver's tail
+    asd_frustum_bank_point(a, a.T_dev, a.skip, q);
     return;
   }
   const float* P = a.Xw + 3 * (size_t)q;
@@ -2293,12 +2258,32 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   fa.rows = up.dev<int>(o_crows); fa.queries = d_q2;
   fa.up = UploadTail{nullptr, nullptr, 0, 0, (ncand + 255) / 256};
   fa.T_dev = d_T1; fa.attr = m->d_attr; fa.skip = d_skip; fa.xw_out = d_cXw;
+  // ASD_FRUSTUM_TAIL=1 (A/B; off by default): the local-map stage's queries are made by the TAIL of the stage-1 solver (asd_between_body, the
+  // workgroup that has just written the pose and the skip flags) instead of by k_frustum_queries -- one launch and its dispatch less between
+  // the stages.  Measured, round 4 (tools/ab_frustum.sh): the stretch from the first solver's end to the second replay's start grows from
+  // 98-124 to 155-158 us -- eight candidates per thread, each a chain of dependent gathers (row, two attribute loads), on one workgroup,
+  // where the kernel spreads 4000 candidates over sixteen -- and the step is unchanged (1202-1214 against 1185-1231 frames/s).
+  // Never in the resident forms 1 / 2: there the search stream needs a kernel of its own to wait for the solver stream's ticket.
+  static const bool frustum_tail = [] { const char* e = getenv("ASD_FRUSTUM_TAIL"); return e && atoi(e) != 0; }();
+  const bool frustum_in_tail = frustum_tail && !resident;
+  {
+    AsdFrustumTail& f = up.host<AsdBetweenArgs>(o_btw)->fr;   // (the pinned block: its copy to the device rides in k_project_queries, launched below)
+    memset(&f, 0, sizeof f);
+    if (frustum_in_tail) {
+      f.n = fa.n; f.n_levels = fa.n_levels; f.bfactor = fa.bfactor; f.rows = fa.rows; f.attr = fa.attr;
+      f.fx = fa.fx; f.fy = fa.fy; f.cx = fa.cx; f.cy = fa.cy; f.min_x = fa.min_x; f.max_x = fa.max_x; f.min_y = fa.min_y; f.max_y = fa.max_y;
+      f.cos_limit = fa.cos_limit; f.th = fa.th;
+      for (int l = 0; l < ASD_MAX_LEVELS; ++l) { f.level_thr[l] = fa.level_thr[l]; f.scale[l] = fa.scale[l]; }
+      f.queries = fa.queries; f.xw_out = fa.xw_out;
+    }
+  }
   auto project = [&]() -> int {
     hipLaunchKernelGGL(k_project_queries, dim3(pa.up.q_blocks + kUploadTailBlocks), dim3(256), 0, st, pa);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
   auto frustum = [&]() -> int {
+    if (frustum_in_tail) return ASD_OK;
     hipLaunchKernelGGL(k_frustum_queries, dim3((ncand + 255) / 256), dim3(256), 0, st, fa);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;

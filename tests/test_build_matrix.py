@@ -21,6 +21,7 @@ CASES = [
     ({"ASD_CHAIN_EARLY": "1", "ASD_SOLVER_IDLE_POLLS": "20"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_CHAIN_EARLY": "2", "ASD_SOLVER_IDLE_POLLS": "20"}, ["tests/test_bench_host.py"]),
     ({"ASD_CHAIN_FUSED": "0"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
+    ({"ASD_FRUSTUM_TAIL": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
     ({"ASD_RESOLVE": "bids"}, ["tests/test_matcher.py", "tests/test_track_chain.py::test_track_motion_model_equals_separate_calls"]),
     ({"ASD_EXTRACT_WORKERS": "1"}, ["tests/test_bench_host.py", "tests/test_kitti_configs.py"]),
     ({"ASD_ASDNET_PERSIST": "1", "ASD_ASDNET_RESERVE": "1"}, ["tests/test_asdnet.py", "tests/test_frontend.py::test_extract_kitti_size_bit_exact"]),
