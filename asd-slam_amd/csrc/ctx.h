@@ -87,8 +87,8 @@ __device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgk
 
 // What Tracking does between its two stages, on the device (asd_track_frame): the matches PoseOptimization marked as outliers are
 // dropped (Tracking.cc:695-714), the optimised pose becomes the frame's pose (Optimizer.cc:405-407 -> Frame::SetPose: Tcw as
-// Converter::toCvMat(SE3Quat) gives it, mOw = -Rcw^T tcw, Frame.cc:150-158), and the map points the frame holds already are marked so
-// that SearchLocalPoints does not project them again (Tracking.cc:811-823).  Runs as the tail of the motion-model stage's k_pose_opt (the
+// Converter::toCvMat(SE3Quat) gives it, mOw = -Rcw^T tcw, Frame.cc:150-158), and the map points the motion-model stage matched -- kept
+// or dropped as outliers (mnLastFrameSeen, :705-707 and :811-823) -- are marked so that SearchLocalPoints does not project them again.  Runs as the tail of the motion-model stage's k_pose_opt (the
 // workgroup that has just written the flags and the pose); outputs feed k_frustum_queries, k_window_search and k_pose_opt of the
 // local-map stage.  The conversions are asd_pose7_to_tcw's and track_local_points_impl's expressions, operation for operation (the
 // caller compiles this with -ffp-contract=off semantics: every product below is rounded before it is added -- see the pragma), so the
@@ -180,7 +180,10 @@ __device__ inline void asd_between_body(const AsdBetweenArgs& a_dev, const int t
     for (int k = 0; k < 3; ++k) a.cur_Xw[3 * (size_t)j + k] = a.n_last > 0 ? a.Xw_last[3 * (size_t)src + k] : 0.f;
     const bool keep = i >= 0 && !outl[j];
     a.occ[j] = keep ? 1 : 0;
-    if (keep && a.last_cand) { const int c = a.last_cand[i]; if (c >= 0 && c < a.n_cand) a.skip[c] = 1; }
+    // the map point of EVERY motion-model match is out of the local-map search: a kept one because the frame holds it (Tracking.cc:811-823),
+    // an outlier's because TrackWithMotionModel stamps it with the frame's id when it drops the match (pMP->mnLastFrameSeen, :705-707) --
+    // the keypoint itself is free again (occ = 0)
+    if (i >= 0 && a.last_cand) { const int c = a.last_cand[i]; if (c >= 0 && c < a.n_cand) a.skip[c] = 1; }
   }
   if (mine) atomicAdd(&s_nmatch, mine);
   asd_syncthreads();

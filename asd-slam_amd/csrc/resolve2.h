@@ -223,7 +223,7 @@ __device__ __forceinline__ void resolve2_body(A& a) {
           // afterwards -- as conditional loads the compiler serialised them, one round trip per entry)
           constexpr int kStep = 4;
           int j = -1;
-          if (n_stage == total) {
+          if (qoff[k] + cnt[k] <= n_stage) {   // this list lies inside the LDS copy (a list that took the search's slow path starts at cap + off: never)
             while (j < 0 && ptr[k] + 1 < cnt[k]) {
               int jj[kStep]; unsigned cc[kStep];
               const int p0 = ptr[k] + 1, lastp = cnt[k] - 1;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void resolve2_body(A& a) {
               for (int i = kStep - 1; i >= 0; --i) if (p0 + i <= lastp && !(cc[i] < (unsigned)q)) { j = jj[i]; adv = i + 1; }
               ptr[k] += adv;
             }
-          } else {   // lists longer than the LDS copy: entry by entry, global beyond it
+          } else {   // lists beyond the LDS copy (long ones, or sorted copies in the buffers' second half): entry by entry, global beyond it
             while (j < 0 && ptr[k] + 1 < cnt[k]) {
               const int cand = list_j(k, ++ptr[k]);
               if (!(peek(cand) < (unsigned)q)) j = cand;
@@ -279,7 +279,7 @@ __device__ __forceinline__ void resolve2_body(A& a) {
       int lvl[QPT], lvl2[QPT];
       // (not `pos < n_stage ? sdist[pos] : a.dist[pos]`: the compiler turns that, and every plain if/else form of it, into ONE flat load
       // through a selected pointer; the empty asm pins the LDS read in front of the branch)
-      auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; float d = sdist[min(pos, n_stage - 1)]; asm volatile("" : "+v"(d)); if (n_stage != total && pos >= n_stage) d = a.dist[pos]; return d; };
+      auto dist_at = [&](int k, int i) { const int pos = qoff[k] + i; float d = sdist[min(pos, n_stage - 1)]; asm volatile("" : "+v"(d)); if (pos >= n_stage) d = a.dist[pos]; return d; };
 #pragma unroll
       for (int k = 0; k < QPT; ++k) {
         if (k >= ka) break;

@@ -44,7 +44,9 @@ struct asd_track_handle {
   // the device, the local map's attributes live in the bank, and the next frame is constructed on the context's second stream
   // (asd_prep_async) beside the stages instead of behind them.  Needs three frame slots (the next frame's grid is written while the
   // motion-model stage may still read the last frame's) and two alternating bank regions.
-  bool chain = true;
+  // OFF by default since round 5: the reference selects its local map between the stages (Tracking::UpdateLocalMap, Tracking.cc:730), which
+  // needs the host there -- the split-phase two-call form above is the one Tracking can bind; this one is a measured variant
+  bool chain = false;
   const asd_do_mapping_inputs* dm = nullptr;   // the batched per-keyframe stage in front of LocalBA (asd_track_set_do_mapping)
   std::vector<int32_t> dm_matches, dm_nmatch, dm_best, dm_distinct;
   std::vector<float> dm_x3d, dm_bdist;
@@ -300,7 +302,6 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       h->Xw[3 * i + 1] = (v - cy) / fy * depth;
       h->Xw[3 * i + 2] = depth;
     }
-    h->has.assign(nl, 1);
     const int n2p = 2 * nl;
     h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
     for (int i = 0; i < nl; ++i)
@@ -340,7 +341,6 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       h->Xw[3 * i + 1] = (v - cy) / fy * depth;
       h->Xw[3 * i + 2] = depth;
     }
-    h->has.assign(nl, 1);
     seg(7);
     if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
     if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, nl, nl)) != ASD_OK) return rc;
@@ -368,7 +368,8 @@ static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t
     nmatch += i >= 0;
     const int src = i >= 0 ? i : 0;
     for (int k = 0; k < 3; ++k) h->cur_Xw[3 * j + k] = h->Xw[3 * src + k];
-    if (i >= 0 && !outl1[j]) { h->keep[j] = 1; h->occ[j] = 1; h->in_frame[i] = 1; }
+    if (i >= 0 && !outl1[j]) { h->keep[j] = 1; h->occ[j] = 1; }
+    if (i >= 0) h->in_frame[i] = 1;   // kept: the frame holds it (:811-823); outlier: mnLastFrameSeen = this frame (:705-707) -- neither is searched again
   }
   if (nmatch >= 3) (void)asd_pose7_to_tcw(pose1, h->T1);
   else memcpy(h->T1, h->T, sizeof h->T1);
@@ -382,6 +383,16 @@ static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t
     h->mind_s[q] = h->mind[i]; h->maxd_s[q] = h->maxd[i];
   }
   return ns;
+}
+
+// The map points frame t holds when it becomes mLastFrame (Tracking.cc:296-349): a keypoint keeps the map point of a kept motion-model
+// match or of a local-map match, unless the local-map stage's PoseOptimization marked it as an outlier (:345-349).  These flags are
+// the next frame's has_mp[] -- derived from this frame's RESULTS, after its last stage has finished.  (The stand-in map gives every
+// keypoint of a frame a position, see prepare_frame; which of them the next frame projects is decided here.)
+static void final_matches_to_has(asd_track_handle* h, int n, bool tracked, const uint8_t* keep1, const int32_t* m2, const uint8_t* outl2) {
+  h->has.resize(n);
+  if (!tracked) { std::fill(h->has.begin(), h->has.end(), (uint8_t)1); return; }   // bootstrap frame: as after initialisation, every keypoint holds a point
+  for (int j = 0; j < n; ++j) h->has[j] = ((keep1[j] || m2[j] >= 0) && !outl2[j]) ? 1 : 0;
 }
 
 static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::vector<int>& next, asd_track_stats* st) {
@@ -401,6 +412,7 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
   h->prep_t = -1;
   memset(st, 0, sizeof *st);
   st->n_kp = n;
+  if (h->ctx_r) { st->stereo_matched = h->prep_stereo; st->has_stereo = 1; }
   const bool had_last = h->have_last;
   int n2p = 0;
   if (had_last) {
@@ -470,9 +482,10 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     st->m2 = h->c2_n2; st->has_m2 = 1;
     int nedge = 0;
     for (int j = 0; j < n; ++j) nedge += h->keep[j] || h->m2[j] >= 0;
-    if (nedge >= 3) { st->inliers = h->c2_ninl; st->has_inliers = 1; }
+    if (nedge >= 3) { st->inliers = h->c2_ninl; st->has_inliers = 1; } else std::fill(h->outl2.begin(), h->outl2.end(), (uint8_t)0);
     seg(6);
   }
+  final_matches_to_has(h, n, had_last, h->keep.data(), h->m2.data(), h->outl2.data());
   if (do_ba && !h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;   // asd_local_ba uses the context's stream: no stage outstanding
   ++h->steps;
   return ASD_OK;
@@ -540,9 +553,12 @@ static int track_step_chain(asd_track_handle* h, int t, bool do_ba, const std::v
     st->m2 = h->f_n2; st->has_m2 = 1;
     int nedge = 0;
     for (int j = 0; j < n; ++j) nedge += (h->m1[j] >= 0 && !h->outl[j]) || h->m2[j] >= 0;
-    if (nedge >= 3) { st->inliers = h->f_inl2; st->has_inliers = 1; }
+    if (nedge >= 3) { st->inliers = h->f_inl2; st->has_inliers = 1; } else std::fill(h->outl2.begin(), h->outl2.end(), (uint8_t)0);
+    h->keep.resize(n);
+    for (int j = 0; j < n; ++j) h->keep[j] = h->m1[j] >= 0 && !h->outl[j];
     seg(6);
   }
+  final_matches_to_has(h, n, had_last, h->keep.data(), h->m2.data(), h->outl2.data());
   if (do_ba && !h->async_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;
   ++h->steps;
   return ASD_OK;
@@ -617,7 +633,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       h->Xw[3 * i + 1] = (v - cy) / fy * depth;
       h->Xw[3 * i + 2] = depth;
     }
-    h->has.assign(nl, 1);
+    if ((int)h->has.size() != nl) h->has.assign(nl, 1);   // (first tracked frame: every keypoint of the bootstrap frame holds a map point)
     // map point descriptors: rows 0..nl-1 = the last frame's descriptors, rows nl..2nl-1 the same again
     seg(7);
     if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
@@ -713,7 +729,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       dev(2, "match");
       seg(5);
       for (int j = 0; j < n; ++j) nedge += h->keep[j] || h->m2[j] >= 0;
-      if (nedge >= 3) { st->inliers = ninl; st->has_inliers = 1; }
+      if (nedge >= 3) { st->inliers = ninl; st->has_inliers = 1; h->outl2.assign(h->outl.begin(), h->outl.begin() + n); } else h->outl2.assign(n, 0);
       seg(6);
     } else {
       if ((rc = asd_match_project_points_bank(ctx, cur, nsel, h->in_view.data(), h->proj.data(), h->level.data(), h->vc.data(), h->sel.data(),
@@ -724,11 +740,12 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       seg(5);
       sel.clear();
       for (int j = 0; j < n; ++j) if (h->keep[j] || h->m2[j] >= 0) sel.push_back(j);
+      h->outl2.assign(n, 0);
       if (sel.size() >= 3) {
         int32_t ninl = 0;
         double pose[7];
         memcpy(pose, pose1, sizeof pose);
-        if ((rc = pose_opt(sel, [&](int j) { return h->keep[j] ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * h->sel[std::max(h->m2[j], 0)]]; }, pose, nullptr, &ninl)) != ASD_OK)
+        if ((rc = pose_opt(sel, [&](int j) { return h->keep[j] ? &h->Xw[3 * h->m1[j]] : &h->Xw2[3 * h->sel[std::max(h->m2[j], 0)]]; }, pose, h->outl2.data(), &ninl)) != ASD_OK)
           return rc;
         st->inliers = ninl; st->has_inliers = 1;
       }
@@ -736,6 +753,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       seg(6);
     }
   }
+  final_matches_to_has(h, n, h->have_last, h->keep.data(), h->m2.data(), h->outl2.data());
   if (do_ba && (rc = submit_ba(h, st, t)) != ASD_OK) return rc;
   seg(7);
   h->last_kps.assign(kps, kps + n);

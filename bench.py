@@ -295,12 +295,14 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=(), t=0):
     if next_handles:
         be.prefetch(next_handles)
     stats = {"n_kp": len(kps)}
+    has_next = np.ones(len(kps), np.uint8)   # bootstrap frame: as after initialisation, every keypoint holds a map point
     if last is not None:
-        lk, ld, lframe = last
+        lk, ld, lframe, has = last
         nl, n_cur = len(lk), len(kps)
         uv = wl.predicted_uv(lk) if hasattr(wl, "predicted_uv") else predicted_uv(lk)
         Xw = backproject_identity(wl.K32, uv, 20.0)
-        has = np.ones(nl, np.uint8)
+        # `has` = the map points the last frame held when it became mLastFrame: its FINAL matches (kept motion-model matches and local-map
+        # matches minus the second PoseOptimization's outliers, Tracking.cc:296-349) -- derived from that frame's results, see the end of this function
         # map point descriptors: the HIP backend keeps them in the device-resident bank (rows 0..n-1 = the last
         # frame's descriptors, rows n..2n-1 = the same again for the displaced copy), the CPU backend gets the table
         be.set_map_descriptors(lframe, ld)
@@ -332,26 +334,32 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=(), t=0):
         # ---- UpdateLocalMap stand-in (Tracking.cc:726, 907-): the local points = the candidates that are not in the frame already
         # (SearchLocalPoints skips those, Tracking.cc:811-823)
         in_frame = np.zeros(2 * nl, bool)
-        in_frame[m1[keep]] = True
+        in_frame[m1[m1 >= 0]] = True       # kept matches (:811-823) AND the dropped outliers' map points (mnLastFrameSeen, :705-707)
         sel = np.nonzero(~in_frame)[0].astype(np.int32)
         occ = keep.astype(np.uint8)
         cur_Xw = Xw[np.maximum(m1, 0)]
         # ---- TrackLocalMap (Tracking.cc:725-736): isInFrustum + SearchByProjection(frame, points) + PoseOptimization from pose1
         if fused:   # frustum test, level prediction and search windows on the device too (asd_track_local_points)
-            m2, n2, _, _, ninl = be.track_local_points(cur, n_cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], sel, occ, cur_Xw, 1.0, 0.8, T1, wl.K32, pose1)
+            m2, n2, _, outl2, ninl = be.track_local_points(cur, n_cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], sel, occ, cur_Xw, 1.0, 0.8, T1, wl.K32, pose1)
             stats["m2"] = int(n2)
             if (keep | (m2 >= 0)).sum() >= 3:
                 stats["inliers"] = int(ninl)
+            else:
+                outl2 = np.zeros(n_cur, np.uint8)
         else:
             fr = be.frustum(cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], T1, wl.K32)
             m2, n2 = be.match_points(cur, n_cur, fr, (ld, ld), sel, occ, 1.0, 0.8)
             stats["m2"] = int(n2)
             jj = np.nonzero(keep | (m2 >= 0))[0]
+            outl2 = np.zeros(n_cur, np.uint8)
             if len(jj) >= 3:
                 X = np.where(keep[jj][:, None], Xw[np.maximum(m1[jj], 0)], Xw2[sel[np.maximum(m2[jj], 0)]])
                 obs = np.stack([kps["x"][jj], kps["y"][jj]], 1).astype(np.float64)
-                _, _, ninl = be.pose_opt(pose1, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
+                _, o2, ninl = be.pose_opt(pose1, X.astype(np.float64), obs, wl.inv_sigma2[kps["octave"][jj]], wl.K64)
+                outl2[jj] = o2
                 stats["inliers"] = int(ninl)
+        # what the frame holds when it becomes the last frame (Tracking.cc:345-349: the local-map stage's outliers are dropped)
+        has_next = ((keep | (m2 >= 0)) & (np.asarray(outl2) == 0)).astype(np.uint8)
     if do_ba:
         prob = ba_problem_for_keyframe(wl.ba, t // KF_INTERVAL)
         if getattr(be, "async_ba", False):
@@ -363,7 +371,7 @@ def track_step(be, wl, image_handle, last, do_ba, next_handles=(), t=0):
         else:
             r = be.local_ba(prob)
             stats["ba_chi2"] = float(r["chi2_second"])
-    return (kps, desc, cur), stats
+    return (kps, desc, cur, has_next), stats
 
 
 class asd_track_stats(__import__("ctypes").Structure):
@@ -483,7 +491,7 @@ class NativeHost:
         self.lib.asd_track_set_fused(self.h, int(getattr(be, "fused", True)))
         self.lib.asd_track_set_async_ba(self.h, int(getattr(be, "async_ba", False)))
         self.lib.asd_track_set_split(self.h, int(getattr(be, "split", True)))
-        self.lib.asd_track_set_chain(self.h, int(getattr(be, "chain", True)))
+        self.lib.asd_track_set_chain(self.h, int(getattr(be, "chain", False)))
         self.lib.asd_track_set_frames_on_host(self.h, int(frames_on_host))
         if drift is not None:
             self.lib.asd_track_set_drift(self.h, *[C.c_float(v) for v in drift])
@@ -793,10 +801,10 @@ class StereoBackend:
         self.native = None
         self.stereo_matched = 0
         self.d_frames = self.dL   # (NativeHost: the left frames; the right ones go in through asd_track_set_stereo)
-        self.fused = True         # the stages as asd_track_motion_model / asd_track_local_points in the Python loop, asd_track_frame in the C++ one
+        self.fused = True         # the stages as asd_track_motion_model / asd_track_local_points (both hosts)
         self.async_ba = False
         self.split = True
-        self.chain = True
+        self.chain = False        # two calls per frame with the host between them (the form the reference's Tracking can bind)
 
     def native_host(self, pkg, pipeline=True):
         """the C++ host loop in stereo mode: both extractors read ahead, asd_stereo_match during frame construction"""
@@ -981,8 +989,11 @@ def main():
                     help="kitti-mono = the headline configuration (BASELINE configs[2]); euroc-stereo = configs[3], a secondary line")
     ap.add_argument("--no-pipeline", action="store_true", help="do not overlap ExtractDesc(t+1) with tracking(t)")
     ap.add_argument("--no-split", action="store_true", help="C++ host: run each asd_track_* stage to completion before any other host work (no asd_track_async / asd_track_finish)")
-    ap.add_argument("--no-chain", action="store_true", help="C++ host: the two tracking stages as two submissions with the host in between (round 3's form) "
-                                                             "instead of one (asd_track_frame) with the next frame constructed on a second stream")
+    ap.add_argument("--chain", action="store_true", help="C++ host: both tracking stages as ONE submission (asd_track_frame) with the next frame constructed on a "
+                                                          "second stream.  Not the default: the reference selects its local map BETWEEN the stages "
+                                                          "(Tracking::UpdateLocalMap, Tracking.cc:730), which this form cannot host; measured as `one_submission_variant`")
+    ap.add_argument("--no-chain", action="store_true", help="(default since round 5, kept for old command lines) two submissions with the host in between")
+    ap.add_argument("--no-one-submission-variant", action="store_true", help="skip the extra pass that measures asd_track_frame (N = 1 only)")
     ap.add_argument("--lane-ba", action="store_true",
                     help="variant: LocalBA on the library's lane (asd_local_ba_submit / _wait) beside the next frames, which then track against the "
                          "pre-BA map -- not the reference's order (Tracking.cc:797 -> LocalMapping.cc:89 runs it in line, the default here)")
@@ -1024,7 +1035,7 @@ def main():
     be.fused = not args.no_fuse
     be.async_ba = bool(args.lane_ba)
     be.split = not args.no_split
-    be.chain = not args.no_chain
+    be.chain = bool(args.chain) and not args.no_chain
     be.native = None
     if args.host == "cxx":
         try:
@@ -1137,6 +1148,33 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS
         roof_kernel = "k_conv_mfma<32,32,32,1,...> (ASDNet conv2, f32 MFMA)"
         roof_extra = {}
+    # Both stages as one submission (asd_track_frame): the host trip between the stages -- where the reference runs UpdateLocalMap() --
+    # is gone, so the local map must be known before the frame is tracked.  The stand-in map allows that; the reference's Tracking does
+    # not in general (include/asd_slam.h).  An extra key, never `value`.
+    one_submission_variant = None
+    if world == 1 and be.native is not None and not be.chain and not args.no_one_submission_variant:
+        be.hip.profile_enable(False)
+        be.native.lib.asd_track_drain(be.native.h)
+        be.native.lib.asd_track_set_chain(be.native.h, 1)
+        tl = prime + args.warmup + 3 * args.steps + 8 * KF_INTERVAL
+        while kf_in(tl + 2 * KF_INTERVAL, args.steps) < want_kf:
+            tl += 1
+        run_steps(be, wl, tl, 2 * KF_INTERVAL, None, prefetch_beyond=True)
+        be.hip.sync(); device_sync(device)
+        o0 = time.perf_counter()
+        run_steps(be, wl, tl + 2 * KF_INTERVAL, args.steps, None, prefetch_beyond=True)
+        be.hip.sync(); device_sync(device)
+        odt = time.perf_counter() - o0
+        one_submission_variant = {"value": args.steps / odt, "unit": "frames/s", "ms_per_step": 1e3 * odt / args.steps, "steps": args.steps,
+                                  "local_ba_in_window": kf_in(tl + 2 * KF_INTERVAL, args.steps),
+                                  "what": "asd_track_frame: both stages in one submission, the outlier drop / pose hand-over / skip flags between them on the "
+                                          "device, the next frame constructed on a second stream (asd_prep_async).  Superset contract: the local map is a "
+                                          "candidate list known BEFORE the frame is tracked -- valid for localisation against a fixed map or a caller that "
+                                          "tracks against the previous frame's local map, NOT for Tracking::UpdateLocalMap as the reference runs it "
+                                          "(Tracking.cc:730, between the stages)"}
+        be.native.lib.asd_track_drain(be.native.h)
+        be.native.lib.asd_track_set_chain(be.native.h, 0)
+
     # The per-keyframe stage of LocalMapping::DoMapping in front of LocalBA (CreateNewMapPoints against 20 neighbours, SearchInNeighbors'
     # Fuse calls, distinctive descriptors) as the library's three batched submissions at every keyframe: reference order
     # (LocalMapping.cc:59-113).  An extra key: the metric -- and `value` -- is tracking + LocalBA.
@@ -1190,6 +1228,7 @@ def main():
         nh.close()
         be.native = keep_native
 
+    be_chain = bool(be.chain)
     be.close()
 
     out = None
@@ -1214,9 +1253,12 @@ def main():
                        "parallelism": f"replicas x{world} (independent sequences, no collective)",
                        "host": "C++ host loop over the C ABI (asd-slam_amd/host/track_loop.cpp)" if args.host == "cxx" else "Python loop (ctypes)",
                        "stages": ("each asd_track_* stage run to completion" if (args.no_split or args.no_fuse or args.host != "cxx") else
-                                  "split-phase (asd_track_async / asd_track_finish): the local-map tables are built under the motion-model stage, the next "
-                                  "frame is constructed (extraction hand-over, grid, descriptor adoption, read-ahead submission) under the local-map stage"
-                                  if args.no_chain else
+                                  "two calls per frame, the host between them where Tracking::UpdateLocalMap sits (Tracking.cc:725-736): "
+                                  "asd_track_motion_model_bank -> results on the host -> outlier drop, local-map stand-in selected from them -> "
+                                  "asd_track_local_points_bank; split-phase (asd_track_async / asd_track_finish): the next frame's extraction hand-over, grid, "
+                                  "descriptor adoption and read-ahead submission run under the local-map stage; the next frame's has_mp[] comes from this "
+                                  "frame's final matches after asd_track_finish (Tracking.cc:296-349)"
+                                  if not be_chain else
                                   "one submission per frame (asd_track_frame: motion-model stage, the outlier drop / pose hand-over / local-map selection between "
                                   "the stages on the device, local-map stage); the next frame is constructed (extraction hand-over, grid, descriptor adoption, "
                                   "map rows of the banks, read-ahead submission) on the context's second stream beside it (asd_prep_async)"),
@@ -1236,6 +1278,8 @@ def main():
         }
         if lane_variant is not None:
             out["lane_variant"] = lane_variant
+        if one_submission_variant is not None:
+            out["one_submission_variant"] = one_submission_variant
         if h2d_variant is not None:
             out["h2d_variant"] = h2d_variant
         if do_mapping_variant is not None:

@@ -295,19 +295,28 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
 int asd_mpbank_put(asd_ctx* ctx, int32_t first_row, int32_t n, const float* Xw, const float* normal, const float* min_dist,
                    const float* max_dist);
 
-/* Both tracking stages of a frame as ONE submission: asd_track_motion_model_bank, then -- on the device, where the host of
- * the two-call form sits -- what Tracking does between them: matches PoseOptimization marked as outliers are dropped
- * (Tracking.cc:695-714), the optimised pose becomes the frame's pose (Frame::SetPose, Frame.cc:150-158), the map points the
- * frame holds now are left out of the local-map search (SearchLocalPoints' mnLastFrameSeen marks, Tracking.cc:811-823); then
- * asd_track_local_points_bank over the candidates, from the motion-model stage's pose and kept matches.  The local map is
- * passed as a SUPERSET known before the frame is tracked: n_cand rows of the attribute + descriptor bank (cand_rows), and per
- * keypoint of the last frame the candidate index of the map point it holds (last_cand[i], -1 = not among the candidates;
- * NULL = none is) -- a candidate whose map point ends up as a kept match of the motion-model stage makes no query.  Results
- * are those of the two calls bit for bit, with match2[j] a CANDIDATE index.  pose7: in = SE3Quat of the predicted pose, out =
- * the local-map stage's optimum; pose1 = the motion-model stage's.  The control flow stays with the caller as before: if the
- * motion-model stage made too few matches (nmatches < 20, Tracking.cc:681-685) it discards match2 / pose7 and runs the retry
- * with the separate calls.  Sizes beyond the one-submission form (more than 4096 last-frame keypoints or candidates, frames
- * beyond the solver's LDS form) return ASD_ERR_CAPACITY: use the two calls.  Honours asd_track_async / asd_track_finish. */
+/* Both tracking stages of a frame as ONE submission -- an OPTIONAL form with a precondition the reference's Tracking does not
+ * meet in general; the form that binds to Tracking.cc as it stands is the two-call one (asd_track_motion_model_bank -> host ->
+ * asd_track_local_points_bank), and that is what bench.py's `value` is measured on.
+ * What it does: asd_track_motion_model_bank, then -- on the device, where the host of the two-call form sits -- what Tracking
+ * does between the stages: matches PoseOptimization marked as outliers are dropped (Tracking.cc:695-714), the optimised pose
+ * becomes the frame's pose (Frame::SetPose, Frame.cc:150-158), the map points the motion-model stage matched -- kept, or
+ * dropped as outliers (both carry mnLastFrameSeen = this frame: :705-707, :811-823) -- are left out of the local-map search;
+ * then asd_track_local_points_bank over the remaining candidates, from the motion-model stage's pose and kept matches.
+ * The precondition: the reference selects mvpLocalMapPoints BETWEEN the stages (Tracking::UpdateLocalMap, Tracking.cc:730 ->
+ * :871-879: UpdateLocalKeyFrames :907-1000 votes over the matches the motion-model stage has just made, UpdateLocalPoints
+ * :881-905 collects those keyframes' points).  This call has no place for that decision: the local map is passed as a list
+ * known BEFORE the frame is tracked -- n_cand rows of the attribute + descriptor bank (cand_rows), and per keypoint of the last
+ * frame the candidate index of the map point it holds (last_cand[i], -1 = not among the candidates; NULL = none is).  Results
+ * equal the reference's only when that list IS the set UpdateLocalMap would select: localisation against a fixed map whose
+ * local set the caller fixes per frame, or a caller that deliberately tracks against the previous frame's local map (one
+ * frame of lag in the keyframe vote).  Any other superset lets the local-map stage match points the reference would not have
+ * searched.  Given the same candidate list the results are those of the two calls bit for bit (match2[j] is a CANDIDATE index).
+ * pose7: in = SE3Quat of the predicted pose, out = the local-map stage's optimum; pose1 = the motion-model stage's.  The
+ * control flow stays with the caller as before: if the motion-model stage made too few matches (nmatches < 20,
+ * Tracking.cc:681-685) it discards match2 / pose7 and runs the retry with the separate calls.  Sizes beyond the one-submission
+ * form (more than 4096 last-frame keypoints, more ACTIVE local-map lists than one replay workgroup takes, frames beyond the
+ * solver's LDS form) return ASD_ERR_CAPACITY: use the two calls.  Honours asd_track_async / asd_track_finish. */
 typedef struct asd_track_frame_args {
   int32_t slot_cur, slot_last;
   const uint8_t* has_mp;            /* [n_last] motion-model stage: as asd_track_motion_model_bank */

@@ -20,12 +20,13 @@ def _bench():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipeline,fused,async_ba,split", [(True, True, False, True), (False, True, False, True), (True, False, False, True), (True, True, True, True),
-                                                             (True, True, False, False)])
-def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split):
+@pytest.mark.parametrize("pipeline,fused,async_ba,split,chain", [(True, True, False, True, False), (False, True, False, True, False), (True, False, False, True, False),
+                                                                   (True, True, True, True, False), (True, True, False, False, False), (True, True, False, True, True)])
+def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split, chain):
     """fused: the stages run as asd_track_motion_model / asd_track_local_map (one submission each, bench default) or as
     matcher + PoseOptimization calls (--no-fuse); async_ba: LocalBA in line (default, the reference's order) or on the optional lane (--lane-ba); split: the C++ host's split-phase
-    stages (asd_track_async / asd_track_finish, default) or each stage run to completion (--no-split)"""
+    stages (asd_track_async / asd_track_finish, default) or each stage run to completion (--no-split); chain: both stages as one submission
+    (asd_track_frame, --chain: the one_submission_variant) instead of two calls with the host between them (default)"""
     bench = _bench()
     wl = bench.Workload(pkg.synth)
     n = bench.KF_INTERVAL + 3          # crosses one LocalBA
@@ -43,6 +44,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split):
     cx.fused = fused
     cx.async_ba = async_ba
     cx.split = split
+    cx.chain = chain
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         got = [cx.native.run(t, 1, True) for t in range(n)]
@@ -56,6 +58,7 @@ def test_cxx_host_equals_python_host(pkg, pipeline, fused, async_ba, split):
     cx.fused = fused
     cx.async_ba = async_ba
     cx.split = split
+    cx.chain = chain
     cx.native = bench.NativeHost(pkg, cx, wl, pipeline=pipeline)
     try:
         whole = cx.native.run(0, n, True)

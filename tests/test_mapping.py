@@ -193,9 +193,11 @@ def _kf_with_neighbours(n, n_nb, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,n_nb", [(2000, 6), (300, 20)])
-def test_create_map_points_batch_equals_the_per_pair_calls(hip, n, n_nb):
+def test_create_map_points_batch_equals_the_per_pair_calls(hip, oracle, n, n_nb):
     """asd_create_map_points_batch (every neighbour in one submission) against asd_match_triangulate + asd_triangulate_pairs per
-    neighbour: the same match ids, the same accept flags, the same coordinates bit for bit"""
+    neighbour AND against the oracle directly (oracle.match_triangulate = ORBmatcher::SearchForTriangulation :669-822,
+    oracle.triangulate_pairs = LocalMapping::CreateNewMapPoints' per-match body :386-519): the same match ids, the same accept
+    flags, the same coordinates bit for bit"""
     kc, dc, Tc, nodes_c, has_c, nbs = _kf_with_neighbours(n, n_nb, 900 + n)
     hip.frame_set(0, kc, dc, BOUNDS)
     hip.frame_set_bow(0, nodes_c)
@@ -204,7 +206,7 @@ def test_create_map_points_batch_equals_the_per_pair_calls(hip, n, n_nb):
         hip.frame_set_bow(1 + b, d["nodes"])
     m, nm, x, ok = hip.create_map_points_batch(0, n, has_c, Tc, K_KITTI, [dict(slot=1 + b, has_mp=d["has"], F12=d["F12"], ex=d["ex"], ey=d["ey"], Tcw=d["T"], K=K_KITTI)
                                                                       for b, d in enumerate(nbs)])
-    total_ok = 0
+    total_ok, ofc = 0, None
     for b, d in enumerate(nbs):
         em, en = hip.match_triangulate(0, 1 + b, n, nodes_c, d["nodes"], has_c, d["has"], d["F12"], d["ex"], d["ey"], False)
         np.testing.assert_array_equal(m[b], em)
@@ -215,16 +217,27 @@ def test_create_map_points_batch_equals_the_per_pair_calls(hip, n, n_nb):
         np.testing.assert_array_equal(x[b][i1], ex_)
         assert not ok[b][em < 0].any() and not x[b][em < 0].any()
         total_ok += int(eok.sum())
+        # the batch kernels (k_tri_match_batch, k_triangulate_batch) against the oracle itself, not only through the per-pair HIP calls
+        if ofc is None:
+            ofc = oracle.frame(kc, dc, BOUNDS)
+        om, on = oracle.match_triangulate(ofc, oracle.frame(d["kps"], d["desc"], BOUNDS), nodes_c, d["nodes"], has_c, d["has"], d["F12"], d["ex"], d["ey"], False)
+        np.testing.assert_array_equal(m[b], om)
+        assert nm[b] == on
+        o1 = np.nonzero(om >= 0)[0].astype(np.int32)
+        ox, ook, _ = oracle.triangulate_pairs(kc, d["kps"], o1, om[o1], Tc, d["T"], K_KITTI, K_KITTI)
+        np.testing.assert_array_equal(ok[b][o1], ook)
+        np.testing.assert_array_equal(x[b][o1], ox)
     assert nm.sum() > 0.1 * n * n_nb * 0.3 and total_ok > 0
 
 
 @pytest.mark.gpu
-def test_fuse_search_batch_equals_the_per_call_search(hip, synth):
-    """asd_fuse_search_batch over several (keyframe, map point list) pairs against asd_fuse_search per pair"""
+def test_fuse_search_batch_equals_the_per_call_search(hip, oracle, synth):
+    """asd_fuse_search_batch over several (keyframe, map point list) pairs against asd_fuse_search per pair and against
+    oracle.fuse_search (ORBmatcher::Fuse :825-936, search half) directly"""
     from tests.test_matcher import backproject, perturbed_descriptors
     rng = np.random.default_rng(77)
     K = np.array(synth.KITTI_K, np.float32)
-    calls, tabs, exp = [], [], []
+    calls, tabs, exp, oexp = [], [], [], []
     first = 0
     for c in range(7):
         kc, dc = make_frame(2000 if c < 5 else 300, 500 + c)
@@ -246,14 +259,17 @@ def test_fuse_search_batch_equals_the_per_call_search(hip, synth):
         valid = (rng.uniform(size=n_mp) < 0.9).astype(np.uint8)
         hip.frame_set(10 + c, kc, dc, BOUNDS)
         exp.append(hip.fuse_search(10 + c, valid, Xw, nrm, mind, maxd, desc, T, K, 3.0))
+        oexp.append(oracle.fuse_search(oracle.frame(kc, dc, BOUNDS), valid, Xw, nrm, mind, maxd, desc, T, K, 3.0))
         calls.append(dict(slot_kf=10 + c, first=first, n=n_mp, Tcw=T, K=K))
         tabs.append((valid, Xw, nrm, mind, maxd, desc))
         first += n_mp
     cat = [np.concatenate([t[k] for t in tabs]) for k in range(6)]
     bi, bd = hip.fuse_search_batch(calls, *cat, th=3.0)
-    for c, (ei, ed) in zip(calls, exp):
+    for c, (ei, ed), (oi, od) in zip(calls, exp, oexp):
         np.testing.assert_array_equal(bi[c["first"]: c["first"] + c["n"]], ei)
         np.testing.assert_array_equal(bd[c["first"]: c["first"] + c["n"]], ed)
+        np.testing.assert_array_equal(bi[c["first"]: c["first"] + c["n"]], oi)      # k_fuse_batch + the shared search against the oracle itself
+        np.testing.assert_array_equal(bd[c["first"]: c["first"] + c["n"]], od)
     assert (bi >= 0).sum() > 2000
     # the map points' descriptors as rows of the descriptor bank instead of 512-byte rows
     hip.bank_put(1000, cat[5])

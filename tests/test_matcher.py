@@ -371,6 +371,76 @@ def test_match_project_points_crowded(hip, oracle, synth, n_mp, n_cur, th):
         assert not ((got >= 0) & (occupied > 0)).any()
 
 
+def _few_long_lists_case(synth, seed, n_bg=500, n_q=48, n_cl=160):
+    """an ordinary small frame (short lists) plus ONE crowd: n_cl current keypoints with near-identical descriptors inside a single grid
+    column, contested by n_q map points -- those few lists take k_window_search<true>'s slow path (more than 64 items in a column),
+    whose sorted copies live in the second half of the candidate buffers, while the frame's total stays far below the replay's LDS
+    staging capacity (the replay then read such lists from the LDS copy, where they are not)"""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, n_bg, seed, frac=1.0)
+    rng = np.random.default_rng(seed + 9)
+    kcl, _ = make_frame(n_cl, seed + 5)
+    kcl["x"] = rng.uniform(592.5, 610.0, n_cl).astype(np.float32)      # round(x * 64 / 1241) == 31 for all of them
+    kcl["y"] = rng.uniform(170, 215, n_cl).astype(np.float32)
+    kcl["octave"] = rng.integers(2, 5, n_cl)
+    base = dl[0]
+    dcl = perturbed_descriptors(np.repeat(base[None], n_cl, 0), 0.02, seed + 6)
+    kq, dq = make_frame(n_q, seed + 7)
+    aim = rng.integers(0, n_cl, n_q)
+    kq["octave"] = kcl["octave"][aim]
+    uvq = (np.stack([kcl["x"][aim], kcl["y"][aim]], 1) + rng.uniform(-3, 3, (n_q, 2))).astype(np.float32)
+    Xq = backproject(T, K, uvq, rng.uniform(5, 40, n_q))
+    mpq = perturbed_descriptors(np.repeat(base[None], n_q, 0), 0.02, seed + 8)
+    # current frame: level-major like the extractor's output; last frame: the crowd's map points scattered among the others
+    oc = np.argsort(np.concatenate([kc["octave"], kcl["octave"]]), kind="stable")
+    kc_all, dc_all = np.concatenate([kc, kcl])[oc], np.concatenate([dc, dcl])[oc]
+    ol = rng.permutation(n_bg + n_q)
+    kl_all, dl_all = np.concatenate([kl, kq])[ol], np.concatenate([dl, dq])[ol]
+    Xw_all, mp_all = np.concatenate([Xw, Xq])[ol], np.concatenate([mp_desc, mpq])[ol]
+    return kl_all, dl_all, kc_all, dc_all, Xw_all, np.ones(n_bg + n_q, np.uint8), mp_all, T, K
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1300, 1301])
+def test_match_project_frame_few_long_lists_in_a_small_frame(hip, oracle, synth, seed):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _few_long_lists_case(synth, seed)
+    n_cur = len(kc)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    oc, ol = oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS)
+    obs = (np.random.default_rng(5).uniform(size=len(kl)) < 0.7).astype(np.uint8)
+    for flags, ori in ((None, False), (None, False), (obs, True), (obs, True)):   # twice each: the second call's staging capacity follows the first call's total
+        got, ng = hip.match_project_frame(0, 1, n_cur, has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=flags)
+        exp, ne = oracle.match_project_frame(oc, ol, has, Xw, mp_desc, T, K, 15.0, ori, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne and ng > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1400, 1401])
+def test_match_project_points_few_long_lists_in_a_small_frame(hip, oracle, synth, seed):
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K = _few_long_lists_case(synth, seed)
+    n_cur = len(kc)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    F = oracle.frame(kc, dc, BOUNDS)
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    nrm = Xw.astype(np.float64) - Ow
+    dist = np.linalg.norm(nrm, axis=1)
+    nrm = (nrm / dist[:, None]).astype(np.float32)
+    maxd = (dist * SCALES[kl["octave"]]).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    in_view, proj, level, vc = hip.frustum(0, Xw, nrm, mind, maxd, T, K)
+    assert in_view.sum() > 0.8 * len(kl)
+    rng = np.random.default_rng(9)
+    occupied = (rng.uniform(size=n_cur) < 0.1).astype(np.uint8)
+    obs = (rng.uniform(size=len(kl)) < 0.6).astype(np.uint8)
+    for flags in (None, None, obs, obs):
+        got, ng = hip.match_project_points(0, n_cur, in_view, proj, level, vc, mp_desc, occupied, 3.0, 0.8, obs_positive=flags)
+        exp, ne = oracle.match_project_points(F, in_view, proj, level, vc, mp_desc, occupied, 3.0, 0.8, obs_positive=flags)
+        np.testing.assert_array_equal(got, exp)
+        assert ng == ne and ng > 0
+        assert not ((got >= 0) & (occupied > 0)).any()
+
+
 @pytest.mark.gpu
 def test_match_project_frame_degenerate(hip, oracle, synth):
     kl, dl, kc, dc, Xw, has, mp_desc, T, K = _m1_case(synth, 300, 77)

@@ -371,7 +371,7 @@ def test_track_frame_equals_the_two_stage_calls(hip, synth, n, th, flags):
     keep = (m1 >= 0) & (outl1 == 0)
     T1 = hip.pose7_to_tcw(pose1) if (m1 >= 0).sum() >= 3 else T
     in_frame = np.zeros(2 * n, bool)
-    lc = last_cand[m1[keep]]
+    lc = last_cand[m1[m1 >= 0]]      # kept matches and dropped outliers alike: neither map point is searched again (Tracking.cc:705-707, :811-823)
     in_frame[lc[lc >= 0]] = True
     sel = np.nonzero(~in_frame)[0].astype(np.int32)
     occ = keep.astype(np.uint8)
@@ -397,6 +397,102 @@ def test_track_frame_equals_the_two_stage_calls(hip, synth, n, th, flags):
         np.testing.assert_array_equal(r["pose"], pose2)
     if n >= 700:
         assert n1 > 0.3 * n and n2 > 0 and inl2 > 0.3 * n
+
+
+def _oracle_frame_composition(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd, last_cand, th, pose0, obs1, obs2, hip_pose1=None):
+    """One tracked frame as the ORACLE composes it: SearchByProjection(cur, last) (ORBmatcher.cc:1318-1452) -> PoseOptimization
+    (Optimizer.cc:239-413) -> what Tracking does between the stages (outliers dropped :695-714 with mnLastFrameSeen stamped :705-707, pose
+    hand-over Frame.cc:150-158, SearchLocalPoints' skip marks :811-823) -> isInFrustum (Frame.cc:160-217) -> SearchByProjection(cur, points)
+    (:44-122) -> PoseOptimization.  hip_pose1: the product's stage-1 pose handed to the stages behind it (the optimiser is tolerance-checked,
+    1e-8; everything behind it is compared bit for bit and must start from the same bits)."""
+    n, n_cur = len(kl), len(kc)
+    oc, ol = oracle.frame(kc, dc, BOUNDS), oracle.frame(kl, dl, BOUNDS)
+    K64 = K.astype(np.float64)
+    m1, n1 = oracle.match_project_frame(oc, ol, has, Xw, mp_desc, T, K, th, True, obs_positive=obs1)
+    j = np.nonzero(m1 >= 0)[0]
+    outl1, pose1, inl1 = np.zeros(n_cur, np.uint8), pose0.copy(), 0
+    if len(j) >= 3:
+        pose1, o, inl1 = oracle.pose_optimize(pose0, Xw[m1[j]].astype(np.float64), np.stack([kc["x"][j], kc["y"][j]], 1).astype(np.float64),
+                                              inv_sigma2[kc["octave"][j]], K64)
+        outl1[j] = o
+    keep = (m1 >= 0) & (outl1 == 0)
+    hand = pose1 if hip_pose1 is None else hip_pose1
+    T1 = oracle.pose7_to_tcw(hand) if len(j) >= 3 else T
+    in_frame = np.zeros(len(Xw2), bool)
+    lc = last_cand[m1[m1 >= 0]]
+    in_frame[lc[lc >= 0]] = True
+    sel = np.nonzero(~in_frame)[0].astype(np.int32)
+    occ = keep.astype(np.uint8)
+    in_view, proj, level, vc = oracle.frustum(oc, Xw2[sel], nrm[sel], mind[sel], maxd[sel], T1, K)
+    d2 = np.concatenate([mp_desc, mp_desc])[sel]
+    m2s, n2 = oracle.match_project_points(oc, in_view, proj, level, vc, d2, occ, 1.0, 0.8, obs_positive=None if obs2 is None else obs2[sel])
+    m2 = np.where(m2s >= 0, sel[np.maximum(m2s, 0)], -1)          # candidate indices
+    jj = np.nonzero(keep | (m2 >= 0))[0]
+    outl2, pose2, inl2 = np.zeros(n_cur, np.uint8), hand.copy(), 0
+    if len(jj) >= 3:
+        X = np.where(keep[jj][:, None], Xw[np.maximum(m1[jj], 0)], Xw2[np.maximum(m2[jj], 0)]).astype(np.float64)
+        pose2, o, inl2 = oracle.pose_optimize(hand, X, np.stack([kc["x"][jj], kc["y"][jj]], 1).astype(np.float64), inv_sigma2[kc["octave"][jj]], K64)
+        outl2[jj] = o
+    return dict(m1=m1, n1=n1, pose1=pose1, outl1=outl1, inl1=inl1, sel=sel, m2=m2, n2=n2, pose2=pose2, outl2=outl2, inl2=inl2, keep=keep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,flags", [(2000, False), (2000, True), (500, True)])
+def test_tracked_frame_against_the_oracle_composition(hip, oracle, synth, n, flags):
+    """The kernels the bench times, held to the oracle DIRECTLY at the bench's size (2000 keypoints, 4000 local-map candidates, Observations()
+    flags off and on): asd_track_frame (k_resolve_pose<0,4> / <1,8>, k_window_search<true>, the bank form of k_frustum_queries, asd_between_body)
+    and the two-call form the headline runs (asd_track_motion_model_bank -> host -> asd_track_local_points_bank).  Match ids, match counts and
+    outlier flags bit-exact; poses within the optimiser's 1e-8."""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd = _frame_case(synth, n, 2300 + n + int(flags))
+    n_cur = len(kc)
+    # a tenth of the keypoints a few pixels off their map point's projection: matched by the motion-model stage, marked as outliers by its
+    # PoseOptimization, dropped between the stages -- keypoint free again, map point NOT searched again (Tracking.cc:695-714)
+    rng = np.random.default_rng(15)
+    off = rng.choice(n_cur, n_cur // 10, replace=False)
+    kc = kc.copy()
+    kc["x"][off] += rng.choice([-1.0, 1.0], len(off)).astype(np.float32) * rng.uniform(3.5, 6.0, len(off)).astype(np.float32)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    base = 500
+    hip.bank_put(base, np.concatenate([mp_desc, mp_desc]))
+    hip.mpbank_put(base, Xw2, nrm, mind, maxd)
+    rows1 = np.arange(base, base + n, dtype=np.int32)
+    cand_rows = np.arange(base, base + 2 * n, dtype=np.int32)
+    rng = np.random.default_rng(14)
+    obs1 = (rng.uniform(size=n) < 0.8).astype(np.uint8) if flags else None
+    obs2 = (rng.uniform(size=2 * n) < 0.8).astype(np.uint8) if flags else None
+    last_cand = np.arange(n, dtype=np.int32)
+    if flags:
+        last_cand[::9] = -1
+    pose0 = _pose7(pose_T(rv=(0.012, -0.018, 0.006), t=(0.12, -0.04, 0.33)))
+    inv_sigma2 = hip.scale_tables()["inv_sigma2"].astype(np.float64)
+    # ---- one submission
+    r = hip.track_frame(0, 1, n_cur, has, Xw, rows1, last_cand, T, K, 15.0, pose0, cand_rows, 1.0, 0.8, last_obs_positive=obs1, cand_obs_positive=obs2)
+    o = _oracle_frame_composition(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd, last_cand, 15.0, pose0, obs1, obs2,
+                                  hip_pose1=r["pose1"])
+    np.testing.assert_array_equal(r["match1"], o["m1"])
+    assert (r["n1"], r["n_inl1"]) == (o["n1"], o["inl1"])
+    np.testing.assert_array_equal(r["outlier1"], o["outl1"])
+    assert np.abs(r["pose1"] - o["pose1"]).max() <= POSE_TOL
+    np.testing.assert_array_equal(r["match2"], o["m2"])
+    assert (r["n2"], r["n_inl2"]) == (o["n2"], o["inl2"])
+    np.testing.assert_array_equal(r["outlier2"], o["outl2"])
+    assert np.abs(r["pose"] - o["pose2"]).max() <= POSE_TOL
+    # ---- the two calls with the host between them (what bench.py's `value` runs): same oracle expectation
+    m1, n1, pose1, outl1, inl1 = hip.track_motion_model(0, 1, n_cur, has, Xw, rows1, T, K, 15.0, pose0, True, obs_positive=obs1)
+    np.testing.assert_array_equal(m1, o["m1"])
+    np.testing.assert_array_equal(outl1, o["outl1"])
+    np.testing.assert_array_equal(pose1, r["pose1"])
+    T1 = hip.pose7_to_tcw(pose1) if (m1 >= 0).sum() >= 3 else T
+    sel = o["sel"]
+    m2, n2, pose2, outl2, inl2 = hip.track_local_points(0, n_cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], cand_rows[sel], T1, K, o["keep"].astype(np.uint8),
+                                                        Xw[np.maximum(m1, 0)], 1.0, 0.8, pose1, obs_positive=None if obs2 is None else obs2[sel])
+    np.testing.assert_array_equal(np.where(m2 >= 0, sel[np.maximum(m2, 0)], -1), o["m2"])
+    assert (n1, inl1, n2, inl2) == (o["n1"], o["inl1"], o["n2"], o["inl2"])
+    np.testing.assert_array_equal(outl2, o["outl2"])
+    assert np.abs(pose2 - o["pose2"]).max() <= POSE_TOL
+    assert o["n1"] > 0.3 * n and o["n2"] > 0 and o["inl2"] > 0.3 * n
+    assert o["outl1"].sum() > 0.02 * n            # the outlier rule between the stages is exercised
 
 
 @pytest.mark.gpu
