@@ -1488,6 +1488,7 @@ int asdnet_alloc(asd_ctx* ctx) {
   if (const char* e = getenv("ASD_ASDNET_RESERVE")) ctx->cu_reserve = atoi(e);
   if (const char* e = getenv("ASD_ASDNET_PERSIST")) ctx->asdnet_persist = atoi(e) != 0;
   if (const char* e = getenv("ASD_ASDNET_PAIR")) ctx->net_pair = atoi(e) != 0;
+  if (const char* e = getenv("ASD_ASDNET_RING")) ctx->ring_mask = atoi(e);
   return ASD_OK;
 }
 
@@ -1650,21 +1651,33 @@ static int asdnet_forward_one(asd_ctx* ctx, const uint8_t* d_patches, int n, flo
   ASD_HIP_CHECK(ctx, (launch_conv_p<L3_CFG>(st, a1, ctx->d_wimg[2], ctx->d_bias[2], a0, n, ctx->num_cu)));
   CALIB(2, a0, 16 * 16 * 64);
   PROF_MARK(3);
-  if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L4S_CFG, false, 3, a0, a1, nullptr, nullptr)));
-  else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
-  CALIB(3, a1, 16 * 16 * 64);
-  PROF_MARK(4);
-  if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L5S_CFG, false, 4, a1, a0, nullptr, nullptr)));
-  else
-  ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
-  CALIB(4, a0, 8 * 8 * 128);
+  const int ring = pair ? ctx->ring_mask : 0;   // asdnet_ring.hip (whole-patch LDS images, weights through an LDS-DMA ring): pair form only
+  float *src6 = a0, *dst6 = a1;   // conv6's input and output (the fc layer reads dst6)
+  if (ring & 4) {   // conv4 + conv5 in one launch (conv4's output never leaves LDS); the profile charges the launch to conv5's slot
+    PROF_MARK(4);
+    { const int rc = asdnet_ring_conv45(ctx, a0, a1, n, st); if (rc != ASD_OK) return rc; }
+    src6 = a1; dst6 = a0;
+  } else {
+    if (ring & 1) { const int rc = asdnet_ring_conv(ctx, 3, a0, a1, n, st); if (rc != ASD_OK) return rc; }
+    else if (ctx->net_split & 4) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L4S_CFG, false, 3, a0, a1, nullptr, nullptr)));
+    else ASD_HIP_CHECK(ctx, (launch_conv<L4_CFG>(st, a0, ctx->d_wimg[3], ctx->d_bias[3], a1, n)));
+    CALIB(3, a1, 16 * 16 * 64);
+    PROF_MARK(4);
+    if (ctx->net_split & 8) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L5S_CFG, false, 4, a1, a0, nullptr, nullptr)));
+    else
+    ASD_HIP_CHECK(ctx, (launch_conv<L5_CFG>(st, a1, ctx->d_wimg[4], ctx->d_bias[4], a0, n)));
+  }
+  CALIB(4, src6, 8 * 8 * 128);
   PROF_MARK(5);
-  if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L6S_CFG, false, 5, a0, a1, nullptr, nullptr)));
-  else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, a0, ctx->d_wimg[5], ctx->d_bias[5], a1, n)));
+  if (ring & 2) { const int rc = asdnet_ring_conv(ctx, 5, src6, dst6, n, st); if (rc != ASD_OK) return rc; }
+  else if (ctx->net_split & 16) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L6S_CFG, false, 5, src6, dst6, nullptr, nullptr)));
+  else ASD_HIP_CHECK(ctx, (launch_conv<L6_CFG>(st, src6, ctx->d_wimg[5], ctx->d_bias[5], dst6, n)));
 #undef X3_LAUNCH
-  CALIB(5, a1, 8 * 8 * 128);
+  CALIB(5, dst6, 8 * 8 * 128);
 #undef CALIB
   PROF_MARK(6);
+  a1 = dst6;   // (the last layer's input)
+  ctx->d_act6 = dst6;
   if (pair)
     hipLaunchKernelGGL(k_fc_x2, dim3((npad + FCS_MP - 1) / FCS_MP, FC_SK), dim3(256), 0, st, reinterpret_cast<const uint8_t*>(a1),
                        static_cast<const uint8_t*>(ctx->d_wx2[6]), ctx->d_part, n, npad, 1.f / (kActScale * ctx->wx2_scale[6]));
@@ -1840,9 +1853,10 @@ extern "C" int asd_debug_act6(asd_ctx* ctx, int n, float* out) {
   if (n < 0 || n > ctx->cfg.max_patches) return ASD_ERR_CAPACITY;
   ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const bool pair = kPairOK && ctx->net_pieces == 2 && (ctx->net_split & 63) == 63 && ctx->net_pair;
-  if (!pair) { ASD_HIP_CHECK(ctx, hipMemcpy(out, ctx->d_act[1], (size_t)n * 8192 * 4, hipMemcpyDeviceToHost)); return ASD_OK; }
+  const float* src = ctx->d_act6 ? ctx->d_act6 : ctx->d_act[1];
+  if (!pair) { ASD_HIP_CHECK(ctx, hipMemcpy(out, src, (size_t)n * 8192 * 4, hipMemcpyDeviceToHost)); return ASD_OK; }
   std::vector<uint16_t> raw((size_t)n * 8192 * 2);
-  ASD_HIP_CHECK(ctx, hipMemcpy(raw.data(), ctx->d_act[1], raw.size() * 2, hipMemcpyDeviceToHost));
+  ASD_HIP_CHECK(ctx, hipMemcpy(raw.data(), src, raw.size() * 2, hipMemcpyDeviceToHost));
   for (size_t e = 0; e < (size_t)n * 8192; ++e) {
     const size_t g = e / 8, j = e % 8;
     _Float16 h, l;

@@ -323,6 +323,8 @@ struct asd_ctx {
   bool pose_chain_kp_flags = false;   // the last pose_chain_enqueue wrote its outlier flags per keypoint (gather form of k_pose_opt)
   bool net_pair = true;         // two-piece form: activations between the layers as the fp16 piece pairs themselves (ASD_ASDNET_PAIR=0: f32 NHWC)
   bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
+  float* d_act6 = nullptr;      // where the last forward left conv6's output (d_act[0] or d_act[1]; asd_debug_act6)
+  int ring_mask = 0;            // ASD_ASDNET_RING: layers on the LDS-image / weight-ring kernels of asdnet_ring.hip (bit 0 conv4, bit 1 conv6, bit 2 conv4+conv5 fused)
   uint8_t* d_patches = nullptr; // [max_patches][1024]
   float* d_desc = nullptr;      // [max_patches][128] descriptors of the last asd_extract / asd_describe
   bool keep_pyramid = false;    // asd_extract_keep_pyramid: every submission keeps a copy of its pyramid for asd_stereo_match
@@ -470,3 +472,6 @@ int asdnet_load_weights(asd_ctx* ctx, const float* const conv_w[7], const float*
 // range_flag: pinned host int the L2-norm kernel sets to 1 when a descriptor row is not finite (null = no report)
 int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag = nullptr);
 int asdnet_profile_collect(asd_ctx* ctx);  // folds pending layer events into the totals (needs a synced stream)
+// asdnet_ring.hip: conv layers with both MFMA operands from LDS (whole-patch images, weights through an LDS-DMA ring); two-piece pair form only
+int asdnet_ring_conv(asd_ctx* ctx, int layer, const void* in, void* out, int n, hipStream_t st);
+int asdnet_ring_conv45(asd_ctx* ctx, const void* in, void* out, int n, hipStream_t st);

@@ -246,6 +246,33 @@ def test_pair_format_is_bit_identical(pkg, synth, asdnet_golden, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mask", [1, 2, 4, 6])
+def test_ring_kernels_are_bit_identical(pkg, synth, asdnet_golden, monkeypatch, mask):
+    """asdnet_ring.hip (whole-patch LDS images, weights through an LDS-DMA ring, conv4 -> conv5 fused through LDS) performs the products of
+    k_conv_x3's two-piece form in the same order, so the activation conv6 hands to the last layer and the descriptors are the same BITS as the
+    layer-by-layer kernels' (ASD_ASDNET_RING=0).  mask: bit 0 conv4, bit 1 conv6, bit 2 conv4 + conv5 in one launch.  Odd patch counts
+    exercise the two-patch tiles of conv6 and the persistent loop (more tiles than workgroups is covered at N = 2000 by the golden tests)."""
+    patches = np.concatenate([asdnet_golden["patches"], synth.random_patches(437, seed=23), np.full((2, 32, 32), 91, np.uint8)])
+    monkeypatch.setenv("ASD_ASDNET_RING", "0")
+    ref = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    monkeypatch.setenv("ASD_ASDNET_RING", str(mask))
+    new = pkg.AsdHip(n_features=500, max_width=640, max_height=240, max_patches=1024)
+    monkeypatch.delenv("ASD_ASDNET_RING")
+    try:
+        w = synth.asdnet_weights(int(asdnet_golden["weight_seed"]))
+        ref.load_weights(w)
+        new.load_weights(w)
+        for n in (len(patches), 1, 64):
+            a, b = new.describe(patches[:n]), ref.describe(patches[:n])
+            np.testing.assert_array_equal(new.debug_act6(n), ref.debug_act6(n))
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a[:64], asdnet_golden["desc"], atol=DESC_ATOL, rtol=0)
+    finally:
+        ref.close()
+        new.close()
+
+
+@pytest.mark.gpu
 def test_f16x2_range_is_an_error_not_a_nan(pkg, synth, monkeypatch):
     """f16x2 carries activations * 16 in fp16: an activation beyond 4094 cannot be represented.  Two guards (include/asd_slam.h,
     asd_asdnet_pieces): asd_load_weights' calibration batch notices weights that drive a layer past 2048 and switches the context to
