@@ -1385,10 +1385,8 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
   constexpr int lds0 = C::LDS_BYTES + (FUSE1 ? ((ROWS + 4) * 36 + 320 + 8) * 4 : 0);
   static_assert(lds0 <= 160 * 1024, "band does not fit LDS");
-  // ASD_X3_MAXWG=<k> (A/B): the LDS request is padded so that at most k of these workgroups share a CU (the rest of the CU -- LDS,
-  // registers, wave slots -- stays free for the tracking stream's kernels)
-  static const int maxwg = [] { const char* e = getenv("ASD_X3_MAXWG"); return e ? atoi(e) : 0; }();
-  const int lds = (maxwg >= 1 && maxwg <= 8) ? std::max(lds0, 160 * 1024 / (maxwg + 1) + 256) : lds0;
+  // (fewer of these workgroups per CU, to leave the tracking stream's kernels room, was measured in round 4: within noise or slower)
+  const int lds = lds0;
   static AsdPerDeviceOnce attr_set;   // per instantiation; the attribute belongs to the current device (the caller selected the context's)
   int dev_ = 0;
   (void)hipGetDevice(&dev_);
@@ -1485,8 +1483,6 @@ int asdnet_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_tq, 16 * sizeof(int)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_range), 64));
   *ctx->h_range = 0;
-  if (const char* e = getenv("ASD_ASDNET_RESERVE")) ctx->cu_reserve = atoi(e);
-  if (const char* e = getenv("ASD_ASDNET_PERSIST")) ctx->asdnet_persist = atoi(e) != 0;
   if (const char* e = getenv("ASD_ASDNET_PAIR")) ctx->net_pair = atoi(e) != 0;
   if (const char* e = getenv("ASD_ASDNET_RING")) ctx->ring_mask = atoi(e);
   return ASD_OK;
@@ -1604,17 +1600,6 @@ int asdnet_forward_device(asd_ctx* ctx, const uint8_t* d_patches, int n, float* 
   if (n == 0) return ASD_OK;
   if (!st) st = ctx->stream;
   std::lock_guard<std::mutex> prof_lock(ctx->prof_mutex);  // prof_* state is shared with asd_profile_enable / _get
-  // ASD_ASDNET_SLICES=k (A/B): the forward as k forwards over n / k patches each, one after the other on the same stream -- k times as many
-  // kernel ends, i.e. moments at which CUs run empty and a waiting whole-CU workgroup of the tracking stream can be placed
-  static const int slices = [] { const char* e = getenv("ASD_ASDNET_SLICES"); return e ? std::max(1, atoi(e)) : 1; }();
-  if (slices > 1 && n >= 256 * slices && !ctx->prof_on && !ctx->d_calib) {
-    const int per = ((n + slices - 1) / slices + 31) / 32 * 32;
-    for (int o = 0; o < n; o += per) {
-      const int rc = asdnet_forward_one(ctx, d_patches + (size_t)o * 1024, std::min(per, n - o), d_desc + (size_t)o * 128, st, range_flag);
-      if (rc != ASD_OK) return rc;
-    }
-    return ASD_OK;
-  }
   return asdnet_forward_one(ctx, d_patches, n, d_desc, st, range_flag);
 }
 static int asdnet_forward_one(asd_ctx* ctx, const uint8_t* d_patches, int n, float* d_desc, hipStream_t st, int* range_flag) {

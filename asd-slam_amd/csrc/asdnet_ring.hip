@@ -222,6 +222,9 @@ __device__ __forceinline__ void conv_ring_loop(const uint8_t* __restrict__ img, 
       if (c + 1 < G::NCHUNK) {
         if (c + 3 < G::NCHUNK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(T::NWW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (the library's rule, tools/check_barriers.py: a wave's LDS operations are complete before it enters a barrier -- the next chunk's
+        // operand reads were issued in the first half of this chunk, so the wait is short)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(ASD_RING_ABL & 8)) __builtin_amdgcn_s_barrier();
       }
     }
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN / 4) void k_conv_ring(const u
     for (int pp = 0; pp < PP; ++pp)
       if (patch0 + pp < n) image_issue<G, T::NW>(in + (size_t)(patch0 + pp) * H * H * CIN * 4, img + pp * G::IMGB, wave, lane);
     ring_prologue<G, T::NW>(wimg, ring, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     accv acc[T::NA][T::NB];
 #pragma unroll
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64 * WM4 * WN4, WM4 * WN4 / 4) void k_conv45_ring(c
     __builtin_amdgcn_s_barrier();
     image_issue<G4, NW>(in + (size_t)patch * 16 * 16 * 64 * 4, img, wave, lane);
     ring_prologue<G4, NW>(w4, ring, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     {
       accv acc[T4::NA][T4::NB];

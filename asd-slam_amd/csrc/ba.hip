@@ -231,16 +231,6 @@ struct PoseOptArgs {
   double pose0[7];      // initial pose (by value: no read of host memory on the kernel's critical path)
   const double* pose0_dev;  // non-null (asd_track_frame: the stage behind another PoseOptimization): the initial pose is read from here
   double* io_dev;           // non-null: the result block is written here as well (device memory, for the kernels of the next stage)
-  // asd_track_frame launches this kernel EARLY on a stream of its own, so that it is resident -- it needs most of a CU, and beside the
-  // extractor's ASDNet workgroups it waited 40-55 us for one (device-clock stamps) -- when the claim replay in front of it
-  // finishes: it then waits for *wait_flag to reach wait_value (set by k_resolve2 behind its last store) instead of for stream order.
-  // The wait is bounded (kPoseWaitPolls): a flag that never comes ends the kernel with io[7] = -1 instead of hanging the device.
-  const unsigned* wait_flag;
-  unsigned wait_value;
-  double host_done;                // 0, or a marker the kernel stores at io[8 + nw + 3] behind everything else (system scope): the host polls it
-                                   // instead of waiting for an event queued behind a kernel that sits on the device (k_resolve_pose)
-  unsigned* done_flag;             // null, or the kernel's own ticket: set to wait_value behind its last store (k_frustum_queries of the
-                                   // local-map stage waits for the motion-model stage's solver this way, asd_track_frame)
   const AsdBetweenArgs* between;   // device memory or null.  asd_track_frame, motion-model stage: the kernel ends with the work between the
                                    // two stages (needs io_dev).  A pointer, not a member: a larger argument block costs the kernel a scratch copy
   double isg_tab[16];   // MODE 2: the distinct information values ...
@@ -254,7 +244,6 @@ struct PoseOptArgs {
 #define ASD_POSE_THREADS 512
 #endif
 constexpr int kPoseThreads = ASD_POSE_THREADS, kPoseWaves = kPoseThreads / 64;
-constexpr int kPoseWaitPolls = kAsdTicketPolls;   // x (one L2 round trip + s_sleep 32 ~ 1 us): ~0.2 s, then the kernel gives up
 struct PoseShared {
   Pose7 T, T0, Tbak, Teval;
   double H[36], b[6], x[6];
@@ -513,36 +502,12 @@ __device__ inline void pose_take_system(PoseShared& S) {  // thread 0: sums -> H
 
 // MODE (the EdgeStore form) is a template parameter, not a run-time switch: with a pointer that may be LDS or global the
 // compiler falls back to FLAT loads, whose latency dominated the edge loop.
-// (A = const PoseOptArgs, in whatever address space the block lives: the kernel's argument segment, or constant memory for k_track_solver)
+// (A = const PoseOptArgs: the kernel's argument segment)
 template <int MODE, class A>
 __device__ __forceinline__ void pose_opt_body(A& a) {
   // (a = the kernel's argument block itself.  No private copy of it: a copy that is indexed at run time (pose0[t], isg_tab[t]) lives in
   // scratch memory, and every a.fx / a.n of the passes then is a scratch load)
-  if (a.wait_flag) {   // resident ahead of its inputs: one lane polls, everybody acquires
-    __shared__ int wait_ok;
-    if (threadIdx.x == 0) wait_ok = asd_ticket_wait(a.wait_flag, a.wait_value) ? 1 : 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    if (!wait_ok) {   // the producer never signalled: report, do not touch anything else
-      if (threadIdx.x == 0) { a.io[7] = -1.0; if (a.io_dev) a.io_dev[7] = -1.0; }
-      return;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
   const unsigned long long rt_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz, device-wide: comparable with other kernels' stamps (ASD_TIMING)
-  // the kernel's own ticket, behind its last store (producer form of MI355X_MICROARCH.md: stores drained, barrier, release, store)
-  auto publish = [&]() __attribute__((always_inline)) {
-    if (!a.done_flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.done_flag, a.wait_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
   int ne = a.n;   // edge count (fused chains: made on the device below, a.n is then only the capacity)
   constexpr int kGatherChunks = 9;   // 150 KB / 35 B per edge: at most 4388 keypoints reach the LDS form
   __shared__ int g_cnt[kGatherChunks * kPoseWaves + 1];
@@ -586,7 +551,6 @@ __device__ __forceinline__ void pose_opt_body(A& a) {
       asd_syncthreads();
       asd_between_body(*a.between, threadIdx.x, kPoseThreads);
     }
-    publish();
     return;
   }
   // this workgroup is the critical path of the tracking thread and usually shares its CU with ASDNet workgroups of
@@ -881,7 +845,6 @@ __device__ __forceinline__ void pose_opt_body(A& a) {
       asd_syncthreads();
       asd_between_body(*a.between, t, kPoseThreads);
     }
-    publish();
     return;
   }
   // outlier flags to the (pinned host) io block, eight per 8-byte store
@@ -903,104 +866,12 @@ __global__ __launch_bounds__(kPoseThreads) void k_pose_opt(PoseOptArgs a_in) { p
 // take every slot a finished workgroup frees (device-clock stamps, profiles/r04_chain_device_clock.txt); here it inherits the replay's.
 template <int KIND, int QPT>
 __global__ __launch_bounds__(kPoseThreads) void k_resolve_pose(Resolve2Args r, PoseOptArgs a_in) {
-  __shared__ int search_ok;
-  auto search_ok_all = [&](const PoseOptArgs&) { return search_ok != 0; };
-  if (a_in.wait_flag) {   // resident ahead of the search that makes its lists (its ticket: a one-lane kernel behind the search): one lane polls
-    if (threadIdx.x == 0) search_ok = asd_ticket_wait(a_in.wait_flag, a_in.wait_value) ? 1 : 0;
-    asd_syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (!search_ok) {   // report, touch nothing else (nothing is published: a kernel waiting for this one reports the same way)
-      if (threadIdx.x == 0) { a_in.io[7] = -1.0; if (a_in.io_dev) a_in.io_dev[7] = -1.0; }
-    }
-  }
-  if (!a_in.wait_flag || search_ok_all(a_in)) {
-    resolve2_body<KIND, QPT, kPoseThreads>(r);
-    // the match table is this workgroup's own stores: complete, then visible to all its waves (and no stale line in the vector L1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    pose_opt_body<2>(a_in);
-  }
-  if (a_in.host_done != 0.0) {   // "done" for a host that polls pinned memory: behind every store of the workgroup
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a_in.io + 8 + (a_in.g_ncur + 7) / 8 + 3, a_in.host_done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
-// ---- asd_track_frame, resident form: ONE solver kernel per frame, launched a frame AHEAD --------------------------------------------
-// k_resolve_pose needs most of a CU and, launched when its frame is submitted, still waits ~50-100 us for one: the extractor's ASDNet
-// workgroups take every slot a finished workgroup frees, so a CU never empties while one of their grids is being dispatched.  This kernel
-// does both stages of a frame -- replay + solver, replay + solver -- and is launched when the PREVIOUS frame is submitted: it has a whole
-// frame time to find its CU and then sits on it, one lane polling the first search's ticket.  What it needs is not known at launch, so its
-// argument blocks come from MEMORY: the host fills the pinned block of the frame before it launches the frame's searches, the kernel
-// copies it to LDS behind the first ticket (the searches are ordered behind the host's stores by their own launch).
-// Bounded: the first wait gives up after idle_polls sleeps (a few ms: no frame came -- LocalBundleAdjustment in line takes 2.6 ms, a
-// paused caller longer) and says so in *expired; the host then launches a fresh kernel for the frame.  Every other wait is
-// asd_ticket_wait's.
-struct AsdSolverBlock { Resolve2Args r1, r2; PoseOptArgs p1, p2; };
-constexpr int kSolverQ0 = 4, kSolverQ1 = 8;   // queries per thread of the two replays: up to 2048 last-frame points, 4096 local-map candidates
-#define ASD_CONST_AS __attribute__((address_space(4)))
-__global__ __launch_bounds__(kPoseThreads) void k_track_solver(const AsdSolverBlock* blk, const unsigned* flags, unsigned seq, int idle_polls, unsigned* expired, unsigned* done, const unsigned* claim) {
-  __shared__ int go;
-  if (threadIdx.x == 0) {
-    int ok = 0;
-    for (int i = 0; i < idle_polls; ++i) {
-      if ((int)(__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) { ok = 1; break; }
-      __builtin_amdgcn_s_sleep(32);
-    }
-    // out of patience -- unless the host has claimed this kernel for its frame meanwhile (it writes the claim word before it looks at
-    // `expired`, so a kernel it counts on does not give up under it; the frame's first search is then on its way: the long bound)
-    if (!ok && __hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) ok = asd_ticket_wait(flags, seq) ? 1 : 0;
-    go = ok;
-    if (!ok) __hip_atomic_store(expired, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  asd_syncthreads();
-  if (!go) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // The blocks are read like a kernel's own arguments: scalar loads from constant address space, values in SGPRs on demand (as LDS or
-  // generic loads every pointer and constant of the solver sits in a vector register for the whole kernel: 256 registers and spills).
-  // Constant memory must not change while the kernel reads it: the host wrote the block before it launched the search whose ticket
-  // has just arrived, and writes it again only after this kernel has ended.  The scalar cache may still hold the PREVIOUS frame's
-  // block (same address): invalidate it once.
-  asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  const ASD_CONST_AS AsdSolverBlock& cb = *reinterpret_cast<const ASD_CONST_AS AsdSolverBlock*>(reinterpret_cast<uintptr_t>(blk));
-  // ---- motion-model stage
-  resolve2_body<0, kSolverQ0, kPoseThreads>(cb.r1);
-  // (the match table is this workgroup's own stores: complete, then visible to all its waves, and no stale line in the vector L1)
+  resolve2_body<KIND, QPT, kPoseThreads>(r);
+  // the match table is this workgroup's own stores: complete, then visible to all its waves (and no stale line in the vector L1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   asd_syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  pose_opt_body<2>(cb.p1);
-  asd_syncthreads();
-  // ---- local-map stage: its search's ticket is the second word group
-  if (threadIdx.x == 0) go = asd_ticket_wait(flags + 32, seq) ? 1 : 0;
-  asd_syncthreads();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  if (!go) {
-    if (threadIdx.x == 0) { cb.p2.io[7] = -1.0; if (cb.p2.io_dev) cb.p2.io_dev[7] = -1.0; }
-  } else {
-    resolve2_body<1, kSolverQ1, kPoseThreads>(cb.r2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    pose_opt_body<2>(cb.p2);
-  }
-  // The host does not wait for an event behind this kernel: a packet queued behind a kernel that sits on the device holds the queue's
-  // command-processor pipe, and the other queues on that pipe -- the extractor's ASDNet stream among them -- fall back (measured: the
-  // ASDNet forward 0.60 -> 0.88-0.97 ms with an event record behind every solver kernel).  The kernel says "done" itself, in pinned
-  // memory, behind its last store (all results are in pinned host memory too: system scope).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asd_syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  pose_opt_body<2>(a_in);
 }
 
 // ---------------------------------------------------------------- fused tracking chains: edges made on the device
@@ -2165,17 +2036,6 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a,
 }
 
 struct BaState {
-  // asd_track_frame's per-frame solver kernel (k_track_solver): two slots, alternating by frame
-  struct Solver {
-    hipStream_t st[2] = {nullptr, nullptr};
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    void* h_blk[2] = {nullptr, nullptr};       // pinned AsdSolverBlock
-    unsigned* h_expired = nullptr;             // pinned [8]: [slot] the seq a kernel gave up waiting for, [2 + slot] the seq a kernel has finished,
-                                               // [4] the seq whose k_frustum_queries gave up waiting for the stage-1 solver, [5 + slot] the host's claim
-    unsigned armed[2] = {0, 0};                // seq the kernel launched last on the slot waits for (0 = none)
-    size_t probed = 0;                         // number of registered streams at the last probe
-    bool usable = false, created = false;
-  } solver;
   DevBuf lvl, HppPart, fixed_d;
   int* h_counts = nullptr;      // pinned [4]: nPf, nLa, Ea, pairs of the structure built on the device
   DevBuf out1, Apack, sblk;   // sblk: the round's structure arrays in one block (uploaded from the pinned h_sblk)
@@ -2223,15 +2083,6 @@ BaState* ba_state(asd_ctx* ctx) {
 }  // namespace
 
 void ba_free(asd_ctx* ctx) {
-  if (ctx->ba) {
-    BaState::Solver& S = static_cast<BaState*>(ctx->ba)->solver;
-    for (int i = 0; i < 2; ++i) {
-      if (S.st[i]) { (void)hipStreamSynchronize(S.st[i]); (void)hipStreamDestroy(S.st[i]); }
-      if (S.ev[i]) (void)hipEventDestroy(S.ev[i]);
-      if (S.h_blk[i]) (void)hipHostFree(S.h_blk[i]);
-    }
-    if (S.h_expired) (void)hipHostFree(S.h_expired);
-  }
   if (!ctx->ba) return;
   BaState* s = static_cast<BaState*>(ctx->ba);
   if (BaLane* ln = s->lane) {   // an outstanding job is allowed to finish (its buffers belong to the caller until then)
@@ -2262,157 +2113,12 @@ void ba_free(asd_ctx* ctx) {
   ctx->ba = nullptr;
 }
 
-static PoseOptArgs pose_chain_args(asd_ctx* ctx, BaState* s, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
-                                   const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
-                                   const AsdBetweenArgs* between, const unsigned* wait_flag, unsigned wait_value, unsigned* done_flag);
-// ---- host side of k_track_solver ---------------------------------------------------------------------------------------------------
-constexpr size_t kSolverLds = 112 * 1024;   // dynamic LDS of the kernel, fixed at launch (the frame's sizes are not known then): both
-                                            // replays' tables (<= 96 KB) and the solver's edge store (35 B per keypoint) must fit
-constexpr int kSolverIdlePolls = 6000;      // ~1 us each: the kernel gives its CU back when no frame comes for ~6 ms
-__global__ void k_solver_probe_wait(const unsigned* flag, unsigned value, int polls, int* out) {
-  int ok = 0;
-  for (int i = 0; i < polls; ++i) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == value) { ok = 1; break; }
-    __builtin_amdgcn_s_sleep(32);
-  }
-  *out = ok;
-}
-__global__ void k_solver_probe_set(unsigned* flag, unsigned value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-bool track_solver_fits(const asd_ctx* ctx, int n_last, int n_cand, int n_cur, size_t lds1, size_t lds2) {
-  return n_last >= 1 && n_last <= kSolverQ0 * kPoseThreads && n_cand >= 1 && n_cand <= kSolverQ1 * kPoseThreads && ctx->cfg.n_levels <= 16 &&
-         (size_t)n_cur * 35 + 16 <= kSolverLds && lds1 <= kSolverLds && lds2 <= kSolverLds;
-}
-
-// Streams, events, pinned blocks -- and the probe: a waiter on each solver stream, a setter on every other stream of the context in turn.
-// A setter that cannot run while the waiter sits on the device shares its hardware queue (GPU_MAX_HW_QUEUES per priority level): the
-// resident form would then wait for its own dependencies, so it is ruled out.
-int track_solver_setup(asd_ctx* ctx, unsigned* flags, bool* usable) {
-  BaState* s = ba_state(ctx);
-  BaState::Solver& S = s->solver;
-  std::vector<hipStream_t> others;
-  { std::lock_guard<std::mutex> g(ctx->aux_mu); others = ctx->aux_streams; }
-  if (S.created && S.probed == others.size()) { *usable = S.usable; return ASD_OK; }
-  if (!S.created) {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    for (int i = 0; i < 2; ++i) {
-      // lowest priority level: a queue pool apart from the tracking stream's (the waves' own priority is s_setprio's, not the queue's)
-      static const int prio_sel = [] { const char* e = getenv("ASD_SOLVE_PRIO"); return e ? atoi(e) : 0; }();   // 0 lowest (default), 1 middle, 2 highest (A/B)
-      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&S.st[i], hipStreamNonBlocking, prio_sel == 2 ? hi : prio_sel == 1 ? lo + (hi - lo) / 2 : lo));
-      ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming));
-      ASD_HIP_CHECK(ctx, hipHostMalloc(&S.h_blk[i], sizeof(AsdSolverBlock), hipHostMallocDefault));
-    }
-    ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&S.h_expired), 8 * sizeof(unsigned), hipHostMallocDefault));
-    for (int i = 0; i < 8; ++i) S.h_expired[i] = 0;
-    ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_track_solver), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSolverLds));
-    S.created = true;
-  } else {
-    for (int i = 0; i < 2; ++i) ASD_HIP_CHECK(ctx, hipStreamSynchronize(S.st[i]));   // (a kernel waiting for a frame gives up within kSolverIdlePolls)
-    S.armed[0] = S.armed[1] = 0;
-  }
-  bool ok = true;
-  unsigned token = 0x5000u + (unsigned)others.size() * 16;
-  int* d_out = reinterpret_cast<int*>(flags + 96);
-  for (int i = 0; i < 2 && ok; ++i) {
-    for (size_t k = 0; k <= others.size() && ok; ++k) {
-      hipStream_t other = k < others.size() ? others[k] : S.st[i ^ 1];   // (last: the two solver streams against each other)
-      ++token;
-      hipLaunchKernelGGL(k_solver_probe_wait, dim3(1), dim3(1), 0, S.st[i], flags + 64, token, 30000, d_out);
-      hipLaunchKernelGGL(k_solver_probe_set, dim3(1), dim3(1), 0, other, flags + 64, token);
-      ASD_HIP_CHECK(ctx, hipGetLastError());
-      ASD_HIP_CHECK(ctx, hipStreamSynchronize(S.st[i]));
-      ASD_HIP_CHECK(ctx, hipStreamSynchronize(other));
-      int got = 0;
-      ASD_HIP_CHECK(ctx, hipMemcpy(&got, d_out, sizeof got, hipMemcpyDeviceToHost));
-      if (!got) ok = false;
-    }
-  }
-  S.usable = ok;
-  S.probed = others.size();
-  if (!ok) {
-    static bool said = false;
-    if (!said) { said = true; fprintf(stderr, "libasdhip: a solver stream shares a hardware queue with another stream of the context (GPU_MAX_HW_QUEUES): asd_track_frame keeps its kernels in stream order\n"); }
-  }
-  *usable = ok;
-  return ASD_OK;
-}
-
-static int track_solver_launch(asd_ctx* ctx, BaState::Solver& S, unsigned seq, unsigned* flags) {
-  const int slot = seq & 1;
-  static const int idle_polls = [] { const char* e = getenv("ASD_SOLVER_IDLE_POLLS"); return e && atoi(e) > 0 ? atoi(e) : kSolverIdlePolls; }();   // (tests: a tiny bound makes every kernel launched ahead give up)
-  hipLaunchKernelGGL(k_track_solver, dim3(1), dim3(kPoseThreads), kSolverLds, S.st[slot], static_cast<const AsdSolverBlock*>(S.h_blk[slot]), flags, seq, idle_polls,
-                     S.h_expired + slot, S.h_expired + 2 + slot, S.h_expired + 5 + slot);
-  ASD_HIP_CHECK(ctx, hipGetLastError());   // (nothing is queued behind it: see the kernel's last lines)
-  S.armed[slot] = seq;
-  return ASD_OK;
-}
-
-int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, const double* K, const AsdSolverStage& s1, const AsdSolverStage& s2) {
-  BaState* s = ba_state(ctx);
-  BaState::Solver& S = s->solver;
-  const int slot = seq & 1;
-  int rc;
-  if ((rc = pose_chain_reserve(ctx, n_cur)) != ASD_OK) return rc;
-  AsdSolverBlock* b = static_cast<AsdSolverBlock*>(S.h_blk[slot]);
-  b->r1 = *static_cast<const Resolve2Args*>(s1.replay);
-  b->r2 = *static_cast<const Resolve2Args*>(s2.replay);
-  // stage 1 publishes its own ticket (word group 1) behind the work between the stages; no stage waits inside the solver body
-  b->p1 = pose_chain_args(ctx, s, n_cur, s1.d_src, s1.d_kp, s1.d_tab, s1.d_hold, s1.d_own, s1.pose7, K, s1.d_io, s1.d_pose0, s1.d_io_dev, s1.between, nullptr, seq, flags + 16);
-  b->p2 = pose_chain_args(ctx, s, n_cur, s2.d_src, s2.d_kp, s2.d_tab, s2.d_hold, s2.d_own, s2.pose7, K, s2.d_io, s2.d_pose0, s2.d_io_dev, s2.between, nullptr, seq, nullptr);
-  ctx->pose_chain_kp_flags = true;
-  // (the block is complete before the frame's first search is launched: the caller launches it after this returns)
-  __atomic_store_n(S.h_expired + 5 + slot, seq, __ATOMIC_SEQ_CST);   // the claim: a kernel that reads it does not give up any more
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  if (S.armed[slot] == seq && __atomic_load_n(S.h_expired + slot, __ATOMIC_ACQUIRE) != seq) return ASD_OK;   // resident, waiting for this frame
-  S.h_expired[slot] = 0;
-  return track_solver_launch(ctx, S, seq, flags);
-}
-
-hipStream_t track_solver_stream(asd_ctx* ctx, int slot) { return ba_state(ctx)->solver.st[slot & 1]; }
-unsigned* track_solver_gate_word(asd_ctx* ctx) { return ba_state(ctx)->solver.h_expired + 4; }
-
-int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags) {
-  BaState::Solver& S = ba_state(ctx)->solver;
-  return track_solver_launch(ctx, S, seq_next, flags);
-}
-
-int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags) {
-  BaState::Solver& S = ba_state(ctx)->solver;
-  const int slot = seq & 1;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (long spin = 0;; ++spin) {
-    if (__atomic_load_n(S.h_expired + 2 + slot, __ATOMIC_ACQUIRE) == seq) {
-      if (__atomic_load_n(S.h_expired + 4, __ATOMIC_ACQUIRE) == seq) {
-        ctx->set_error("asd_track_frame: k_frustum_queries gave up waiting for the motion-model stage's solver (a kernel launched ahead gave up as its frame "
-                       "arrived and the call was not finished for %d polls): the local-map stage searched nothing", kAsdTicketPolls);
-        return ASD_ERR_HIP;
-      }
-      return ASD_OK;
-    }
-    if (__atomic_load_n(S.h_expired + slot, __ATOMIC_ACQUIRE) == seq) {
-      // the kernel launched a frame ahead gave up just as the frame arrived (the host had still seen it waiting): the searches have
-      // run, their tickets stand -- a fresh kernel goes straight through
-      S.h_expired[slot] = 0;
-      int rc;
-      if ((rc = track_solver_launch(ctx, S, seq, flags)) != ASD_OK) return rc;
-    }
-    if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
-      ctx->set_error("asd_track_frame: the frame's solver kernel did not finish within 5 s");
-      return ASD_ERR_HIP;
-    }
-    __builtin_ia32_pause();
-  }
-}
-
 // Fused tracking chains (asd_track_motion_model / asd_track_local_map, matcher.hip): PoseOptimization enqueued on the context's
 // stream directly behind the kernels that made the matches -- k_pose_edges builds the edge records from the device-resident
 // match table, k_pose_opt reads their count from the device -- so the chain needs ONE synchronisation, at its end.  The results
 // (pose, n_bad, outlier byte per edge in keypoint order) are copied to *h_io; the caller synchronises and unpacks them.
 // Everything pose_chain_enqueue may have to ask the runtime for -- scratch buffers, the kernel's dynamic-LDS attribute -- done ahead of
-// time.  asd_track_frame calls it before its first launch: once a PoseOptimization kernel sits on the device waiting for its ticket,
-// the host must not enter a runtime call that could wait for the device (an allocation, a function attribute) before the kernel that
-// publishes the ticket has been launched.
+// time (asd_track_frame calls it before its first launch).
 int pose_chain_reserve(asd_ctx* ctx, int n_cur) {
   BaState* s = ba_state(ctx);
   int rc;
@@ -2432,14 +2138,16 @@ int pose_chain_reserve(asd_ctx* ctx, int n_cur) {
 }
 
 bool pose_chain_fused_ok(const asd_ctx* ctx, int kind, int nq, int n_cur, size_t lds) {
-  return (kind == 0 || kind == 1) && nq >= 1 && nq <= 8 * kPoseThreads && pose_chain_lds_form(ctx, n_cur) && lds <= 150 * 1024;
+  // kind 0: every last-frame point is a slot of the replay (8 per thread); kind 1: the map points with candidates are replayed in chunks
+  // (resolve2.h), what bounds nq is the compaction's round count
+  const int max_q = kind == 0 ? 8 * kPoseThreads : kResolve2MaxRounds * kPoseThreads;
+  return (kind == 0 || kind == 1) && nq >= 1 && nq <= max_q && nq < 65536 && pose_chain_lds_form(ctx, n_cur) && lds <= 150 * 1024;
 }
 
-// the solver's argument block for device-resident matches (gather form, mode 2) -- shared by pose_chain_enqueue and the per-frame
-// solver kernel of asd_track_frame (k_track_solver), which takes its blocks from memory
+// the solver's argument block for device-resident matches (gather form, mode 2)
 static PoseOptArgs pose_chain_args(asd_ctx* ctx, BaState* s, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                                    const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
-                                   const AsdBetweenArgs* between, const unsigned* wait_flag, unsigned wait_value, unsigned* done_flag) {
+                                   const AsdBetweenArgs* between) {
   PoseOptArgs a{};
   a.n = n_cur;
   a.g_src = d_src; a.g_hold = d_hold; a.g_tab = d_tab; a.g_own = d_own; a.g_kp = d_kp; a.g_ncur = n_cur;
@@ -2447,7 +2155,6 @@ static PoseOptArgs pose_chain_args(asd_ctx* ctx, BaState* s, int n_cur, const in
   if (pose7) memcpy(a.pose0, pose7, 56);
   a.pose0_dev = d_pose0; a.io_dev = d_io_dev;
   a.between = between;
-  a.wait_flag = wait_flag; a.wait_value = wait_value; a.done_flag = done_flag;
   a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
   a.soa_g = s->po_err.as<double>(); a.flags_g = s->po_level.as<uint8_t>(); a.io = d_io;
   a.use_lds = 2;
@@ -2457,19 +2164,18 @@ static PoseOptArgs pose_chain_args(asd_ctx* ctx, BaState* s, int n_cur, const in
 
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0, double* d_io_dev,
-                       const AsdBetweenArgs* between, hipStream_t st_early, const unsigned* wait_flag, unsigned wait_value, const AsdFusedReplay* fused, unsigned* done_flag, double host_done) {
+                       const AsdBetweenArgs* between, const AsdFusedReplay* fused) {
   // every input is already on the device (the caller packed the tables into its one upload block), the results go to d_io
   // inside the caller's one result block: no copy is enqueued here
   BaState* s = ba_state(ctx);
-  hipStream_t st = st_early ? st_early : ctx->stream;
+  hipStream_t st = ctx->stream;
   int rc;
   if ((rc = pose_chain_reserve(ctx, n_cur)) != ASD_OK) return rc;
   const size_t idx_off = (size_t)n_cur * 48;
   const size_t lds_compact = (size_t)n_cur * 35 + 16;
   const int mode = pose_chain_lds_form(ctx, n_cur) ? 2 : 0;
-  PoseOptArgs a = pose_chain_args(ctx, s, n_cur, d_src, d_kp, d_tab, d_hold, d_own, pose7, K, d_io, d_pose0, d_io_dev, between, wait_flag, wait_value, done_flag);
+  PoseOptArgs a = pose_chain_args(ctx, s, n_cur, d_src, d_kp, d_tab, d_hold, d_own, pose7, K, d_io, d_pose0, d_io_dev, between);
   a.use_lds = mode;
-  a.host_done = fused ? host_done : 0.0;
   if (mode != 2) {   // larger than LDS: edge records through HBM
     a.g_src = nullptr; a.g_hold = nullptr; a.g_tab = nullptr; a.g_own = nullptr; a.g_kp = nullptr; a.g_ncur = 0;
     PoseEdgesArgs e{};
@@ -2481,7 +2187,6 @@ int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* 
     a.n_dev = s->pc_n.as<int>();
     a.edges = s->po_Xw.as<double>(); a.isgi = s->po_Xw.as<uint8_t>() + idx_off;
   }
-  if (wait_flag && mode != 2) { ctx->set_error("pose chain: the early launch needs the LDS form of the solver"); return ASD_ERR_CAPACITY; }
   if ((d_pose0 || d_io_dev) && mode != 2) { ctx->set_error("pose chain: the device-side hand-over needs the LDS form of the solver (frame too large)"); return ASD_ERR_CAPACITY; }
   if (fused) {
     if (mode != 2 || !pose_chain_fused_ok(ctx, fused->kind, fused->nq, n_cur, fused->lds)) { ctx->set_error("pose chain: no fused replay + solver form for this frame"); return ASD_ERR_CAPACITY; }
@@ -2563,11 +2268,10 @@ int asd_pose_optimize(asd_ctx* ctx, double* pose7, int32_t n, const double* Xw, 
   a.soa_g = s->po_err.as<double>();
   a.flags_g = s->po_level.as<uint8_t>();
   a.io = s->po_pose.as<double>();
-  static const bool no_lds = getenv("ASD_POSE_NO_LDS") != nullptr, no_compact = getenv("ASD_POSE_NO_COMPACT") != nullptr;
   const size_t lds_full = (size_t)n * 48 + (size_t)2 * n + 16, lds_compact = (size_t)n * 35 + 16;
   int mode = 0;
-  if (!no_lds && compact && !no_compact && lds_compact <= 150 * 1024) mode = 2;
-  else if (!no_lds && lds_full <= 150 * 1024) mode = 1;
+  if (compact && lds_compact <= 150 * 1024) mode = 2;
+  else if (lds_full <= 150 * 1024) mode = 1;
   a.use_lds = mode;
   a.debug = getenv("ASD_POSE_DEBUG") ? 1 : 0;
   static AsdPerDeviceOnce attr_set;
@@ -2926,8 +2630,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
           ASD_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_ba_solve_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
           attr_set.done(ctx->cfg.device);
         }
-        static const bool old_chol = getenv("ASD_BA_CHOL") != nullptr;   // A/B: the round-2 Cholesky kernel
-        if (nPf <= kSolveMaxBlocks && !old_chol) {
+        if (nPf <= kSolveMaxBlocks) {
           const size_t lds = (nbk * 36 + (size_t)2 * (kSolveMaxBlocks - 1) * 36 + 192 + 72 + 2) * sizeof(double) + nbk * sizeof(short2) + 16;
           hipLaunchKernelGGL(k_ba_solve_lds, dim3(1), dim3(kSolveThreads), lds, st, d.Apack, d.bs, d.x, n, d.lm);
         } else if (nPf <= 32) {

@@ -167,7 +167,6 @@ int asd_ctx_destroy(asd_ctx* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   for (int set = 0; set < 2; ++set)
     for (int i = 0; i < 9; ++i) if (ctx->prof_ev[set][i]) (void)hipEventDestroy(ctx->prof_ev[set][i]);
-  if (ctx->d_chain_flags) (void)hipFree(ctx->d_chain_flags);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   if (ctx->stream_prep) (void)hipStreamDestroy(ctx->stream_prep);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

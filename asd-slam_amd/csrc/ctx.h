@@ -70,16 +70,6 @@ hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t byte
 // flaky tests/test_bench_host.py).  Every barrier in the library is written through these two, and `make check-isa` checks that
 // every s_barrier in the device code has the wait directly in front of it.
 #if defined(__HIPCC__)
-// Consumer side of a ticket word (MI355X_MICROARCH.md, "Valid forms"): ONE lane polls with a bounded number of sleeps (~0.2 s), the caller
-// follows with a barrier and an agent-scope acquire fence.  false = the producer never signalled.
-constexpr int kAsdTicketPolls = 200000;
-__device__ inline bool asd_ticket_wait(const unsigned* flag, unsigned value) {
-  for (int i = 0; i < kAsdTicketPolls; ++i) {
-    if ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) >= 0) return true;
-    __builtin_amdgcn_s_sleep(32);
-  }
-  return false;
-}
 #define asd_syncthreads() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 __device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return __syncthreads_or(pred); }
 #endif
@@ -95,16 +85,6 @@ __device__ inline int asd_syncthreads_or(int pred) { asm volatile("s_waitcnt lgk
 // stage behind sees the bits a host in between would have handed it.
 // A window query = one GetFeaturesInArea call + the descriptor it is matched against (k_window_search's input; matcher.hip)
 struct AsdWinQuery { float x, y, r; int min_level, max_level, qrow; };
-// Frame::isInFrustum + PredictScale + the search window for the local-map candidates of asd_track_frame (rows of the attribute bank): the
-// arguments of the per-candidate arithmetic, shared by k_frustum_queries (matcher.hip) and the tail of the stage-1 solver (asd_between_body),
-// which makes the queries itself when `n` > 0 -- a launch and its dispatch less between the stages
-struct AsdFrustumTail {
-  int n, n_levels, bfactor;
-  const int* rows; const float* attr;
-  float fx, fy, cx, cy, min_x, max_x, min_y, max_y, cos_limit, th;
-  float level_thr[ASD_MAX_LEVELS], scale[ASD_MAX_LEVELS];
-  AsdWinQuery* queries; float* xw_out;
-};
 struct AsdBetweenArgs {
   int n_cur, n_last, n_cand;
   const int* match1;        // [n_cur] last-frame keypoint or -1
@@ -116,12 +96,11 @@ struct AsdBetweenArgs {
   float* cur_Xw;            // out [n_cur][3]: that map point's position
   uint8_t* skip;            // out [n_cand]
   float* T1;                // out [19]: Tcw (row major 4x4), Ow
-  AsdFrustumTail fr;        // fr.n > 0: the local-map stage's queries are made here as well
 };
 #if defined(__HIPCC__)
 // one candidate of the bank form: the arithmetic of asd_frustum, operation for operation (f32 with the reference's two double accumulations;
 // no contraction; IEEE division and square root), the level from comparisons with thresholds the host derived from its own logf
-// (F = AsdFrustumTail, or k_frustum_queries' own argument block, which carries the same fields: no private copy of the level tables)
+// (F = k_frustum_queries' argument block: no private copy of the level tables)
 template <class F>
 __device__ inline void asd_frustum_bank_point(const F& a, const float* T_dev, const uint8_t* skip, const int q) {
 #pragma clang fp contract(off)
@@ -211,14 +190,6 @@ __device__ inline void asd_between_body(const AsdBetweenArgs& a_dev, const int t
       a.T1[16 + i] = (float)(-1.0 * sum);
     }
   }
-  if (a_dev.fr.n > 0) {   // the local-map stage's queries from the pose and the skip flags just written (this workgroup's own stores: complete,
-    // then visible to all its waves, no stale line in the vector L1).  The frustum arguments are read in place (device memory): a private
-    // copy of a block with run-time indexed arrays would live in scratch.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    for (int q = t; q < a_dev.fr.n; q += nt) asd_frustum_bank_point(a_dev.fr, a.T1, a.skip, q);
-  }
 }
 #endif
 
@@ -278,11 +249,7 @@ struct asd_ctx {
   asd_config cfg{};
   hipStream_t stream = nullptr;
   hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
-  unsigned* d_chain_flags = nullptr;  // [128] asd_track_frame, resident form: ticket words (search 1 at 0, stage-1 solver at 16, search 2 at 32), probe words (64, 96)
-  unsigned chain_seq = 0;
-  // every stream this context's entry points or worker threads launch into (registered when created): the per-frame solver kernel of
-  // asd_track_frame sits on the device waiting for a ticket, so its stream must not share a hardware queue with any stream whose work that
-  // ticket depends on -- track_solver_setup probes them all (asd_register_stream / aux_streams)
+  // every stream this context's entry points or worker threads launch into (registered when created)
   std::vector<hipStream_t> aux_streams;
   std::mutex aux_mu;
   hipStream_t stream_prep = nullptr; // asd_prep_async: frame construction (grid / descriptor / bank copies) beside the stages in flight
@@ -425,23 +392,7 @@ bool pose_chain_fused_ok(const asd_ctx* ctx, int kind, int nq, int n_cur, size_t
 // between (optional, with d_io_dev; DEVICE memory): the work between the two tracking stages as the kernel's tail (asd_between_body)
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
-                       double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, hipStream_t st_early = nullptr,
-                       const unsigned* wait_flag = nullptr, unsigned wait_value = 0, const AsdFusedReplay* fused = nullptr,
-                       unsigned* done_flag = nullptr, double host_done = 0.0);
-// ---- the per-frame solver kernel of asd_track_frame (k_track_solver, ba.hip; see its comment)
-// everything below returns ASD_OK or an error; `usable` = false when the streams' hardware queues rule the resident form out
-struct AsdSolverStage {   // pose_chain_enqueue's inputs of one stage
-  const void* replay; size_t replay_lds;   // Resolve2Args (resolve2.h)
-  const int* d_src; const float4* d_kp; const float* d_tab; const uint8_t* d_hold; const float* d_own; const double* pose7; double* d_io;
-  const double* d_pose0; double* d_io_dev; const AsdBetweenArgs* between;
-};
-int track_solver_setup(asd_ctx* ctx, unsigned* flags, bool* usable);
-bool track_solver_fits(const asd_ctx* ctx, int n_last, int n_cand, int n_cur, size_t lds1, size_t lds2);
-int track_solver_submit(asd_ctx* ctx, unsigned seq, unsigned* flags, int n_cur, const double* K, const AsdSolverStage& s1, const AsdSolverStage& s2);   // fill the frame's block; launch unless resident
-int track_solver_prelaunch(asd_ctx* ctx, unsigned seq_next, unsigned* flags);   // next frame's kernel, a frame ahead
-int track_solver_wait(asd_ctx* ctx, unsigned seq, unsigned* flags);
-hipStream_t track_solver_stream(asd_ctx* ctx, int slot);
-unsigned* track_solver_gate_word(asd_ctx* ctx);      // pinned: k_frustum_queries stores the frame's seq there when its wait for the stage-1 solver runs out   // (after track_solver_setup said usable)             // host: until the frame's kernel has ended (relaunches one that gave up waiting)
+                       double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, const AsdFusedReplay* fused = nullptr);
 inline void asd_register_stream(asd_ctx* ctx, hipStream_t st) { std::lock_guard<std::mutex> g(ctx->aux_mu); ctx->aux_streams.push_back(st); }
 inline void asd_unregister_stream(asd_ctx* ctx, hipStream_t st) {
   std::lock_guard<std::mutex> g(ctx->aux_mu);

@@ -1024,17 +1024,14 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     // will ever take (asd_extract_wait would block forever).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    const int prio_mid = prio_least + (prio_greatest - prio_least) / 2;
     AsyncExtract* ax = new AsyncExtract();
     hipStream_t sx = nullptr;
     auto build = [&]() -> int {
-      static const bool front_mid = getenv("ASD_FRONT_PRIO_MID") != nullptr;   // A/B only
-      static const bool front_low = getenv("ASD_FRONT_PRIO_LOW") != nullptr;   // A/B only: the workers' streams in the ASDNet stream's pool
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
       asd_register_stream(ctx, sx);
       ax->fe[0] = ctx->fe;
       for (int w = 0; w < kWorkers; ++w) {
-        ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f[w], hipStreamDefault, front_low ? prio_least : front_mid ? prio_mid : prio_greatest));
+        ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f[w], hipStreamDefault, prio_greatest));
         asd_register_stream(ctx, ax->stream_f[w]);
         ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners[w]));
         int r;

@@ -64,9 +64,6 @@ struct SortArgs {
   const uint8_t* occ;      // [n_cur] or null: keypoints that cannot be matched (occupied on entry)
   float th_cut;            // q_cnt counts the entries with distance <= th_cut (they are the list's head); +inf = all
   uint16_t* top_idx;       // [nq][kTop] keypoint (0xffff = no entry)
-  // null, or a ticket: every workgroup counts itself in done_ctr behind its last store, the last one resets the counter and sets
-  // *done_flag = done_value -- a kernel resident on another stream (k_resolve_pose, asd_track_frame) waits for that instead of stream order
-  unsigned* done_ctr; unsigned* done_flag; unsigned done_value;
 };
 template <bool SORT>
 __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, const WinQuery* __restrict__ queries, int nq,
@@ -220,22 +217,7 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
     return;
   }
   // ---- SORT: the list in preference order + the compact head table
-  auto ticket = [&]() {   // (every wave of the workgroup comes here)
-    if (!S.done_flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const unsigned prev = __hip_atomic_fetch_add(S.done_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev + 1 == gridDim.x) {
-        __hip_atomic_store(S.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(S.done_flag, S.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  };
-  if (!live) { ticket(); return; }
+  if (!live) return;
   const bool fits = off + cnt <= cap;   // (an overflowing search is run again by the host: nothing of it is read)
   int n_keep = 0, s_off = off;
   auto put = [&](int base, int rank, int idx, float d) {
@@ -303,7 +285,6 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
   }
   if (lane < kTop && lane >= (fits ? cnt : 0)) S.top_idx[(size_t)q * kTop + lane] = 0xffffu;
   if (lane == 0) { q_cnt[q] = n_keep; q_off[q] = cnt ? s_off : 0; }
-  ticket();
 }
 
 // Node-restricted search (BoW-guided matchers): query q is matched against the explicit candidate list
@@ -452,271 +433,9 @@ hipError_t copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes) {
 // LAST writer = the largest q picking it.
 // KIND 0 = SearchByProjection(frame, frame) (:1318-1452): best only, TH_HIGH, rotation histogram over every write.
 // KIND 1 = SearchByProjection(frame, points) (:44-122): best / second best with levels and the ratio test; counts twice.
-struct ResolveArgs {
-  int nq, n_cur;
-  const int* q_off; const int* q_cnt; const int* idx; const float* dist;   // k_window_search output
-  const int* total; int cap;  // candidates produced / capacity of idx, dist: beyond it the lists are truncated -> no replay
-  const unsigned* meta;       // per candidate: position in its list << 16 | query (k_window_search)
-  const uint8_t* obs_pos;     // [nq] or null
-  const uint8_t* occupied;    // KIND 1: [n_cur]
-  const float4* kp_cur;       // (x, y, octave bits, angle)
-  const float4* kp_last;      // KIND 0: query q = last-frame keypoint q
-  int check_ori;
-  float nn_ratio;
-  int* pick;                  // [nq] scratch: the keypoint q writes (-1 none)
-  int* match_cur;             // out [n_cur]
-  int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations
-  int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches: the kernel stores its outputs there as
-                              // well, so the host needs no copy command behind the chain (the device copy feeds the pose solver)
-  int ov_cap;                 // candidates beyond the register slots that the workgroup keeps in LDS (12 B each) instead of
-                              // reading them from L2 in every iteration; a longer tail than this falls back to the L2 reads
-};
-constexpr int kResolveThreads = 512, kResolveMaxQPT = 8;   // up to 4096 queries
-// SLOTS = candidates a thread keeps in registers (template parameter: 8, 16 or 24, i.e. up to 12288 candidates register resident;
-// the launcher picks by the size of the previous search of the same kind, longer lists are read from L2 every iteration)
-
-// Shape of an iteration.  A thread per QUERY pays, per wave, for the longest candidate list among its 64 lanes (lists run
-// from 0 to ~100 entries: 12 us per iteration).  So the scan is flat over CANDIDATES: candidate c (keypoint j, query q,
-// position in q's list, distance d) is looked at by thread c % 512, which keeps it in registers for the whole kernel, and an
-// available candidate posts key = (bits of d, position, j) by a 64-bit atomicMin on its query's slot -- distances are
-// non-negative, so the bit pattern orders like the value, and the position breaks ties exactly as the reference's strict
-// `<` does (first in Frame::GetFeaturesInArea order).  The owner of q (thread q % 512) then reads the winner and posts the
-// claim.  The reference's best / second-best walk (KIND 1) equals the two smallest keys: the second best and ITS level are
-// the smallest key among the others (a candidate tying with the best lands there too; among equal values the first in list
-// order sets the level and later ones, not being `<`, leave it).  Everything the iterations touch is in registers or LDS.
-template <int KIND, int QPT, int kResolveSlots>
-__global__ __launch_bounds__(kResolveThreads, 4) void k_resolve(ResolveArgs a) {   // <= 128 VGPRs: 8 waves beside one ASDNet workgroup
-#define OUT(i, v) do { const int v_ = (v); a.match_cur[i] = v_; if (a.mirror) a.mirror[i] = v_; } while (0)
-#define CNT(i, v) do { const int v_ = (v); a.n_matches[i] = v_; if (a.mirror) a.mirror[a.n_cur + (i)] = v_; } while (0)
-  extern __shared__ unsigned long long lds_q[];
-  unsigned long long* key1 = lds_q;                                   // [nq]
-  unsigned long long* key2 = lds_q + a.nq;                            // [nq] (KIND 1)
-  unsigned* claim0 = reinterpret_cast<unsigned*>(lds_q + (KIND == 1 ? 2 : 1) * a.nq);
-  unsigned* claim[2] = {claim0, claim0 + a.n_cur};
-  uint8_t* oct_occ = reinterpret_cast<uint8_t*>(claim0 + 2 * a.n_cur);   // octave | 0x80 if occupied on entry
-  unsigned* ov_lo = reinterpret_cast<unsigned*>(oct_occ + (a.n_cur + 15) / 16 * 16);   // [ov_cap] the tail beyond the registers:
-  unsigned* ov_db = ov_lo + a.ov_cap;                                                  // key low word, distance bits, query
-  unsigned* ov_q = ov_db + a.ov_cap;
-  __shared__ int n_written, hist[HISTO], keep[3], n_removed;
-  const int t = threadIdx.x;
-  const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
-  const int total = *a.total;
-  if (total > a.cap) {   // truncated lists: the host grows the buffers and searches again
-    // the match table is still written (no match anywhere): a fused chain behind this kernel gathers its edges from it, and
-    // stale rows would send PoseOptimization out of the position table's bounds
-    for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, -1);
-    if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
-    return;
-  }
-  if (total == 0) {      // nothing in any window
-    for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, -1);
-    if (t == 0) { CNT(0, 0); CNT(1, 0); CNT(2, 0); }
-    return;
-  }
-  constexpr unsigned long long kNone = ~0ull;
-  for (int q = t; q < (KIND == 1 ? 2 : 1) * a.nq; q += kResolveThreads) lds_q[q] = kNone;
-  for (int j = t; j < 2 * a.n_cur; j += kResolveThreads) claim0[j] = 0xffffffffu;
-  if (KIND == 1)
-    for (int j = t; j < a.n_cur; j += kResolveThreads)
-      oct_occ[j] = (uint8_t)((__float_as_int(a.kp_cur[j].z) & 0x7f) | (a.occupied[j] ? 0x80 : 0));
-  if (t == 0) { n_written = 0; n_removed = 0; }
-  if (t < HISTO) hist[t] = 0;
-  // the thread's candidates: key low word (position << 16 | keypoint), distance bits, and the query (16 bits, two per register;
-  // 0xffff = empty slot)
-  unsigned clo[kResolveSlots], cdb[kResolveSlots], cqp[kResolveSlots / 2];
-#pragma unroll
-  for (int i = 0; i < kResolveSlots / 2; ++i) cqp[i] = 0xffffffffu;
-#pragma unroll
-  for (int i = 0; i < kResolveSlots; ++i) {
-    const int c = min(t + i * kResolveThreads, total - 1);   // clamped: the loads of all slots are issued unconditionally
-    const bool v = t + i * kResolveThreads < total;
-    const unsigned meta = a.meta[c];
-    clo[i] = (meta & 0xffff0000u) | (unsigned)a.idx[c];
-    cdb[i] = __float_as_uint(a.dist[c]);
-    if (v) cqp[i / 2] = (cqp[i / 2] & ~(0xffffu << (16 * (i & 1)))) | ((meta & 0xffffu) << (16 * (i & 1)));
-  }
-  // the tail of a long list (12 k candidates against 16 x 512 slots): staged once in LDS; an iteration then pays ~100 cycles per
-  // dependent access instead of an L2 round trip (measured: see DESIGN.md, claim replay)
-  const int n_ov = total - kResolveSlots * kResolveThreads;
-  const bool ov_lds = n_ov > 0 && n_ov <= a.ov_cap;
-  if (ov_lds)
-    for (int i = t; i < n_ov; i += kResolveThreads) {
-      const int c = kResolveSlots * kResolveThreads + i;
-      const unsigned meta = a.meta[c];
-      ov_lo[i] = (meta & 0xffff0000u) | (unsigned)a.idx[c];
-      ov_db[i] = __float_as_uint(a.dist[c]);
-      ov_q[i] = meta & 0xffffu;
-    }
-#define CQ(i) ((cqp[(i) / 2] >> (16 * ((i) & 1))) & 0xffffu)
-  int pick[QPT];
-  unsigned posmask = 0;
-#pragma unroll
-  for (int k = 0; k < QPT; ++k) {
-    const int q = t + k * kResolveThreads;
-    if (q < a.nq && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
-    pick[k] = -1;
-  }
-  asd_syncthreads();
-  const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
-  const unsigned th_bits = __float_as_uint(TH_HIGH);
-  unsigned long long ts_it0 = ts1;
-  int ph[4] = {0, 0, 0, 0};   // thread 0's view: bids, barrier, owners, closing barrier (10 ns units)
-  const int max_it = a.nq + 2;
-  int it = 0;
-  for (;; ++it) {
-    // read the claims of iteration it-1 (table it & 1, tag it), post this iteration's picks into the other table (tag it+1)
-    const unsigned* rd = claim[it & 1];
-    unsigned* wr = claim[(it + 1) & 1];
-    const unsigned tag_rd = (unsigned)(0xffff - it), tag_wr = (unsigned)(0xffff - (it + 1));
-    const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
-    // phase 1: every available candidate bids for its query.  The claim-table reads of eight candidates are in flight together
-    // (the scan is latency bound: ~100 cycles per dependent LDS access); in phase 1b (KIND 1) the query's winner is left out so
-    // that the minimum of the others comes out.  Measured and not kept: a contiguous piece of the buffers per thread with one
-    // atomic per run of equal queries (fewer atomics, but the piece's tail beyond the registers costs serial L2 round trips:
-    // 72 instead of 42 us of bids); folding the lanes of a run with three DPP row shifts before the atomic (63 us: the shifts
-    // and 64-bit selects cost more than the same-address atomics they save).
-    auto scan = [&](unsigned long long* keys, bool second) {
-      auto take = [&](unsigned q, unsigned lo, unsigned db, unsigned cl, unsigned long long w) {
-        bool ok = !((cl >> 16) == tag_rd && (cl & 0xffffu) < q);
-        if (KIND == 0) ok = ok && db <= th_bits;                       // beyond TH_HIGH it can never be picked
-        if (KIND == 1) ok = ok && !(oct_occ[lo & 0xffffu] & 0x80);
-        const unsigned long long k = ((unsigned long long)db << 32) | lo;
-        if (ok && (!second || k != w)) atomicMin(&keys[q], k);
-      };
-#pragma unroll
-      for (int g = 0; g < kResolveSlots; g += 8) {
-        unsigned cl[8];
-        unsigned long long w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          cl[i] = rd[clo[g + i] & 0xffffu];
-          w[i] = (second && CQ(g + i) != 0xffffu) ? key1[CQ(g + i)] : 0ull;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          if (CQ(g + i) != 0xffffu) take(CQ(g + i), clo[g + i], cdb[g + i], cl[i], w[i]);
-      }
-      if (ov_lds) {   // beyond the registers, from LDS: four candidates' reads in flight
-        for (int i0 = t; i0 < n_ov; i0 += 4 * kResolveThreads) {
-          unsigned q[4], lo[4], db[4], cl[4];
-          unsigned long long w[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int k = min(i0 + i * kResolveThreads, n_ov - 1);
-            q[i] = ov_q[k]; lo[i] = ov_lo[k]; db[i] = ov_db[k];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { cl[i] = rd[lo[i] & 0xffffu]; w[i] = second ? key1[q[i]] : 0ull; }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (i0 + i * kResolveThreads < n_ov) take(q[i], lo[i], db[i], cl[i], w[i]);
-        }
-      } else
-      for (int c0 = t + kResolveSlots * kResolveThreads; c0 < total; c0 += 4 * kResolveThreads) {   // beyond the registers: 12 loads in flight
-        unsigned meta[4], lo[4], db[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = min(c0 + i * kResolveThreads, total - 1);
-          meta[i] = a.meta[c]; lo[i] = (unsigned)a.idx[c]; db[i] = __float_as_uint(a.dist[c]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (c0 + i * kResolveThreads < total)
-            take(meta[i] & 0xffffu, (meta[i] & 0xffff0000u) | lo[i], db[i], rd[lo[i]], second ? key1[meta[i] & 0xffffu] : 0ull);
-      }
-    };
-    scan(key1, false);
-    const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
-    asd_syncthreads();
-    const unsigned long long p2 = __builtin_amdgcn_s_memrealtime();
-    if (KIND == 1) {   // phase 1b: the smallest key among the others = second best (value and level)
-      scan(key2, true);
-      asd_syncthreads();
-    }
-    // phase 2: the owner of a query takes the winner and posts the claim
-    int changed = 0;
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      const int q = t + k * kResolveThreads;
-      if (q >= a.nq) continue;
-      const unsigned long long k1 = key1[q];
-      key1[q] = kNone;
-      int p = -1;
-      if (k1 != kNone) {
-        p = (int)(k1 & 0xffffu);
-        const float best = __uint_as_float((unsigned)(k1 >> 32));
-        if (KIND == 1) {
-          const unsigned long long k2 = key2[q];
-          key2[q] = kNone;
-          const float best2 = k2 != kNone ? __uint_as_float((unsigned)(k2 >> 32)) : 256.f;
-          const int lvl = oct_occ[p] & 0x7f, lvl2 = k2 != kNone ? (oct_occ[k2 & 0xffffu] & 0x7f) : -1;
-          if (!(best <= TH_HIGH) || (lvl == lvl2 && best > a.nn_ratio * best2)) p = -1;
-        }
-      }
-      changed |= p != pick[k];
-      pick[k] = p;
-      if (p >= 0 && (posmask >> k & 1)) atomicMin(&wr[p], (tag_wr << 16) | (unsigned)q);
-    }
-    const unsigned long long p3 = __builtin_amdgcn_s_memrealtime();
-    const bool more = asd_syncthreads_or(changed) && it < max_it;
-    ph[0] += (int)(p1 - p0); ph[1] += (int)(p2 - p1); ph[2] += (int)(p3 - p2); ph[3] += (int)(__builtin_amdgcn_s_memrealtime() - p3);
-    if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
-    if (!more) break;
-  }
-  const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
-  // ---- outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
-  int* last = reinterpret_cast<int*>(claim0);
-  for (int j = t; j < a.n_cur; j += kResolveThreads) last[j] = -1;
-  asd_syncthreads();
-  int mine = 0;
-#pragma unroll
-  for (int k = 0; k < QPT; ++k)
-    if (pick[k] >= 0) { atomicMax(&last[pick[k]], t + k * kResolveThreads); ++mine; }
-  if (mine) atomicAdd(&n_written, mine);
-  asd_syncthreads();
-  for (int j = t; j < a.n_cur; j += kResolveThreads) OUT(j, last[j]);
-  if (KIND == 0 && a.check_ori) {
-    int bin[QPT];
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      bin[k] = -1;
-      if (pick[k] < 0) continue;
-      float rot = a.kp_last[t + k * kResolveThreads].w - a.kp_cur[pick[k]].w;   // ORBmatcher.cc:1419-1425
-      if (rot < 0.0) rot += 360.0f;
-      int b = (int)roundf(rot * (1.0f / HISTO));
-      if (b == HISTO) b = 0;
-      bin[k] = b;
-      atomicAdd(&hist[b], 1);
-    }
-    asd_syncthreads();   // also orders the match_cur stores above before the removals below
-    if (t == 0) {      // ComputeThreeMaxima (:1584-1625)
-      int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-      for (int i = 0; i < HISTO; i++) {
-        const int s = hist[i];
-        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-        else if (s > max3) { max3 = s; ind3 = i; }
-      }
-      if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-      else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
-      keep[0] = ind1; keep[1] = ind2; keep[2] = ind3;
-    }
-    asd_syncthreads();
-    int removed = 0;
-#pragma unroll
-    for (int k = 0; k < QPT; ++k)   // every write in a discarded bin clears the keypoint and is subtracted (:1437-1450)
-      if (bin[k] >= 0 && bin[k] != keep[0] && bin[k] != keep[1] && bin[k] != keep[2]) { OUT(pick[k], -1); ++removed; }
-    if (removed) atomicAdd(&n_removed, removed);
-  }
-  asd_syncthreads();
-  if (t == 0) { CNT(0, (KIND == 1 ? 2 : 1) * n_written - n_removed); CNT(1, *a.total); CNT(2, it + 1);
-    // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs -- in units of 10 ns
-    CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
-    for (int i = 0; i < 4; ++i) CNT(7 + i, ph[i]); }
-}
-#undef OUT
-#undef CNT
-
+// Round 2-3 solved the recurrence with every candidate bidding for its query in every iteration (k_resolve: 86-91 us for the frame-to-frame
+// search); since round 4 the search hands its lists over in preference order and the replay walks their heads (resolve2.h: 33-40 us) --
+// the bidding kernel was removed in round 5 (DESIGN.md section 4.0c keeps its numbers).
 // (the claim replay over sorted lists -- Resolve2Args, resolve2_body -- lives in resolve2.h: ba.hip runs it inside k_resolve_pose)
 template <int KIND, int QPT>
 __global__ __launch_bounds__(kResolve2Threads) void k_resolve2(Resolve2Args a) {
@@ -758,25 +477,12 @@ struct FrustumArgs {
   // min / max distance), candidates flagged in `skip` are in the frame already (Tracking.cc:811-823) and make no query, and every
   // candidate's position is also written to xw_out[q] for the edges of the pose solver behind the search
   const float* T_dev; const float* attr; const uint8_t* skip; float* xw_out;
-  // null, or the ticket of the kernel that writes T_dev / skip (the stage-1 solver of asd_track_frame, resident on another stream): every
-  // workgroup waits for it (bounded) before it reads them; a workgroup that never sees it makes no query and sets *wait_failed
-  const unsigned* wait_flag; unsigned wait_value; unsigned* wait_failed;
 };
 __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
   if (upload_tail_block(a.up)) return;
-  bool gate_ok = true;
-  if (a.wait_flag) {
-    __shared__ int ok_s;
-    if (threadIdx.x == 0) ok_s = asd_ticket_wait(a.wait_flag, a.wait_value) ? 1 : 0;
-    asd_syncthreads();
-    gate_ok = ok_s != 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (!gate_ok && threadIdx.x == 0) __hip_atomic_store(a.wait_failed, a.wait_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
-  if (!gate_ok) { a.queries[q] = Q; return; }
   if (a.attr) {   // bank form (asd_track_frame): the per-candidate arithmetic lives in ctx.h, shared with the stage-1 solver's tail
     asd_frustum_bank_point(a, a.T_dev, a.skip, q);
     return;
@@ -1075,22 +781,15 @@ int window_search(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int nq, 
 // where the claim / ratio / histogram replay runs: on the device (k_resolve, default) or on the host over the copied-back
 // candidate lists (ASD_MATCH_REPLAY=host in the environment of asd_ctx_create; also taken when the tables would
 // not fit the workgroup's LDS or there are more than 4096 queries)
-// ASD_RESOLVE=bids: round 2/3's k_resolve (every candidate bids in every iteration) instead of the sorted-list replay, for A/B runs
-bool resolve_by_bids() { static const bool b = [] { const char* e = getenv("ASD_RESOLVE"); return e && !strcmp(e, "bids"); }(); return b; }
 size_t resolve_lds_bytes(int kind, int n_cur, int nq) {
-  if (!resolve_by_bids())   // k_resolve2: the two claim tables, angle / octave table, last-writer table, (local map) the compacted list of map points with candidates
-    return resolve2_fixed_lds(kind, n_cur) + (size_t)n_cur * 4 + (kind == 1 ? ((size_t)nq * 2 + 15) / 16 * 16 : 0);
-  return (size_t)(kind == 1 ? 2 : 1) * nq * 8 + (size_t)n_cur * 2 * sizeof(int) + (size_t)(n_cur + 15) / 16 * 16;
-}
-// room for the tail of the candidate lists in LDS (k_resolve, ov_cap): what the previous search of this kind produced beyond `slots`
-// register slots per thread, a quarter on top, as far as the 96 KB this kernel may ask for allow
-int resolve_overflow_cap(int kind, int n_cur, int nq, int last_total, int slots) {
-  const long long want = ((long long)last_total * 5 / 4 - (long long)slots * kResolveThreads + 511) / 512 * 512;
-  const long long room = ((long long)96 * 1024 - (long long)resolve_lds_bytes(kind, n_cur, nq)) / 12 / 512 * 512;
-  return (int)std::max<long long>(0, std::min(want, room));
+  // k_resolve2: the two claim tables, angle / octave table, last-writer table, (local map) the compacted list of map points with candidates
+  return resolve2_fixed_lds(kind, n_cur) + (size_t)n_cur * 4 + (kind == 1 ? ((size_t)nq * 2 + 15) / 16 * 16 : 0);
 }
 bool replay_on_device(const MatcherState* m, int kind, int n_cur, int nq) {
-  return !m->replay_host && n_cur > 0 && n_cur < 65536 && nq <= kResolveThreads * kResolveMaxQPT && resolve_lds_bytes(kind, n_cur, nq) <= 96 * 1024;
+  // kind 0 (frame to frame): every last-frame point is a slot of the replay workgroup; kind 1 (local map): the map points that HAVE candidates are
+  // replayed in chunks (resolve2.h), so the count of candidates is bounded only by the compaction's rounds and the 16-bit indices
+  const int max_q = kind == 0 ? kResolve2Threads * 4 : std::min(kResolve2MaxRounds * 512, 65535);
+  return !m->replay_host && n_cur > 0 && n_cur < 65536 && nq <= max_q && resolve_lds_bytes(kind, n_cur, nq) <= 96 * 1024;
 }
 
 // k_window_search + k_resolve<KIND> behind one synchronisation: queries are in m->h_queries[0..nq), flags (may be null) are
@@ -1164,8 +863,8 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     int* d_cnt = m->d_q_off + nq;
     int* d_total = up.dev<int>(o_total);
     int rc;
-    // ASD_UPLOAD_SEPARATE=1: the upload as a launch of its own; ASD_UPLOAD_COPY=1 (copy commands instead of copy kernels) implies it
-    static const bool tail_upload = getenv("ASD_UPLOAD_SEPARATE") == nullptr && getenv("ASD_UPLOAD_COPY") == nullptr;
+    // ASD_UPLOAD_COPY=1 (copy commands instead of copy kernels) makes the upload a command of its own
+    static const bool tail_upload = getenv("ASD_UPLOAD_COPY") == nullptr;
     const bool carried = dev_queries && tail_upload;
     if (!carried) ASD_HIP_CHECK(ctx, up.upload(st));
     void *d_tab[kChainTabs], *h_tab[kChainTabs];
@@ -1182,10 +881,10 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
     GridDev G{F.d_kp, F.d_cell_start, F.d_cell_items, F.min_x, F.min_y, F.inv_w, F.inv_h};
     // (the "match" stage clock of asd_last_stage_ms: two timed event records per chain, each a barrier packet on the stream -- only
     // when somebody asked for timings)
-    static const bool stage_timing = getenv("ASD_TIMING") != nullptr || getenv("ASD_STAGE_TIMING") != nullptr;
+    static const bool stage_timing = getenv("ASD_TIMING") != nullptr;
     if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, st));
-    static const bool zero_copy = getenv("ASD_RESULT_COPY") == nullptr;   // results stored by the kernels straight into the pinned block
-    if (!resolve_by_bids()) {
+    constexpr bool zero_copy = true;   // results stored by the kernels straight into the pinned block
+    {
       // the lists in preference order (k_window_search<true>), the replay over their heads (k_resolve2)
       SortArgs sa{KIND == 1 ? up.dev<uint8_t>(o_occ) : nullptr, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top_idx};
       hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off,
@@ -1217,37 +916,6 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       };
       if (nq <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 2>));
       else ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 4>));
-    } else {
-    hipLaunchKernelGGL(k_window_search<false>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, up.dev<WinQuery>(o_q), nq, d_q, F.d_desc, d_off, d_cnt,
-                       d_total, m->cand_cap, m->d_idx, m->d_dist, m->d_meta, SortArgs{});
-    ASD_HIP_CHECK(ctx, hipGetLastError());
-    ResolveArgs a{};
-    a.nq = nq; a.n_cur = n_cur;
-    a.q_off = d_off; a.q_cnt = d_cnt; a.idx = m->d_idx; a.dist = m->d_dist; a.meta = m->d_meta;
-    a.total = d_total; a.cap = m->cand_cap;
-    a.obs_pos = has_obs ? up.dev<uint8_t>(o_obs) : nullptr;
-    a.occupied = up.dev<uint8_t>(o_occ);
-    a.kp_cur = F.d_kp; a.kp_last = kp_last;
-    a.check_ori = check_ori; a.nn_ratio = nn_ratio;
-    a.pick = d_pick; a.match_cur = d_out; a.n_matches = d_out + n_cur;
-    a.mirror = zero_copy ? down.host<int>(o_out) : nullptr;
-    // register-resident candidates per thread: 8, or 16 for long frame-to-frame lists (KIND 1 with 16 spills under the cap)
-    constexpr int kBig = KIND == 0 ? 16 : 8;
-    const bool small = m->last_total[KIND] <= 8 * kResolveThreads;
-    a.ov_cap = resolve_overflow_cap(KIND, n_cur, nq, m->last_total[KIND], small ? 8 : kBig);
-    const size_t lds = resolve_lds_bytes(KIND, n_cur, nq) + (size_t)a.ov_cap * 12;
-    auto launch = [&](auto kern) -> hipError_t {
-      static AsdPerDeviceOnce attr_set;   // per instantiation and device: more than 64 KB of dynamic LDS has to be asked for once
-      if (attr_set.need(ctx->cfg.device)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set.done(ctx->cfg.device);
-      }
-      hipLaunchKernelGGL(kern, dim3(1), dim3(kResolveThreads), lds, st, a);
-      return hipGetLastError();
-    };
-    if (nq <= 4 * kResolveThreads) { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 4, kBig>)); }
-    else { if (small) ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, 8>)); else ASD_HIP_CHECK(ctx, launch(k_resolve<KIND, 8, kBig>)); }
     }
     if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
     if (chain) {
@@ -1282,7 +950,7 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       }
       break;
     }
-    static const bool stage_timing = getenv("ASD_TIMING") != nullptr || getenv("ASD_STAGE_TIMING") != nullptr;
+    static const bool stage_timing = getenv("ASD_TIMING") != nullptr;
     if (stage_timing) ASD_HIP_CHECK(ctx, hipEventElapsedTime(&ctx->ms_match, ctx->ev0, ctx->ev1));
     else ctx->ms_match = 0.f;
     memcpy(match_cur, h_out, (size_t)n_cur * sizeof(int));
@@ -2072,20 +1740,6 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
 
 }
 
-// ---- both tracking stages of a frame as ONE submission (round 4) ------------------------------------------------------------
-// asd_track_motion_model_bank, then what Tracking does between its stages (outlier matches dropped, the optimised pose becomes
-// the frame's pose, map points the frame holds are left out of the local-map search: Tracking.cc:695-714, 725-726, 811-823) as a
-// device kernel (k_between), then asd_track_local_points_bank over the candidate rows of the attribute bank -- eight kernels back to
-// back on the context's stream, no host decision and no upload in between (the host's turn-around between the two submissions was
-// 50-60 us of an 0.7 ms frame, plus a 130 KB upload of gathered tables).  Same kernels and the same arithmetic as the two calls:
-// tests/test_track_chain.py holds the results to the same bits.
-// A kernel that waits on the device for a ticket another stream's kernel publishes needs the two streams on DIFFERENT hardware queues:
-// HIP multiplexes its streams onto a few AQL queues (GPU_MAX_HW_QUEUES, 4 by default, per priority level) and orders the packets of
-// streams that share one with barrier bits -- the publisher would then wait for the waiter to END.  (Found the hard way: a solver
-// stream landed on the main stream's queue in a process that had created other streams first, and every frame ran into the waiter's
-// timeout.)  track_solver_setup (ba.hip) probes every registered stream of the context against the solver streams before the resident
-// form is used.  k_probe_set is also the searches' ticket in that form (a one-lane kernel behind the search).
-__global__ void k_probe_set(unsigned* flag, unsigned value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 namespace {
 int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<int()>* defer) {
@@ -2097,10 +1751,10 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   (void)hipSetDevice(ctx->cfg.device);
   MatcherState* m = mstate(ctx);
   const int nl = L->n, nc = C->n, ncand = A.n_cand;
-  if (nl < 1 || nc < 1 || !replay_on_device(m, 0, nc, nl) || !replay_on_device(m, 1, nc, ncand) || resolve_by_bids() || !pose_chain_lds_form(ctx, nc)) {
+  if (nl < 1 || nc < 1 || !replay_on_device(m, 0, nc, nl) || !replay_on_device(m, 1, nc, ncand) || !pose_chain_lds_form(ctx, nc)) {
     ctx->set_error("asd_track_frame: %d / %d keypoints, %d candidates are outside what the one-submission form handles (empty frame, more than "
-                   "%d queries, or tables beyond the workgroup's LDS): use asd_track_motion_model_bank + asd_track_local_points_bank", nc, nl, ncand,
-                   kResolve2Threads * 4);
+                   "%d last-frame points or %d candidates, or tables beyond the workgroup's LDS): use asd_track_motion_model_bank + asd_track_local_points_bank", nc, nl, ncand,
+                   kResolve2Threads * 4, kResolve2MaxRounds * 512);
     return ASD_ERR_CAPACITY;
   }
   for (int i = 0; i < nl; ++i)
@@ -2149,25 +1803,8 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     b.occ = d_occ; b.cur_Xw = d_curXw; b.skip = d_skip; b.T1 = d_T1;
     memcpy(up.host<char>(o_btw), &b, sizeof b);
   }
-  // The replay + solver kernel needs most of a CU (512 threads x 213-221 registers, 70-110 KB of LDS) and, launched in stream order, waits
-  // 35-100 us for one beside the extractor's ASDNet workgroups, twice per frame (device-clock stamps, profiles/r04_chain_device_clock.txt).
-  // ASD_CHAIN_EARLY selects the RESIDENT form instead: one solver kernel per frame (k_track_solver, ba.hip) on a stream of its own, launched
-  // ahead of its frame (1: when the previous frame is submitted, 2: when it completes), waiting on the device for the searches' tickets.
-  // OFF by default.  Measured, round 4 (tools/ab_resident*.sh): on the device's own clock the chain from the first replay to the second
-  // solver's end shrinks from 500-540 to 445-480 us per frame -- the waits for a CU are gone -- but the ASDNet forward beside it slows from
-  // 0.59 to 0.67-0.97 ms depending on the variant (0.67: tickets from one-lane kernels, next frame's kernel launched at completion), the
-  // extractor becomes the side the tracking thread waits for (0.34-0.69 ms per step) and the step gets slower end to end: 820-1140
-  // frames/s against 1180-1230 in stream order on the same boxes.  The extractor (ASDNet 0.59 ms + 0.07 ms between forwards) and the
-  // tracking thread (0.64 ms + LocalBA's share) are within a few percent of each other: neither side alone moves the step.
-  static const int early_sel = [] { const char* e = getenv("ASD_CHAIN_EARLY"); return e ? atoi(e) : 0; }();   // 1: next frame's kernel launched at submit, 2: at completion;
-                                                                                                            // 3: only the local-map stage's kernel resident, launched with its frame
-  static const bool early = early_sel != 0;
-  unsigned seq = 0;
-  unsigned* flags = nullptr;
   {
-    // every runtime request of the chain that is not a launch happens HERE, before the first kernel goes out: with a solver kernel on
-    // the device waiting for its ticket, an allocation or a function attribute in front of the launch that publishes the ticket could
-    // wait for that very kernel
+    // every runtime request of the chain that is not a launch happens here, before the first kernel goes out
     if ((rc = pose_chain_reserve(ctx, nc)) != ASD_OK) return rc;
     static AsdPerDeviceOnce attrs;
     if (attrs.need(ctx->cfg.device)) {
@@ -2176,15 +1813,6 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       for (const void* k : ks) ASD_HIP_CHECK(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       attrs.done(ctx->cfg.device);
     }
-  }
-  bool early_now = false;
-  if (early) {
-    if (!ctx->d_chain_flags) {
-      ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_chain_flags, 512));
-      ASD_HIP_CHECK(ctx, hipMemset(ctx->d_chain_flags, 0, 512));
-    }
-    if ((rc = track_solver_setup(ctx, ctx->d_chain_flags, &early_now)) != ASD_OK) return rc;
-    flags = ctx->d_chain_flags;
   }
   // ---- motion-model stage: projection arguments (launched below)
   ProjectArgs pa{};
@@ -2219,17 +1847,11 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     *lds_out = fixed + (size_t)a.stage_cap * per;
     return a;
   };
-  auto search = [&](int KIND, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in, unsigned* ticket) -> int {
+  auto search = [&](int KIND, int nq, const WinQuery* d_q, int* d_off, int* d_cnt, int* d_total, uint16_t* d_top, const uint8_t* d_occ_in) -> int {
     GridDev G{C->d_kp, C->d_cell_start, C->d_cell_items, C->min_x, C->min_y, C->inv_w, C->inv_h};
-    // The search's ticket is a one-lane kernel BEHIND it, not the search's own last workgroup (SortArgs::done_flag can do that): a ticket
-    // from inside needs an agent-scope release in each of the ~500 workgroups, and on this chip that is a write-back of the whole L2 of
-    // the workgroup's XCD -- 1000 of them per frame under the extractor's ASDNet layers, which are writing 260 MB per launch through
-    // those L2s, slowed the ASDNet forward from 0.60 to 0.72-0.97 ms (tools/ab_resident*.sh).  A kernel's end releases once.
-    static const bool ticket_inside = getenv("ASD_TICKET_INSIDE") != nullptr;   // A/B only
-    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top, ticket && ticket_inside ? ticket + 8 : nullptr, ticket && ticket_inside ? ticket : nullptr, seq};
+    SortArgs sa{d_occ_in, KIND == 0 ? TH_HIGH : __builtin_huge_valf(), d_top};
     hipLaunchKernelGGL(k_window_search<true>, dim3((nq + kSearchWaves - 1) / kSearchWaves), dim3(64 * kSearchWaves), 0, st, G, d_q, nq, m->d_bank, C->d_desc, d_off, d_cnt,
                        d_total, m->cand_cap, m->d_idx, m->d_dist, (unsigned*)nullptr, sa);
-    if (ticket && !ticket_inside) hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, st, ticket, seq);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
@@ -2238,17 +1860,9 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
                                  down.dev<int>(o_out1), down.host<int>(o_out1), &lds1);
   Resolve2Args ra2 = replay_args(1, ncand, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, has_obs2 ? up.dev<uint8_t>(o_obs2) : nullptr, nullptr, 0, A.nn_ratio,
                                  down.dev<int>(o_out2), down.host<int>(o_out2), &lds2);
-  // ASD_CHAIN_FUSED=0: the replay and the solver as two kernels (the form up to the middle of round 4)
-  static const bool fused_on = [] { const char* e = getenv("ASD_CHAIN_FUSED"); return !e || atoi(e) != 0; }();
-  const bool fuse_now = fused_on && pose_chain_fused_ok(ctx, 0, nl, nc, lds1) && pose_chain_fused_ok(ctx, 1, ncand, nc, lds2);
+  // replay + solver of a stage as ONE workgroup where the stage's tables fit (k_resolve_pose); two kernels otherwise
+  const bool fuse_now = pose_chain_fused_ok(ctx, 0, nl, nc, lds1) && pose_chain_fused_ok(ctx, 1, ncand, nc, lds2);
   AsdFusedReplay fr1{&ra1, 0, nl, lds1}, fr2{&ra2, 1, ncand, lds2};
-  // Resident form (early_now, with the fused kernels): the two replay + solver kernels go onto the solver stream, the first BEFORE anything
-  // else -- it finds its CU while the projection and the first search run -- and every hand-over between the streams is a ticket word:
-  // search -> replay (k_window_search's last workgroup), stage-1 solver -> k_frustum_queries (behind the work between the stages), search
-  // -> second replay.  No event crosses the streams; the host waits for the solver stream's last kernel.
-  const bool resident = early_now && early_sel != 3 && fuse_now && track_solver_fits(ctx, nl, ncand, nc, lds1, lds2);
-  const bool resident2 = early_now && early_sel == 3 && fuse_now;
-  static const bool poll_marker = [] { const char* e = getenv("ASD_CHAIN_POLL"); return e && atoi(e) != 0; }();   // stage 2's replay + solver on a solver stream, waiting for its search's ticket
   FrustumArgs fa{};
   fa.n = ncand; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = A.th_local != 1.0;
   fa.fx = A.K[0]; fa.fy = A.K[1]; fa.cx = A.K[2]; fa.cy = A.K[3];
@@ -2258,64 +1872,18 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   fa.rows = up.dev<int>(o_crows); fa.queries = d_q2;
   fa.up = UploadTail{nullptr, nullptr, 0, 0, (ncand + 255) / 256};
   fa.T_dev = d_T1; fa.attr = m->d_attr; fa.skip = d_skip; fa.xw_out = d_cXw;
-  // ASD_FRUSTUM_TAIL=1 (A/B; off by default): the local-map stage's queries are made by the TAIL of the stage-1 solver (asd_between_body, the
-  // workgroup that has just written the pose and the skip flags) instead of by k_frustum_queries -- one launch and its dispatch less between
-  // the stages.  Measured, round 4 (tools/ab_frustum.sh): the stretch from the first solver's end to the second replay's start grows from
-  // 98-124 to 155-158 us -- eight candidates per thread, each a chain of dependent gathers (row, two attribute loads), on one workgroup,
-  // where the kernel spreads 4000 candidates over sixteen -- and the step is unchanged (1202-1214 against 1185-1231 frames/s).
-  // Never in the resident forms 1 / 2: there the search stream needs a kernel of its own to wait for the solver stream's ticket.
-  static const bool frustum_tail = [] { const char* e = getenv("ASD_FRUSTUM_TAIL"); return e && atoi(e) != 0; }();
-  const bool frustum_in_tail = frustum_tail && !resident;
-  {
-    AsdFrustumTail& f = up.host<AsdBetweenArgs>(o_btw)->fr;   // (the pinned block: its copy to the device rides in k_project_queries, launched below)
-    memset(&f, 0, sizeof f);
-    if (frustum_in_tail) {
-      f.n = fa.n; f.n_levels = fa.n_levels; f.bfactor = fa.bfactor; f.rows = fa.rows; f.attr = fa.attr;
-      f.fx = fa.fx; f.fy = fa.fy; f.cx = fa.cx; f.cy = fa.cy; f.min_x = fa.min_x; f.max_x = fa.max_x; f.min_y = fa.min_y; f.max_y = fa.max_y;
-      f.cos_limit = fa.cos_limit; f.th = fa.th;
-      for (int l = 0; l < ASD_MAX_LEVELS; ++l) { f.level_thr[l] = fa.level_thr[l]; f.scale[l] = fa.scale[l]; }
-      f.queries = fa.queries; f.xw_out = fa.xw_out;
-    }
-  }
   auto project = [&]() -> int {
     hipLaunchKernelGGL(k_project_queries, dim3(pa.up.q_blocks + kUploadTailBlocks), dim3(256), 0, st, pa);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
   auto frustum = [&]() -> int {
-    if (frustum_in_tail) return ASD_OK;
     hipLaunchKernelGGL(k_frustum_queries, dim3((ncand + 255) / 256), dim3(256), 0, st, fa);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
-  if (resident) {
-    seq = ++ctx->chain_seq;
-    // the frame's argument blocks first (the kernel reads them behind the first search's ticket), then -- unless the kernel launched a
-    // frame ago still sits there waiting -- the kernel; then the searches; then the NEXT frame's kernel
-    AsdSolverStage s1{&ra1, lds1, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, down.host<double>(o_res1), nullptr, d_io1,
-                      up.dev<AsdBetweenArgs>(o_btw)};
-    AsdSolverStage s2{&ra2, lds2, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, down.host<double>(o_res2), d_io1, nullptr, nullptr};
-    if ((rc = track_solver_submit(ctx, seq, flags, nc, Kd.data(), s1, s2)) != ASD_OK) return rc;
-    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, flags)) != ASD_OK) return rc;
-    fa.wait_flag = flags + 16; fa.wait_value = seq; fa.wait_failed = track_solver_gate_word(ctx);
-    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
-    if (early_sel == 1 && (rc = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rc;
-  } else if (resident2) {
-    // Stage 1 in stream order; stage 2's kernel goes onto a solver stream NOW and finds its CU while stage 1 runs (in stream order it waits
-    // 30-60 us for one behind its search); it waits there for the second search's ticket.  The host polls the kernel's "done" marker in the
-    // pinned result block: an event queued behind a waiting kernel would hold its queue's command-processor pipe.
-    seq = ++ctx->chain_seq;
-    hipStream_t sb = track_solver_stream(ctx, (int)seq);
-    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
-                                 sb, flags + 32, seq, &fr2, nullptr, (double)seq)) != ASD_OK)
-      return rc;
-    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, nullptr)) != ASD_OK) return rc;
-    if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), nullptr, nullptr, 0, &fr1)) != ASD_OK)
-      return rc;
-    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, flags + 32)) != ASD_OK) return rc;
-  } else {
-    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr, nullptr)) != ASD_OK) return rc;
+  {
+    if ((rc = project()) != ASD_OK || (rc = search(0, nl, up.dev<WinQuery>(o_q1), d_off1, d_cnt1, up.dev<int>(o_tot1), d_top1, nullptr)) != ASD_OK) return rc;
     if (!fuse_now) {
       if (nl <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<0, 2>, ra1, lds1));
       else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<0, 4>, ra1, lds1));
@@ -2323,17 +1891,15 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
     // ... what happens between the stages is the tail of the stage's PoseOptimization kernel (the workgroup that has just written the
     // flags and the pose: no launch, no second read of them)
     if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out1), C->d_kp, up.dev<float>(o_Xw), nullptr, nullptr, A.pose7, Kd.data(), down.host<double>(o_res1), nullptr,
-                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), nullptr, nullptr, 0, fuse_now ? &fr1 : nullptr)) != ASD_OK)
+                                 d_io1, up.dev<AsdBetweenArgs>(o_btw), fuse_now ? &fr1 : nullptr)) != ASD_OK)
       return rc;
-    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ, nullptr)) != ASD_OK) return rc;
+    if ((rc = frustum()) != ASD_OK || (rc = search(1, ncand, d_q2, d_off2, d_cnt2, up.dev<int>(o_tot2), d_top2, d_occ)) != ASD_OK) return rc;
     if (!fuse_now) {
       if (ncand <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<1, 2>, ra2, lds2));
       else ASD_HIP_CHECK(ctx, resolve_launch(k_resolve2<1, 4>, ra2, lds2));
     }
-    // (ASD_CHAIN_POLL=1, A/B: the host polls the last kernel's marker in the pinned result block in front of hipEventSynchronize)
-    if (poll_marker && fuse_now) seq = ++ctx->chain_seq;
     if ((rc = pose_chain_enqueue(ctx, nc, down.dev<int>(o_out2), C->d_kp, d_cXw, d_occ, d_curXw, nullptr, Kd.data(), down.host<double>(o_res2), d_io1, nullptr, nullptr,
-                                 nullptr, nullptr, 0, fuse_now ? &fr2 : nullptr, nullptr, poll_marker && fuse_now ? (double)seq : 0.0)) != ASD_OK)
+                                 fuse_now ? &fr2 : nullptr)) != ASD_OK)
       return rc;
   }
   if (!ctx->ev_chain) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
@@ -2343,22 +1909,6 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
   std::array<double, 7> p_in;
   memcpy(p_in.data(), A.pose7, 56);
   auto complete = [=]() -> int {
-    if (resident) {
-      int rw = track_solver_wait(ctx, seq, flags);
-      if (rw != ASD_OK) return rw;
-      if (early_sel == 2 && (rw = track_solver_prelaunch(ctx, seq + 1, flags)) != ASD_OK) return rw;   // the next frame's kernel: ~100 us ahead of its first ticket
-    }
-    if (resident2 || (poll_marker && fuse_now && !resident)) {   // the stage-2 kernel's marker, behind all of its stores
-      const double* mk = ctx->down.host<double>(o_res2) + 8 + (nc + 7) / 8 + 3;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (long spin = 0; __atomic_load_n(reinterpret_cast<const unsigned long long*>(mk), __ATOMIC_ACQUIRE) != (unsigned long long)__builtin_bit_cast(unsigned long long, (double)seq); ++spin) {
-        if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 5.0) {
-          ctx->set_error("asd_track_frame: the local-map stage's kernel did not finish within 5 s");
-          return ASD_ERR_HIP;
-        }
-        __builtin_ia32_pause();
-      }
-    }
     ASD_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev_chain));
     const int *h1 = ctx->down.host<int>(o_out1), *h2 = ctx->down.host<int>(o_out2);
     m->last_total[0] = h1[nc + 1]; m->last_total[1] = h2[nc + 1];
@@ -2374,12 +1924,6 @@ int track_frame_impl(asd_ctx* ctx, const asd_track_frame_args& A, std::function<
       memcpy(pose, ne < 3 ? p_start : h_io, 56);   // Optimizer.cc:323-324: fewer than 3 correspondences leave the pose alone
       *n_inl = ne < 3 ? 0 : ne - (int)(h_io[7] + 0.5);
     };
-    if (ctx->down.host<double>(o_res1)[7] < 0 || ctx->down.host<double>(o_res2)[7] < 0) {
-      ctx->set_error("asd_track_frame: a PoseOptimization kernel launched ahead of its inputs never received the claim replay's ticket (stage 1: %g, stage 2: %g; "
-                     "replay counters %d / %d candidates, %d / %d iterations)", ctx->down.host<double>(o_res1)[7], ctx->down.host<double>(o_res2)[7], h1[nc + 1], h2[nc + 1],
-                     h1[nc + 2], h2[nc + 2]);
-      return ASD_ERR_HIP;
-    }
     unpack(h1, ctx->down.host<double>(o_res1), p_in.data(), O.match1, O.n_matches1, O.outlier1, O.pose1, O.n_inliers1);
     double p1[7];
     memcpy(p1, O.pose1, 56);
@@ -3064,10 +2608,8 @@ int asd_prep_async(asd_ctx* ctx, int32_t on) {
     if (!ctx->stream_prep) {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      // highest priority, like the main stream (a middle level slows the ASDNet stream while a solver kernel waits on the device: see
-      // the solver stream's comment in track_frame_impl)
-      static const int prep_prio_sel = [] { const char* e = getenv("ASD_PREP_PRIO"); return e ? atoi(e) : 2; }();   // 0 lowest, 1 middle, 2 highest (A/B)
-      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, prep_prio_sel == 2 ? hi : prep_prio_sel == 0 ? lo : lo + (hi - lo) / 2));
+      // highest priority, like the main stream
+      ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, hi));
       asd_register_stream(ctx, ctx->stream_prep);
       ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     }

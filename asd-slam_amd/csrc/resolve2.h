@@ -42,13 +42,12 @@ struct Resolve2Args {
   int* n_matches;             // out: [0] n_matches, [1] total candidates, [2] iterations, [3..6] stamps
   int* mirror;                // null, or pinned host memory laid out like match_cur | n_matches
   int stage_cap;              // list entries [0, stage_cap) are copied into LDS (2 B each, KIND 1: 6 B) for the walks beyond the heads
-  unsigned* done_flag;        // null, or a ticket word: set to done_value behind the kernel's last store (a kernel resident on another
-  unsigned done_value;        // stream waits for it instead of for stream order: k_pose_opt, asd_track_frame)
 };
 __host__ __device__ inline size_t resolve2_fixed_lds(int kind, int n_cur) {   // claim tables + angle table (KIND 0) / octave table (KIND 1)
   return (size_t)n_cur * 8 + (kind == 0 ? (size_t)n_cur * 4 : ((size_t)n_cur + 15) / 16 * 16);
 }
 constexpr int kResolve2Threads = 1024;
+constexpr int kResolve2MaxRounds = 64;   // KIND 1: up to 64 rounds of NT map points are compacted (32768 on the solver's 512 threads, 65535 on 1024)
 // The replay as a device function over NT threads of ONE workgroup (dynamic LDS from offset 0): k_resolve2 (matcher.hip) is it on 1024
 // threads; k_resolve_pose (ba.hip) runs it on PoseOptimization's 512 in front of the solver, in the same workgroup -- the solver then
 // needs no dispatch of its own (it waited 35-50 us for a CU beside the extractor's ASDNet workgroups, twice per frame).
@@ -73,23 +72,10 @@ __device__ __forceinline__ void resolve2_body(A& a) {
   const int t = threadIdx.x;
   const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
   const int total = *a.total;
-  // every store of this workgroup is complete and written back before the ticket moves: waves drain their stores, barrier, one lane
-  // releases at agent scope and stores the ticket (MI355X_MICROARCH.md, "Valid forms": producer)
-  auto publish = [&]() {
-    if (!a.done_flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asd_syncthreads();
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.done_flag, a.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  };
   if (total > a.cap || total == 0) {   // truncated lists (the host grows the buffers and searches again) / nothing in any window:
     // the match table is still written (no match anywhere) -- a fused chain behind this kernel gathers its edges from it
     for (int j = t; j < a.n_cur; j += NT) OUT(j, -1);
     if (t == 0) { CNT(0, 0); CNT(1, total); CNT(2, 0); }
-    publish();
     return;
   }
   // the thread's queries first (their loads are then in flight under the LDS fills below): list length and start, the heads
@@ -104,59 +90,83 @@ __device__ __forceinline__ void resolve2_body(A& a) {
   // skipped by the loops below instead of being executed under an empty mask (8 queries per thread on the solver's 512 threads).
   int qid[QPT];
   int ka = QPT;   // slots [0, ka) hold map points somewhere in the workgroup (wave-uniform)
+  int n_act = a.nq;   // KIND 1: map points that have a candidate list; they are replayed in CHUNKS of NT * QPT (below)
+  unsigned short* act_s = reinterpret_cast<unsigned short*>(last + a.n_cur);   // KIND 1: [nq], behind the last-writer table (resolve_lds_bytes counts it)
   if constexpr (KIND == 1) {
+    // ballot + prefix over (round, wave) in the map points' original order, as the solver's edge gather does -- over as many rounds of NT map
+    // points as nq needs (round 5: the local map may hold far more points than one chunk of the replay; Tracking.cc:881-905 collects every
+    // point of up to 80 keyframes), two passes so that no per-round state stays in registers
     constexpr int NW = NT / 64;
-    unsigned short* act_s = reinterpret_cast<unsigned short*>(last + a.n_cur);   // [nq], behind the last-writer table (resolve_lds_bytes counts it)
-    __shared__ int wbase[QPT * NW + 1];
+    __shared__ int wbase[kResolve2MaxRounds * NW + 1];
     const int lane = t & 63, wave = t >> 6;
-    unsigned long long bal[QPT];
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      const int q = t + k * NT;
+    const int rounds = (a.nq + NT - 1) / NT;   // <= kResolve2MaxRounds (the host checks)
+    for (int kb = 0; kb < rounds; ++kb) {
+      const int q = t + kb * NT;
       const bool actv = q < a.nq && a.q_cnt[min(q, a.nq - 1)] > 0;
-      bal[k] = __ballot(actv);
-      if (lane == 0) wbase[k * NW + wave] = __popcll(bal[k]);
+      const unsigned long long bal = __ballot(actv);
+      if (lane == 0) wbase[kb * NW + wave] = __popcll(bal);
     }
     asd_syncthreads();
-    if (t == 0) {
+    if (t < 64) {   // exclusive prefix over rounds * NW counts by one wave: NW consecutive entries per lane, then a wave scan
+      int loc[NW];
       int sum = 0;
-      for (int i = 0; i < QPT * NW; ++i) { const int v = wbase[i]; wbase[i] = sum; sum += v; }
-      wbase[QPT * NW] = sum;
+      for (int base = 0; base < rounds * NW; base += 64 * NW) {
+        int mine_ = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { const int e = base + t * NW + i; loc[i] = e < rounds * NW ? wbase[e] : 0; mine_ += loc[i]; }
+        int inc = mine_;
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (t >= off) inc += v; }
+        int run = sum + inc - mine_;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { const int e = base + t * NW + i; if (e < rounds * NW) wbase[e] = run; run += loc[i]; }
+        sum += __shfl(inc, 63);
+      }
+      if (t == 0) wbase[rounds * NW] = sum;
     }
     asd_syncthreads();
-#pragma unroll
-    for (int k = 0; k < QPT; ++k)
-      if (bal[k] >> lane & 1) act_s[wbase[k * NW + wave] + __popcll(bal[k] & ((1ull << lane) - 1))] = (unsigned short)(t + k * NT);
+    for (int kb = 0; kb < rounds; ++kb) {
+      const int q = t + kb * NT;
+      const bool actv = q < a.nq && a.q_cnt[min(q, a.nq - 1)] > 0;
+      const unsigned long long bal = __ballot(actv);
+      if (actv) act_s[wbase[kb * NW + wave] + __popcll(bal & ((1ull << lane) - 1))] = (unsigned short)q;
+    }
     asd_syncthreads();
-    const int n_act = wbase[QPT * NW];
-    ka = __builtin_amdgcn_readfirstlane((n_act + NT - 1) / NT);
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      const int slot = t + k * NT;
-      const bool v = slot < n_act;
-      const int q = v ? (int)act_s[slot] : 0;
-      qid[k] = q;
-      cnt[k] = v ? a.q_cnt[q] : 0;
-      qoff[k] = a.q_off[q];
-      tj[k] = make_uint2(*reinterpret_cast<const unsigned*>(a.top_idx + (size_t)q * kTop), 0u);
-      if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
-      pick[k] = -1;
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-      const int q = t + k * NT;
-      const bool v = q < a.nq;
-      const int qc = v ? q : 0;
-      qid[k] = q;
-      cnt[k] = v ? a.q_cnt[qc] : 0;
-      qoff[k] = a.q_off[qc];
-      tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
-      ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
-      if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
-      pick[k] = -1;
-    }
+    n_act = wbase[rounds * NW];
   }
+  // the thread's queries of one chunk (c0 = first slot of the chunk): list length and start, the heads
+  auto load_chunk = [&](int c0) {
+    posmask = 0;
+    if constexpr (KIND == 1) {
+      ka = __builtin_amdgcn_readfirstlane((min(n_act - c0, NT * QPT) + NT - 1) / NT);
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) {
+        const int slot = c0 + t + k * NT;
+        const bool v = slot < n_act && k < ka;
+        const int q = v ? (int)act_s[slot] : 0;
+        qid[k] = q;
+        cnt[k] = v ? a.q_cnt[q] : 0;
+        qoff[k] = a.q_off[q];
+        tj[k] = make_uint2(*reinterpret_cast<const unsigned*>(a.top_idx + (size_t)q * kTop), 0u);
+        if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
+        pick[k] = -1;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < QPT; ++k) {
+        const int q = t + k * NT;
+        const bool v = q < a.nq;
+        const int qc = v ? q : 0;
+        qid[k] = q;
+        cnt[k] = v ? a.q_cnt[qc] : 0;
+        qoff[k] = a.q_off[qc];
+        tj[k] = *reinterpret_cast<const uint2*>(a.top_idx + (size_t)qc * kTop);
+        ang_last[k] = a.check_ori ? a.kp_last[qc].w : 0.f;
+        if (v && (!a.obs_pos || a.obs_pos[q])) posmask |= 1u << k;
+        pick[k] = -1;
+      }
+    }
+  };
+  load_chunk(0);   // (its loads are in flight under the LDS fills below)
   for (int j = t; j < 2 * a.n_cur; j += NT) claim0[j] = 0xffffffffu;
   for (int j = t; j < a.n_cur; j += NT) last[j] = -1;
   if (KIND == 0) { if (a.check_ori) for (int j = t; j < a.n_cur; j += NT) ang[j] = a.kp_cur[j].w; }
@@ -174,8 +184,8 @@ __device__ __forceinline__ void resolve2_body(A& a) {
   }
   asd_syncthreads();
   const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
-  const int max_it = a.nq + 2;
   int it = 0, f_cur = 0;   // f_cur = it % 3
+  int it_limit = (KIND == 1 ? min(n_act, NT * QPT) : a.nq) + 2;
   unsigned long long ts_it0 = ts1;
   // the claims an iteration starts from are read at the END of the one before, in the same LDS round trip as its "anything changed" flag
   // (a dependent chain of LDS round trips is what an iteration costs beside ASDNet workgroups that keep the CU's LDS queues full)
@@ -194,12 +204,20 @@ __device__ __forceinline__ void resolve2_body(A& a) {
     for (int k = 0; k < QPT; ++k) if (curj[k] >= 0 && (posmask >> k & 1)) atomicMin(&lds_c[curj[k]], (unsigned)(t + k * NT));
   } else load_claims(0);
   int ph_work = 0, ph_bar = 0;   // thread 0's view (10 ns units): loop top -> barrier, barrier -> verdict
+  int mine = 0;
+  int bin[QPT];
+  // KIND 1: the map points with candidates are replayed in chunks of NT * QPT, in index order.  A map point's pick depends on EARLIER map
+  // points only, so a chunk's fixed point is final; its claims stay in both tables with tag 0 (atomicMin keeps them: every live tag is
+  // larger) and every later chunk sees them as held.  The bench's 1000 lists, and any local map with up to NT * QPT of them, are one chunk.
+  for (int c0 = 0;;) {
   for (;; ++it) {
     const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
     // read the claims of iteration it-1 (table it & 1, tag it), post this iteration's picks into the other table (tag it+1)
     const int rd = (it & 1) ? a.n_cur : 0, wr = a.n_cur - rd;   // offsets into lds_c
     const unsigned tag_rd = (unsigned)(0xffff - it), tag_wr = (unsigned)(0xffff - (it + 1));
-    auto held = [&](unsigned c, int q) { return (c >> 16) == tag_rd && (c & 0xffffu) < (unsigned)q; };   // an earlier map point holds it
+    // an earlier map point holds it: a claim of the previous iteration by a smaller index, or (tag 0) the final claim of a map point of an
+    // EARLIER CHUNK (KIND 1; all of them have smaller indices)
+    auto held = [&](unsigned c, int q) { return ((c >> 16) == tag_rd && (c & 0xffffu) < (unsigned)q) || (KIND == 1 && (c >> 16) == 0u); };
     int changed = 0;
     if (KIND == 0) {
       // Frame-to-frame search keeps the BEST candidate only, so a map point's position in its list only ever moves forward and a keypoint's
@@ -307,16 +325,13 @@ __device__ __forceinline__ void resolve2_body(A& a) {
     const unsigned long long p1 = __builtin_amdgcn_s_memrealtime();
     asd_syncthreads();
     if (KIND == 1) load_claims(wr);       // the next iteration's claims ...
-    const bool more = flag[f_cur] != 0 && it < max_it;   // ... and this one's verdict: one round trip
+    const bool more = flag[f_cur] != 0 && it < it_limit;   // ... and this one's verdict: one round trip
     f_cur = f_next;
     { const unsigned long long p2 = __builtin_amdgcn_s_memrealtime(); ph_work += (int)(p1 - p0); ph_bar += (int)(p2 - p1); }
     if (it == 0) ts_it0 = __builtin_amdgcn_s_memrealtime();
     if (!more) break;
   }
-  const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
-  // ---- outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
-  int mine = 0;
-  int bin[QPT];
+  // ---- the chunk's outputs: the last writer of every keypoint, the number of writes, the rotation histogram over all writes
 #pragma unroll
   for (int k = 0; k < QPT; ++k) {
     bin[k] = -1;
@@ -332,6 +347,21 @@ __device__ __forceinline__ void resolve2_body(A& a) {
       atomicAdd(&hist[b], 1);
     }
   }
+  if (KIND == 0) break;
+  c0 += NT * QPT;
+  if (c0 >= n_act) break;
+  // the next chunk: this one's claims become permanent (plain stores: the iteration's last barrier lies behind every post), the tags move
+  // past the ones still in the tables, the threads take their next map points
+#pragma unroll
+  for (int k = 0; k < QPT; ++k)
+    if (pick[k] >= 0 && (posmask >> k & 1)) { lds_c[pick[k]] = (unsigned)qid[k]; lds_c[a.n_cur + pick[k]] = (unsigned)qid[k]; }
+  it += 2;
+  it_limit = it + min(n_act - c0, NT * QPT) + 2;
+  load_chunk(c0);   // (the flag rotation simply goes on: flag[f_cur] was cleared before the last barrier)
+  asd_syncthreads();
+  load_claims((it & 1) ? a.n_cur : 0);
+  }
+  const unsigned long long ts2 = __builtin_amdgcn_s_memrealtime();
   if (mine) atomicAdd(&n_written, mine);
   asd_syncthreads();
   if (KIND == 0 && a.check_ori) {
@@ -361,7 +391,6 @@ __device__ __forceinline__ void resolve2_body(A& a) {
     // 100 MHz stamps (ASD_TIMING): staging, iterations, outputs, the first iteration -- in units of 10 ns
     CNT(3, (int)(ts1 - ts0)); CNT(4, (int)(ts2 - ts1)); CNT(5, (int)(__builtin_amdgcn_s_memrealtime() - ts2)); CNT(6, (int)(ts_it0 - ts1));
     CNT(7, ph_work); CNT(8, ph_bar); CNT(9, (int)(ts0 & 0x7fffffffull)); CNT(10, (int)(__builtin_amdgcn_s_memrealtime() & 0x7fffffffull)); }
-  publish();
 }
 #undef OUT
 #undef CNT

@@ -47,6 +47,7 @@ struct asd_track_handle {
   // OFF by default since round 5: the reference selects its local map between the stages (Tracking::UpdateLocalMap, Tracking.cc:730), which
   // needs the host there -- the split-phase two-call form above is the one Tracking can bind; this one is a measured variant
   bool chain = false;
+  int map_copies = 2;       // the stand-in local map: every point of the last frame and map_copies - 1 displaced copies of it (asd_track_set_map_copies)
   const asd_do_mapping_inputs* dm = nullptr;   // the batched per-keyframe stage in front of LocalBA (asd_track_set_do_mapping)
   std::vector<int32_t> dm_matches, dm_nmatch, dm_best, dm_distinct;
   std::vector<float> dm_x3d, dm_bdist;
@@ -131,6 +132,7 @@ void asd_track_set_fused(asd_track_handle* h, int32_t on) { if (h) h->fused = on
 void asd_track_set_async_ba(asd_track_handle* h, int32_t on) { if (h) h->async_ba = on != 0; }
 void asd_track_set_split(asd_track_handle* h, int32_t on) { if (h) h->split = on != 0; }
 void asd_track_set_chain(asd_track_handle* h, int32_t on) { if (h) h->chain = on != 0; }
+void asd_track_set_map_copies(asd_track_handle* h, int32_t copies) { if (h && copies >= 1 && copies <= 16) h->map_copies = copies; }
 // hands every read-ahead submission of this handle back to the library (another handle of the same context can then start)
 int asd_track_drain(asd_track_handle* h) {
   if (!h) return ASD_ERR_INVALID;
@@ -219,6 +221,27 @@ void asd_track_destroy(asd_track_handle* h) {
 // descriptors, keep the read-ahead queue full, and -- when there is a previous frame -- the inputs of the motion-model stage
 // (projected points of the previous frame, its descriptors as bank rows).  Everything here is enqueued on the context's stream
 // behind whatever stage is still in flight and reads none of its results.
+// the stand-in local map's attribute tables: candidate c * nl + i = the last frame's point i displaced by c * 0.02 m in every coordinate
+// (c = 0: the point itself), with its normal, distance and the distance range of the point's pyramid level -- numpy f32 arithmetic, mirrored
+// term by term in bench.py's track_step (two copies there)
+static void build_candidate_tables(asd_track_handle* h, int nl) {
+  const std::vector<asd_keypoint>& lk = h->last_kps;
+  const int nc = h->map_copies * nl;
+  h->Xw2.resize((size_t)3 * nc); h->nrm.resize((size_t)3 * nc); h->dist.resize(nc); h->maxd.resize(nc); h->mind.resize(nc);
+  for (int c = 0; c < h->map_copies; ++c)
+    for (int i = 0; i < nl; ++i)
+      for (int k = 0; k < 3; ++k) h->Xw2[3 * ((size_t)c * nl + i) + k] = c == 0 ? h->Xw[3 * i + k] : h->Xw[3 * i + k] + (c == 1 ? 0.02f : 0.02f * (float)c);
+  for (int i = 0; i < nc; ++i) {
+    const float* P = &h->Xw2[3 * (size_t)i];
+    const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
+    for (int k = 0; k < 3; ++k) h->nrm[3 * (size_t)i + k] = P[k] / nn;
+    h->dist[i] = nn;
+    const int lv = lk[i % nl].octave;
+    h->maxd[i] = nn * h->scale32[lv];
+    h->mind[i] = h->maxd[i] / h->scale32[7];
+  }
+}
+
 static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& next) {
   asd_ctx* ctx = h->ctx;
   asd_ctx* ctxr = h->ctx_r;   // stereo mode: the right image's extractor, its queue in lockstep with the left one's
@@ -302,25 +325,14 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       h->Xw[3 * i + 1] = (v - cy) / fy * depth;
       h->Xw[3 * i + 2] = depth;
     }
-    const int n2p = 2 * nl;
-    h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
-    for (int i = 0; i < nl; ++i)
-      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
-    for (int i = 0; i < n2p; ++i) {
-      const float* P = &h->Xw2[3 * i];
-      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
-      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
-      h->dist[i] = nn;
-      const int lv = lk[i % nl].octave;
-      h->maxd[i] = nn * h->scale32[lv];
-      h->mind[i] = h->maxd[i] / h->scale32[7];
-    }
+    const int n2p = h->map_copies * nl;
+    build_candidate_tables(h, nl);
     seg(7);
-    h->bank_base = h->bank_base ? 0 : 8192;
+    h->bank_base = h->bank_base ? 0 : 65536;
     const int base = h->bank_base;
-    if (n2p > 8192) return ASD_ERR_CAPACITY;
-    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, base, nl)) != ASD_OK) return rc;
-    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, base + nl, nl)) != ASD_OK) return rc;
+    if (n2p > 65536) return ASD_ERR_CAPACITY;
+    for (int c = 0; c < h->map_copies; ++c)
+      if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, base + c * nl, nl)) != ASD_OK) return rc;
     if ((rc = asd_mpbank_put(ctx, base, n2p, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data())) != ASD_OK) return rc;
     h->rows.resize(nl); h->last_cand.resize(nl); h->cand_rows.resize(n2p);
     for (int i = 0; i < nl; ++i) { h->rows[i] = base + i; h->last_cand[i] = i; }
@@ -342,10 +354,10 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       h->Xw[3 * i + 2] = depth;
     }
     seg(7);
-    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
-    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, nl, nl)) != ASD_OK) return rc;
-    h->rows.resize((size_t)2 * nl);
-    for (int i = 0; i < 2 * nl; ++i) h->rows[i] = i;
+    for (int c = 0; c < h->map_copies; ++c)
+      if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, c * nl, nl)) != ASD_OK) return rc;
+    h->rows.resize((size_t)h->map_copies * nl);
+    for (int i = 0; i < h->map_copies * nl; ++i) h->rows[i] = i;
     seg(2);
   }
   h->prep_t = t; h->prep_kps = kps; h->prep_n = n;
@@ -360,7 +372,7 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t);
 // sel and the selected tables, T1; returns the number of selected points.  Mirrors bench.py's track_step line by line.
 static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t* outl1, const double* pose1) {
   h->keep.assign(n, 0); h->occ.assign(n, 0);
-  h->in_frame.assign((size_t)2 * nl, 0);
+  h->in_frame.assign((size_t)h->map_copies * nl, 0);
   h->cur_Xw.assign((size_t)3 * n, 0.f);
   int nmatch = 0;
   for (int j = 0; j < n; ++j) {
@@ -374,7 +386,7 @@ static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t
   if (nmatch >= 3) (void)asd_pose7_to_tcw(pose1, h->T1);
   else memcpy(h->T1, h->T, sizeof h->T1);
   h->sel.clear();
-  for (int i = 0; i < 2 * nl; ++i) if (!h->in_frame[i]) h->sel.push_back(i);
+  for (int i = 0; i < h->map_copies * nl; ++i) if (!h->in_frame[i]) h->sel.push_back(i);
   const int ns = (int)h->sel.size();
   h->Xs.resize((size_t)3 * ns); h->ns.resize((size_t)3 * ns); h->mind_s.resize(ns); h->maxd_s.resize(ns);
   for (int q = 0; q < ns; ++q) {
@@ -430,19 +442,8 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
       return rc;
     seg(2);
     // ---- under it: the local map's tables (the last frame's points plus a jittered copy; nothing here needs the stage's result)
-    n2p = 2 * nl;
-    h->Xw2.resize((size_t)3 * n2p); h->nrm.resize((size_t)3 * n2p); h->dist.resize(n2p); h->maxd.resize(n2p); h->mind.resize(n2p);
-    for (int i = 0; i < nl; ++i)
-      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
-    for (int i = 0; i < n2p; ++i) {
-      const float* P = &h->Xw2[3 * i];
-      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
-      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
-      h->dist[i] = nn;
-      const int lv = lk[i % nl].octave;
-      h->maxd[i] = nn * h->scale32[lv];
-      h->mind[i] = h->maxd[i] / h->scale32[7];
-    }
+    n2p = h->map_copies * nl;
+    build_candidate_tables(h, nl);
     seg(7);
     if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
     st->m1 = n1; st->has_m1 = 1;
@@ -636,10 +637,10 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
     if ((int)h->has.size() != nl) h->has.assign(nl, 1);   // (first tracked frame: every keypoint of the bootstrap frame holds a map point)
     // map point descriptors: rows 0..nl-1 = the last frame's descriptors, rows nl..2nl-1 the same again
     seg(7);
-    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, 0, nl)) != ASD_OK) return rc;
-    if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, nl, nl)) != ASD_OK) return rc;
-    h->rows.resize((size_t)2 * nl);
-    for (int i = 0; i < 2 * nl; ++i) h->rows[i] = i;
+    for (int c = 0; c < h->map_copies; ++c)
+      if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, c * nl, nl)) != ASD_OK) return rc;
+    h->rows.resize((size_t)h->map_copies * nl);
+    for (int i = 0; i < h->map_copies * nl; ++i) h->rows[i] = i;
     h->m1.assign(n, -1);
     int32_t n1 = 0;
     auto dev = [&](int i, const char* stage) { float ms = 0.f; if (asd_last_stage_ms(ctx, stage, &ms) == ASD_OK) h->kern_ms[i] += ms; };
@@ -659,19 +660,7 @@ static int track_step(asd_track_handle* h, int t, bool do_ba, const std::vector<
       return r;
     };
     // attributes of the candidate map points (they exist before the frame is tracked): the last frame's points plus a displaced copy
-    const int n2all = 2 * nl;
-    h->Xw2.resize((size_t)3 * n2all); h->nrm.resize((size_t)3 * n2all); h->dist.resize(n2all); h->maxd.resize(n2all); h->mind.resize(n2all);
-    for (int i = 0; i < nl; ++i)
-      for (int k = 0; k < 3; ++k) { h->Xw2[3 * i + k] = h->Xw[3 * i + k]; h->Xw2[3 * (nl + i) + k] = h->Xw[3 * i + k] + 0.02f; }
-    for (int i = 0; i < n2all; ++i) {
-      const float* P = &h->Xw2[3 * i];
-      const float nn = std::sqrt((P[0] * P[0] + P[1] * P[1]) + P[2] * P[2]);  // numpy: sqrt(add.reduce(x * x)), float32
-      for (int k = 0; k < 3; ++k) h->nrm[3 * i + k] = P[k] / nn;
-      h->dist[i] = nn;
-      const int lv = lk[i % nl].octave;
-      h->maxd[i] = nn * h->scale32[lv];
-      h->mind[i] = h->maxd[i] / h->scale32[7];
-    }
+    build_candidate_tables(h, nl);
     std::vector<int> sel;
     std::vector<uint8_t> outl1(n, 0);
     double pose1[7];
@@ -815,12 +804,8 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
     h->ba_out = true;
     h->ba_step = h->steps;
   } else {
-    // ASD_BA_HOLD_EXTRACT=1 (A/B; off by default): the extractor stands back while LocalBA runs in line.  Measured, round 4 (tools/ab_hold.sh):
-    // LocalBA 2.67 ms instead of 2.73-2.92, but the tracking thread then waits longer for the extractor; 1104-1190 frames/s with, 1142-1167 without.
-    static const bool hold = [] { const char* e = getenv("ASD_BA_HOLD_EXTRACT"); return e && atoi(e) != 0; }();
-    if (hold) { (void)asd_extract_hold(ctx, 1); if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 1); }
+    // (holding the extractor back while LocalBA runs in line -- asd_extract_hold -- was measured in round 4: 1104-1190 frames/s with, 1142-1167 without)
     rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r);
-    if (hold) { (void)asd_extract_hold(ctx, 0); if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 0); }
     if (rc != ASD_OK) return rc;
     st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
   }

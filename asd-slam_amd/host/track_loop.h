@@ -32,6 +32,8 @@ void asd_track_set_split(asd_track_handle* h, int32_t on);
 /* 1 (default, with fused + split): both stages as one submission (asd_track_frame), the next frame constructed on the context's second
  * stream beside them (asd_prep_async); 0 = two submissions with the host in between */
 void asd_track_set_chain(asd_track_handle* h, int32_t on);
+/* the stand-in local map holds `copies` candidates per point of the last frame (default 2; bench.py's local_map_sweep: 2 / 4 / 8 = 4 k / 8 k / 16 k candidates) */
+void asd_track_set_map_copies(asd_track_handle* h, int32_t copies);
 /* 1 = the frame pointers given to asd_track_create are page-locked HOST memory: every frame's image goes host -> device inside the step
  * (asd_extract_submit(device_resident = 0)), as kitti.cc:116-155 hands images over; 0 (default) = frames resident in HBM */
 void asd_track_set_frames_on_host(asd_track_handle* h, int32_t on);

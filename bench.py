@@ -994,6 +994,7 @@ def main():
                                                           "(Tracking::UpdateLocalMap, Tracking.cc:730), which this form cannot host; measured as `one_submission_variant`")
     ap.add_argument("--no-chain", action="store_true", help="(default since round 5, kept for old command lines) two submissions with the host in between")
     ap.add_argument("--no-one-submission-variant", action="store_true", help="skip the extra pass that measures asd_track_frame (N = 1 only)")
+    ap.add_argument("--no-local-map-sweep", action="store_true", help="skip the extra passes with 8 k and 16 k local-map candidates per frame (N = 1 only)")
     ap.add_argument("--lane-ba", action="store_true",
                     help="variant: LocalBA on the library's lane (asd_local_ba_submit / _wait) beside the next frames, which then track against the "
                          "pre-BA map -- not the reference's order (Tracking.cc:797 -> LocalMapping.cc:89 runs it in line, the default here)")
@@ -1175,6 +1176,31 @@ def main():
         be.native.lib.asd_track_drain(be.native.h)
         be.native.lib.asd_track_set_chain(be.native.h, 0)
 
+    # Larger local maps (Tracking.cc:881-905 collects every map point of up to 80 local keyframes): the headline form with 2 / 4 / 8 candidates
+    # per point of the last frame = 4 k / 8 k / 16 k local-map candidates per frame.  Extra key; `value` keeps the 4 k stand-in.
+    local_map_sweep = None
+    if world == 1 and be.native is not None and not args.no_local_map_sweep:
+        be.hip.profile_enable(False)
+        local_map_sweep = {"what": "the headline's two-call form with k candidates per point of the last frame in the stand-in local map (k x 2000 candidates per frame; "
+                                   "the claim replay runs over the map points that have a candidate list, in chunks of 4096)", "runs": []}
+        nsw = max(2 * KF_INTERVAL, args.steps // 2)
+        for copies in (2, 4, 8):
+            be.native.lib.asd_track_drain(be.native.h)
+            be.native.lib.asd_track_set_map_copies(be.native.h, copies)
+            tl = prime + args.warmup + 5 * args.steps + 16 * KF_INTERVAL
+            run_steps(be, wl, tl, 2 * KF_INTERVAL, None, prefetch_beyond=True)
+            be.hip.sync(); device_sync(device)
+            tm_a = be.native.times()
+            s0 = time.perf_counter()
+            _, st_sw = run_steps(be, wl, tl + 2 * KF_INTERVAL, nsw, None, prefetch_beyond=True)
+            be.hip.sync(); device_sync(device)
+            sdt = time.perf_counter() - s0
+            tm_b = be.native.times()
+            local_map_sweep["runs"].append({"candidates_per_frame": copies * int(st_sw.get("n_kp", 0)), "value": nsw / sdt, "unit": "frames/s", "steps": nsw,
+                                            "ms_tracking_per_frame": (1e3 * sdt - (tm_b[0] - tm_a[0])) / nsw, "local_map_matches_last_frame": int(st_sw.get("m2", 0))})
+        be.native.lib.asd_track_drain(be.native.h)
+        be.native.lib.asd_track_set_map_copies(be.native.h, 2)
+
     # The per-keyframe stage of LocalMapping::DoMapping in front of LocalBA (CreateNewMapPoints against 20 neighbours, SearchInNeighbors'
     # Fuse calls, distinctive descriptors) as the library's three batched submissions at every keyframe: reference order
     # (LocalMapping.cc:59-113).  An extra key: the metric -- and `value` -- is tracking + LocalBA.
@@ -1280,6 +1306,8 @@ def main():
             out["lane_variant"] = lane_variant
         if one_submission_variant is not None:
             out["one_submission_variant"] = one_submission_variant
+        if local_map_sweep is not None:
+            out["local_map_sweep"] = local_map_sweep
         if h2d_variant is not None:
             out["h2d_variant"] = h2d_variant
         if do_mapping_variant is not None:

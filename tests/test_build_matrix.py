@@ -9,22 +9,12 @@ import pytest
 from tests.conftest import ROOT
 
 CASES = [
-    ({"ASD_RESULT_COPY": "1", "ASD_UPLOAD_COPY": "1"}, ["tests/test_track_chain.py", "tests/test_matcher.py::test_host_and_device_replay_agree"]),
-    ({"ASD_UPLOAD_SEPARATE": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    ({"ASD_FRONT_PRIO_MID": "1"}, ["tests/test_bench_host.py"]),
-    # asd_track_frame in its resident form (one solver kernel per frame launched ahead, tickets between the streams; opt-in), replay and
-    # solver as separate kernels, the old bid-based claim replay, one extraction worker
-    ({"ASD_CHAIN_EARLY": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    ({"ASD_CHAIN_EARLY": "2"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    ({"ASD_CHAIN_EARLY": "3"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    # ... and with kernels launched ahead that give up after ~20 us: every frame finds its kernel gone and launches a fresh one
-    ({"ASD_CHAIN_EARLY": "1", "ASD_SOLVER_IDLE_POLLS": "20"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    ({"ASD_CHAIN_EARLY": "2", "ASD_SOLVER_IDLE_POLLS": "20"}, ["tests/test_bench_host.py"]),
-    ({"ASD_CHAIN_FUSED": "0"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    ({"ASD_FRUSTUM_TAIL": "1"}, ["tests/test_track_chain.py", "tests/test_bench_host.py"]),
-    ({"ASD_RESOLVE": "bids"}, ["tests/test_matcher.py", "tests/test_track_chain.py::test_track_motion_model_equals_separate_calls"]),
+    # copy commands instead of copy kernels for the tracking stages' upload blocks
+    ({"ASD_UPLOAD_COPY": "1"}, ["tests/test_track_chain.py", "tests/test_matcher.py::test_host_and_device_replay_agree"]),
+    # one extraction worker instead of two
     ({"ASD_EXTRACT_WORKERS": "1"}, ["tests/test_bench_host.py", "tests/test_kitti_configs.py"]),
-    ({"ASD_ASDNET_PERSIST": "1", "ASD_ASDNET_RESERVE": "1"}, ["tests/test_asdnet.py", "tests/test_frontend.py::test_extract_kitti_size_bit_exact"]),
+    # the experimental LDS-image / weight-ring ASDNet kernels (asdnet_ring.hip) through the whole extractor
+    ({"ASD_ASDNET_RING": "6"}, ["tests/test_asdnet.py", "tests/test_frontend.py::test_extract_kitti_size_bit_exact"]),
 ]
 
 

@@ -399,7 +399,17 @@ def test_track_frame_equals_the_two_stage_calls(hip, synth, n, th, flags):
         assert n1 > 0.3 * n and n2 > 0 and inl2 > 0.3 * n
 
 
-def _oracle_frame_composition(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd, last_cand, th, pose0, obs1, obs2, hip_pose1=None):
+def _active_lists(oframe, in_view, proj, level, vc, th, occ):
+    """map points whose search window holds at least one unoccupied keypoint (ORBmatcher.cc:62-84): the lists the replay walks"""
+    n = 0
+    for q in np.nonzero(in_view)[0]:
+        r = (2.5 if vc[q] > 0.998 else 4.0) * (th if th != 1.0 else 1.0) * SCALES[level[q]]
+        idx = oframe.features_in_area(np.float32(proj[q, 0]), np.float32(proj[q, 1]), np.float32(r), int(level[q]) - 1, int(level[q]))
+        n += bool(len(idx)) and not occ[idx].all()
+    return n
+
+
+def _oracle_frame_composition(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd, last_cand, th, pose0, obs1, obs2, hip_pose1=None, cand_desc=None, th_local=1.0):
     """One tracked frame as the ORACLE composes it: SearchByProjection(cur, last) (ORBmatcher.cc:1318-1452) -> PoseOptimization
     (Optimizer.cc:239-413) -> what Tracking does between the stages (outliers dropped :695-714 with mnLastFrameSeen stamped :705-707, pose
     hand-over Frame.cc:150-158, SearchLocalPoints' skip marks :811-823) -> isInFrustum (Frame.cc:160-217) -> SearchByProjection(cur, points)
@@ -424,8 +434,9 @@ def _oracle_frame_composition(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_de
     sel = np.nonzero(~in_frame)[0].astype(np.int32)
     occ = keep.astype(np.uint8)
     in_view, proj, level, vc = oracle.frustum(oc, Xw2[sel], nrm[sel], mind[sel], maxd[sel], T1, K)
-    d2 = np.concatenate([mp_desc, mp_desc])[sel]
-    m2s, n2 = oracle.match_project_points(oc, in_view, proj, level, vc, d2, occ, 1.0, 0.8, obs_positive=None if obs2 is None else obs2[sel])
+    d2 = (np.concatenate([mp_desc, mp_desc]) if cand_desc is None else cand_desc)[sel]
+    m2s, n2 = oracle.match_project_points(oc, in_view, proj, level, vc, d2, occ, th_local, 0.8, obs_positive=None if obs2 is None else obs2[sel])
+    n_active = _active_lists(oc, in_view, proj, level, vc, th_local, occ)
     m2 = np.where(m2s >= 0, sel[np.maximum(m2s, 0)], -1)          # candidate indices
     jj = np.nonzero(keep | (m2 >= 0))[0]
     outl2, pose2, inl2 = np.zeros(n_cur, np.uint8), hand.copy(), 0
@@ -433,7 +444,7 @@ def _oracle_frame_composition(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_de
         X = np.where(keep[jj][:, None], Xw[np.maximum(m1[jj], 0)], Xw2[np.maximum(m2[jj], 0)]).astype(np.float64)
         pose2, o, inl2 = oracle.pose_optimize(hand, X, np.stack([kc["x"][jj], kc["y"][jj]], 1).astype(np.float64), inv_sigma2[kc["octave"][jj]], K64)
         outl2[jj] = o
-    return dict(m1=m1, n1=n1, pose1=pose1, outl1=outl1, inl1=inl1, sel=sel, m2=m2, n2=n2, pose2=pose2, outl2=outl2, inl2=inl2, keep=keep)
+    return dict(m1=m1, n1=n1, pose1=pose1, outl1=outl1, inl1=inl1, sel=sel, m2=m2, n2=n2, pose2=pose2, outl2=outl2, inl2=inl2, keep=keep, n_active=n_active)
 
 
 @pytest.mark.gpu
@@ -496,6 +507,63 @@ def test_tracked_frame_against_the_oracle_composition(hip, oracle, synth, n, fla
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("copies", [4, 8])
+def test_large_local_map_against_the_oracle(hip, oracle, synth, copies):
+    """Local maps beyond one chunk of the replay workgroup (Tracking.cc:881-905 collects every point of up to 80 local keyframes): 8000 and
+    16000 candidates for a frame of 2000 keypoints, most of them in view with a candidate list -- the replay runs over the map points that
+    HAVE a list in chunks of 4096, in index order (resolve2.h).  asd_track_frame and the two-call form against the oracle's composition."""
+    n = 2000
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, _, _, _, _ = _frame_case(synth, n, 5100 + copies)
+    n_cur = len(kc)
+    Xw2 = np.concatenate([Xw + np.float32(0.015 * j) for j in range(copies)])
+    Ow = -(T[:3, :3].astype(np.float64).T @ T[:3, 3].astype(np.float64))
+    d = Xw2.astype(np.float64) - Ow
+    dist = np.linalg.norm(d, axis=1)
+    nrm = (d / dist[:, None]).astype(np.float32)
+    lv = np.concatenate([kl["octave"]] * copies)
+    maxd = (dist * SCALES[lv]).astype(np.float32)
+    mind = (maxd / np.float32(SCALES[7])).astype(np.float32)
+    cand_desc = np.concatenate([perturbed_descriptors(mp_desc, 0.01 * j, 77 + j) if j else mp_desc for j in range(copies)])
+    ncand = copies * n
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.frame_set(1, kl, dl, BOUNDS)
+    base = 700
+    hip.bank_put(base, cand_desc)
+    hip.mpbank_put(base, Xw2, nrm, mind, maxd)
+    rows1 = np.arange(base, base + n, dtype=np.int32)
+    cand_rows = np.arange(base, base + ncand, dtype=np.int32)
+    rng = np.random.default_rng(3)
+    obs2 = (rng.uniform(size=ncand) < 0.85).astype(np.uint8)
+    last_cand = np.arange(n, dtype=np.int32)
+    pose0 = _pose7(pose_T(rv=(0.012, -0.018, 0.006), t=(0.12, -0.04, 0.33)))
+    inv_sigma2 = hip.scale_tables()["inv_sigma2"].astype(np.float64)
+    r = hip.track_frame(0, 1, n_cur, has, Xw, rows1, last_cand, T, K, 15.0, pose0, cand_rows, 3.0, 0.8, cand_obs_positive=obs2)
+    o = _oracle_frame_composition_th(oracle, inv_sigma2, kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd, last_cand, 15.0, pose0, None, obs2,
+                                     hip_pose1=r["pose1"], cand_desc=cand_desc, th_local=3.0)
+    np.testing.assert_array_equal(r["match1"], o["m1"])
+    np.testing.assert_array_equal(r["match2"], o["m2"])
+    assert (r["n1"], r["n_inl1"], r["n2"], r["n_inl2"]) == (o["n1"], o["inl1"], o["n2"], o["inl2"])
+    np.testing.assert_array_equal(r["outlier2"], o["outl2"])
+    assert np.abs(r["pose"] - o["pose2"]).max() <= POSE_TOL
+    if copies == 8:
+        assert o["n_active"] > 4096, o["n_active"]      # more lists than one chunk of either replay workgroup takes
+    # the two calls with the host between them
+    m1, n1, pose1, outl1, inl1 = hip.track_motion_model(0, 1, n_cur, has, Xw, rows1, T, K, 15.0, pose0, True)
+    np.testing.assert_array_equal(m1, o["m1"])
+    T1 = hip.pose7_to_tcw(pose1) if (m1 >= 0).sum() >= 3 else T
+    sel = o["sel"]
+    m2, n2, pose2, outl2, inl2 = hip.track_local_points(0, n_cur, Xw2[sel], nrm[sel], mind[sel], maxd[sel], cand_rows[sel], T1, K, o["keep"].astype(np.uint8),
+                                                        Xw[np.maximum(m1, 0)], 3.0, 0.8, pose1, obs_positive=obs2[sel])
+    np.testing.assert_array_equal(np.where(m2 >= 0, sel[np.maximum(m2, 0)], -1), o["m2"])
+    assert (n2, inl2) == (o["n2"], o["inl2"])
+    np.testing.assert_array_equal(outl2, o["outl2"])
+
+
+def _oracle_frame_composition_th(*args, th_local=1.0, **kw):
+    return _oracle_frame_composition(*args, **kw, th_local=th_local)
+
+
+@pytest.mark.gpu
 def test_track_frame_refuses_what_it_cannot_chain(hip, synth):
     kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd = _frame_case(synth, 300, 77)
     hip.frame_set(0, kc, dc, BOUNDS)
@@ -505,7 +573,9 @@ def test_track_frame_refuses_what_it_cannot_chain(hip, synth):
     pose0 = _pose7(pose_T())
     with pytest.raises(RuntimeError):        # candidate row beyond the banks
         hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.arange(10_000_000, 10_000_600, dtype=np.int32), 1.0, 0.8)
-    with pytest.raises(RuntimeError):        # more candidates than one replay workgroup takes
-        hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.zeros(5000, np.int32), 1.0, 0.8)
+    with pytest.raises(RuntimeError):        # more candidates than the compaction in front of the replay takes (64 rounds of 512)
+        hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.zeros(40000, np.int32), 1.0, 0.8)
+    big = hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.tile(np.arange(600, dtype=np.int32), 9)[:5000], 1.0, 0.8)
+    assert big["n1"] > 0                     # 5000 candidates (round 4 refused more than 4096)
     r = hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.arange(600, dtype=np.int32), 1.0, 0.8)
     assert r["n1"] > 0
