@@ -444,7 +444,6 @@ struct FrontendState {
   int* h_level_start = nullptr;   // pinned
   short4 *d_kps = nullptr, *h_kps = nullptr;
   float *d_angles = nullptr, *h_angles = nullptr, *h_desc = nullptr;
-  bool consts_set = false;
   // last extract, host side
   std::vector<float> raw_x[ASD_MAX_LEVELS], raw_y[ASD_MAX_LEVELS], raw_r[ASD_MAX_LEVELS];
   std::vector<int> sel[ASD_MAX_LEVELS];
@@ -524,7 +523,13 @@ void frontend_free(asd_ctx* ctx) { fe_free(ctx->fe); ctx->fe = nullptr; }
 static int configure_size(asd_ctx* ctx, FrontendState* fe, int w, int h) {
   if (fe->cfg_w == w && fe->cfg_h == h) return ASD_OK;
   const int nl = ctx->cfg.n_levels;
-  if (!fe->consts_set) {
+  // The constant-memory tables belong to the DEVICE (one copy per code object and device), not to a front-end state: uploaded once per
+  // device under a lock.  (Per front-end state -- round 4 -- the second extraction worker's first job ran hipMemcpyToSymbol, a null-stream
+  // synchronising call, while the first worker's kernels were reading the same symbols.  Every context computes the same umax table.)
+  static std::mutex consts_mu;
+  static AsdPerDeviceOnce consts_once;
+  std::lock_guard<std::mutex> consts_lock(consts_mu);
+  if (consts_once.need(ctx->cfg.device)) {
     // getGaussianKernel(7, 2, CV_32F) -> convertTo(CV_32S, 256) (smooth.cpp / filter.cpp, bits = 8)
     int gk[7];
     float cf[7];
@@ -542,7 +547,7 @@ static int configure_size(asd_ctx* ctx, FrontendState* fe, int w, int h) {
     if (nd > 768) { ctx->set_error("orientation disc has %d pixels", nd); return ASD_ERR_INVALID; }
     ASD_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_disc), disc.data(), nd * sizeof(short2)));
     ASD_HIP_CHECK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_ndisc), &nd, sizeof nd));
-    fe->consts_set = true;
+    consts_once.done(ctx->cfg.device);
   }
   PyrDev& P = fe->pyr;
   P.nlevels = nl;
@@ -701,13 +706,16 @@ static int extract_front(asd_ctx* ctx, FrontendState* fe, const ExtractJob& J, E
     // device memory and page-locked host memory go through the copy kernel; pageable host memory (asd_extract with an ordinary buffer)
     // needs the runtime's staging copy
     bool by_kernel = J.on_device;
+    const uint8_t* src_dev = J.image;
     if (!by_kernel) {
       hipPointerAttribute_t at{};
       by_kernel = hipPointerGetAttributes(&at, J.image) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
       if (!by_kernel) (void)hipGetLastError();   // (an unregistered pointer is reported as an error: not ours)
+      // the device-side address of the mapping: equal to the host address for hipHostMalloc memory, not necessarily for hipHostRegister'ed memory
+      else src_dev = static_cast<const uint8_t*>(at.devicePointer) + (J.image - static_cast<const uint8_t*>(at.hostPointer ? at.hostPointer : J.image));
     }
     if (by_kernel) {
-      hipLaunchKernelGGL(k_copy_image, dim3((width + 1023) / 1024, height), dim3(256), 0, st, J.image, stride, width, height, fe->d_pyr + P.lv[0].off, P.lv[0].pitch);
+      hipLaunchKernelGGL(k_copy_image, dim3((width + 1023) / 1024, height), dim3(256), 0, st, src_dev, stride, width, height, fe->d_pyr + P.lv[0].off, P.lv[0].pitch);
       ASD_HIP_CHECK(ctx, hipGetLastError());
     } else {
       ASD_HIP_CHECK(ctx, hipMemcpy2DAsync(fe->d_pyr + P.lv[0].off, P.lv[0].pitch, J.image, stride, width, height, hipMemcpyHostToDevice, st));

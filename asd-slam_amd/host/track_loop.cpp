@@ -475,7 +475,7 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     after.push_back(next.back() + 1);   // the queue of frame t+1: t+2 .. t+1+lookahead (asd_track_run trims it at the end of a run)
     if ((int)after.size() > h->lookahead) after.resize(h->lookahead);
     if (h->stop_after >= 0) while (!after.empty() && after.back() > h->stop_after) after.pop_back();
-    if ((rc = prepare_frame(h, t + 1, after)) != ASD_OK) return rc;
+    if ((rc = prepare_frame(h, t + 1, after)) != ASD_OK) { if (had_last) (void)asd_track_finish(ctx); return rc; }
     tp = std::chrono::steady_clock::now();
   }
   if (had_last) {
@@ -541,11 +541,12 @@ static int track_step_chain(asd_track_handle* h, int t, bool do_ba, const std::v
     after.push_back(next.back() + 1);
     if ((int)after.size() > h->lookahead) after.resize(h->lookahead);
     if (h->stop_after >= 0) while (!after.empty() && after.back() > h->stop_after) after.pop_back();
-    if ((rc = asd_prep_async(ctx, 1)) != ASD_OK) return rc;
+    // (on an error the stage submitted above is finished before the error is returned: its completion holds pointers into this handle's
+    // vectors, and the context stays busy until asd_track_finish)
+    if ((rc = asd_prep_async(ctx, 1)) != ASD_OK) { if (had_last) (void)asd_track_finish(ctx); return rc; }
     rc = prepare_frame(h, t + 1, after);
     const int rc2 = asd_prep_async(ctx, 0);
-    if (rc != ASD_OK) return rc;
-    if (rc2 != ASD_OK) return rc2;
+    if (rc != ASD_OK || rc2 != ASD_OK) { if (had_last) (void)asd_track_finish(ctx); return rc != ASD_OK ? rc : rc2; }
     tp = std::chrono::steady_clock::now();
   }
   if (had_last) {
