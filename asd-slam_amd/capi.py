@@ -407,6 +407,23 @@ class AsdHip:
             return None
         return match, n.value, pose, outl[:n_cur], ninl.value
 
+    def track_local_points_rows(self, slot_cur, n_cur, rows, Tcw, K, occupied, cur_Xw, th, nn_ratio, pose7, cos_limit=0.5, obs_positive=None, split=False):
+        """asd_track_local_points_rows: the map points by row of the descriptor + attribute banks"""
+        rows = _c(rows, np.int32)
+        Tcw, K, occupied, cur_Xw = _c(Tcw, np.float32), _c(K, np.float32), _c(occupied, np.uint8), _c(cur_Xw, np.float32)
+        match, outl = np.empty(n_cur, np.int32), np.empty(max(n_cur, 1), np.uint8)
+        pose = _c(pose7, np.float64).copy()
+        n, ninl = C.c_int32(), C.c_int32()
+        if split:
+            self._chk(self.lib.asd_track_async(self.ctx))
+        self._chk(self.lib.asd_track_local_points_rows(self.ctx, slot_cur, len(rows), _p(rows), _p(Tcw), _p(K), C.c_float(cos_limit), _p(occupied), _p(cur_Xw),
+                                                       C.c_float(th), C.c_float(nn_ratio), _p(None if obs_positive is None else _c(obs_positive, np.uint8)),
+                                                       _p(pose), _p(match), C.byref(n), _p(outl), C.byref(ninl)))
+        if split:
+            self._track_job = (match, n, pose, outl, ninl, n_cur)
+            return None
+        return match, n.value, pose, outl[:n_cur], ninl.value
+
     def mpbank_put(self, first_row, Xw, normal, min_dist, max_dist):
         Xw, normal, min_dist, max_dist = (_c(a, np.float32) for a in (Xw, normal, min_dist, max_dist))
         self._chk(self.lib.asd_mpbank_put(self.ctx, first_row, len(min_dist), _p(Xw), _p(normal), _p(min_dist), _p(max_dist)))

@@ -628,6 +628,32 @@ __device__ inline int tile_next(const TileQueue& q, int* slot) {
   return *slot;
 }
 
+// input_norm's statistics (ASDNet.py:360-365) of every patch, once per forward: mean and unbiased std + 1e-7 over the 1024 pixels.  conv2's
+// workgroups (four bands per patch) used to compute them in their prologue, each for itself: the patch load, two wave + LDS reductions and two
+// barriers in front of conv1 were 7.9 k of a workgroup's 23 k cycles under load (profiles/r04_asdnet_phases.txt).  Same thread <-> pixel
+// assignment and the same expressions as that prologue (kept below for callers without a statistics buffer): the same bits.
+__global__ __launch_bounds__(256) void k_patch_stats(const uint8_t* __restrict__ patches, float* __restrict__ stats, int n) {
+  __shared__ float red[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, patch = blockIdx.x;
+  const uchar4 v = reinterpret_cast<const uchar4*>(patches + (size_t)patch * 1024)[t];
+  const float inv255 = (float)(1.0 / 255);  // ORBextractor.cc:1125
+  float x[4] = {v.x * inv255, v.y * inv255, v.z * inv255, v.w * inv255};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(x[k]));   // the ROUNDED products are the operands (see conv2's prologue)
+  float sum = (x[0] + x[1]) + (x[2] + x[3]);
+  for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+  if (lane == 0) red[wave] = sum;
+  asd_syncthreads();
+  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
+  float d[4], ss = 0.f;
+  for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
+  for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+  if (lane == 0) red[4 + wave] = ss;
+  asd_syncthreads();
+  const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
+  if (t == 0) { stats[2 * (size_t)patch] = mean; stats[2 * (size_t)patch + 1] = sd; }
+}
+
 // PAIR (two-piece form only): activations travel between the layers as the fp16 pieces themselves -- per pixel and group of eight
 // channels 16 B of h then 16 B of l, [pixel][c/8][h | l][8], the pieces of kActScale * x: the LDS band's own layout and the same
 // 4 B per element as f32.  The producer's epilogue splits each value once (split4_mix); a consumer stages its band with plain 16-B
@@ -638,7 +664,8 @@ template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, b
 __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
-                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale) {
+                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale,
+                                                         const float* __restrict__ stats = nullptr) {
   // NP = 3: bf16 pieces, six products (in_scale = out_scale = 1); NP = 2: fp16 pieces of x * in_scale, three products, the
   // accumulators are multiplied by out_scale = 1 / (in_scale * the layer's weight scale) in the epilogue (powers of two: exact)
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
@@ -694,7 +721,12 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
     float* wsh = pin + (ROWS + 4) * 36;                            // [32*9 + 32]
     float* red = wsh + 320;                                        // [8]
     const uint8_t* patches = static_cast<const uint8_t*>(in_);
-    for (int i = t; i < (ROWS + 4) * 36; i += NTH) pin[i] = 0.f;
+    // zero padding of the normalised rows: every entry that is not a pixel of the patch (those are written by their owners below; no entry
+    // is written twice, so the statistics path needs no barrier between the two)
+    for (int i = t; i < (ROWS + 4) * 36; i += NTH) {
+      const int j = i / 36, c = i % 36, y = r0 - 2 + j;
+      if (!(c >= 1 && c <= 32 && y >= 0 && y < 32)) pin[i] = 0.f;
+    }
     for (int i = t; i < 288; i += NTH) wsh[i] = w1[i];
     if (t < 32) wsh[288 + t] = b1[t];
     // the 1024 pixels of the patch sit in the first four waves (4 per lane); further waves only help with conv1 below
@@ -708,18 +740,26 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
     // multiply, so the barrier is an empty asm on the value.)
 #pragma unroll
     for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(x[k]));
-    float sum = (x[0] + x[1]) + (x[2] + x[3]);
-    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
-    X3_STAMP(9);
-    if (lane == 0 && ld) red[wave] = sum;
-    asd_syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
-    float d[4], ss = 0.f;
-    for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
-    if (lane == 0 && ld) red[4 + wave] = ss;
-    asd_syncthreads();
-    const float sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
+    float d[4], sd;
+    if (stats) {   // mean and std + 1e-7 of the patch from k_patch_stats (round 5): no reduction, no barrier in front of conv1
+      const float mean = stats[2 * (size_t)patch];
+      sd = stats[2 * (size_t)patch + 1];
+      for (int k = 0; k < 4; ++k) d[k] = x[k] - mean;
+      X3_STAMP(9);
+    } else {
+      float sum = (x[0] + x[1]) + (x[2] + x[3]);
+      for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+      X3_STAMP(9);
+      if (lane == 0 && ld) red[wave] = sum;
+      asd_syncthreads();
+      const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 1024.0f);
+      float ss = 0.f;
+      for (int k = 0; k < 4; ++k) { d[k] = x[k] - mean; ss += d[k] * d[k]; }
+      for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+      if (lane == 0 && ld) red[4 + wave] = ss;
+      asd_syncthreads();
+      sd = sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / 1023.0f)) + 1e-7f;  // unbiased std
+    }
     if (ld) {
       const int idx = t * 4, y = idx >> 5, x0 = idx & 31;  // this thread's 4 pixels sit in row y
       const int j = y - (r0 - 2);
@@ -1010,10 +1050,11 @@ template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, b
 __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? ASD_L2_MINWG : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
-                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale, TileQueue tq) {
+                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale, TileQueue tq,
+                                                         const float* __restrict__ stats) {
   __shared__ int tile_slot;
   for (int tile = tile_first(tq, &tile_slot); tile >= 0; tile = tile_next(tq, &tile_slot))
-    conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(tile, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale);
+    conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(tile, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale, stats);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1379,7 +1420,8 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3, bool PAIR = false>
 hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
                           const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr,
-                          float in_scale = 1.f, float out_scale = 1.f, int* tq_counter = nullptr, int reserve = 0, int num_cu = 256) {
+                          float in_scale = 1.f, float out_scale = 1.f, int* tq_counter = nullptr, int reserve = 0, int num_cu = 256,
+                          const float* stats = nullptr) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>;
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
@@ -1401,7 +1443,7 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
   const int per_cu = std::max(1, std::min(3, (160 * 1024) / (lds + 64)));
   const int grid = tq_counter ? std::min(ntiles, num_cu * per_cu) : ntiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,
-                     in_scale, out_scale, TileQueue{tq_counter, ntiles, reserve});
+                     in_scale, out_scale, TileQueue{tq_counter, ntiles, reserve}, stats);
   return hipGetLastError();
 }
 
@@ -1618,14 +1660,22 @@ static int asdnet_forward_one(asd_ctx* ctx, const uint8_t* d_patches, int n, flo
   // persistent launches: one tile counter per layer, zeroed here on the forward's own stream
   int* const tq = ctx->asdnet_persist ? ctx->d_tq : nullptr;
   if (tq) ASD_HIP_CHECK(ctx, hipMemsetAsync(tq, 0, 16 * sizeof(int), st));
+  const float* x3_stats = nullptr;   // conv2 only: the patches' normalisation statistics (k_patch_stats)
 #define X3_LAUNCH(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                       \
   (pair ? launch_conv_x3<CFG, FUSE, 2, kPairOK>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,       \
-                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu)           \
+                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu, x3_stats)           \
    : p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,               \
-                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu)           \
+                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu, x3_stats)           \
       : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, 1.f, 1.f,                \
-                                     tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu))
-  if (ctx->net_split & 1) ASD_HIP_CHECK(ctx, (X3_LAUNCH(L2S_CFG, true, 1, d_patches, a1, ctx->d_w1, ctx->d_bias[0])));
+                                     tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu, x3_stats))
+  if (ctx->net_split & 1) {
+    // input_norm's mean / std of every patch once (k_patch_stats), in the head of the last layer's partial-sum buffer (free until that layer)
+    hipLaunchKernelGGL(k_patch_stats, dim3(n), dim3(256), 0, st, d_patches, ctx->d_part, n);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    x3_stats = ctx->d_part;
+    ASD_HIP_CHECK(ctx, (X3_LAUNCH(L2S_CFG, true, 1, d_patches, a1, ctx->d_w1, ctx->d_bias[0])));
+    x3_stats = nullptr;
+  }
   else ASD_HIP_CHECK(ctx, (launch_conv<L2_CFG, true>(st, d_patches, ctx->d_wimg[1], ctx->d_bias[1], a1, n, ctx->d_w1, ctx->d_bias[0])));
   // calibration (asd_load_weights): the largest |activation| each layer hands to the next one
 #define CALIB(l, buf, elems) do { if (ctx->d_calib) { hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, buf, (size_t)n * (elems), ctx->d_calib + (l)); ASD_HIP_CHECK(ctx, hipGetLastError()); } } while (0)

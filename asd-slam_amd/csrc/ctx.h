@@ -108,7 +108,7 @@ __device__ inline void asd_frustum_bank_point(const F& a, const float* T_dev, co
   const int row = a.rows[q];
   const float4 A0 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row], A1 = reinterpret_cast<const float4*>(a.attr)[2 * (size_t)row + 1];
   a.xw_out[3 * (size_t)q] = A0.x; a.xw_out[3 * (size_t)q + 1] = A0.y; a.xw_out[3 * (size_t)q + 2] = A0.z;
-  if (!skip[q]) {
+  if (!skip || !skip[q]) {   // (skip == null: every candidate is looked at)
     float T[16], Ow[3];
     for (int i = 0; i < 16; ++i) T[i] = T_dev[i];
     for (int i = 0; i < 3; ++i) Ow[i] = T_dev[16 + i];

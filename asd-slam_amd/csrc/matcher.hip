@@ -483,8 +483,14 @@ __global__ __launch_bounds__(256) void k_frustum_queries(FrustumArgs a) {
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= a.n) return;
   WinQuery Q{0.f, 0.f, 0.f, 0, 0, -1};
-  if (a.attr) {   // bank form (asd_track_frame): the per-candidate arithmetic lives in ctx.h, shared with the stage-1 solver's tail
-    asd_frustum_bank_point(a, a.T_dev, a.skip, q);
+  if (a.attr) {   // bank form: the map points are rows of the attribute bank (the per-candidate arithmetic lives in ctx.h)
+    if (a.T_dev) asd_frustum_bank_point(a, a.T_dev, a.skip, q);   // asd_track_frame: pose and skip flags from the stage in front
+    else {                                                        // asd_track_local_points_rows: pose from the host, by value
+      float Tl[19];
+      for (int i = 0; i < 16; ++i) Tl[i] = a.T[i];
+      for (int i = 0; i < 3; ++i) Tl[16 + i] = a.Ow[i];
+      asd_frustum_bank_point(a, Tl, a.skip, q);
+    }
     return;
   }
   const float* P = a.Xw + 3 * (size_t)q;
@@ -628,6 +634,8 @@ struct MatcherState {
   // map-point attribute bank, same row ids: [row][8] = mWorldPos, mNormalVector, mfMinDistance, mfMaxDistance (asd_mpbank_put)
   float* d_attr = nullptr;
   int attr_cap = 0;
+  float* d_cxw = nullptr;     // asd_track_local_points_rows: the candidates' positions as k_frustum_queries read them from the bank (the solver's table)
+  size_t cxw_cap = 0;
   float* h_attr[2] = {nullptr, nullptr};   // pinned staging, used alternately
   size_t h_attr_cap[2] = {0, 0};
   hipEvent_t ev_attr[2] = {nullptr, nullptr};
@@ -992,6 +1000,7 @@ AsdFrameSlot* slot_of(asd_ctx* ctx, int s) {
 hipError_t asd_copy_rows(hipStream_t st, void* dst, const void* src, size_t bytes) { return copy_rows(st, dst, src, bytes); }
 
 void matcher_free(asd_ctx* ctx) {
+  if (ctx->matcher && static_cast<MatcherState*>(ctx->matcher)->d_cxw) (void)hipFree(static_cast<MatcherState*>(ctx->matcher)->d_cxw);
   for (auto& f : ctx->frames) {
     if (f.d_desc) (void)hipFree(f.d_desc);
     if (f.d_fv) (void)hipFree(f.d_fv);
@@ -1668,6 +1677,83 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
   return fin();
 }
 
+// The same with the map points named by ROW of the banks (descriptor bank: MapPoint::mDescriptor, attribute bank: position, normal, distance
+// range -- asd_bank_put*, asd_mpbank_put): what the host uploads per candidate shrinks from 36 bytes (position, normal, distances, row) to 4,
+// and it gathers nothing.  Same kernels as asd_track_frame's local-map stage (k_frustum_queries' bank form), same results as
+// asd_track_local_points_bank given the same attributes.
+int track_local_points_rows_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const int32_t* rows, const float* Tcw, const float* K, float cos_limit,
+                                 const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive,
+                                 double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers, std::function<int()>* defer) {
+  AsdFrameSlot* F = slot_of(ctx, slot_cur);
+  if (!F || n_mp < 1 || !rows || !Tcw || !K || !pose7 || !match_cur || !n_matches || !outlier || !n_inliers || F->n < 1 || !occupied || !cur_Xw) return ASD_ERR_INVALID;
+  (void)hipSetDevice(ctx->cfg.device);
+  MatcherState* m = mstate(ctx);
+  if (!replay_on_device(m, 1, F->n, n_mp)) {
+    ctx->set_error("asd_track_local_points_rows: %d map points / %d keypoints are outside the device replay (use asd_track_local_points_bank)", n_mp, F->n);
+    return ASD_ERR_CAPACITY;
+  }
+  for (int q = 0; q < n_mp; ++q)
+    if (rows[q] < 0 || rows[q] >= m->bank_cap || rows[q] >= m->attr_cap) { ctx->set_error("row %d out of range (descriptor bank %d rows, attribute bank %d)", rows[q], m->bank_cap, m->attr_cap); return ASD_ERR_INVALID; }
+  std::fill(match_cur, match_cur + F->n, -1);
+  *n_matches = 0;
+  int rc = ensure_queries(ctx, m, n_mp);
+  if (rc != ASD_OK) return rc;
+  if (m->cxw_cap < (size_t)n_mp * 3) {
+    if (m->d_cxw) { ASD_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(m->d_cxw); m->d_cxw = nullptr; m->cxw_cap = 0; }
+    const size_t want = (size_t)n_mp * 3 + (size_t)n_mp / 2 * 3 + 3072;
+    ASD_HIP_CHECK(ctx, hipMalloc(&m->d_cxw, want * sizeof(float)));
+    m->cxw_cap = want;
+  }
+  const std::array<double, 4> Kd = {(double)K[0], (double)K[1], (double)K[2], (double)K[3]};
+  std::array<double, 7> p0;
+  memcpy(p0.data(), pose7, sizeof(double) * 7);
+  FrustumArgs fa{};
+  fa.n = n_mp; fa.n_levels = ctx->cfg.n_levels; fa.bfactor = th != 1.0;
+  memcpy(fa.T, Tcw, sizeof fa.T);
+  for (int i = 0; i < 3; ++i) {  // mOw = -mRcw.t()*mtcw (Frame.cc:157): transposed gemm accumulates in double
+    double sum = 0;
+    for (int k = 0; k < 3; ++k) sum += (double)Tcw[k * 4 + i] * (double)Tcw[k * 4 + 3];
+    fa.Ow[i] = (float)(-1.0 * sum);
+  }
+  fa.fx = K[0]; fa.fy = K[1]; fa.cx = K[2]; fa.cy = K[3];
+  fa.min_x = F->min_x; fa.max_x = F->max_x; fa.min_y = F->min_y; fa.max_y = F->max_y;
+  fa.cos_limit = cos_limit; fa.th = th;
+  for (int l = 0; l < ASD_MAX_LEVELS; ++l) { fa.level_thr[l] = ctx->level_thr[l]; fa.scale[l] = l < ctx->cfg.n_levels ? ctx->scale[l] : 0.f; }
+  fa.attr = m->d_attr; fa.T_dev = nullptr; fa.skip = nullptr; fa.xw_out = m->d_cxw;
+  auto chain = std::make_shared<ChainHook>();
+  chain->src[1] = cur_Xw; chain->bytes[1] = (size_t)F->n * 12;
+  chain->src[2] = occupied; chain->bytes[2] = (size_t)F->n;
+  chain->src[6] = rows; chain->bytes[6] = (size_t)n_mp * 4;
+  chain->result_bytes = pose_chain_io_bytes(F->n);
+  chain->prepare = [ctx, fa, n_mp](WinQuery* d_queries, void* const*, void* const* h_tab, const UploadTail& tail) -> int {
+    FrustumArgs a = fa;
+    a.rows = static_cast<const int*>(h_tab[6]);
+    a.queries = d_queries;
+    a.up = tail;
+    a.up.q_blocks = (n_mp + 255) / 256;
+    hipLaunchKernelGGL(k_frustum_queries, dim3(a.up.q_blocks + (tail.n16 ? kUploadTailBlocks : 0)), dim3(256), 0, ctx->stream, a);
+    ASD_HIP_CHECK(ctx, hipGetLastError());
+    return ASD_OK;
+  };
+  float* d_cxw = m->d_cxw;
+  chain->enqueue = [ctx, F, Kd, p0, d_cxw](const int* d_match, void* const* d_tab, void* d_result) {
+    return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, d_cxw, static_cast<const uint8_t*>(d_tab[2]), static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(),
+                              static_cast<double*>(d_result));
+  };
+  std::function<int()> search_done;
+  rc = search_and_resolve<1>(ctx, m, *F, n_mp, m->d_bank, nullptr, mp_obs_positive, occupied, 0, nn_ratio, match_cur, n_matches, chain.get(), defer ? &search_done : nullptr);
+  if (rc != ASD_OK) return rc;
+  auto occ = std::make_shared<std::vector<uint8_t>>(occupied, occupied + F->n);   // the completion must not read the caller's inputs
+  auto fin = [=]() -> int {
+    if (search_done) { const int r = search_done(); if (r != ASD_OK) return r; }
+    const uint8_t* oc = occ->data();
+    return finish_pose_chain(ctx, *F, [=](int j) -> const float* { return (oc[j] || match_cur[j] >= 0) ? reinterpret_cast<const float*>(oc) : nullptr; },
+                             true, static_cast<const double*>(chain->h_result), Kd.data(), pose7, outlier, n_inliers, chain->kp_flags);
+  };
+  if (defer && search_done) { *defer = fin; return ASD_OK; }
+  return fin();
+}
+
 // asd_track_async / asd_track_finish: run an asd_track_* entry point split in two
 extern "C++" {
 template <typename Impl>
@@ -1738,6 +1824,14 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
     return track_local_points_impl(ctx, slot_cur, n_mp, Xw, normal, min_dist, max_dist, nullptr, rows, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th,
                                    nn_ratio, mp_obs_positive, pose7, match_cur, n_matches, outlier, n_inliers, defer); });
 
+}
+
+int asd_track_local_points_rows(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const int32_t* rows, const float* Tcw, const float* K, float viewing_cos_limit,
+                                const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio, const uint8_t* mp_obs_positive,
+                                double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers) {
+  return run_track(ctx, [&](std::function<int()>* defer) {
+    return track_local_points_rows_impl(ctx, slot_cur, n_mp, rows, Tcw, K, viewing_cos_limit, occupied, cur_Xw, th, nn_ratio, mp_obs_positive, pose7, match_cur,
+                                        n_matches, outlier, n_inliers, defer); });
 }
 
 

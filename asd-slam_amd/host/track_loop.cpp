@@ -47,6 +47,7 @@ struct asd_track_handle {
   // OFF by default since round 5: the reference selects its local map between the stages (Tracking::UpdateLocalMap, Tracking.cc:730), which
   // needs the host there -- the split-phase two-call form above is the one Tracking can bind; this one is a measured variant
   bool chain = false;
+  int tables_for = -1;      // the frame whose candidate tables (Xw2 ...) prepare_frame has built and stored in the attribute bank
   int map_copies = 2;       // the stand-in local map: every point of the last frame and map_copies - 1 displaced copies of it (asd_track_set_map_copies)
   const asd_do_mapping_inputs* dm = nullptr;   // the batched per-keyframe stage in front of LocalBA (asd_track_set_do_mapping)
   std::vector<int32_t> dm_matches, dm_nmatch, dm_best, dm_distinct;
@@ -358,6 +359,11 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       if ((rc = asd_bank_put_from_frame(ctx, h->last_slot, c * nl, nl)) != ASD_OK) return rc;
     h->rows.resize((size_t)h->map_copies * nl);
     for (int i = 0; i < h->map_copies * nl; ++i) h->rows[i] = i;
+    // the candidates' attributes (MapPoint::mWorldPos, mNormalVector, mfMin/MaxDistance: they exist before the frame is tracked) into the
+    // attribute bank, rows as the descriptors': the local-map stage then names its points by row (asd_track_local_points_rows)
+    build_candidate_tables(h, nl);
+    if ((rc = asd_mpbank_put(ctx, 0, h->map_copies * nl, h->Xw2.data(), h->nrm.data(), h->mind.data(), h->maxd.data())) != ASD_OK) return rc;
+    h->tables_for = t;
     seg(2);
   }
   h->prep_t = t; h->prep_kps = kps; h->prep_n = n;
@@ -370,7 +376,7 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t);
 // outliers, take the optimised pose as the frame's pose, and put the local map together from what is not in the frame already --
 // here: the candidates (the last frame's points + their displaced copies) that no kept match refers to.  Fills keep / occ / cur_Xw,
 // sel and the selected tables, T1; returns the number of selected points.  Mirrors bench.py's track_step line by line.
-static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t* outl1, const double* pose1) {
+static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t* outl1, const double* pose1, bool gather = true) {
   h->keep.assign(n, 0); h->occ.assign(n, 0);
   h->in_frame.assign((size_t)h->map_copies * nl, 0);
   h->cur_Xw.assign((size_t)3 * n, 0.f);
@@ -388,6 +394,7 @@ static int select_local_points(asd_track_handle* h, int n, int nl, const uint8_t
   h->sel.clear();
   for (int i = 0; i < h->map_copies * nl; ++i) if (!h->in_frame[i]) h->sel.push_back(i);
   const int ns = (int)h->sel.size();
+  if (!gather) return ns;   // (the stage names its points by bank row: no tables to put together)
   h->Xs.resize((size_t)3 * ns); h->ns.resize((size_t)3 * ns); h->mind_s.resize(ns); h->maxd_s.resize(ns);
   for (int q = 0; q < ns; ++q) {
     const int i = h->sel[q];
@@ -443,13 +450,13 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     seg(2);
     // ---- under it: the local map's tables (the last frame's points plus a jittered copy; nothing here needs the stage's result)
     n2p = h->map_copies * nl;
-    build_candidate_tables(h, nl);
+    if (h->tables_for != t) build_candidate_tables(h, nl);   // (prepare_frame built them and stored them in the attribute bank)
     seg(7);
     if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
     st->m1 = n1; st->has_m1 = 1;
     seg(3);
     // ---- between the stages: outlier matches dropped, the optimised pose becomes the frame's pose, the local map is put together
-    const int nsel = select_local_points(h, n, nl, h->outl.data(), pose);
+    const int nsel = select_local_points(h, n, nl, h->outl.data(), pose, h->tables_for != t);
     n2p = nsel;
     // ---- Tracking::TrackLocalMap's numeric body, enqueued (Tracking.cc:725-736, 803-851), from the motion-model stage's pose
     h->m2.assign(n, -1);
@@ -458,10 +465,15 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     h->c2_n2 = 0; h->c2_ninl = 0;
     seg(7);
     if ((rc = asd_track_async(ctx)) != ASD_OK) return rc;
-    if ((rc = asd_track_local_points_bank(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->sel.data(), h->T1,
-                                          h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose, h->m2.data(), &h->c2_n2,
-                                          h->outl2.data(), &h->c2_ninl)) != ASD_OK)
-      return rc;
+    // the selected points by ROW of the banks (their attributes were stored when the frame was prepared): 4 bytes per point go up
+    if (nsel > 0 && h->tables_for == t)
+      rc = asd_track_local_points_rows(ctx, cur, nsel, h->sel.data(), h->T1, h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose,
+                                       h->m2.data(), &h->c2_n2, h->outl2.data(), &h->c2_ninl);
+    else
+      rc = asd_track_local_points_bank(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->sel.data(), h->T1,
+                                       h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose, h->m2.data(), &h->c2_n2,
+                                       h->outl2.data(), &h->c2_ninl);
+    if (rc != ASD_OK) return rc;
     seg(5);
   }
   // ---- under the local-map stage: this frame becomes the last frame, LocalBA goes to its lane, the next frame is constructed

@@ -288,6 +288,16 @@ int asd_track_local_points_bank(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, co
                                 float nn_ratio, const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur,
                                 int32_t* n_matches, uint8_t* outlier, int32_t* n_inliers);
 
+/* asd_track_local_points_bank with the map points named by ROW of both banks (descriptor bank + the attribute bank below: position, normal,
+ * distance range as asd_mpbank_put stored them): Tracking::SearchLocalPoints' loop (Tracking.cc:817-835) walks mvpLocalMapPoints, whose
+ * attributes change once per keyframe (UpdateNormalAndDepth) -- per frame the host then names the points it selected (4 bytes each) instead
+ * of gathering and uploading 36 bytes per point.  Results as asd_track_local_points_bank on the same attributes, bit for bit.  n_mp >= 1;
+ * sizes beyond the device replay return ASD_ERR_CAPACITY (use the _bank form).  Honours asd_track_async / asd_track_finish. */
+int asd_track_local_points_rows(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const int32_t* rows, const float* Tcw, const float* K,
+                                float viewing_cos_limit, const uint8_t* occupied, const float* cur_Xw, float th, float nn_ratio,
+                                const uint8_t* mp_obs_positive, double* pose7, int32_t* match_cur, int32_t* n_matches, uint8_t* outlier,
+                                int32_t* n_inliers);
+
 /* Map-point attribute bank, the companion of the descriptor bank (same row ids): MapPoint::mWorldPos, mNormalVector,
  * mfMinDistance, mfMaxDistance (MapPoint.cc:60-77, 340-391; rewritten by UpdateNormalAndDepth once per keyframe, read by
  * Frame::isInFrustum for every local map point of every frame, Frame.cc:160-217).  Xw[n][3], normal[n][3], min_dist[n],

@@ -234,6 +234,17 @@ def test_track_local_points_equals_frustum_plus_chain(hip, oracle, synth, n_mp, 
     for a, b in zip(gb, exp):
         np.testing.assert_array_equal(a, b)
     assert got[1] > 0 and got[4] > 100
+    # the map points by ROW of the descriptor + attribute banks (asd_track_local_points_rows): same attributes, same bits
+    hip.mpbank_put(12000, Xw, normal, mind, maxd)
+    gr = hip.track_local_points_rows(0, 2000, np.arange(12000, 12000 + n_mp, dtype=np.int32), T, K, occupied, cur_Xw, th, 0.8, pose0)
+    for a, b in zip(gr, exp):
+        np.testing.assert_array_equal(a, b)
+    sub = np.nonzero(rng.uniform(size=n_mp) < 0.6)[0].astype(np.int32)          # a selection of the bank's points, as Tracking names them per frame
+    e2 = hip.track_local_points(0, 2000, Xw[sub], normal[sub], mind[sub], maxd[sub], 12000 + sub, T, K, occupied, cur_Xw, th, 0.8, pose0)
+    assert hip.track_local_points_rows(0, 2000, 12000 + sub, T, K, occupied, cur_Xw, th, 0.8, pose0, split=True) is None
+    g2 = hip.track_finish()
+    for a, b in zip(g2, e2):
+        np.testing.assert_array_equal(a, b)
     # split in two: every input is consumed when the call returns
     cp = [a.copy() for a in (Xw, normal, mind, maxd, occupied, cur_Xw, pose0)]
     assert hip.track_local_points(0, 2000, cp[0], cp[1], cp[2], cp[3], desc, T, K, cp[4], cp[5], th, 0.8, cp[6], split=True) is None
