@@ -814,7 +814,8 @@ struct ChainHook {
   // (h_tab: the same tables inside the pinned upload block; tail: the copy the kernel carries, see UploadTail)
   std::function<int(WinQuery* d_queries, void* const* d_tab, void* const* h_tab, const UploadTail& tail)> prepare;
   // enqueue the chain's kernels: match table, the uploaded tables, where the results go (all device pointers)
-  std::function<int(const int* d_match, void* const* d_tab, void* d_result)> enqueue;
+  // fused (may be null): the stage's claim replay, to run in FRONT of the solver inside its workgroup (k_resolve_pose) instead of as a kernel of its own
+  std::function<int(const int* d_match, void* const* d_tab, void* d_result, const AsdFusedReplay* fused)> enqueue;
   const void* h_result = nullptr;     // out: the chain's results on the host after the call
   bool kp_flags = false;              // out: the form pose_chain_enqueue gave the flags in that block (per keypoint + edge count, or per edge) --
                                       // carried with the chain: the context-wide pose_chain_kp_flags belongs to whichever chain was enqueued last
@@ -922,14 +923,26 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
         hipLaunchKernelGGL(kern, dim3(1), dim3(kResolve2Threads), lds, st, a);
         return hipGetLastError();
       };
-      if (nq <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 2>));
-      else ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 4>));
-    }
-    if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
-    if (chain) {
-      if ((rc = chain->enqueue(d_out, d_tab, zero_copy ? down.host<void>(o_res) : down.dev<void>(o_res))) != ASD_OK) return rc;
-      chain->h_result = down.host<void>(o_res);
-      chain->kp_flags = ctx->pose_chain_kp_flags;
+      // With a PoseOptimization chained behind the search, replay and solver are ONE workgroup (k_resolve_pose: resolve2_body on the solver's
+      // threads, then the solver) where the stage's tables fit: as two kernels the solver waits 35-55 us for a CU of its own behind the replay,
+      // beside the extractor's ASDNet workgroups (round 4 had this form in asd_track_frame only; the two-call form is the headline since round 5)
+      const bool fuse = chain && pose_chain_fused_ok(ctx, KIND, nq, n_cur, lds);
+      if (fuse) {
+        const AsdFusedReplay fr{&a, KIND, nq, lds};
+        if ((rc = chain->enqueue(d_out, d_tab, down.host<void>(o_res), &fr)) != ASD_OK) return rc;
+        chain->h_result = down.host<void>(o_res);
+        chain->kp_flags = ctx->pose_chain_kp_flags;
+        if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));   // (the "match" stage clock then covers the solver too)
+      } else {
+        if (nq <= 2 * kResolve2Threads) ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 2>));
+        else ASD_HIP_CHECK(ctx, launch(k_resolve2<KIND, 4>));
+        if (stage_timing) ASD_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, st));
+        if (chain) {
+          if ((rc = chain->enqueue(d_out, d_tab, zero_copy ? down.host<void>(o_res) : down.dev<void>(o_res), nullptr)) != ASD_OK) return rc;
+          chain->h_result = down.host<void>(o_res);
+          chain->kp_flags = ctx->pose_chain_kp_flags;
+        }
+      }
     }
     if (!zero_copy) ASD_HIP_CHECK(ctx, down.download(st));
     // the completion waits for THIS point of the stream, not for the stream: a split-phase caller enqueues the next frame's grid
@@ -1510,8 +1523,9 @@ int track_motion_model_impl(asd_ctx* ctx, int32_t slot_cur, int32_t slot_last, c
   auto chain = std::make_shared<ChainHook>();
   chain->src[0] = Xw; chain->bytes[0] = (size_t)L->n * 12;
   chain->result_bytes = pose_chain_io_bytes(C->n);
-  chain->enqueue = [ctx, C, Kd, p0](const int* d_match, void* const* d_tab, void* d_result) {
-    return pose_chain_enqueue(ctx, C->n, d_match, C->d_kp, static_cast<const float*>(d_tab[0]), nullptr, nullptr, p0.data(), Kd.data(), static_cast<double*>(d_result));
+  chain->enqueue = [ctx, C, Kd, p0](const int* d_match, void* const* d_tab, void* d_result, const AsdFusedReplay* fused) {
+    return pose_chain_enqueue(ctx, C->n, d_match, C->d_kp, static_cast<const float*>(d_tab[0]), nullptr, nullptr, p0.data(), Kd.data(), static_cast<double*>(d_result),
+                              nullptr, nullptr, nullptr, fused);
   };
   if (has_mp && Xw && Tcw && L->n > 0) {   // the projection loop on the device too (2000 points: ~45 us of host time otherwise)
     chain->src[1] = has_mp; chain->bytes[1] = (size_t)L->n;
@@ -1563,9 +1577,9 @@ int track_local_map_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const uin
   chain->src[1] = cur_Xw; chain->bytes[1] = (size_t)F->n * 12;
   chain->src[2] = occupied; chain->bytes[2] = (size_t)F->n;
   chain->result_bytes = pose_chain_io_bytes(F->n);
-  chain->enqueue = [ctx, F, Kd, p0](const int* d_match, void* const* d_tab, void* d_result) {
+  chain->enqueue = [ctx, F, Kd, p0](const int* d_match, void* const* d_tab, void* d_result, const AsdFusedReplay* fused) {
     return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
-                              static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(), static_cast<double*>(d_result));
+                              static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(), static_cast<double*>(d_result), nullptr, nullptr, nullptr, fused);
   };
   bool chained = false;
   std::function<int()> search_done;
@@ -1657,9 +1671,9 @@ int track_local_points_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, const 
     ASD_HIP_CHECK(ctx, hipGetLastError());
     return ASD_OK;
   };
-  chain->enqueue = [ctx, F, Kd, p0](const int* d_match, void* const* d_tab, void* d_result) {
+  chain->enqueue = [ctx, F, Kd, p0](const int* d_match, void* const* d_tab, void* d_result, const AsdFusedReplay* fused) {
     return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, static_cast<const float*>(d_tab[0]), static_cast<const uint8_t*>(d_tab[2]),
-                              static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(), static_cast<double*>(d_result));
+                              static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(), static_cast<double*>(d_result), nullptr, nullptr, nullptr, fused);
   };
   std::function<int()> search_done;
   rc = search_and_resolve<1>(ctx, m, *F, n_mp, desc ? m->d_qdesc : m->d_bank, nullptr, mp_obs_positive, occupied, 0, nn_ratio, match_cur, n_matches,
@@ -1736,9 +1750,9 @@ int track_local_points_rows_impl(asd_ctx* ctx, int32_t slot_cur, int32_t n_mp, c
     return ASD_OK;
   };
   float* d_cxw = m->d_cxw;
-  chain->enqueue = [ctx, F, Kd, p0, d_cxw](const int* d_match, void* const* d_tab, void* d_result) {
+  chain->enqueue = [ctx, F, Kd, p0, d_cxw](const int* d_match, void* const* d_tab, void* d_result, const AsdFusedReplay* fused) {
     return pose_chain_enqueue(ctx, F->n, d_match, F->d_kp, d_cxw, static_cast<const uint8_t*>(d_tab[2]), static_cast<const float*>(d_tab[1]), p0.data(), Kd.data(),
-                              static_cast<double*>(d_result));
+                              static_cast<double*>(d_result), nullptr, nullptr, nullptr, fused);
   };
   std::function<int()> search_done;
   rc = search_and_resolve<1>(ctx, m, *F, n_mp, m->d_bank, nullptr, mp_obs_positive, occupied, 0, nn_ratio, match_cur, n_matches, chain.get(), defer ? &search_done : nullptr);
