@@ -65,7 +65,7 @@ struct asd_track_handle {
   int32_t prep_stereo = -1;   // stereo matches of the prepared frame
   int frames_on_host = 0;   // the frame pointers are (pinned) host memory: asd_extract_submit(device_resident = 0), the image crosses PCIe per frame
   int bank_base = 0;        // first bank row of the map the prepared frame is tracked against
-  std::vector<int32_t> last_cand, cand_rows;
+  std::vector<int32_t> last_cand, cand_rows, sel_rows;
   asd_track_frame_args fa;
   int32_t f_n1 = 0, f_inl1 = 0, f_n2 = 0, f_inl2 = 0;
   double f_pose[7], f_pose1[7];
@@ -283,7 +283,9 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
       kps_r = h->kps_r.data();
     }
   }
-  const bool chain = h->fused && h->split && h->chain;
+  // split-phase forms (two calls or one submission): the next frame is constructed on the context's second stream BESIDE the stage in flight
+  // (asd_prep_async), so it writes a third frame slot and the other bank region -- nothing the stage in flight reads
+  const bool chain = h->fused && h->split;
   if (chain) h->slot = (h->slot + 1) % 3; else h->slot ^= 1;
   seg(7);
   if ((rc = asd_frame_set(ctx, h->slot, kps, nullptr, n, 0.f, (float)h->W, 0.f, (float)h->H)) != ASD_OK) return rc;
@@ -338,6 +340,7 @@ static int prepare_frame(asd_track_handle* h, int t, const std::vector<int>& nex
     h->rows.resize(nl); h->last_cand.resize(nl); h->cand_rows.resize(n2p);
     for (int i = 0; i < nl; ++i) { h->rows[i] = base + i; h->last_cand[i] = i; }
     for (int i = 0; i < n2p; ++i) h->cand_rows[i] = base + i;
+    h->tables_for = t;
     seg(2);
   } else if (h->have_last) {
     const std::vector<asd_keypoint>& lk = h->last_kps;
@@ -428,6 +431,7 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
   const asd_keypoint* kps = h->prep_kps;
   const int32_t n = h->prep_n;
   const int cur = h->slot;
+  const int base = h->bank_base;     // the bank region that holds THIS frame's map (the next frame's goes to the other one)
   h->prep_t = -1;
   memset(st, 0, sizeof *st);
   st->n_kp = n;
@@ -466,11 +470,14 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     seg(7);
     if ((rc = asd_track_async(ctx)) != ASD_OK) return rc;
     // the selected points by ROW of the banks (their attributes were stored when the frame was prepared): 4 bytes per point go up
-    if (nsel > 0 && h->tables_for == t)
-      rc = asd_track_local_points_rows(ctx, cur, nsel, h->sel.data(), h->T1, h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose,
+    h->sel_rows.resize(nsel);
+    for (int q = 0; q < nsel; ++q) h->sel_rows[q] = base + h->sel[q];
+    if (nsel > 0 && h->tables_for == t) {
+      rc = asd_track_local_points_rows(ctx, cur, nsel, h->sel_rows.data(), h->T1, h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose,
                                        h->m2.data(), &h->c2_n2, h->outl2.data(), &h->c2_ninl);
+    }
     else
-      rc = asd_track_local_points_bank(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->sel.data(), h->T1,
+      rc = asd_track_local_points_bank(ctx, cur, nsel, h->Xs.data(), h->ns.data(), h->mind_s.data(), h->maxd_s.data(), h->sel_rows.data(), h->T1,
                                        h->K32, 0.5f, h->occ.data(), h->cur_Xw.data(), 1.0f, 0.8f, nullptr, h->c2_pose, h->m2.data(), &h->c2_n2,
                                        h->outl2.data(), &h->c2_ninl);
     if (rc != ASD_OK) return rc;
@@ -487,7 +494,13 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     after.push_back(next.back() + 1);   // the queue of frame t+1: t+2 .. t+1+lookahead (asd_track_run trims it at the end of a run)
     if ((int)after.size() > h->lookahead) after.resize(h->lookahead);
     if (h->stop_after >= 0) while (!after.empty() && after.back() > h->stop_after) after.pop_back();
-    if ((rc = prepare_frame(h, t + 1, after)) != ASD_OK) { if (had_last) (void)asd_track_finish(ctx); return rc; }
+    // the next frame's construction (grid, descriptor adoption, the map's bank rows) on the context's second stream, beside the local-map stage:
+    // enqueued behind it on the tracking stream, its five copy kernels (16-60 us each beside ASDNet) sat between this frame's solver and the
+    // next frame's projection -- 150 us of every frame (profiles/r05_tracking_timeline_before.txt)
+    if ((rc = asd_prep_async(ctx, 1)) != ASD_OK) { if (had_last) (void)asd_track_finish(ctx); return rc; }
+    rc = prepare_frame(h, t + 1, after);
+    const int rc2 = asd_prep_async(ctx, 0);
+    if (rc != ASD_OK || rc2 != ASD_OK) { if (had_last) (void)asd_track_finish(ctx); return rc != ASD_OK ? rc : rc2; }
     tp = std::chrono::steady_clock::now();
   }
   if (had_last) {
