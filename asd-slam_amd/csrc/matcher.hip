@@ -982,10 +982,9 @@ int search_and_resolve(asd_ctx* ctx, MatcherState* m, const AsdFrameSlot& F, int
       acc[KIND] += ctx->ms_match; rounds[KIND] += h_out[n_cur + 2];
       for (int i = 0; i < 8; ++i) st_us[KIND][i] += 0.01 * h_out[n_cur + 3 + i];
       if (++calls[KIND] % 200 == 0)
-        fprintf(stderr, "[search+resolve kind %d] device %.3f ms, %.1f iterations, %d candidates; k_resolve: staging %.1f us, iterations %.1f us (the first %.1f; bids %.1f barrier %.1f owners %.1f closing %.1f), outputs %.1f us\n", KIND,
+        fprintf(stderr, "[search+resolve kind %d] device %.3f ms, %.1f iterations, %d candidates; replay: staging %.1f us, iterations %.1f us (the first %.1f; thread 0 work %.1f, barrier + verdict %.1f), outputs %.1f us\n", KIND,
                 acc[KIND] / calls[KIND], (double)rounds[KIND] / calls[KIND], h_out[n_cur + 1], st_us[KIND][0] / calls[KIND], st_us[KIND][1] / calls[KIND],
-                st_us[KIND][3] / calls[KIND], st_us[KIND][4] / calls[KIND], st_us[KIND][5] / calls[KIND], st_us[KIND][6] / calls[KIND],
-                st_us[KIND][7] / calls[KIND], st_us[KIND][2] / calls[KIND]);
+                st_us[KIND][3] / calls[KIND], st_us[KIND][4] / calls[KIND], st_us[KIND][5] / calls[KIND], st_us[KIND][2] / calls[KIND]);
     }
     return ASD_OK;
   };
