@@ -985,6 +985,9 @@ struct BaDev {
   LmState* lm_host;   // pinned mirror, written by k_ba_lm_control / k_ba_lm_begin
   LmLog* lm_log;      // device, [kLmLogCap]
   double* partial;    // device: per-block partial sums: [0, scale_off) residual cost, [scale_off, ..) gain-ratio terms
+  int* tickets;       // device, zero between launches: [0] workgroups of k_ba_error that have stored their partial sum, [1 + h] of k_ba_reduce's
+                      // kPoseSplit workgroups of pose h.  The workgroup that draws the last ticket does what a kernel of its own did up to
+                      // round 4 (the Levenberg control behind k_ba_error, the second stage of the pose sums) and puts the counter back to 0
   int scale_off, gE, gL, gP;
 };
 
@@ -1002,8 +1005,35 @@ __device__ inline void ba_project_error(const BaDev& d, int e, int buf) {
 }
 
 // computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114): partial[blockIdx] = block sum
-__global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust, int always) {
+// Hand-over of a few values between the workgroups of ONE launch (they may sit on different XCDs, each with an L2 of its own): the values
+// are stored write-through (agent-scope atomic stores: sc1) and read back the same way, every wave waits for its stores, the
+// workgroup draws a ticket.  No release fence: an agent-scope release is a write-back of the XCD's whole L2 -- behind k_ba_linearize that is
+// 12 MB of per-edge blocks, and __threadfence() in every workgroup made a trial 32 us SLOWER than the two launches this replaces.
+__device__ inline void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// true in every thread of the workgroup that is the last of the launch's `total` to arrive here; the counter is back at zero afterwards
+__device__ inline bool last_workgroup(int* ticket, int total) {
+  __shared__ int last_flag;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asd_syncthreads();
+  if (threadIdx.x == 0) {
+    const int drawn = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = drawn == total - 1;
+    if (last_flag) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asd_syncthreads();
+  return last_flag != 0;
+}
+constexpr int kLmThreads = 256, kLmMaxPartials = 2048;
+__device__ void lm_begin_body(const BaDev& d, int iterations, double* sh);
+__device__ void lm_control_body(const BaDev& d, double* sh);
+
+// computeActiveErrors + the robustified chi2 of the estimate under test; the workgroup that finishes last runs the Levenberg control on the
+// launch's sums (k_ba_lm_begin / k_ba_lm_control were launches of their own up to round 4: 5 us per trial for one thread's work)
+__global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust, int always, int iterations) {
   __shared__ double red[4 * 32], out[1];
+  __shared__ double sh[kLmMaxPartials];
+  static_assert(kLmThreads == 256, "the control code runs in a workgroup of k_ba_error");
   if (!always && d.lm->done) return;
   const int buf = always ? d.lm->cur : 1 - d.lm->cur;   // the round's first pass looks at the accepted estimate, every other at the trial
   const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1019,7 +1049,10 @@ __global__ __launch_bounds__(256) void k_ba_error(BaDev d, int robust, int alway
     }
   }
   block_reduce<1>(part, red, out);
-  if (threadIdx.x == 0) d.partial[blockIdx.x] = out[0];
+  if (threadIdx.x == 0) st_agent(d.partial + blockIdx.x, out[0]);
+  if (!last_workgroup(d.tickets, (int)gridDim.x)) return;
+  if (always) lm_begin_body(d, iterations, sh);
+  else lm_control_body(d, sh);
 }
 
 // linearizeOplus + constructQuadraticForm per active edge (uses the stored error, like g2o)
@@ -1097,7 +1130,16 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev d) {
       for (int q = 0; q < 27; ++q) acc[q] += hc[q];
     }
     block_reduce<27>(acc, red, out);
-    if (threadIdx.x < 27) d.HppPart[((size_t)h * kPoseSplit + sp) * 27 + threadIdx.x] = out[threadIdx.x];
+    if (threadIdx.x < 27) st_agent(d.HppPart + ((size_t)h * kPoseSplit + sp) * 27 + threadIdx.x, out[threadIdx.x]);
+    // second stage, by the last of the pose's workgroups to get here: the kPoseSplit partials in index order (k_ba_reduce_pose2 up to round 4)
+    if (!last_workgroup(d.tickets + 1 + h, kPoseSplit)) return;
+    const int t = threadIdx.x;
+    if (t >= 27) return;
+    double s = 0.0;
+    for (int q = 0; q < kPoseSplit; ++q) s += ld_agent(d.HppPart + ((size_t)h * kPoseSplit + q) * 27 + t);
+    d.Hpp[(size_t)h * 27 + t] = s;
+    // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
+    if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(&d.lm->maxdiag_bits, fabs(s));
     return;
   }
   const int h = ((int)blockIdx.x - npose_blk) * 256 + threadIdx.x;
@@ -1108,16 +1150,6 @@ __global__ __launch_bounds__(256) void k_ba_reduce(BaDev d) {
     for (int q = 0; q < 9; ++q) s[q] += d.Hl[(size_t)k * 9 + q];
   for (int q = 0; q < 9; ++q) d.Hll[(size_t)h * 9 + q] = s[q];
   atomic_max_pos_double(&d.lm->maxdiag_bits, fmax(fabs(s[0]), fmax(fabs(s[3]), fabs(s[5]))));
-}
-__global__ __launch_bounds__(64) void k_ba_reduce_pose2(BaDev d) {
-  if (d.lm->done || !d.lm->need_lin) return;
-  const int h = blockIdx.x, t = threadIdx.x;
-  if (t >= 27) return;
-  double s = 0.0;
-  for (int sp = 0; sp < kPoseSplit; ++sp) s += d.HppPart[((size_t)h * kPoseSplit + sp) * 27 + t];
-  d.Hpp[(size_t)h * 27 + t] = s;
-  // diagonal entries of the upper-packed 6x6: 0, 6, 11, 15, 18, 20
-  if (t == 0 || t == 6 || t == 11 || t == 15 || t == 18 || t == 20) atomic_max_pos_double(&d.lm->maxdiag_bits, fabs(s));
 }
 
 // per landmark: Dinv = (Hll + lambda I)^-1 (symmetric 3x3 by cofactors) and db = Dinv bl.  Evaluated where it is needed (per edge in
@@ -1690,16 +1722,14 @@ __device__ inline double cube_rn(double x) {
   return q + (f + e * x);
 }
 // the per-workgroup partial sums come into LDS with one coalesced read; thread 0 then adds them in index order
-constexpr int kLmThreads = 256, kLmMaxPartials = 2048;
 __device__ inline int lm_stage_partials(const BaDev& d, double* sh) {
   const int np = min(d.scale_off + d.gL + d.gP, kLmMaxPartials);
-  for (int i = threadIdx.x; i < np; i += kLmThreads) sh[i] = d.partial[i];
+  for (int i = threadIdx.x; i < np; i += kLmThreads) sh[i] = ld_agent(d.partial + i);   // this launch's own sums among them
   asd_syncthreads();
   return np;
 }
 // start of a round: computeActiveErrors + activeRobustChi2 have just run (k_ba_error, always)
-__global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin(BaDev d, int iterations) {
-  __shared__ double sh[kLmMaxPartials];
+__device__ void lm_begin_body(const BaDev& d, int iterations, double* sh) {
   lm_stage_partials(d, sh);
   if (threadIdx.x != 0) return;
   LmState S;
@@ -1713,9 +1743,7 @@ __global__ __launch_bounds__(kLmThreads) void k_ba_lm_begin(BaDev d, int iterati
   *d.lm_host = S;
 }
 // behind every trial (solve, update, computeActiveErrors): accept or reject, next lambda, end of iteration / of the round
-__global__ __launch_bounds__(kLmThreads) void k_ba_lm_control(BaDev d) {
-  __shared__ double sh[kLmMaxPartials];
-  if (d.lm->done) return;
+__device__ void lm_control_body(const BaDev& d, double* sh) {
   lm_stage_partials(d, sh);
   if (threadIdx.x != 0) return;
   LmState S = *d.lm;
@@ -2350,7 +2378,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     s->h_partial_cap = npartial * 2;
   }
   if (!s->h_lm) ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_lm), sizeof(LmState)));
-  ENS(lm, sizeof(LmState) + 64 + sizeof(LmLog) * kLmLogCap);
+  ENS(lm, sizeof(LmState) + 64 + sizeof(LmLog) * kLmLogCap + sizeof(int) * ((size_t)P + 2));
   if (npartial > (size_t)kLmMaxPartials) { ctx->set_error("asd_local_ba: %d edges exceed the control kernel's %d partial sums", E, kLmMaxPartials); return ASD_ERR_CAPACITY; }
 
   // upload the problem: poses normalised like SE3Quat's constructor does
@@ -2398,6 +2426,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   d.lm_host = s->h_lm;
   d.lm_log = reinterpret_cast<LmLog*>(s->lm.as<char>() + sizeof(LmState) + 64 - (sizeof(LmState) % 8));
   d.partial = s->partial.as<double>();
+  d.tickets = reinterpret_cast<int*>(reinterpret_cast<char*>(d.lm_log) + sizeof(LmLog) * kLmLogCap);
+  ASD_HIP_CHECK(ctx, hipMemsetAsync(d.tickets, 0, sizeof(int) * ((size_t)P + 2), st));
 
   const auto t_uploaded = std::chrono::steady_clock::now();
   std::vector<uint8_t> level(E, 0);
@@ -2619,7 +2649,6 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     auto enqueue_block = [&]() -> int {
       hipLaunchKernelGGL(k_ba_linearize, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
       hipLaunchKernelGGL(k_ba_reduce, dim3(nPf * kPoseSplit + gL), dim3(256), 0, st, d);
-      if (nPf > 0) hipLaunchKernelGGL(k_ba_reduce_pose2, dim3(nPf), dim3(64), 0, st, d);
       if (nPf > 0) {
         hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_ba_schur, dim3(nblk + nPf), dim3(kSchurThreads), 0, st, d, sb, nblk);
@@ -2641,14 +2670,12 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         }
       }
       hipLaunchKernelGGL(k_ba_step, dim3(gL + gP), dim3(256), 0, st, d);
-      hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 0);
-      hipLaunchKernelGGL(k_ba_lm_control, dim3(1), dim3(kLmThreads), 0, st, d);
+      hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 0, 0);   // + the Levenberg control, in its last workgroup
       ASD_HIP_CHECK(ctx, hipGetLastError());
       return ASD_OK;
     };
     // computeActiveErrors + activeRobustChi2 at the round's first estimate (levenberg.cpp:70-76), state reset
-    hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 1);
-    hipLaunchKernelGGL(k_ba_lm_begin, dim3(1), dim3(kLmThreads), 0, st, d, iterations);
+    hipLaunchKernelGGL(k_ba_error, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0, 1, iterations);
     ASD_HIP_CHECK(ctx, hipGetLastError());
     int& predicted = s->lm_blocks[round_idx];
     int chunk = predicted > 0 ? predicted : iterations;
