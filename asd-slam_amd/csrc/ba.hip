@@ -2066,6 +2066,7 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a,
 struct BaState {
   DevBuf lvl, HppPart, fixed_d;
   int* h_counts = nullptr;      // pinned [4]: nPf, nLa, Ea, pairs of the structure built on the device
+  hipEvent_t ev_counts = nullptr;   // behind k_ba_struct_offsets: nPf, nLa, Ea are on the host while the scatter and the sort still run
   DevBuf out1, Apack, sblk;   // sblk: the round's structure arrays in one block (uploaded from the pinned h_sblk)
   char* h_sblk = nullptr;
   size_t h_sblk_cap = 0;
@@ -2135,6 +2136,7 @@ void ba_free(asd_ctx* ctx) {
   if (s->h_partial) (void)hipHostFree(s->h_partial);
   if (s->h_lm) (void)hipHostFree(s->h_lm);
   if (s->h_counts) (void)hipHostFree(s->h_counts);
+  if (s->ev_counts) (void)hipEventDestroy(s->ev_counts);
   if (s->h_sblk) (void)hipHostFree(s->h_sblk);
   if (s->h_po) (void)hipHostFree(s->h_po);
   delete s;
@@ -2403,6 +2405,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ENS(fixed_d, (size_t)std::max(P, 1));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(s->fixed_d.p, pr->fixed, (size_t)P, hipMemcpyHostToDevice, st));
   if (!s->h_counts) ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), 64));
+  if (!s->ev_counts) ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&s->ev_counts, hipEventDisableTiming));
   ASD_HIP_CHECK(ctx, hipEventRecord(ev0, st));
 
   BaDev d{};
@@ -2506,11 +2509,14 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         hipLaunchKernelGGL(k_ba_struct_vertices, dim3(1), dim3(kStructThreads), 0, st, sd, pflag);
         hipLaunchKernelGGL(k_ba_struct_count, dim3(gEs), dim3(256), 0, st, sd);
         hipLaunchKernelGGL(k_ba_struct_offsets, dim3(1), dim3(kStructThreads), 0, st, sd);
+        ASD_HIP_CHECK(ctx, hipEventRecord(s->ev_counts, st));
         hipLaunchKernelGGL(k_ba_struct_scatter, dim3(gEs), dim3(256), 0, st, sd);
         hipLaunchKernelGGL(k_ba_struct_sort, dim3((L + 255) / 256), dim3(256), 0, st, sd);
       }
       ASD_HIP_CHECK(ctx, hipGetLastError());
-      ASD_HIP_CHECK(ctx, hipStreamSynchronize(st));   // the launch dimensions of everything that follows: nPf, nLa
+      // the launch dimensions of everything that follows (nPf, nLa, Ea) are complete behind k_ba_struct_offsets: the host reads them and
+      // enqueues the rest while the scatter and the sort run (a synchronisation behind the sort left the stream empty for 20-50 us)
+      ASD_HIP_CHECK(ctx, hipEventSynchronize(s->ev_counts));
       nPf = s->h_counts[0]; nLa = s->h_counts[1]; Ea = s->h_counts[2];
       nblk = nPf * (nPf + 1) / 2;
       if (nPf > 0) {
