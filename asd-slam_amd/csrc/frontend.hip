@@ -1027,7 +1027,15 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     // ioctl; round 2 also saw hipStreamDestroy itself hang); leaked, rocprofiler-sdk's static destructor segfaults inside
     // libhsa-runtime64 when the process was profiled.  Both reproduce without this library (tools/ubench/masked_stream_exit.hip,
     // tools/diag/masked_stream_py.py; profiles/r03_teardown_diagnostics.txt), so the mechanism is gone rather than worked around;
-    // ASD_EXTRACT_RESERVE_CUS is ignored.  The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
+    // ASD_EXTRACT_RESERVE_CUS is ignored.  Looked at again in round 5 (the masked stream created once per process and leaked, A/B on one box):
+    // with 16 CUs kept out of the ASDNet stream the tracking chain drops from 0.62 to 0.45 ms per frame -- and the tracking thread then
+    // waits 0.15 ms per frame for the extractor (forward 0.59 -> 0.62 ms on 240 CUs plus its 50-70 us of read-back between forwards):
+    // 1228-1248 frames/s against 1235-1238, nothing gained (1284 with the descriptor read-back skipped, i.e. +4 % is the bound of what
+    // a cheaper read-back could add).  The read-back on a stream of its own was tried for that and is a trap: ONE MORE STREAM in the
+    // process changes how the runtime spreads the streams over its hardware queues -- with the stream merely existing the ASDNet forward
+    // read 0.72 instead of 0.59 ms (1030-1100 frames/s).  Six streams (tracking, frame construction, ASDNet, two front halves, the null
+    // stream's copies) map to six queues today (rocprofv3 kernel trace: Queue_Id 1-6); a seventh does not get its own.
+    // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
     // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
     // will ever take (asd_extract_wait would block forever).
     int prio_least = 0, prio_greatest = 0;

@@ -99,11 +99,15 @@ __global__ __launch_bounds__(64 * kSearchWaves) void k_window_search(GridDev G, 
     if (!(fabsf(dx) < Q.r && fabsf(dy) < Q.r)) ok = false;
     return ok;
   };
+  // the query's row is the same for the whole wave: read through the scalar cache (no vector registers, no address per lane), which leaves
+  // room for sixteen candidate quads in flight per lane -- two dependent round trips per distance instead of four (beside the ASDNet
+  // grids a dependent read takes 2-3 us, and this kernel's time is its waves' chains of them)
+  const int qrow_u = __builtin_amdgcn_readfirstlane(Q.qrow < 0 ? 0 : Q.qrow);
   auto distance = [&](int idx) {   // exact summation order of DescriptorDistance (sequential f32)
-    const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)Q.qrow * 128);
+    const float4* a = reinterpret_cast<const float4*>(qdesc + (size_t)qrow_u * 128);
     const float4* bb = reinterpret_cast<const float4*>(cdesc + (size_t)idx * 128);
     float sqd = 0.f;
-#pragma unroll 8
+#pragma unroll 16
     for (int k = 0; k < 32; ++k) {
       const float4 x = a[k], y = bb[k];
       float d;
