@@ -481,6 +481,10 @@ __global__ __launch_bounds__(256) void k_conv_mfma_p(const float* __restrict__ i
 #define ASD_X3_S16 1
 #endif
 #define ASD_X3_PD 2  // A-operand prefetch distance in sub-tiles
+#ifndef ASD_X3_RB
+#define ASD_X3_RB 3  // chunks of B operands (weights) in flight per wave, where the layer's chunk count divides by it.  Round 5, N = 2000:
+                     // 6 -> conv4 97 -> 105 us, conv5 66 -> 64, conv6 unchanged; 9 -> conv2 150 -> 275 (registers), conv3 96 -> 93, conv5 84, conv6 109
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -713,7 +717,7 @@ __device__ __forceinline__ void conv_x3_tile(const int bid, const void* __restri
   };
   // B operands run RB - 1 chunks ahead through a register ring of RB slots; the chunk loop is unrolled RB times so that the
   // slot of every chunk is a compile-time constant (no register copies)
-  constexpr int RB = 3;
+  constexpr int RB = C::NCHUNK % ASD_X3_RB == 0 ? ASD_X3_RB : 3;
   static_assert(C::NCHUNK % RB == 0, "chunk count");
   u32x4 br[RB][NB][NP];
 #pragma unroll

@@ -1035,6 +1035,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     // process changes how the runtime spreads the streams over its hardware queues -- with the stream merely existing the ASDNet forward
     // read 0.72 instead of 0.59 ms (1030-1100 frames/s).  Six streams (tracking, frame construction, ASDNet, two front halves, the null
     // stream's copies) map to six queues today (rocprofv3 kernel trace: Queue_Id 1-6); a seventh does not get its own.
+    // With a read-ahead of five frames instead of three beside the 16 reserved CUs the waiting goes away (tracking 0.555 ms per frame) but
+    // LocalBA, which then never has the chip to itself, takes 3.3 instead of 2.75 ms: 1285-1289 against 1240-1257 frames/s at K = 300 and
+    // nothing at the driver's K = 20 (two LocalBAs in twenty frames) -- not worth a stream that cannot be destroyed.
     // The extractor is built completely -- streams, events, slots, worker thread -- before ctx->ax publishes it: a failure on
     // the way leaves ctx->ax null and everything released, so the next call starts over instead of queueing a job no worker
     // will ever take (asd_extract_wait would block forever).
