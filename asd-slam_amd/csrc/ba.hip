@@ -425,6 +425,9 @@ __device__ inline void pose_pass(A& a, const EdgeStore<MODE>& E, const uint8_t* 
   const int iters = (n + kPoseThreads - 1) / kPoseThreads;
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
+    // a wave whose 64 edges of this iteration all lie beyond the list is done (wave-uniform): with 1250 edges on 512 threads the third
+    // iteration holds edges for four of the eight waves only -- the other four ran it with weight 0, a sixth of the pass's fp64 issue slots
+    if (it * kPoseThreads + (int)(threadIdx.x & ~63u) >= n) break;
     const int i0 = threadIdx.x + it * kPoseThreads;
     const int i = min(i0, n - 1);
     const bool act = i0 < n && !lvl[i];
