@@ -18,7 +18,7 @@
 //   k_ba_error      edge-parallel residual + robust cost            -> per-block partial sums
 //   k_ba_linearize  edge-parallel Jacobians, Huber weight, per-edge blocks (Hpp/Hll/Hpl parts)
 //   k_ba_reduce_*   per-pose / per-landmark segmented sums (CSR built once per round on the host)
-//   k_ba_edge_y     edge-parallel (Hll + lambda I)^-1 (recomputed per edge), Y = B*Dinv, c = B*db
+//   (k_ba_edge_y, rounds 1-4: Y = B*Dinv, c = B*db per edge; since round 5 formed inside k_ba_schur)
 //   k_ba_schur      one workgroup per upper 6x6 block: Hpp + lambda I - sum_l (B Dinv) B^T  (dense)
 //   k_ba_chol       blocked Cholesky + triangular solves in one workgroup
 //   k_ba_step       landmark-parallel xl = Dinv (bl - B^T xp) + pose-parallel oplus into the TRIAL buffer, gain-ratio partials
@@ -967,12 +967,11 @@ struct BaDev {
   const int* pt_start;   // [nLa+1] into act-order k
   const int* ps_start;   // [nPf+1]
   const int* ps_edges;   // k indices of each free pose's edges
+  const int* ps_h;       // ... and the landmark (h index) of each of them
   // per active edge (index k)
   double* Bk;   // [Ea][18]
   double* Hc;   // [Ea][27]  (21 upper of Jc^T W Jc, 6 of b)
   double* Hl;   // [Ea][9]   (6 upper of Jp^T W Jp, 3 of b)
-  double* Yk;   // [Ea][18]  B * Dinv
-  double* ck;   // [Ea][6]   B * db
   // per vertex
   double* Hpp;  // [nPf][27]
   double* HppPart;  // [nPf][kPoseSplit][27] partial sums of k_ba_reduce_pose
@@ -1167,33 +1166,18 @@ __device__ inline void point_dinv(const double* H, double lambda, double (&I)[9]
   for (int r = 0; r < 3; ++r) dbv[r] = I[r * 3] * H[6] + I[r * 3 + 1] * H[7] + I[r * 3 + 2] * H[8];
 }
 
-// Y_k = B_k Dinv_l and c_k = B_k (Dinv_l bl) for every active edge to a free pose: one lane per edge (the per-landmark
-// loop this replaces ran on 24 workgroups only and read its edges with an 18-double stride between lanes)
-__global__ __launch_bounds__(256) void k_ba_edge_y(BaDev d) {
-  if (d.lm->done) return;
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= d.Ea) return;
-  const int e = d.act[k];
-  if (d.pose_h[d.e_ps[e]] < 0) return;
-  const int h = d.pt_h[d.e_pt[e]];
-  double I[9], dbv[3];
-  point_dinv(d.Hll + (size_t)h * 9, lm_lambda(d.lm), I, dbv);
-  const double* B = d.Bk + (size_t)k * 18;
-  double* Y = d.Yk + (size_t)k * 18;
-  double* cc = d.ck + (size_t)k * 6;
-  for (int r = 0; r < 6; ++r) {
-    for (int q = 0; q < 3; ++q) Y[r * 3 + q] = B[r * 3] * I[q] + B[r * 3 + 1] * I[3 + q] + B[r * 3 + 2] * I[6 + q];
-    cc[r] = B[r * 3] * dbv[0] + B[r * 3 + 1] * dbv[1] + B[r * 3 + 2] * dbv[2];
-  }
-}
-
 // Schur complement, one workgroup per upper block (bi <= bj):
 //   A(bi,bj) = [bi==bj](Hpp + lambda I) - sum_pairs Y_a B_b^T ;  bs(bi) = bp - sum_edges c
 // pairs of a block are (ka, kb) act-order indices, grouped on the host (fixed order).
+// Y_a = B_a Dinv_l and c_k = B_k (Dinv_l bl) are formed HERE, per pair / per edge, from the landmark's Hll (round 5; up to round 4 a kernel
+// of its own, k_ba_edge_y, wrote them per edge: 11 us and 5.6 MB per trial for ~100 flops per pair that this kernel's lanes have time for --
+// they wait for their gathers).  The landmark of a pair / of a pose's edge comes with the lists (pair_h, ps_h), so its Hll is fetched beside
+// the B blocks, not behind them.
 struct SchurBlocks {
   const int* blk_i; const int* blk_j;  // [nblk]
   const int* pair_start;               // [nblk+1]
   const int2* pairs;
+  const int* pair_h;                   // landmark (h index) of every pair: its two edges observe the same one
 };
 // Latency, not arithmetic, sets this kernel's time (6 M fp64 FMAs chip-wide): a diagonal block has ~1200 pairs whose operands sit
 // behind two dependent gathers (pair -> edge indices -> 2 x 144 B).  Round 2's form -- 256 threads walking the list five deep, then
@@ -1207,10 +1191,13 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BaDev d, SchurBlocks
   if ((int)blockIdx.x >= nblk) {   // right-hand side of one pose
     const int h = blockIdx.x - nblk;
     double acc[6] = {0, 0, 0, 0, 0, 0};
+    const double lam = lm_lambda(d.lm);
     for (int i = d.ps_start[h] + t; i < d.ps_start[h + 1]; i += kSchurThreads) {
-      const double* cc = d.ck + (size_t)d.ps_edges[i] * 6;
+      const double* B = d.Bk + (size_t)d.ps_edges[i] * 18;
+      double I[9], dbv[3];
+      point_dinv(d.Hll + (size_t)d.ps_h[i] * 9, lam, I, dbv);
 #pragma unroll
-      for (int r = 0; r < 6; ++r) acc[r] += cc[r];
+      for (int r = 0; r < 6; ++r) acc[r] += B[r * 3] * dbv[0] + B[r * 3 + 1] * dbv[1] + B[r * 3 + 2] * dbv[2];
     }
     block_reduce<6, kSchurThreads / 64>(acc, red, out);
     if (t < 6) d.bs[6 * h + t] = d.Hpp[(size_t)h * 27 + 21 + t] - out[t];
@@ -1227,13 +1214,35 @@ __global__ __launch_bounds__(kSchurThreads) void k_ba_schur(BaDev d, SchurBlocks
     const int p1 = p0 + kSchurThreads;
     const bool two = p1 < pend;
     const int2 pr0 = sb.pairs[p0], pr1 = sb.pairs[two ? p1 : p0];
-    const double* Y0 = d.Yk + (size_t)pr0.x * 18;
+    const int h0 = sb.pair_h[p0], h1 = sb.pair_h[two ? p1 : p0];
+    const double* Y0 = d.Bk + (size_t)pr0.x * 18;
     const double* B0 = d.Bk + (size_t)pr0.y * 18;
-    const double* Y1 = d.Yk + (size_t)pr1.x * 18;
+    const double* Y1 = d.Bk + (size_t)pr1.x * 18;
     const double* B1 = d.Bk + (size_t)pr1.y * 18;
-    double y0[18], b0[18], y1[18], b1[18];
+    const double* H0 = d.Hll + (size_t)h0 * 9;
+    const double* H1 = d.Hll + (size_t)h1 * 9;
+    double y0[18], b0[18], y1[18], b1[18], hh0[9], hh1[9];
 #pragma unroll
     for (int q = 0; q < 18; ++q) { y0[q] = Y0[q]; b0[q] = B0[q]; y1[q] = Y1[q]; b1[q] = B1[q]; }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { hh0[q] = H0[q]; hh1[q] = H1[q]; }
+    {   // Y = B_a Dinv, row by row in place
+      double I[9], dbv[3];
+      point_dinv(hh0, lambda, I, dbv);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double u0 = y0[r * 3], u1 = y0[r * 3 + 1], u2 = y0[r * 3 + 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) y0[r * 3 + q] = u0 * I[q] + u1 * I[3 + q] + u2 * I[6 + q];
+      }
+      point_dinv(hh1, lambda, I, dbv);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double u0 = y1[r * 3], u1 = y1[r * 3 + 1], u2 = y1[r * 3 + 2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) y1[r * 3 + q] = u0 * I[q] + u1 * I[3 + q] + u2 * I[6 + q];
+      }
+    }
     if (!two) {
 #pragma unroll
       for (int q = 0; q < 18; ++q) y1[q] = 0.0;   // the second slot of a lone pair adds exact zeros
@@ -1664,6 +1673,10 @@ __global__ __launch_bounds__(1024) void k_ba_chol(double* __restrict__ A, const 
 // The step applied: one launch, two kinds of workgroup.  [0, gL): xl = Dinv (bl - B^T xp) and the trial point = accepted point + xl;
 // [gL, gL + gP): the trial pose = exp(xp) * accepted pose (VertexSE3Expmap::oplusImpl).  Both write the TRIAL buffer and leave the
 // accepted estimate alone; each workgroup also leaves its part of the gain-ratio denominator sum_j x_j (lambda x_j + b_j).
+// solve for the landmarks (back-substitution), update the estimate (oplus), the gain ratio's denominator terms.  (Round 5 also tried the trial
+// pass's errors and the Levenberg control in here -- a landmark's thread knows its new position, the free keyframes' new poses formed per
+// workgroup in LDS -- to save k_ba_error's launch: the edge loop per landmark thread costs what the launch saves, 1172 against 1147 us
+// per ten trials alone and no difference inside the pipeline; not kept.)
 __global__ __launch_bounds__(256) void k_ba_step(BaDev d) {
   __shared__ double red[4 * 32], out[1];
   if (d.lm->done) return;
@@ -1865,7 +1878,10 @@ struct BaStructDev {
   int* pt_free0;       // [L] act position of the landmark's first edge to a free pose
   int* ps_cnt;         // [32]
   int* ps_start; int* ps_edges;
+  int* h_of_k;         // [E] landmark h-index of the k-th edge in act order
+  int* ps_h;           // [E] landmark of every entry of ps_edges
   int* blk_i; int* blk_j; int* pair_cnt; int* pair_start; int2* pairs;
+  int* pair_h;         // landmark of every pair
   int* counts;         // pinned host [4]: nPf, nLa, Ea, pairs
 };
 constexpr int kStructThreads = 1024, kStructMaxP = 1024, kStructMaxFree = 32;
@@ -1967,6 +1983,7 @@ __global__ __launch_bounds__(256) void k_ba_struct_sort(BaStructDev a) {
     for (int i = s0; i < s1; ++i) {
       const int pv = a.pose_h[a.e_ps[a.act[i]]];
       a.ph_of_k[i] = pv;
+      a.h_of_k[i] = h;
       if (pv >= 0) { free0 = min(free0, i); if (pv < kStructMaxFree) { mask |= 1u << pv; atomicAdd(&pcnt[pv], 1); } }
     }
     a.pt_mask[h] = mask;
@@ -1993,7 +2010,7 @@ __global__ __launch_bounds__(kStructThreads) void k_ba_struct_pose_edges(BaStruc
     asd_syncthreads();
     int off = __popcll(bal & ((1ull << lane) - 1)), all = 0;
     for (int q = 0; q < NW; ++q) { if (q < w) off += wsum[q]; all += wsum[q]; }
-    if (f) a.ps_edges[run + off] = k;
+    if (f) { a.ps_edges[run + off] = k; a.ps_h[run + off] = a.h_of_k[k]; }
     run += all;
     asd_syncthreads();
   }
@@ -2050,12 +2067,12 @@ __global__ __launch_bounds__(kPairThreads) void k_ba_struct_pairs(BaStructDev a,
     for (int b = 0; b < NW; ++b) { if (b < w) off += wsum[b]; all += wsum[b]; }
     if (FILL && cnt) {
       int o = run + off;
-      if (simple) a.pairs[o] = make_int2(f0 + __popc(m & (bi - 1)), f0 + __popc(m & (bj - 1)));
+      if (simple) { a.pairs[o] = make_int2(f0 + __popc(m & (bi - 1)), f0 + __popc(m & (bj - 1))); a.pair_h[o] = h; }
       else
         for (int x = f0; x < s1; ++x)
           if (a.ph_of_k[x] == i)
             for (int y = x; y < s1; ++y)
-              if (a.ph_of_k[y] == j) a.pairs[o++] = make_int2(x, y);
+              if (a.ph_of_k[y] == j) { a.pair_h[o] = h; a.pairs[o++] = make_int2(x, y); }
     }
     run += all; total += all;
     asd_syncthreads();
@@ -2370,8 +2387,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   ENS(err, (size_t)E * 16); ENS(act, (size_t)E * 4); ENS(pose_h, (size_t)P * 4); ENS(pt_h, (size_t)L * 4);
   ENS(pose_of_h, (size_t)P * 4); ENS(pt_of_h, (size_t)L * 4); ENS(pt_start, (size_t)(L + 1) * 4);
   ENS(ps_start, (size_t)(P + 1) * 4); ENS(ps_edges, (size_t)E * 4);
-  ENS(Bk, (size_t)E * 18 * 8); ENS(Hc, (size_t)E * 27 * 8); ENS(Hl, (size_t)E * 9 * 8); ENS(Yk, (size_t)E * 18 * 8);
-  ENS(ck, (size_t)E * 6 * 8); ENS(Hpp, (size_t)P * 27 * 8); ENS(Hll, (size_t)L * 9 * 8); ENS(Dinv, (size_t)L * 6 * 8);
+  ENS(Bk, (size_t)E * 18 * 8); ENS(Hc, (size_t)E * 27 * 8); ENS(Hl, (size_t)E * 9 * 8); ENS(Hpp, (size_t)P * 27 * 8); ENS(Hll, (size_t)L * 9 * 8); ENS(Dinv, (size_t)L * 6 * 8);
   ENS(db, (size_t)L * 3 * 8); ENS(x, ((size_t)6 * P + 3 * L) * 8); ENS(A, (size_t)36 * P * P * 8); ENS(Apack, (size_t)18 * P * (P + 1) * 8); ENS(bs, (size_t)6 * P * 8);
   ENS(misc, 64); ENS(chi2, (size_t)E * 8); ENS(dpos, (size_t)E); ENS(lvl, (size_t)E); ENS(out1, (size_t)E); ENS(HppPart, (size_t)P * kPoseSplit * 27 * 8);
   const int nblk_e = (E + 255) / 256, nblk_l = (L + 255) / 256, nblk_p = (P + 255) / 256;
@@ -2421,8 +2437,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
   d.act = s->act.as<int>(); d.pose_h = s->pose_h.as<int>(); d.pt_h = s->pt_h.as<int>();
   d.pose_of_h = s->pose_of_h.as<int>(); d.pt_of_h = s->pt_of_h.as<int>(); d.pt_start = s->pt_start.as<int>();
   d.ps_start = s->ps_start.as<int>(); d.ps_edges = s->ps_edges.as<int>();
-  d.Bk = s->Bk.as<double>(); d.Hc = s->Hc.as<double>(); d.Hl = s->Hl.as<double>(); d.Yk = s->Yk.as<double>();
-  d.ck = s->ck.as<double>(); d.Hpp = s->Hpp.as<double>(); d.Hll = s->Hll.as<double>(); d.Dinv = s->Dinv.as<double>();
+  d.Bk = s->Bk.as<double>(); d.Hc = s->Hc.as<double>(); d.Hl = s->Hl.as<double>(); d.Hpp = s->Hpp.as<double>(); d.Hll = s->Hll.as<double>(); d.Dinv = s->Dinv.as<double>();
   d.db = s->db.as<double>(); d.x = s->x.as<double>(); d.A = s->A.as<double>(); d.Apack = s->Apack.as<double>(); d.bs = s->bs.as<double>();
   // status and the per-workgroup partial sums are read by the host after every trial: the kernels store them straight into
   // pinned host memory (a few hundred doubles), which removes two copy commands per trial from the lane's queue
@@ -2437,7 +2452,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
 
   const auto t_uploaded = std::chrono::steady_clock::now();
   std::vector<uint8_t> level(E, 0);
-  std::vector<int> act, pose_h(P), pt_h(L), pose_of_h, pt_of_h, pt_start, ps_start, ps_edges, blk_i, blk_j, pair_start, ph_of_k, cursor,
+  std::vector<int> act, pose_h(P), pt_h(L), pose_of_h, pt_of_h, pt_start, ps_start, ps_edges, ps_hv, blk_i, blk_j, pair_start, ph_of_k, cursor,
       row_off;
   std::vector<int2> pairs;
 
@@ -2483,7 +2498,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
       const size_t o_act = place((size_t)E * 4), o_pose_h = place((size_t)P * 4), o_pt_h = place((size_t)L * 4), o_pose_of_h = place((size_t)P * 4),
                    o_pt_of_h = place((size_t)L * 4), o_pt_start = place((size_t)(L + 1) * 4), o_ps_start = place((size_t)(P + 1) * 4),
                    o_ps_edges = place((size_t)E * 4), o_blk_i = place((size_t)std::max(nblk_max, 1) * 4), o_blk_j = place((size_t)std::max(nblk_max, 1) * 4),
-                   o_pair_start = place((size_t)(nblk_max + 1) * 4), o_pairs = place(pairs_cap * 8), o_ph = place((size_t)E * 4),
+                   o_pair_start = place((size_t)(nblk_max + 1) * 4), o_pairs = place(pairs_cap * 8), o_pair_h = place(pairs_cap * 4), o_ph = place((size_t)E * 4),
+                   o_hk = place((size_t)E * 4), o_ps_h = place((size_t)E * 4),
                    o_cursor = place((size_t)(L + 1) * 4), o_mask = place((size_t)L * 4), o_pscnt = place(kStructMaxFree * 4),
                    o_paircnt = place((size_t)std::max(std::max(nblk_max, P), 1) * 4), o_free0 = place((size_t)L * 4);
       if ((r2 = s->sblk.ensure(ctx, off)) != ASD_OK) return r2;
@@ -2500,7 +2516,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
       sd.ps_start = reinterpret_cast<int*>(db + o_ps_start); sd.ps_edges = reinterpret_cast<int*>(db + o_ps_edges);
       sd.blk_i = reinterpret_cast<int*>(db + o_blk_i); sd.blk_j = reinterpret_cast<int*>(db + o_blk_j);
       sd.pair_cnt = reinterpret_cast<int*>(db + o_paircnt); sd.pair_start = reinterpret_cast<int*>(db + o_pair_start);
-      sd.pairs = reinterpret_cast<int2*>(db + o_pairs);
+      sd.pairs = reinterpret_cast<int2*>(db + o_pairs); sd.pair_h = reinterpret_cast<int*>(db + o_pair_h);
+      sd.h_of_k = reinterpret_cast<int*>(db + o_hk); sd.ps_h = reinterpret_cast<int*>(db + o_ps_h);
       sd.counts = s->h_counts;
       s->h_counts[3] = 0;
       {
@@ -2529,8 +2546,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         ASD_HIP_CHECK(ctx, hipGetLastError());
       }
       d.act = sd.act; d.pose_h = sd.pose_h; d.pt_h = sd.pt_h; d.pose_of_h = sd.pose_of_h; d.pt_of_h = sd.pt_of_h;
-      d.pt_start = sd.pt_start; d.ps_start = sd.ps_start; d.ps_edges = sd.ps_edges;
-      sb = SchurBlocks{sd.blk_i, sd.blk_j, sd.pair_start, sd.pairs};
+      d.pt_start = sd.pt_start; d.ps_start = sd.ps_start; d.ps_edges = sd.ps_edges; d.ps_h = sd.ps_h;
+      sb = SchurBlocks{sd.blk_i, sd.blk_j, sd.pair_start, sd.pairs, sd.pair_h};
       d.Ea = Ea; d.nPf = nPf; d.nLa = nLa;
       n_pairs_total = 0;   // (on the device; read from the pinned counts when the round reports)
     } else
@@ -2569,9 +2586,12 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     for (int k = 0; k < Ea; ++k) if (ph_of_k[k] >= 0) ++ps_start[ph_of_k[k] + 1];
     for (int h = 0; h < nPf; ++h) ps_start[h + 1] += ps_start[h];
     ps_edges.assign(std::max(ps_start[nPf], 1), 0);
+    ps_hv.assign(ps_edges.size(), 0);
     {
       cursor.assign(ps_start.begin(), ps_start.end() - 1);
-      for (int k = 0; k < Ea; ++k) if (ph_of_k[k] >= 0) ps_edges[cursor[ph_of_k[k]]++] = k;
+      for (int h = 0; h < nLa; ++h)
+        for (int k = pt_start[h]; k < pt_start[h + 1]; ++k)   // (k ascending over the landmarks in order: the same order as a plain loop over k)
+          if (ph_of_k[k] >= 0) { const int o = cursor[ph_of_k[k]]++; ps_edges[o] = k; ps_hv[o] = h; }
     }
     // Schur pair lists per upper block (bi <= bj), blocks numbered row-major over the upper triangle.  Every upper
     // block gets a workgroup, also those no landmark connects: the in-place Cholesky leaves fill-in in A, so blocks
@@ -2602,7 +2622,8 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     const size_t o_act = place((size_t)std::max(Ea, 1) * 4), o_pose_h = place((size_t)P * 4), o_pt_h = place((size_t)L * 4),
                  o_pose_of_h = place((size_t)std::max(nPf, 1) * 4), o_pt_of_h = place((size_t)std::max(nLa, 1) * 4), o_pt_start = place((size_t)(nLa + 1) * 4),
                  o_ps_start = place((size_t)(nPf + 1) * 4), o_ps_edges = place(ps_edges.size() * 4), o_blk_i = place((size_t)std::max(nblk, 1) * 4),
-                 o_blk_j = place((size_t)std::max(nblk, 1) * 4), o_pair_start = place((size_t)(nblk + 1) * 4), o_pairs = place(npairs * 8);
+                 o_blk_j = place((size_t)std::max(nblk, 1) * 4), o_pair_start = place((size_t)(nblk + 1) * 4), o_pairs = place(npairs * 8),
+                 o_pair_h = place(npairs * 4), o_ps_h = place(ps_edges.size() * 4);
     if ((r2 = s->sblk.ensure(ctx, off)) != ASD_OK) return r2;
     if (s->h_sblk_cap < off) {
       if (s->h_sblk) (void)hipHostFree(s->h_sblk);
@@ -2613,13 +2634,14 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     char* hb = s->h_sblk;
     auto put = [&](size_t o, const std::vector<int>& v) { if (!v.empty()) memcpy(hb + o, v.data(), v.size() * 4); };
     put(o_act, act); put(o_pose_h, pose_h); put(o_pt_h, pt_h); put(o_pose_of_h, pose_of_h); put(o_pt_of_h, pt_of_h); put(o_pt_start, pt_start);
-    put(o_ps_start, ps_start); put(o_ps_edges, ps_edges); put(o_pair_start, pair_start);
+    put(o_ps_start, ps_start); put(o_ps_edges, ps_edges); put(o_pair_start, pair_start); put(o_ps_h, ps_hv);
     {
       int* bi_ = reinterpret_cast<int*>(hb + o_blk_i);
       int* bj_ = reinterpret_cast<int*>(hb + o_blk_j);
       for (int i = 0, q = 0; i < nPf; ++i)
         for (int j = i; j < nPf; ++j, ++q) { bi_[q] = i; bj_[q] = j; }
       int2* pp = reinterpret_cast<int2*>(hb + o_pairs);
+      int* ph_ = reinterpret_cast<int*>(hb + o_pair_h);
       cursor.assign(pair_start.begin(), pair_start.end() - 1);
       for (int h = 0; h < nLa; ++h) {
         const int s1 = pt_start[h + 1];
@@ -2627,7 +2649,7 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
         while (a < s1 && ph_of_k[a] < 0) ++a;
         for (; a < s1; ++a) {
           const int ro = row_off[ph_of_k[a]];
-          for (int b = a; b < s1; ++b) pp[cursor[ro + ph_of_k[b]]++] = make_int2(a, b);
+          for (int b = a; b < s1; ++b) { const int o = cursor[ro + ph_of_k[b]]++; pp[o] = make_int2(a, b); ph_[o] = h; }
         }
       }
     }
@@ -2637,9 +2659,9 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
     d.act = reinterpret_cast<const int*>(db + o_act); d.pose_h = reinterpret_cast<const int*>(db + o_pose_h); d.pt_h = reinterpret_cast<const int*>(db + o_pt_h);
     d.pose_of_h = reinterpret_cast<const int*>(db + o_pose_of_h); d.pt_of_h = reinterpret_cast<const int*>(db + o_pt_of_h);
     d.pt_start = reinterpret_cast<const int*>(db + o_pt_start); d.ps_start = reinterpret_cast<const int*>(db + o_ps_start);
-    d.ps_edges = reinterpret_cast<const int*>(db + o_ps_edges);
+    d.ps_edges = reinterpret_cast<const int*>(db + o_ps_edges); d.ps_h = reinterpret_cast<const int*>(db + o_ps_h);
     sb = SchurBlocks{reinterpret_cast<const int*>(db + o_blk_i), reinterpret_cast<const int*>(db + o_blk_j), reinterpret_cast<const int*>(db + o_pair_start),
-                     reinterpret_cast<const int2*>(db + o_pairs)};
+                     reinterpret_cast<const int2*>(db + o_pairs), reinterpret_cast<const int*>(db + o_pair_h)};
     d.Ea = Ea; d.nPf = nPf; d.nLa = nLa;
     }   // round_idx == 0
     t_prep = std::chrono::steady_clock::now();
@@ -2659,7 +2681,6 @@ int local_ba_impl(asd_ctx* ctx, BaState* s, asd_ba_problem* pr, asd_ba_result* r
       hipLaunchKernelGGL(k_ba_linearize, dim3(gE), dim3(256), 0, st, d, robust ? 1 : 0);
       hipLaunchKernelGGL(k_ba_reduce, dim3(nPf * kPoseSplit + gL), dim3(256), 0, st, d);
       if (nPf > 0) {
-        hipLaunchKernelGGL(k_ba_edge_y, dim3(gE), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_ba_schur, dim3(nblk + nPf), dim3(kSchurThreads), 0, st, d, sb, nblk);
         const size_t nbk = (size_t)(nPf * (nPf + 1) / 2);
         static AsdPerDeviceOnce attr_set;   // the dynamic-LDS attribute is per device

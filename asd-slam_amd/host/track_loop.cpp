@@ -830,9 +830,16 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
     h->ba_out = true;
     h->ba_step = h->steps;
   } else {
-    // (holding the extractor back while LocalBA runs in line -- asd_extract_hold -- was measured in round 4: 1104-1190 frames/s with, 1142-1167 without; again in round 5 with the
-    // shorter LocalBA: 2.47 instead of 2.75 ms per LocalBA, tracking 0.623 instead of 0.610 ms per frame, 1262-1275 against 1257-1262 frames/s: within noise)
+    // No further ASDNet forward is ENQUEUED while LocalBA runs in line (asd_extract_hold; forwards already on the device finish, front
+    // halves continue): the reference does nothing else during LocalBundleAdjustment either, and the tracking thread is blocked for as long
+    // as it takes.  Round 4 (extractor and tracking thread balanced): no gain.  Round 5 (the tracking thread is the longer side, the extractor
+    // has ~12 % of slack to catch up with): 2.5-2.7 instead of 2.9-3.1 ms per LocalBA, tracking 0.64 instead of 0.63 ms per frame:
+    // +2.2 % at the driver's K = 20 (median of eight alternating pairs on one box: 1097 against 1073 frames/s), +0.7 % at K = 300.
+    (void)asd_extract_hold(ctx, 1);
+    if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 1);
     rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r);
+    (void)asd_extract_hold(ctx, 0);
+    if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 0);
     if (rc != ASD_OK) return rc;
     st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
   }

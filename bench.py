@@ -628,7 +628,13 @@ class HipBackend:
         return self.hip.pose7_to_tcw(pose)
 
     def local_ba(self, prob):
-        return self.hip.local_ba(prob)
+        # in line: no further ASDNet forward is enqueued meanwhile (host/track_loop.cpp::submit_ba does the same; the reference does nothing
+        # else during LocalBundleAdjustment either)
+        self.hip.extract_hold(True)
+        try:
+            return self.hip.local_ba(prob)
+        finally:
+            self.hip.extract_hold(False)
 
     def local_ba_submit(self, prob):
         self.hip.local_ba_submit(prob)
