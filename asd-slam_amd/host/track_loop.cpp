@@ -102,6 +102,7 @@ struct asd_track_handle {
   std::vector<double> ba_poses, ba_points, ba_chi2;
   std::vector<uint8_t> ba_dpos, ba_out1;
   double wait_ms = 0.0, ba_ms = 0.0;  // ASD_TIMING: time blocked on the extractor / inside LocalBA
+  double ba_prep_ms = 0.0;            // ... and putting the keyframe's LocalBA problem together on the host (the stand-in for Optimizer.cc:415-600's graph assembly)
   double seg_ms[8] = {};              // frame_set, submit, bank+M1, pose1, frustum, M2, pose2, host glue
   double kern_ms[4] = {};             // device time of M1, pose1, M2, pose2 (asd_last_stage_ms)
   long steps = 0;
@@ -207,8 +208,8 @@ void asd_track_destroy(asd_track_handle* h) {
   (void)collect_ba(h, nullptr, -1);
   if (getenv("ASD_TIMING") && h->steps)
   {
-    fprintf(stderr, "[track_loop] steps %ld  extract wait %.3f ms/step  local BA %.3f ms/step\n", h->steps, h->wait_ms / h->steps,
-            h->ba_ms / h->steps);
+    fprintf(stderr, "[track_loop] steps %ld  extract wait %.3f ms/step  local BA %.3f ms/step (+ %.3f ms/step putting its problem together on the host)\n", h->steps,
+            h->wait_ms / h->steps, h->ba_ms / h->steps, h->ba_prep_ms / h->steps);
     static const char* nm[8] = {"frame_set", "submit", "bank+M1", "pose1", "frustum", "M2", "pose2", "host glue"};
     for (int i = 0; i < 8; ++i) fprintf(stderr, "[track_loop]   %-10s %.3f ms/step\n", nm[i], h->seg_ms[i] / h->steps);
     fprintf(stderr, "[track_loop]   device time: M1 %.3f pose1 %.3f M2 %.3f pose2 %.3f ms/step\n", h->kern_ms[0] / h->steps, h->kern_ms[1] / h->steps,
@@ -805,7 +806,7 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
   asd_ctx* ctx = h->ctx;
   int rc;
   if ((rc = collect_ba(h, nullptr, -1)) != ASD_OK) return rc;   // the previous keyframe's run (its buffers are reused below)
-  if (h->dm && !h->async_ba && (rc = do_mapping_stage(h)) != ASD_OK) return rc;   // (in line only: with the lane a tracking stage is outstanding here)
+  const auto p0 = std::chrono::steady_clock::now();
   const asd_ba_problem& B = h->ba;
   h->ba_poses.assign(B.poses, B.poses + (size_t)7 * B.n_poses);
   h->ba_points.assign(B.points, B.points + (size_t)3 * B.n_points);
@@ -824,22 +825,25 @@ static int submit_ba(asd_track_handle* h, asd_track_stats* st, int t) {
   h->ba_p.poses = h->ba_poses.data(); h->ba_p.points = h->ba_points.data(); h->ba_p.e_obs = h->ba_obs.data();
   memset(&h->ba_r, 0, sizeof h->ba_r);
   h->ba_r.edge_chi2 = h->ba_chi2.data(); h->ba_r.edge_depth_pos = h->ba_dpos.data(); h->ba_r.edge_outlier1 = h->ba_out1.data();
+  h->ba_prep_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - p0).count();
+  // No further ASDNet forward is ENQUEUED while the per-keyframe stage and LocalBA run in line (asd_extract_hold; forwards already on the
+  // device finish, front halves continue): the reference does nothing else during DoMapping either, and the tracking thread is blocked for as
+  // long as it takes.  Round 4 (extractor and tracking thread balanced): no gain.  Round 5 (the tracking thread is the longer side, the
+  // extractor has ~12 % of slack to catch up with): 2.3-2.5 instead of 2.75-2.85 ms per LocalBA, tracking 0.64 instead of 0.62 ms per frame:
+  // +2.2 % at the driver's K = 20 (median of eight alternating pairs on one box: 1097 against 1073 frames/s), +0.7 % at K = 300.
+  struct ExtractHold {
+    asd_ctx *a, *b;
+    ExtractHold(asd_ctx* a_, asd_ctx* b_, bool on) : a(on ? a_ : nullptr), b(on ? b_ : nullptr) { if (a) (void)asd_extract_hold(a, 1); if (b) (void)asd_extract_hold(b, 1); }
+    ~ExtractHold() { if (a) (void)asd_extract_hold(a, 0); if (b) (void)asd_extract_hold(b, 0); }
+  } hold(ctx, h->ctx_r, !h->async_ba);
+  if (h->dm && !h->async_ba && (rc = do_mapping_stage(h)) != ASD_OK) return rc;   // (in line only: with the lane a tracking stage is outstanding here)
   const auto b0 = std::chrono::steady_clock::now();
   if (h->async_ba) {
     if ((rc = asd_local_ba_submit(ctx, &h->ba_p, &h->ba_r)) != ASD_OK) return rc;
     h->ba_out = true;
     h->ba_step = h->steps;
   } else {
-    // No further ASDNet forward is ENQUEUED while LocalBA runs in line (asd_extract_hold; forwards already on the device finish, front
-    // halves continue): the reference does nothing else during LocalBundleAdjustment either, and the tracking thread is blocked for as long
-    // as it takes.  Round 4 (extractor and tracking thread balanced): no gain.  Round 5 (the tracking thread is the longer side, the extractor
-    // has ~12 % of slack to catch up with): 2.5-2.7 instead of 2.9-3.1 ms per LocalBA, tracking 0.64 instead of 0.63 ms per frame:
-    // +2.2 % at the driver's K = 20 (median of eight alternating pairs on one box: 1097 against 1073 frames/s), +0.7 % at K = 300.
-    (void)asd_extract_hold(ctx, 1);
-    if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 1);
     rc = asd_local_ba(ctx, &h->ba_p, &h->ba_r);
-    (void)asd_extract_hold(ctx, 0);
-    if (h->ctx_r) (void)asd_extract_hold(h->ctx_r, 0);
     if (rc != ASD_OK) return rc;
     st->ba_chi2 = h->ba_r.chi2_second; st->has_ba = 1;
   }
