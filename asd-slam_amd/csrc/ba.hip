@@ -161,52 +161,6 @@ __device__ inline void block_reduce(double (&v)[N], double* red, double* out /*[
   asd_syncthreads();
 }
 
-// every loop fully unrolled: with run-time indices A[] and inv[] live in scratch memory (336 B per lane, ~1450 cycles per solve on
-// the single lane that runs it); unrolled they are registers
-__device__ inline bool chol6_solve(const double* H, double lambda, const double* b, double* x) {
-  double A[36], inv[6];
-#pragma unroll
-  for (int i = 0; i < 36; ++i) A[i] = H[i];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) A[j * 7] += lambda;
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double d = A[j * 6 + j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= A[j * 6 + k] * A[j * 6 + k];
-    if (!(d > 0)) ok = false;
-    inv[j] = asd_rsqrt(d);
-    A[j * 6 + j] = d * inv[j];
-#pragma unroll
-    for (int i = j + 1; i < 6; ++i) {
-      double s = A[i * 6 + j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
-      A[i * 6 + j] = s * inv[j];
-    }
-  }
-  if (!ok) return false;
-  double y[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double s = b[i];
-#pragma unroll
-    for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * y[k];
-    y[i] = s * inv[i];
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    double s = y[i];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * y[k];
-    y[i] = s * inv[i];
-  }
-#pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = y[i];
-  return true;
-}
-
 // ---------------------------------------------------------------- P1: PoseOptimization, one workgroup
 // Edge data ([n][6] = Xw, obs, info), the stored errors and the level / outlier flags live in LDS for
 // the whole optimisation (64 B + 2 B per edge: n <= 2300 fits the 160 KiB of a CU; larger n streams

@@ -438,7 +438,6 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
   st->n_kp = n;
   if (h->ctx_r) { st->stereo_matched = h->prep_stereo; st->has_stereo = 1; }
   const bool had_last = h->have_last;
-  int n2p = 0;
   if (had_last) {
     const std::vector<asd_keypoint>& lk = h->last_kps;
     const int nl = (int)lk.size();
@@ -454,7 +453,6 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
       return rc;
     seg(2);
     // ---- under it: the local map's tables (the last frame's points plus a jittered copy; nothing here needs the stage's result)
-    n2p = h->map_copies * nl;
     if (h->tables_for != t) build_candidate_tables(h, nl);   // (prepare_frame built them and stored them in the attribute bank)
     seg(7);
     if ((rc = asd_track_finish(ctx)) != ASD_OK) return rc;
@@ -462,7 +460,6 @@ static int track_step_split(asd_track_handle* h, int t, bool do_ba, const std::v
     seg(3);
     // ---- between the stages: outlier matches dropped, the optimised pose becomes the frame's pose, the local map is put together
     const int nsel = select_local_points(h, n, nl, h->outl.data(), pose, h->tables_for != t);
-    n2p = nsel;
     // ---- Tracking::TrackLocalMap's numeric body, enqueued (Tracking.cc:725-736, 803-851), from the motion-model stage's pose
     h->m2.assign(n, -1);
     h->outl2.resize(n);
