@@ -585,61 +585,10 @@ __device__ __forceinline__ void split4_mix(float x0, float x1, float x2, float x
       : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(s));
 }
 
-// ---- tile queue + CU reservation in software ----------------------------------------------------------------------------
-// The tracking stream's single-workgroup kernels (k_pose_opt, k_resolve: 50-100 KB of LDS, latency-bound) run 20-30 % slower when
-// they share their CU with ASDNet workgroups, and wait for a CU with room when ASDNet has filled the chip.  Rounds 1-2 kept 32 CUs
-// out of ASDNet's reach with a CU-masked stream -- which ROCm 7.2 cannot tear down ("Teardown").  The same effect
-// without a special stream: the conv layers are PERSISTENT launches (about as many workgroups as fit the chip) whose workgroups
-// pull tiles = (patch, band) from a counter in HBM; a workgroup that finds itself on a reserved CU (s_getreg HW_ID / XCC_ID) leaves
-// without taking a tile.  Which tile a workgroup computes never affects the tile's result, so placement changes nothing but
-// speed; the LAST workgroup of the grid ignores the reservation and drains the queue, so every tile is computed even if every
-// other workgroup were to land on reserved CUs.  Single-workgroup launches on an otherwise free XCD go to XCC 0 / SE 0
-// (tools/ubench/cu_census.hip): mode 1 reserves exactly that shader engine (8 of 256 CUs).
-// MEASURED AND NOT ADOPTED (round 3, tools/ab_reserve.sh, in-line LocalBA, one box): one workgroup per tile 1069 frames/s (ASDNet
-// 0.582 ms); persistent without reservation 998 (0.604 ms); reserving XCC 0 / SE 0: 1000-1004, all of XCC 0: 983, half of SE 0 in
-// every XCC: 1010, two SEs of XCC 0: 1003.  Persistent workgroups hold their CUs for a whole layer (~100 us) where the
-// occupancy-based form frees a slot every few microseconds, so the tracking kernels wait longer for room, and under load their
-// single workgroups evidently do not land on the reserved CUs.  The form stays behind ASD_ASDNET_PERSIST=1 / ASD_ASDNET_RESERVE=<mode>
-// (tested: tests/test_build_matrix.py); the default is one workgroup per tile.
-__device__ inline bool asd_cu_reserved(int mode) {
-  if (mode == 0) return false;
-  unsigned hw, xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const unsigned se = (hw >> 13) & 0x7, cu = (hw >> 8) & 0xf;
-  xcc &= 0xf;
-  if (mode == 1) return xcc == 0 && se == 0;          // one shader engine of XCC 0: 8 CUs
-  if (mode == 2) return xcc == 0;                      // all of XCC 0: 32 CUs
-  if (mode == 3) return se == 0 && cu >= 4;            // the upper half of SE 0 in every XCC: 32 CUs
-  if (mode == 4) return xcc == 0 && se <= 1;           // two shader engines of XCC 0: 16 CUs
-  return false;
-}
-struct TileQueue {
-  int* counter;   // zeroed before the launch; null = one tile per workgroup, blockIdx.x (the non-persistent form)
-  int ntiles;
-  int reserve;    // asd_cu_reserved mode
-};
-// next tile of this workgroup or -1; `slot` is a __shared__ int.  Ends with a barrier: the previous tile's LDS is free afterwards.
-__device__ inline int tile_first(const TileQueue& q, int* slot) {
-  if (!q.counter) return blockIdx.x;
-  if (threadIdx.x == 0) {
-    int tl = -1;
-    if (blockIdx.x == gridDim.x - 1 || !asd_cu_reserved(q.reserve)) tl = atomicAdd(q.counter, 1);
-    *slot = tl >= 0 && tl < q.ntiles ? tl : -1;
-  }
-  asd_syncthreads();
-  return *slot;
-}
-__device__ inline int tile_next(const TileQueue& q, int* slot) {
-  if (!q.counter) return -1;
-  asd_syncthreads();   // every wave is done with the tile's LDS and with *slot
-  if (threadIdx.x == 0) {
-    const int tl = atomicAdd(q.counter, 1);
-    *slot = tl < q.ntiles ? tl : -1;
-  }
-  asd_syncthreads();
-  return *slot;
-}
+// (Round 3 ran the conv layers as PERSISTENT launches as well -- workgroups pulling tiles from a counter, a workgroup that found itself on a
+// "reserved" CU leaving without one, to keep CUs free for the tracking stream in software: 998-1010 frames/s against 1069 with one workgroup per
+// tile.  Persistent workgroups hold their CUs for a whole layer where the occupancy-based form frees a slot every few microseconds, and the
+// tracking kernels' single workgroups did not land on the reserved CUs.  Removed in round 5 with its switches.)
 
 // input_norm's statistics (ASDNet.py:360-365) of every patch, once per forward: mean and unbiased std + 1e-7 over the 1024 pixels.  conv2's
 // workgroups (four bands per patch) used to compute them in their prologue, each for itself: the patch load, two wave + LDS reductions and two
@@ -1081,11 +1030,9 @@ template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, b
 __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? ASD_L2_MINWG : 1) void k_conv_x3(const void* __restrict__ in_, const uint8_t* __restrict__ wimg,
                                                          const float* __restrict__ bias, float* __restrict__ out,
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
-                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale, TileQueue tq,
+                                                         unsigned long long* __restrict__ stamps, float in_scale, float out_scale,
                                                          const float* __restrict__ stats) {
-  __shared__ int tile_slot;
-  for (int tile = tile_first(tq, &tile_slot); tile >= 0; tile = tile_next(tq, &tile_slot))
-    conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(tile, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale, stats);
+  conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(blockIdx.x, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale, stats);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1451,8 +1398,7 @@ hipError_t launch_conv_p(hipStream_t st, const float* in, const float* wimg, con
 template <int CIN, int COUT, int HIN, int S, int ROWS, int WM, int WN, int PP, bool FUSE1 = false, int NP = 3, bool PAIR = false>
 hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, const float* bias, float* out, int n,
                           const float* w1 = nullptr, const float* b1 = nullptr, unsigned long long* stamps = nullptr, int* grid_out = nullptr,
-                          float in_scale = 1.f, float out_scale = 1.f, int* tq_counter = nullptr, int reserve = 0, int num_cu = 256,
-                          const float* stats = nullptr) {
+                          float in_scale = 1.f, float out_scale = 1.f, const float* stats = nullptr) {
   using C = X3Cfg<CIN, COUT, HIN, S, ROWS, WM, WN, PP, NP>;
   auto kern = k_conv_x3<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>;
   // (padding the request to force one workgroup per CU was measured in round 2: ASDNet 0.79 -> 0.99 ms, 703 frames/s; not kept)
@@ -1470,11 +1416,8 @@ hipError_t launch_conv_x3(hipStream_t st, const void* in, const void* wimg, cons
   }
   const int ntiles = ((n + PP - 1) / PP) * (C::HO / ROWS);
   if (grid_out) *grid_out = ntiles;
-  // persistent form: as many workgroups as fit the chip (LDS-limited, at most three per CU as the occupancy-based form ran)
-  const int per_cu = std::max(1, std::min(3, (160 * 1024) / (lds + 64)));
-  const int grid = tq_counter ? std::min(ntiles, num_cu * per_cu) : ntiles;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,
-                     in_scale, out_scale, TileQueue{tq_counter, ntiles, reserve}, stats);
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(C::NTH), lds, st, in, static_cast<const uint8_t*>(wimg), bias, out, w1, b1, n, stamps,
+                     in_scale, out_scale, stats);
   return hipGetLastError();
 }
 
@@ -1553,7 +1496,6 @@ int asdnet_alloc(asd_ctx* ctx) {
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_part, (size_t)FC_SK * npad * 128 * sizeof(float)));
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_patches, np * 1024));
   ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_desc, np * 128 * sizeof(float)));
-  ASD_HIP_CHECK(ctx, hipMalloc(&ctx->d_tq, 16 * sizeof(int)));
   ASD_HIP_CHECK(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_range), 64));
   *ctx->h_range = 0;
   if (const char* e = getenv("ASD_ASDNET_PAIR")) ctx->net_pair = atoi(e) != 0;
@@ -1566,7 +1508,6 @@ void asdnet_free(asd_ctx* ctx) {
   if (ctx->d_part) (void)hipFree(ctx->d_part);
   if (ctx->d_patches) (void)hipFree(ctx->d_patches);
   if (ctx->d_desc) (void)hipFree(ctx->d_desc);
-  if (ctx->d_tq) (void)hipFree(ctx->d_tq);
   if (ctx->h_range) (void)hipHostFree(ctx->h_range);
   if (ctx->d_w1) (void)hipFree(ctx->d_w1);
   for (int i = 0; i < 7; ++i) {
@@ -1688,17 +1629,14 @@ static int asdnet_forward_one(asd_ctx* ctx, const uint8_t* d_patches, int n, flo
   const bool p2 = ctx->net_pieces == 2;
   // pair format between the layers: every layer on the two-piece kernels, and not the calibration pass (k_absmax reads f32)
   const bool pair = kPairOK && p2 && (ctx->net_split & 63) == 63 && ctx->net_pair && !ctx->d_calib;
-  // persistent launches: one tile counter per layer, zeroed here on the forward's own stream
-  int* const tq = ctx->asdnet_persist ? ctx->d_tq : nullptr;
-  if (tq) ASD_HIP_CHECK(ctx, hipMemsetAsync(tq, 0, 16 * sizeof(int), st));
   const float* x3_stats = nullptr;   // conv2 only: the patches' normalisation statistics (k_patch_stats)
 #define X3_LAUNCH(CFG, FUSE, l, src, dst, w1p, b1p)                                                                                       \
   (pair ? launch_conv_x3<CFG, FUSE, 2, kPairOK>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,       \
-                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu, x3_stats)           \
+                                     1.f / (kActScale * ctx->wx2_scale[l]), x3_stats)                                                               \
    : p2 ? launch_conv_x3<CFG, FUSE, 2>(st, src, ctx->d_wx2[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, kActScale,               \
-                                     1.f / (kActScale * ctx->wx2_scale[l]), tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu, x3_stats)           \
+                                     1.f / (kActScale * ctx->wx2_scale[l]), x3_stats)                                                               \
       : launch_conv_x3<CFG, FUSE, 3>(st, src, ctx->d_wx3[l], ctx->d_bias[l], dst, n, w1p, b1p, nullptr, nullptr, 1.f, 1.f,                \
-                                     tq ? tq + l : nullptr, ctx->cu_reserve, ctx->num_cu, x3_stats))
+                                     x3_stats))
   if (ctx->net_split & 1) {
     // input_norm's mean / std of every patch once (k_patch_stats), in the head of the last layer's partial-sum buffer (free until that layer)
     hipLaunchKernelGGL(k_patch_stats, dim3(n), dim3(256), 0, st, d_patches, ctx->d_part, n);

@@ -2095,7 +2095,7 @@ void ba_free(asd_ctx* ctx) {
     }
     ln->cv.notify_all();
     if (ln->th.joinable()) ln->th.join();
-    if (ln->st) { asd_unregister_stream(ctx, ln->st); (void)hipStreamDestroy(ln->st); }
+    if (ln->st) { (void)hipStreamDestroy(ln->st); }
     if (ln->e0) (void)hipEventDestroy(ln->e0);
     if (ln->e1) (void)hipEventDestroy(ln->e1);
     delete ln;
@@ -2796,7 +2796,7 @@ int asd_local_ba_submit(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
   if (!s->lane) {   // built completely before it is published
     BaLane* ln = new BaLane();
     auto fail = [&](const char* what) {
-      if (ln->st) { asd_unregister_stream(ctx, ln->st); (void)hipStreamDestroy(ln->st); }
+      if (ln->st) { (void)hipStreamDestroy(ln->st); }
       if (ln->e0) (void)hipEventDestroy(ln->e0);
       if (ln->e1) (void)hipEventDestroy(ln->e1);
       delete ln;
@@ -2810,7 +2810,6 @@ int asd_local_ba_submit(asd_ctx* ctx, asd_ba_problem* pr, asd_ba_result* res) {
     // 5 -> 15 us), so the run should be over quickly.  Measured: 964-976 frames/s with the lane at the highest priority against
     // 922-931 at the lowest (and 850-875 with LocalBA in line).
     if (hipStreamCreateWithPriority(&ln->st, hipStreamNonBlocking, prio_greatest) != hipSuccess) return fail("hipStreamCreateWithPriority");
-    asd_register_stream(ctx, ln->st);
     if (hipEventCreate(&ln->e0) != hipSuccess || hipEventCreate(&ln->e1) != hipSuccess) return fail("hipEventCreate");
     ln->th = std::thread(lane_main, ctx, s, ln);
     s->lane = ln;

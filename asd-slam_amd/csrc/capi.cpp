@@ -132,7 +132,6 @@ int asd_ctx_create(const asd_config* cfg, asd_ctx** out) {
     delete c;
     return ASD_ERR_NO_DEVICE;
   }
-  asd_register_stream(c, c->stream);
   int rc = asdnet_alloc(c);
   if (rc == ASD_OK) rc = frontend_alloc(c);
   if (rc != ASD_OK) {

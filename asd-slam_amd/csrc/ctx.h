@@ -250,8 +250,6 @@ struct asd_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream_x = nullptr;    // back halves (ASDNet) of the pipelined extractor
   // every stream this context's entry points or worker threads launch into (registered when created)
-  std::vector<hipStream_t> aux_streams;
-  std::mutex aux_mu;
   hipStream_t stream_prep = nullptr; // asd_prep_async: frame construction (grid / descriptor / bank copies) beside the stages in flight
   hipEvent_t ev_prep = nullptr;
   bool prep_on = false;
@@ -285,11 +283,8 @@ struct asd_ctx {
   int* h_range = nullptr;       // pinned: set by k_l2norm when a descriptor of an asd_describe* call came out non-finite (fp16x2 range)
   std::string calib_note;       // what asd_load_weights' calibration found (empty: nothing to report)
   unsigned* d_calib = nullptr;  // calibration only: per-layer max |activation| as float bits (asdnet_forward_device fills it when set)
-  int* d_tq = nullptr;          // tile counters of the persistent conv launches of one forward (asdnet.hip, TileQueue), one per layer
-  int cu_reserve = 0;           // asd_cu_reserved mode of the persistent conv launches (ASD_ASDNET_RESERVE at asd_ctx_create)
   bool pose_chain_kp_flags = false;   // the last pose_chain_enqueue wrote its outlier flags per keypoint (gather form of k_pose_opt)
   bool net_pair = true;         // two-piece form: activations between the layers as the fp16 piece pairs themselves (ASD_ASDNET_PAIR=0: f32 NHWC)
-  bool asdnet_persist = false;  // ASD_ASDNET_PERSIST=1: conv layers as persistent tile-queue launches (measured slower, see asdnet.hip)
   float* d_act6 = nullptr;      // where the last forward left conv6's output (d_act[0] or d_act[1]; asd_debug_act6)
   int ring_mask = 0;            // ASD_ASDNET_RING: layers on the LDS-image / weight-ring kernels of asdnet_ring.hip (bit 0 conv4, bit 1 conv6, bit 2 conv4+conv5 fused)
   uint8_t* d_patches = nullptr; // [max_patches][1024]
@@ -393,11 +388,6 @@ bool pose_chain_fused_ok(const asd_ctx* ctx, int kind, int nq, int n_cur, size_t
 int pose_chain_enqueue(asd_ctx* ctx, int n_cur, const int* d_src, const float4* d_kp, const float* d_tab, const uint8_t* d_hold,
                        const float* d_own, const double* pose7, const double* K, double* d_io, const double* d_pose0 = nullptr,
                        double* d_io_dev = nullptr, const AsdBetweenArgs* between = nullptr, const AsdFusedReplay* fused = nullptr);
-inline void asd_register_stream(asd_ctx* ctx, hipStream_t st) { std::lock_guard<std::mutex> g(ctx->aux_mu); ctx->aux_streams.push_back(st); }
-inline void asd_unregister_stream(asd_ctx* ctx, hipStream_t st) {
-  std::lock_guard<std::mutex> g(ctx->aux_mu);
-  for (size_t i = 0; i < ctx->aux_streams.size(); ++i) if (ctx->aux_streams[i] == st) { ctx->aux_streams.erase(ctx->aux_streams.begin() + i); break; }
-}
 int pose_chain_reserve(asd_ctx* ctx, int n_cur);   // its allocations and kernel attributes, ahead of time (see the definition)
 // true when pose_chain_enqueue will take the LDS (gather) form for a frame of n_cur keypoints
 inline bool pose_chain_lds_form(const asd_ctx* ctx, int n_cur) { return ctx->cfg.n_levels <= 16 && (size_t)n_cur * 35 + 16 <= 150 * 1024; }

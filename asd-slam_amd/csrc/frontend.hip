@@ -1047,11 +1047,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     hipStream_t sx = nullptr;
     auto build = [&]() -> int {
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&sx, hipStreamDefault, prio_least));
-      asd_register_stream(ctx, sx);
       ax->fe[0] = ctx->fe;
       for (int w = 0; w < kWorkers; ++w) {
         ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ax->stream_f[w], hipStreamDefault, prio_greatest));
-        asd_register_stream(ctx, ax->stream_f[w]);
         ASD_HIP_CHECK(ctx, hipEventCreate(&ax->ev_corners[w]));
         int r;
         if (w > 0 && (r = fe_alloc(ctx, &ax->fe[w])) != ASD_OK) return r;
@@ -1068,9 +1066,9 @@ int asd_extract_submit(asd_ctx* ctx, const uint8_t* image, int32_t device_reside
     if ((rc = build()) != ASD_OK) {
       for (auto& S : ax->slots) slot_free(S);
       for (hipEvent_t e : ax->ev_corners) if (e) (void)hipEventDestroy(e);
-      for (hipStream_t st : ax->stream_f) if (st) { asd_unregister_stream(ctx, st); (void)hipStreamDestroy(st); }
+      for (hipStream_t st : ax->stream_f) if (st) { (void)hipStreamDestroy(st); }
       for (int w = 1; w < kWorkers; ++w) fe_free(ax->fe[w]);
-      if (sx) { asd_unregister_stream(ctx, sx); (void)hipStreamDestroy(sx); }
+      if (sx) { (void)hipStreamDestroy(sx); }
       delete ax;
       return rc;
     }

@@ -2721,7 +2721,6 @@ int asd_prep_async(asd_ctx* ctx, int32_t on) {
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
       // highest priority, like the main stream
       ASD_HIP_CHECK(ctx, hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, hi));
-      asd_register_stream(ctx, ctx->stream_prep);
       ASD_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
     }
     ctx->prep_on = true;
