@@ -804,6 +804,9 @@ static int extract_front(asd_ctx* ctx, FrontendState* fe, const ExtractJob& J, E
     hipLaunchKernelGGL(k_angle_patch, dim3((n + 3) / 4), dim3(256), 0, st, P, fe->d_pyr, fe->d_blur, fe->d_kps, n,
                        S.d_angles, S.d_patches);
     ASD_HIP_CHECK(ctx, hipGetLastError());
+    // the angles go back to the host from HERE (the stream that made them), not behind the ASDNet forward: one copy command less between two
+    // forwards on the ASDNet stream, whose every command boundary is 10-15 us of idle matrix cores (ev_end still covers it: the forward waits for ev_front)
+    ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_angles, S.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   }
   ASD_HIP_CHECK(ctx, hipEventRecord(S.ev_front, st));
   if (timing) fprintf(stderr, "[extract front] launch+counts %.0f us, corners D2H %.0f us (%d), quadtree %.0f us\n", us(t_start, t_counts), us(t_counts, t_corners), total, us(t_corners, t_quad));
@@ -816,7 +819,6 @@ static int extract_back_enqueue(asd_ctx* ctx, ExtractSlot& S, int n, hipStream_t
   if (S.h_range) *S.h_range = 0;   // (the slot's previous user was waited for before the slot came round again)
   const int rc = asdnet_forward_device(ctx, S.d_patches, n, S.d_desc, st, S.h_range);
   if (rc != ASD_OK) return rc;
-  ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_angles, S.d_angles, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)n * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
   ASD_HIP_CHECK(ctx, hipEventRecord(S.ev_end, st));
   return ASD_OK;
