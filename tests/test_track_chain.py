@@ -590,3 +590,27 @@ def test_track_frame_refuses_what_it_cannot_chain(hip, synth):
     assert big["n1"] > 0                     # 5000 candidates (round 4 refused more than 4096)
     r = hip.track_frame(0, 1, 300, has, Xw, np.arange(300, dtype=np.int32), None, T, K, 15.0, pose0, np.arange(600, dtype=np.int32), 1.0, 0.8)
     assert r["n1"] > 0
+
+
+@pytest.mark.gpu
+def test_track_local_points_rows_refuses_bad_rows(hip, synth):
+    """asd_track_local_points_rows names its map points by bank row: a row outside the banks is an error of the call, reported before
+    anything is enqueued (no stage left outstanding), and the same call with good rows goes through afterwards."""
+    kl, dl, kc, dc, Xw, has, mp_desc, T, K, Xw2, nrm, mind, maxd = _frame_case(synth, 300, 78)
+    hip.frame_set(0, kc, dc, BOUNDS)
+    hip.bank_put(0, np.concatenate([mp_desc, mp_desc]))
+    hip.mpbank_put(0, Xw2, nrm, mind, maxd)
+    pose0 = _pose7(pose_T())
+    occ = np.zeros(300, np.uint8)
+    cur_Xw = np.zeros((300, 3), np.float32)
+    rows = np.arange(600, dtype=np.int32)
+    bad = rows.copy()
+    bad[17] = 50_000_000
+    with pytest.raises(RuntimeError):
+        hip.track_local_points_rows(0, 300, bad, T, K, occ, cur_Xw, 1.0, 0.8, pose0)
+    neg = rows.copy()
+    neg[0] = -1
+    with pytest.raises(RuntimeError):
+        hip.track_local_points_rows(0, 300, neg, T, K, occ, cur_Xw, 1.0, 0.8, pose0, split=True)
+    good = hip.track_local_points_rows(0, 300, rows, T, K, occ, cur_Xw, 1.0, 0.8, pose0)
+    assert good[1] > 0
