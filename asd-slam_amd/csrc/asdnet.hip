@@ -1032,7 +1032,11 @@ __global__ __launch_bounds__(64 * WM * WN, (FUSE1 && NP == 2) ? ASD_L2_MINWG : 1
                                                          const float* __restrict__ w1, const float* __restrict__ b1, int n,
                                                          unsigned long long* __restrict__ stamps, float in_scale, float out_scale,
                                                          const float* __restrict__ stats) {
-  conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(blockIdx.x, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale, stats);
+  // conv3 reads the 262 MB conv2 has just written -- a little more than the memory-side cache (256 MB) holds.  It walks the patches from the LAST one written to
+  // the first, so that what the cache still holds is read before it is evicted (in the order of writing, LRU evicts every line just before it is read): 101 -> 98 us.
+  // The layers behind it read 131 MB or less: any order.
+  const int bid = (S == 2 && CIN == 32) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+  conv_x3_tile<CIN, COUT, HIN, S, ROWS, WM, WN, PP, FUSE1, NP, PAIR>(bid, in_, wimg, bias, out, w1, b1, n, stamps, in_scale, out_scale, stats);
 }
 
 // ------------------------------------------------------------------------------------------
